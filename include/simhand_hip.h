@@ -1,0 +1,214 @@
+/*
+ * simhand_hip.h -- C ABI of libsimhand_hip.so (gfx950 / MI355X).
+ *
+ * The reference (ut-vision/SiMHand) has no C/FFI/plugin API: its operator
+ * boundary is Python (torch ops dispatched to cuDNN/cuBLAS/ATen).  Each entry
+ * point below names the reference call site (file:line under /root/reference)
+ * whose arithmetic it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (a live torch
+ *     tensor); no ownership transfer, no allocation inside the library;
+ *   - workspaces are caller-allocated after a *_workspace_bytes() query;
+ *   - every launch takes an explicit hipStream_t (as void*), is asynchronous
+ *     and holds no global mutable state (the optional profiler excepted);
+ *   - return 0 on success, non-zero on error; simhand_last_error() returns a
+ *     thread-local message;
+ *   - activations are NHWC, conv weights KRSC ([Cout][R][S][Cin]); dtype enum
+ *     selects fp32 (parity mode, f32 MFMA) or bf16 (bf16 MFMA, fp32 accumulate).
+ */
+#ifndef SIMHAND_HIP_H
+#define SIMHAND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sh_stream_t; /* hipStream_t */
+
+enum sh_dtype { SH_F32 = 0, SH_BF16 = 1 };
+
+/* joint-distance definitions of get_weights_* (src/models/utils.py:218-388) */
+enum sh_dist_mode {
+  SH_DIST_MPJPE = 0,  /* mean_j ||dxy||                       :229-231,:251-253 */
+  SH_DIST_W_ABS = 1,  /* pos: ||mean_j |d|||_2 ; neg: ||mean_xy |d|||_2 over joints  :224-227,:246-249 */
+  SH_DIST_W_O_ABS = 2,/* pos: ||mean_j d||_2   ; neg: ||mean_xy d||_2 over joints    :219-222,:241-244 */
+  SH_DIST_L2 = 3      /* plain L2 over F features (the *_with_pca variants :264-301) */
+};
+enum sh_weight_type { SH_W_NONE = 0, SH_W_LINEAR = 1, SH_W_NONLINEAR = 2 };
+
+int simhand_abi_version(void);
+const char* simhand_last_error(void);
+/* 0 when a gfx950 device is usable from this process */
+int simhand_device_check(void);
+
+/* ---- optional per-kernel-class HIP-event profiler (used by bench.py) ----- */
+enum sh_prof_class { SH_PROF_CONV_FWD = 0, SH_PROF_CONV_DGRAD = 1, SH_PROF_CONV_WGRAD = 2,
+                     SH_PROF_BN = 3, SH_PROF_POOL = 4, SH_PROF_LOSS = 5, SH_PROF_MISC = 6, SH_PROF_NCLASS = 7 };
+int simhand_prof_enable(int on);
+/* blocks until recorded events completed; out_ms/out_flops/out_bytes/out_count are host arrays of SH_PROF_NCLASS */
+int simhand_prof_collect(double* out_ms, double* out_flops, double* out_bytes, int64_t* out_count);
+int simhand_prof_reset(void);
+
+/* ===========================================================================
+ * Loss: similarity-weighted NT-Xent over the gathered global batch
+ *   replaces get_weights_linear / get_weights_nonlinear (+_with_pca)
+ *   (src/models/utils.py:218-388) and vanila_{,weights_,pos_weights_,neg_weights_}
+ *   contrastive_loss (:157-189,:391-501) incl. their autograd backward.
+ *
+ * Row order of Z_all / J_all is the reference's cat(view1, view2): row k and
+ * row B+k form pair k (N = 2B).  This rank owns pairs [pair_off, pair_off+b_loc):
+ * local row l < b_loc is global row pair_off+l, local row l >= b_loc is global
+ * row B+pair_off+(l-b_loc).  rows_loc = 2*b_loc.
+ * =========================================================================== */
+
+/* stats layout (double[8]): [0]=max D, [1]=min D, [2]=sum D (row block),
+ * [3]=max d+, [4]=min d+, [5]=sum d+ ; [6],[7] reserved.  The caller all-reduces
+ * [0..2] (MAX, MIN, SUM) across ranks between dist and fwd. */
+#define SH_NTXENT_NSTATS 8
+
+/* d+_k for all B pairs + its stats; J_all fp32 [N][F] */
+int simhand_pos_dist(const float* J_all, int B, int F, int dist_mode,
+                     float* d_pos /*[B]*/, double* stats /*[8]*/, sh_stream_t stream);
+
+/* D row block [rows_loc][N] fp32 + stats[0..2] of the block */
+size_t simhand_neg_dist_workspace_bytes(int rows_loc, int N);
+int simhand_neg_dist(const float* J_all, int B, int F, int dist_mode, int b_loc, int pair_off,
+                     float* D_loc /*[rows_loc][N]*/, double* stats /*[8]*/,
+                     void* workspace, size_t workspace_bytes, sh_stream_t stream);
+
+typedef struct sh_ntxent_params {
+  int B;            /* global pairs; N = 2B */
+  int dim;          /* projection width, must be 128 (output_dim of *_config.json) */
+  int b_loc;        /* local pairs */
+  int pair_off;     /* first local pair */
+  int weight_type;  /* sh_weight_type */
+  int use_wpos;     /* pos_neg in {pos_neg,pos} */
+  int use_wneg;     /* pos_neg in {pos_neg,neg} */
+  float temperature;/* 0.5 */
+  float lambda_pos; /* non_linear only */
+  float lambda_neg;
+} sh_ntxent_params;
+
+size_t simhand_ntxent_workspace_bytes(const sh_ntxent_params* p);
+/* forward: neg_loc[rows_loc] = sum_{j!=i} exp(w-_ij s_ij / t); loss_part[0] = (1/N) sum over local rows of
+ * (log neg_i - w+_k s_{i,pair(i)} / t)  (sum of loss_part over ranks = the reference's loss). */
+int simhand_ntxent_fwd(const sh_ntxent_params* p, const float* Z_all, const float* D_loc, const float* d_pos,
+                       const double* stats, float* neg_loc, float* loss_part,
+                       void* workspace, size_t workspace_bytes, sh_stream_t stream);
+/* backward for the local rows: dZ_loc[rows_loc][dim] = dloss * dL/dz_i (closed form).
+ * neg_all[N] = gathered negative sums in global row order; dloss = device scalar or NULL (=1). */
+int simhand_ntxent_bwd(const sh_ntxent_params* p, const float* Z_all, const float* D_loc, const float* d_pos,
+                       const double* stats, const float* neg_all, const float* dloss, float* dZ_loc,
+                       void* workspace, size_t workspace_bytes, sh_stream_t stream);
+
+/* ===========================================================================
+ * Projection post-process (per row of 128 = 64 2-D points)
+ *   replaces F.normalize -> translate_encodings -> rotate_encoding -> F.normalize
+ *   (simhand_w_model.py:56-93, src/models/utils.py:606-684) and its backward,
+ *   and get_projection_stats (simhand_w_model.py:138-151).
+ *   jitter_x/jitter_y: int64 [N] or NULL (flag "crop" off); angle: float64 [N]
+ *   degrees or NULL (flag "rotate" off) -- dtypes as collated.
+ * =========================================================================== */
+int simhand_proj_postprocess_fwd(const float* P /*[N][128]*/, int N, const int64_t* jitter_x, const int64_t* jitter_y,
+                                 const double* angle, int img_h, int img_w, float* Z /*[N][128]*/, sh_stream_t stream);
+int simhand_proj_postprocess_bwd(const float* P, int N, const int64_t* jitter_x, const int64_t* jitter_y,
+                                 const double* angle, int img_h, int img_w, const float* dZ, float* dP, sh_stream_t stream);
+/* out[8] = batch means of per-row {x_mean,x_median,x_min,x_max,y_mean,y_median,y_min,y_max}; row_ws [N][8] */
+int simhand_proj_stats(const float* P, int N, float* row_ws, float* out, sh_stream_t stream);
+
+/* ===========================================================================
+ * Backbone operators (replace torchvision resnet -> torch.nn.Conv2d /
+ * BatchNorm2d / ReLU / MaxPool2d / AdaptiveAvgPool2d / Linear dispatched to
+ * cuDNN/cuBLAS/ATen; call sites src/models/resnet_model.py:13-58,
+ * src/models/unsupervised/simclr_model.py:22-39)
+ * =========================================================================== */
+typedef struct sh_conv_desc {
+  int n, h, w, cin;      /* input NHWC */
+  int cout, r, s;        /* filter KRSC */
+  int stride, pad;
+  int ho, wo;            /* output spatial */
+  int dtype;             /* sh_dtype of activations and weights */
+} sh_conv_desc;
+
+/* y = conv(x, w).  If bn_partial != NULL the epilogue also writes per-row-block
+ * partial (sum, sum of squares) of the fp32 accumulators per output channel:
+ * bn_partial [nblk_m][2][cout] fp32 with nblk_m = simhand_conv2d_fwd_stat_blocks(). */
+int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d);
+int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void* y, float* bn_partial, sh_stream_t stream);
+/* dx = conv_transpose(dy, w).  wt = weights permuted to [Cin][R][S][Cout] (simhand_permute_krsc_to_crsk).
+ * accumulate != 0: dx += result (residual branch merge). */
+int simhand_conv2d_dgrad(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, sh_stream_t stream);
+/* dw (fp32, KRSC) = sum over output pixels of dy (x) patches(x); deterministic two-stage split-K */
+size_t simhand_conv2d_wgrad_workspace_bytes(const sh_conv_desc* d);
+int simhand_conv2d_wgrad(const sh_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, sh_stream_t stream);
+
+/* test hook: bf16 wgrad LDS transpose path (1 = ds_read_b64_tr_b16 [default], 0 = scalar LDS reads) */
+int simhand_wgrad_set_tr(int on);
+
+/* layout / dtype transforms.  k_pad = padded length of one flattened KRSC weight row
+ * (>= r*s*c; rows are zero padded) -- r*s*c for ordinary convs, 192 for the im2col'd stem. */
+int simhand_nchw_f32_to_nhwc(const float* src, void* dst, int n, int c, int h, int w, int c_pad, int dtype, sh_stream_t stream);
+int simhand_oihw_f32_to_krsc(const float* src, void* dst, int k, int c, int r, int s, int k_pad, int dtype, sh_stream_t stream);
+int simhand_oihw_f32_to_crsk(const float* src, void* dst, int k, int c, int r, int s, int dtype, sh_stream_t stream);
+int simhand_krsc_f32_to_oihw(const float* src, float* dst, int k, int c, int r, int s, int k_pad, sh_stream_t stream);
+int simhand_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t count, sh_stream_t stream);
+/* stem lowering: NCHW fp32 images -> [n*ho*wo][k_pad] patch matrix, column (r*S+s)*cin+c, zero padded.
+ * The 7x7/2 stem then runs as a 1x1 conv with cin = k_pad through conv2d_fwd / conv2d_wgrad. */
+int simhand_im2col_nchw_f32(const float* x, void* col, int n, int cin, int h, int w, int r, int s, int stride, int pad,
+                            int k_pad, int dtype, sh_stream_t stream);
+
+/* train-mode BatchNorm over [M][C] (M = N*H*W), eps 1e-5, momentum 0.1 (torch defaults).
+ * Level-1 partial sums [nblk][2][C] fp32 come either from the conv epilogue (nblk =
+ * simhand_conv2d_fwd_stat_blocks) or from simhand_bn_partial_stats (nblk = simhand_bn_stat_blocks). */
+int simhand_bn_stat_blocks(int64_t m, int c);
+int simhand_bn_partial_stats(const void* y, int64_t m, int c, int dtype, float* partial, sh_stream_t stream);
+/* partials -> mean / invstd, scale = gamma*invstd, shift = beta - mean*scale; updates running_mean /
+ * running_var (unbiased, momentum) and num_batches_tracked like torch.  pre_bias (or NULL): bias of a
+ * Linear feeding this BN -- it only shifts the batch mean that goes into running_mean. */
+size_t simhand_bn_finalize_workspace_bytes(int nblk, int c);
+int simhand_bn_finalize(const float* partial, int nblk, int64_t m, int c, const float* gamma, const float* beta,
+                        const float* pre_bias, float eps, float momentum, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                        void* workspace, size_t workspace_bytes, sh_stream_t stream);
+/* a = act(y*scale + shift (+ residual)), act = relu if relu != 0 */
+int simhand_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, int relu,
+                     void* a, int64_t m, int c, int dtype, sh_stream_t stream);
+/* backward: g = da * (a > 0 if relu); partial [simhand_bn_stat_blocks][2][C] sums of g and g*xhat;
+ * finalize -> dbeta, dgamma; apply: dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), dres (optional) = g */
+int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const float* mean, const float* invstd, int relu,
+                           int64_t m, int c, int dtype, float* partial, sh_stream_t stream);
+int simhand_bn_bwd_finalize(const float* partial, int nblk, int c, float* dgamma, float* dbeta, sh_stream_t stream);
+int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const float* mean, const float* invstd,
+                         const float* gamma, const float* dgamma, const float* dbeta, int relu,
+                         void* dy, void* dres, int64_t m, int c, int dtype, sh_stream_t stream);
+
+/* pooling (NHWC): MaxPool2d(3, stride 2, pad 1) (idx = winning tap 0..8 per output element, uint8)
+ * and AdaptiveAvgPool2d(1) */
+int simhand_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int n, int h, int w, int c, int dtype, sh_stream_t stream);
+int simhand_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int n, int h, int w, int c, int dtype, sh_stream_t stream);
+int simhand_avgpool_fwd(const void* x, void* y, int n, int hw, int c, int dtype, sh_stream_t stream);
+int simhand_avgpool_bwd(const void* dy, void* dx, int n, int hw, int c, int dtype, sh_stream_t stream);
+
+/* column sums of [M][C] (Linear bias gradient); partial: (2*simhand_bn_stat_blocks(m,c) + 1) * c floats */
+int simhand_colsum(const void* x, int64_t m, int c, int dtype, float* partial, float* out, sh_stream_t stream);
+
+/* ===========================================================================
+ * Optimizer ("next" row 8f-1): LARSWrapper(Adam) step, pl_bolts 0.2.2 semantics
+ * (call site src/models/base_model.py:59-106) -- PARITY UNPINNED, restated from
+ * the published source.  One launch per parameter tensor group element.
+ * =========================================================================== */
+int simhand_sumsq_partial(const float* x, int64_t count, float* partial, int nblk, sh_stream_t stream);
+int simhand_lars_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                           const float* p_sumsq, const float* g_sumsq, int nblk_norm,
+                           float lr, float beta1, float beta2, float adam_eps, float weight_decay,
+                           float lars_eta, float lars_eps, int lars_clip, int use_lars, int step, sh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMHAND_HIP_H */

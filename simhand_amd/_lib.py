@@ -1,0 +1,138 @@
+"""ctypes binding of ``libsimhand_hip.so`` (the C ABI declared in
+``include/simhand_hip.h``).
+
+There is NO CPU fallback: if the shared library is missing, or a compute entry
+point is called without a gfx950 device, this module raises.  torch is used by
+the callers only as the owner of device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsimhand_hip.so")
+
+# enums of include/simhand_hip.h
+SH_F32, SH_BF16 = 0, 1
+DIST_MODES = {"mpjpe": 0, "w_abs": 1, "w_o_abs": 2, "l2": 3}
+WEIGHT_TYPES = {None: 0, "none": 0, "linear": 1, "non_linear": 2}
+PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn", "pool", "loss", "misc")
+
+
+class SimhandHipError(RuntimeError):
+    pass
+
+
+class NtxentParams(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("dim", C.c_int), ("b_loc", C.c_int), ("pair_off", C.c_int),
+        ("weight_type", C.c_int), ("use_wpos", C.c_int), ("use_wneg", C.c_int),
+        ("temperature", C.c_float), ("lambda_pos", C.c_float), ("lambda_neg", C.c_float),
+    ]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("cin", C.c_int),
+        ("cout", C.c_int), ("r", C.c_int), ("s", C.c_int),
+        ("stride", C.c_int), ("pad", C.c_int), ("ho", C.c_int), ("wo", C.c_int), ("dtype", C.c_int),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+_S = C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/simhand_hip.h declares
+SIGNATURES = {
+    "simhand_abi_version": (_I, []),
+    "simhand_last_error": (C.c_char_p, []),
+    "simhand_device_check": (_I, []),
+    "simhand_prof_enable": (_I, [_I]),
+    "simhand_prof_collect": (_I, [_P, _P, _P, _P]),
+    "simhand_prof_reset": (_I, []),
+    "simhand_pos_dist": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "simhand_neg_dist_workspace_bytes": (_S, [_I, _I]),
+    "simhand_neg_dist": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _S, _P]),
+    "simhand_ntxent_workspace_bytes": (_S, [C.POINTER(NtxentParams)]),
+    "simhand_ntxent_fwd": (_I, [C.POINTER(NtxentParams), _P, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "simhand_ntxent_bwd": (_I, [C.POINTER(NtxentParams), _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "simhand_proj_postprocess_fwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P]),
+    "simhand_proj_postprocess_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "simhand_proj_stats": (_I, [_P, _I, _P, _P, _P]),
+    "simhand_conv2d_fwd_stat_blocks": (_I, [C.POINTER(ConvDesc)]),
+    "simhand_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "simhand_conv2d_dgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),
+    "simhand_conv2d_wgrad_workspace_bytes": (_S, [C.POINTER(ConvDesc)]),
+    "simhand_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _S, _P]),
+    "simhand_wgrad_set_tr": (_I, [_I]),
+    "simhand_nchw_f32_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "simhand_oihw_f32_to_krsc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "simhand_oihw_f32_to_crsk": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "simhand_krsc_f32_to_oihw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "simhand_cast": (_I, [_P, _I, _P, _I, _L, _P]),
+    "simhand_im2col_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "simhand_bn_stat_blocks": (_I, [_L, _I]),
+    "simhand_bn_partial_stats": (_I, [_P, _L, _I, _I, _P, _P]),
+    "simhand_bn_finalize_workspace_bytes": (_S, [_I, _I]),
+    "simhand_bn_finalize": (_I, [_P, _I, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "simhand_bn_apply": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P]),
+    "simhand_bn_bwd_partial": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P]),
+    "simhand_bn_bwd_finalize": (_I, [_P, _I, _I, _P, _P, _P]),
+    "simhand_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P]),
+    "simhand_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "simhand_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "simhand_avgpool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "simhand_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "simhand_colsum": (_I, [_P, _L, _I, _I, _P, _P, _P]),
+    "simhand_sumsq_partial": (_I, [_P, _L, _P, _I, _P]),
+    "simhand_lars_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Load the in-tree shared library (built by ``__graft_entry__.build()`` /
+    ``make -C simhand_amd/csrc``).  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise SimhandHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the SiMHand hot path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI and this table disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().simhand_last_error()
+        raise SimhandHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else 'unknown error'}")
+
+
+_device_ok = False
+
+
+def require_device() -> None:
+    """Fail loudly unless a gfx950 GPU is usable (no CPU path exists)."""
+    global _device_ok
+    if _device_ok:
+        return
+    lib = load()
+    check(lib.simhand_device_check(), "simhand_device_check")
+    _device_ok = True

@@ -1,0 +1,394 @@
+// Train-mode BatchNorm (2d over [N*H*W][C] NHWC, 1d over [N][C]) + ReLU + residual add,
+// forward and backward.  HBM-bound streaming kernels: 16-B vector accesses, fp32 math,
+// deterministic two-stage channel reductions (no float atomics).
+//
+// Replaces (reference): torch.nn.BatchNorm2d / BatchNorm1d (training statistics, eps 1e-5,
+// momentum 0.1), ReLU and the residual add inside torchvision's BasicBlock / Bottleneck
+// (src/models/resnet_model.py:13-58) and the projection head's BatchNorm1d + ReLU
+// (src/models/unsupervised/simclr_model.py:30-31), plus their autograd backward.
+#include "common.h"
+
+namespace sh {
+
+constexpr int kChunk = 256;  // level-1 partial blocks folded per level-2 block
+
+// rows-per-block plan shared by the column-reduction kernels
+static inline void col_plan(int64_t m, int* rows_per_blk, int* nblk) {
+  int64_t rpb = (m + 2047) / 2048;
+  if (rpb < 64) rpb = 64;
+  rpb = (rpb + 15) / 16 * 16;
+  *rows_per_blk = (int)rpb;
+  *nblk = (int)((m + rpb - 1) / rpb);
+}
+
+// ---- generic column reduction skeleton --------------------------------------------------
+// F(row, cvec, out s1[VE], s2[VE]) accumulates VE channels of one row.
+template <typename T, typename F>
+__device__ __forceinline__ void column_reduce(int64_t m, int c, int rows_per_blk, float* partial, F body) {
+  constexpr int VE = Vec16<T>::N;
+  __shared__ float red[2][256][VE];
+  const int cvecs = c / VE;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+  int64_t r1 = r0 + rows_per_blk;
+  if (r1 > m) r1 = m;
+  // thread layout: lanes along channel vectors first (coalesced), remaining threads along rows
+  const int span = cvecs < 256 ? cvecs : 256;   // channel vectors handled concurrently
+  const int rowlanes = 256 / span;              // >= 1
+  const int cv_l = threadIdx.x % span, rl = threadIdx.x / span;
+  for (int cv0 = 0; cv0 < cvecs; cv0 += span) {
+    const int cv = cv0 + cv_l;
+    float s1[VE], s2[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s1[e] = s2[e] = 0.f;
+    if (cv < cvecs && rl < rowlanes)
+      for (int64_t r = r0 + rl; r < r1; r += rowlanes) body(r, cv, s1, s2);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      red[0][threadIdx.x][e] = s1[e];
+      red[1][threadIdx.x][e] = s2[e];
+    }
+    __syncthreads();
+    if (rl == 0 && cv < cvecs) {
+      for (int j = 1; j < rowlanes; ++j)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          s1[e] += red[0][j * span + cv_l][e];
+          s2[e] += red[1][j * span + cv_l][e];
+        }
+      float* o1 = partial + ((int64_t)blockIdx.x * 2 + 0) * c + cv * VE;
+      float* o2 = partial + ((int64_t)blockIdx.x * 2 + 1) * c + cv * VE;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        o1[e] = s1[e];
+        o2[e] = s2[e];
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_partial_stats_kernel(const T* __restrict__ y, int64_t m, int c, int rows_per_blk,
+                                                               float* __restrict__ partial) {
+  constexpr int VE = Vec16<T>::N;
+  column_reduce<T>(m, c, rows_per_blk, partial, [&](int64_t r, int cv, float(&s1)[VE], float(&s2)[VE]) {
+    float v[VE];
+    Vec16<T>::load(y + r * c + cv * VE, v);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      s1[e] += v[e];
+      s2[e] += v[e] * v[e];
+    }
+  });
+}
+
+// level-1 partial [nblk][2][c] float -> level-2 [nchunk][2][c] double
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partial, int nblk, int c,
+                                                            double* __restrict__ lvl2) {
+  __shared__ double red[4][2][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int ch = blockIdx.y * 64 + cl;
+  const int b0 = blockIdx.x * kChunk;
+  int b1 = b0 + kChunk;
+  if (b1 > nblk) b1 = nblk;
+  double s1 = 0.0, s2 = 0.0;
+  if (ch < c)
+    for (int b = b0 + rl; b < b1; b += 4) {
+      s1 += (double)partial[((int64_t)b * 2 + 0) * c + ch];
+      s2 += (double)partial[((int64_t)b * 2 + 1) * c + ch];
+    }
+  red[rl][0][cl] = s1;
+  red[rl][1][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && ch < c) {
+    for (int j = 1; j < 4; ++j) {
+      s1 += red[j][0][cl];
+      s2 += red[j][1][cl];
+    }
+    lvl2[((int64_t)blockIdx.x * 2 + 0) * c + ch] = s1;
+    lvl2[((int64_t)blockIdx.x * 2 + 1) * c + ch] = s2;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ lvl2, int nchunk, int64_t m, int c,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ pre_bias, float eps, float momentum,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          int64_t* __restrict__ nbt, float* __restrict__ mean_o,
+                                                          float* __restrict__ invstd_o, float* __restrict__ scale_o,
+                                                          float* __restrict__ shift_o) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch == 0 && nbt) nbt[0] += 1;
+  if (ch >= c) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nchunk; ++b) {
+    s1 += lvl2[((int64_t)b * 2 + 0) * c + ch];
+    s2 += lvl2[((int64_t)b * 2 + 1) * c + ch];
+  }
+  const double mean = s1 / (double)m;
+  double var = s2 / (double)m - mean * mean;  // biased (normalisation) variance
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[ch] : 1.0f, b = beta ? beta[ch] : 0.0f;
+  const float sc = g * invstd;
+  mean_o[ch] = (float)mean;
+  invstd_o[ch] = invstd;
+  scale_o[ch] = sc;
+  shift_o[ch] = b - (float)mean * sc;
+  if (running_mean) {
+    const double mfull = mean + (pre_bias ? (double)pre_bias[ch] : 0.0);  // Linear bias shifts only the mean
+    const double unbiased = m > 1 ? var * (double)m / (double)(m - 1) : var;
+    running_mean[ch] = (1.0f - momentum) * running_mean[ch] + momentum * (float)mfull;
+    running_var[ch] = (1.0f - momentum) * running_var[ch] + momentum * (float)unbiased;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const T* __restrict__ res, int relu,
+                                                       T* __restrict__ a, int64_t nvec, int cvecs) {
+  constexpr int VE = Vec16<T>::N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cvecs);
+    float v[VE], o[VE];
+    Vec16<T>::load(y + i * VE, v);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) o[e] = v[e] * scale[cv * VE + e] + shift[cv * VE + e];
+    if (res) {
+      float r[VE];
+      Vec16<T>::load(res + i * VE, r);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) o[e] += r[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+    }
+    Vec16<T>::store(a + i * VE, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ da, const T* __restrict__ a,
+                                                             const T* __restrict__ y, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int relu, int64_t m, int c,
+                                                             int rows_per_blk, float* __restrict__ partial) {
+  constexpr int VE = Vec16<T>::N;
+  column_reduce<T>(m, c, rows_per_blk, partial, [&](int64_t r, int cv, float(&s1)[VE], float(&s2)[VE]) {
+    float g[VE], yy[VE];
+    Vec16<T>::load(da + r * c + cv * VE, g);
+    Vec16<T>::load(y + r * c + cv * VE, yy);
+    if (relu) {
+      float aa[VE];
+      Vec16<T>::load(a + r * c + cv * VE, aa);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) g[e] = aa[e] > 0.f ? g[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const float xh = (yy[e] - mean[cv * VE + e]) * invstd[cv * VE + e];
+      s1[e] += g[e];
+      s2[e] += g[e] * xh;
+    }
+  });
+}
+
+// dbeta = sum g, dgamma = sum g*xhat  (one thread per channel over <= ~2048 partial blocks, 16 row lanes)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int c,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double red[16][2][16];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (ch < c)
+    for (int b = rl; b < nblk; b += 16) {
+      s1 += (double)partial[((int64_t)b * 2 + 0) * c + ch];
+      s2 += (double)partial[((int64_t)b * 2 + 1) * c + ch];
+    }
+  red[rl][0][cl] = s1;
+  red[rl][1][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && ch < c) {
+    for (int j = 1; j < 16; ++j) {
+      s1 += red[j][0][cl];
+      s2 += red[j][1][cl];
+    }
+    dbeta[ch] = (float)s1;
+    dgamma[ch] = (float)s2;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ da, const T* __restrict__ a,
+                                                           const T* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                           int relu, T* __restrict__ dy, T* __restrict__ dres, int64_t nvec,
+                                                           int cvecs, float inv_m) {
+  constexpr int VE = Vec16<T>::N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cvecs);
+    float g[VE], yy[VE], o[VE];
+    Vec16<T>::load(da + i * VE, g);
+    Vec16<T>::load(y + i * VE, yy);
+    if (relu) {
+      float aa[VE];
+      Vec16<T>::load(a + i * VE, aa);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) g[e] = aa[e] > 0.f ? g[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int ch = cv * VE + e;
+      const float is = invstd[ch];
+      const float xh = (yy[e] - mean[ch]) * is;
+      const float gm = gamma ? gamma[ch] : 1.0f;
+      o[e] = gm * is * (g[e] - dbeta[ch] * inv_m - xh * dgamma[ch] * inv_m);
+    }
+    Vec16<T>::store(dy + i * VE, o);
+    if (dres) Vec16<T>::store(dres + i * VE, g);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t m, int c, int rows_per_blk,
+                                                     float* __restrict__ partial) {
+  constexpr int VE = Vec16<T>::N;
+  column_reduce<T>(m, c, rows_per_blk, partial, [&](int64_t r, int cv, float(&s1)[VE], float(&s2)[VE]) {
+    float v[VE];
+    Vec16<T>::load(x + r * c + cv * VE, v);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s1[e] += v[e];
+  });
+}
+
+static inline int stream_grid(int64_t nvec) {
+  int64_t g = (nvec + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace sh
+
+using namespace sh;
+
+extern "C" {
+
+int simhand_bn_stat_blocks(int64_t m, int c) {
+  (void)c;
+  int rpb, nblk;
+  col_plan(m, &rpb, &nblk);
+  return nblk;
+}
+
+int simhand_bn_partial_stats(const void* y, int64_t m, int c, int dtype, float* partial, sh_stream_t stream) {
+  SH_REQUIRE(y && partial, "bn_partial_stats: NULL pointer");
+  SH_REQUIRE(m >= 1 && c >= 1, "bn_partial_stats: bad shape");
+  SH_REQUIRE(c % (dtype == SH_F32 ? 4 : 8) == 0, "bn_partial_stats: c=%d not a multiple of the 16-B vector", c);
+  int rpb, nblk;
+  col_plan(m, &rpb, &nblk);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2));
+  if (dtype == SH_F32) bn_partial_stats_kernel<float><<<nblk, 256, 0, s>>>((const float*)y, m, c, rpb, partial);
+  else bn_partial_stats_kernel<bf16_t><<<nblk, 256, 0, s>>>((const bf16_t*)y, m, c, rpb, partial);
+  return check_launch("bn_partial_stats");
+}
+
+size_t simhand_bn_finalize_workspace_bytes(int nblk, int c) {
+  return (size_t)ceil_div(nblk, kChunk) * 2 * c * sizeof(double);
+}
+
+int simhand_bn_finalize(const float* partial, int nblk, int64_t m, int c, const float* gamma, const float* beta,
+                        const float* pre_bias, float eps, float momentum, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                        void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+  SH_REQUIRE(partial && mean && invstd && scale && shift && workspace, "bn_finalize: NULL pointer");
+  SH_REQUIRE(nblk >= 1 && m >= 1 && c >= 1, "bn_finalize: bad shape");
+  SH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must be given together");
+  SH_REQUIRE(workspace_bytes >= simhand_bn_finalize_workspace_bytes(nblk, c), "bn_finalize: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunk = ceil_div(nblk, kChunk);
+  ProfScope ps(SH_PROF_BN, s, 0, (double)nblk * 2 * c * 4);
+  fold_partials_kernel<<<dim3(nchunk, ceil_div(c, 64)), 256, 0, s>>>(partial, nblk, c, (double*)workspace);
+  if (check_launch("bn fold_partials")) return 1;
+  bn_finalize_kernel<<<ceil_div(c, 256), 256, 0, s>>>((const double*)workspace, nchunk, m, c, gamma, beta, pre_bias, eps, momentum,
+                                                       running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift);
+  return check_launch("bn_finalize");
+}
+
+int simhand_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, int relu, void* a, int64_t m,
+                     int c, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(y && scale && shift && a, "bn_apply: NULL pointer");
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  SH_REQUIRE(c % ve == 0, "bn_apply: c=%d not a multiple of %d", c, ve);
+  const int64_t nvec = m * c / ve;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (residual ? 3 : 2));
+  if (dtype == SH_F32)
+    bn_apply_kernel<float><<<stream_grid(nvec), 256, 0, s>>>((const float*)y, scale, shift, (const float*)residual, relu, (float*)a, nvec, c / ve);
+  else
+    bn_apply_kernel<bf16_t><<<stream_grid(nvec), 256, 0, s>>>((const bf16_t*)y, scale, shift, (const bf16_t*)residual, relu, (bf16_t*)a, nvec, c / ve);
+  return check_launch("bn_apply");
+}
+
+int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const float* mean, const float* invstd, int relu,
+                           int64_t m, int c, int dtype, float* partial, sh_stream_t stream) {
+  SH_REQUIRE(da && y && mean && invstd && partial, "bn_bwd_partial: NULL pointer");
+  SH_REQUIRE(!relu || a, "bn_bwd_partial: relu mask needs the activation output");
+  SH_REQUIRE(c % (dtype == SH_F32 ? 4 : 8) == 0, "bn_bwd_partial: c=%d not a multiple of the 16-B vector", c);
+  int rpb, nblk;
+  col_plan(m, &rpb, &nblk);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (relu ? 3 : 2));
+  if (dtype == SH_F32)
+    bn_bwd_partial_kernel<float><<<nblk, 256, 0, s>>>((const float*)da, (const float*)a, (const float*)y, mean, invstd, relu, m, c, rpb, partial);
+  else
+    bn_bwd_partial_kernel<bf16_t><<<nblk, 256, 0, s>>>((const bf16_t*)da, (const bf16_t*)a, (const bf16_t*)y, mean, invstd, relu, m, c, rpb, partial);
+  return check_launch("bn_bwd_partial");
+}
+
+int simhand_bn_bwd_finalize(const float* partial, int nblk, int c, float* dgamma, float* dbeta, sh_stream_t stream) {
+  SH_REQUIRE(partial && dgamma && dbeta, "bn_bwd_finalize: NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_BN, s, 0, (double)nblk * 2 * c * 4);
+  bn_bwd_finalize_kernel<<<ceil_div(c, 16), 256, 0, s>>>(partial, nblk, c, dgamma, dbeta);
+  return check_launch("bn_bwd_finalize");
+}
+
+int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const float* mean, const float* invstd, const float* gamma,
+                         const float* dgamma, const float* dbeta, int relu, void* dy, void* dres, int64_t m, int c, int dtype,
+                         sh_stream_t stream) {
+  SH_REQUIRE(da && y && mean && invstd && dgamma && dbeta && dy, "bn_bwd_apply: NULL pointer");
+  SH_REQUIRE(!relu || a, "bn_bwd_apply: relu mask needs the activation output");
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  SH_REQUIRE(c % ve == 0, "bn_bwd_apply: c=%d not a multiple of %d", c, ve);
+  const int64_t nvec = m * c / ve;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (3 + (relu ? 1 : 0) + (dres ? 1 : 0)));
+  const float inv_m = (float)(1.0 / (double)m);
+  if (dtype == SH_F32)
+    bn_bwd_apply_kernel<float><<<stream_grid(nvec), 256, 0, s>>>((const float*)da, (const float*)a, (const float*)y, mean, invstd, gamma, dgamma, dbeta,
+                                                               relu, (float*)dy, (float*)dres, nvec, c / ve, inv_m);
+  else
+    bn_bwd_apply_kernel<bf16_t><<<stream_grid(nvec), 256, 0, s>>>((const bf16_t*)da, (const bf16_t*)a, (const bf16_t*)y, mean, invstd, gamma, dgamma,
+                                                                dbeta, relu, (bf16_t*)dy, (bf16_t*)dres, nvec, c / ve, inv_m);
+  return check_launch("bn_bwd_apply");
+}
+
+int simhand_colsum(const void* x, int64_t m, int c, int dtype, float* partial, float* out, sh_stream_t stream) {
+  SH_REQUIRE(x && partial && out, "colsum: NULL pointer");
+  SH_REQUIRE(c % (dtype == SH_F32 ? 4 : 8) == 0, "colsum: c=%d not a multiple of the 16-B vector", c);
+  int rpb, nblk;
+  col_plan(m, &rpb, &nblk);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_MISC, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2));
+  if (dtype == SH_F32) colsum_kernel<float><<<nblk, 256, 0, s>>>((const float*)x, m, c, rpb, partial);
+  else colsum_kernel<bf16_t><<<nblk, 256, 0, s>>>((const bf16_t*)x, m, c, rpb, partial);
+  if (check_launch("colsum")) return 1;
+  // reuse the bwd finalize reducer: "dbeta" slot = sum of s1, "dgamma" slot (s2 = 0) goes to scratch inside partial
+  bn_bwd_finalize_kernel<<<ceil_div(c, 16), 256, 0, s>>>(partial, nblk, c, partial + (int64_t)nblk * 2 * c, out);
+  return check_launch("colsum finalize");
+}
+
+}  // extern "C"

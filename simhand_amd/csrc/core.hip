@@ -1,0 +1,135 @@
+// Error plumbing, device check and the per-kernel-class HIP-event profiler.
+#include <stdarg.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace sh {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return 1;
+  }
+  return 0;
+}
+
+// ---- profiler: one event pair per launch, recorded on the launch stream ----
+struct ProfRec {
+  hipEvent_t a, b;
+  int cls;
+  double flops, bytes;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
+
+ProfScope::ProfScope(int c, hipStream_t s, double flops, double bytes) : cls(c), stream(s), on(false), slot(-1) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r;
+  if (!g_pool.empty()) {
+    r.a = g_pool.back().first;
+    r.b = g_pool.back().second;
+    g_pool.pop_back();
+  } else {
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  }
+  r.cls = c;
+  r.flops = flops;
+  r.bytes = bytes;
+  hipEventRecord(r.a, s);
+  g_recs.push_back(r);
+  slot = (int)g_recs.size() - 1;
+  on = true;
+}
+
+ProfScope::~ProfScope() {
+  if (!on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  hipEventRecord(g_recs[slot].b, stream);
+}
+
+}  // namespace sh
+
+extern "C" {
+
+int simhand_abi_version(void) { return 1; }
+
+const char* simhand_last_error(void) { return sh::g_err; }
+
+int simhand_device_check(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    sh::set_error("no HIP device visible");
+    return 1;
+  }
+  int dev = 0;
+  hipGetDevice(&dev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    sh::set_error("hipGetDeviceProperties failed");
+    return 1;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    sh::set_error("device is %s; this library is built for gfx950 only", prop.gcnArchName);
+    return 2;
+  }
+  return 0;
+}
+
+int simhand_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(sh::g_prof_mu);
+  sh::g_prof_on = on != 0;
+  return 0;
+}
+
+int simhand_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(sh::g_prof_mu);
+  for (auto& r : sh::g_recs) {
+    hipEventSynchronize(r.b);
+    sh::g_pool.push_back({r.a, r.b});
+  }
+  sh::g_recs.clear();
+  return 0;
+}
+
+int simhand_prof_collect(double* out_ms, double* out_flops, double* out_bytes, int64_t* out_count) {
+  std::lock_guard<std::mutex> lk(sh::g_prof_mu);
+  for (int i = 0; i < SH_PROF_NCLASS; ++i) {
+    out_ms[i] = 0;
+    out_flops[i] = 0;
+    out_bytes[i] = 0;
+    out_count[i] = 0;
+  }
+  for (auto& r : sh::g_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) {
+      sh::set_error("hipEventSynchronize failed in prof_collect");
+      return 1;
+    }
+    float ms = 0;
+    hipEventElapsedTime(&ms, r.a, r.b);
+    out_ms[r.cls] += ms;
+    out_flops[r.cls] += r.flops;
+    out_bytes[r.cls] += r.bytes;
+    out_count[r.cls] += 1;
+    sh::g_pool.push_back({r.a, r.b});
+  }
+  sh::g_recs.clear();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,385 @@
+// Pooling, layout / dtype transforms and the stem im2col.  All HBM-bound streaming kernels
+// with 16-B vector accesses on the NHWC side.
+//
+// Replaces (reference): nn.MaxPool2d(3, 2, 1) and nn.AdaptiveAvgPool2d(1) of torchvision's
+// ResNet (src/models/resnet_model.py:17-26), `z.flatten(start_dim=1)` (:53), and the implicit
+// NCHW / OIHW tensor layouts of torch.nn.Conv2d (the 7x7 stride-2 stem is lowered to
+// im2col + GEMM because its 3 input channels cannot feed a k-contiguous MFMA operand).
+#include "common.h"
+
+namespace sh {
+
+static inline int stream_grid(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---- MaxPool 3x3 s2 p1: forward stores the winning tap (0..8) per element ------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
+                                                          int n, int h, int w, int c, int ho, int wo) {
+  constexpr int VE = Vec16<T>::N;
+  const int cvecs = c / VE;
+  const int64_t total = (int64_t)n * ho * wo * cvecs;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cvecs);
+    int64_t t = i / cvecs;
+    const int ow = (int)(t % wo);
+    t /= wo;
+    const int oh = (int)(t % ho);
+    const int img = (int)(t / ho);
+    float best[VE];
+    int bi[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      best[e] = -INFINITY;
+      bi[e] = 0;
+    }
+    // scan order kh then kw, strict '>' (first maximum wins) like ATen's max_pool2d
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh * 2 - 1 + kh;
+      if ((unsigned)ih >= (unsigned)h) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow * 2 - 1 + kw;
+        if ((unsigned)iw >= (unsigned)w) continue;
+        float v[VE];
+        Vec16<T>::load(x + (((int64_t)img * h + ih) * w + iw) * c + cv * VE, v);
+#pragma unroll
+        for (int e = 0; e < VE; ++e)
+          if (v[e] > best[e] || v[e] != v[e]) {
+            best[e] = v[e];
+            bi[e] = kh * 3 + kw;
+          }
+      }
+    }
+    Vec16<T>::store(y + i * VE, best);
+    uint8_t* ip = idx + i * VE;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) ip[e] = (uint8_t)bi[e];
+  }
+}
+
+// gather form: every input element sums dy of the (<= 4) windows whose stored winner is itself
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                          T* __restrict__ dx, int n, int h, int w, int c, int ho, int wo) {
+  constexpr int VE = Vec16<T>::N;
+  const int cvecs = c / VE;
+  const int64_t total = (int64_t)n * h * w * cvecs;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cvecs);
+    int64_t t = i / cvecs;
+    const int iw = (int)(t % w);
+    t /= w;
+    const int ih = (int)(t % h);
+    const int img = (int)(t / h);
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    // windows oh with oh*2-1+kh == ih  ->  kh = ih + 1 - 2*oh in [0,2]
+    for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {
+      const int kh = ih + 1 - 2 * oh;
+      if (kh < 0 || kh > 2 || oh >= ho) continue;
+      for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
+        const int kw = iw + 1 - 2 * ow;
+        if (kw < 0 || kw > 2 || ow >= wo) continue;
+        const int64_t o = ((((int64_t)img * ho + oh) * wo + ow) * cvecs + cv) * VE;
+        float g[VE];
+        Vec16<T>::load(dy + o, g);
+        const uint8_t* ip = idx + o;
+        const int me = kh * 3 + kw;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] += ip[e] == me ? g[e] : 0.f;
+      }
+    }
+    Vec16<T>::store(dx + i * VE, acc);
+  }
+}
+
+// ---- global average pool ---------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int hw, int c) {
+  constexpr int VE = Vec16<T>::N;
+  const int cvecs = c / VE;
+  const int64_t total = (int64_t)n * cvecs;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cvecs);
+    const int img = (int)(i / cvecs);
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    for (int p = 0; p < hw; ++p) {
+      float v[VE];
+      Vec16<T>::load(x + ((int64_t)img * hw + p) * c + cv * VE, v);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) acc[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] /= (float)hw;
+    Vec16<T>::store(y + i * VE, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int n, int hw, int c) {
+  constexpr int VE = Vec16<T>::N;
+  const int cvecs = c / VE;
+  const int64_t total = (int64_t)n * hw * cvecs;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cvecs);
+    const int img = (int)(i / ((int64_t)hw * cvecs));
+    float g[VE];
+    Vec16<T>::load(dy + ((int64_t)img * cvecs + cv) * VE, g);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) g[e] /= (float)hw;
+    Vec16<T>::store(dx + i * VE, g);
+  }
+}
+
+// ---- im2col for small-cin convolutions (the stem): NCHW fp32 image -> [N*Ho*Wo][k_pad] ----------
+// column k = (r*S + s)*Cin + c (KRSC flattening), zero-filled for k >= R*S*Cin and for the halo
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restrict__ x, T* __restrict__ col, int n, int cin, int h,
+                                                          int w, int R, int S, int stride, int pad, int ho, int wo, int k_pad) {
+  constexpr int VE = Vec16<T>::N;
+  const int kvecs = k_pad / VE;
+  const int kreal = R * S * cin;
+  const int64_t total = (int64_t)n * ho * wo * kvecs;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int kv = (int)(i % kvecs);
+    int64_t t = i / kvecs;
+    const int ow = (int)(t % wo);
+    t /= wo;
+    const int oh = (int)(t % ho);
+    const int img = (int)(t / ho);
+    float v[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int k = kv * VE + e;
+      float val = 0.f;
+      if (k < kreal) {
+        const int c = k % cin;
+        const int rs = k / cin;
+        const int s = rs % S, r = rs / S;
+        const int ih = oh * stride - pad + r, iw = ow * stride - pad + s;
+        if ((unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w) val = x[(((int64_t)img * cin + c) * h + ih) * w + iw];
+      }
+      v[e] = val;
+    }
+    Vec16<T>::store(col + i * VE, v);
+  }
+}
+
+// ---- weights: OIHW fp32 -> [K][k_pad] (KRSC rows, zero padded) / [C][R][S][K] ; and back ---------------
+template <typename T>
+__global__ __launch_bounds__(256) void oihw_to_krsc_kernel(const float* __restrict__ src, T* __restrict__ dst, int k, int c, int r,
+                                                           int s, int k_pad) {
+  const int64_t total = (int64_t)k * k_pad;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int col = (int)(i % k_pad);
+    const int ko = (int)(i / k_pad);
+    float v = 0.f;
+    if (col < r * s * c) {
+      const int ci = col % c;
+      const int rs = col / c;
+      v = src[(((int64_t)ko * c + ci) * r + rs / s) * s + rs % s];
+    }
+    Elem<T>::store(dst + i, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void oihw_to_crsk_kernel(const float* __restrict__ src, T* __restrict__ dst, int k, int c, int r,
+                                                           int s) {
+  const int64_t total = (int64_t)k * c * r * s;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // dst index = ((ci*R + rr)*S + ss)*K + ko
+    const int ko = (int)(i % k);
+    int64_t t = i / k;
+    const int ss = (int)(t % s);
+    t /= s;
+    const int rr = (int)(t % r);
+    const int ci = (int)(t / r);
+    Elem<T>::store(dst + i, src[(((int64_t)ko * c + ci) * r + rr) * s + ss]);
+  }
+}
+
+__global__ __launch_bounds__(256) void krsc_to_oihw_kernel(const float* __restrict__ src, float* __restrict__ dst, int k, int c,
+                                                           int r, int s, int k_pad) {
+  const int64_t total = (int64_t)k * c * r * s;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // dst index = ((ko*C + ci)*R + rr)*S + ss
+    const int ss = (int)(i % s);
+    int64_t t = i / s;
+    const int rr = (int)(t % r);
+    t /= r;
+    const int ci = (int)(t % c);
+    const int ko = (int)(t / c);
+    dst[i] = src[(int64_t)ko * k_pad + ((int64_t)rr * s + ss) * c + ci];
+  }
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    Elem<TD>::store(dst + i, Elem<TS>::load(src + i));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int n, int c, int h,
+                                                           int w, int c_pad) {
+  const int64_t total = (int64_t)n * h * w * c_pad;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ci = (int)(i % c_pad);
+    int64_t t = i / c_pad;
+    const int iw = (int)(t % w);
+    t /= w;
+    const int ih = (int)(t % h);
+    const int img = (int)(t / h);
+    Elem<T>::store(dst + i, ci < c ? src[(((int64_t)img * c + ci) * h + ih) * w + iw] : 0.f);
+  }
+}
+
+}  // namespace sh
+
+using namespace sh;
+
+#define SH_DISPATCH(dtype, CALL_F32, CALL_BF16) \
+  do {                                          \
+    if ((dtype) == SH_F32) { CALL_F32; }        \
+    else { CALL_BF16; }                         \
+  } while (0)
+
+extern "C" {
+
+static int vec_ok(int c, int dtype, const char* who) {
+  SH_REQUIRE(dtype == SH_F32 || dtype == SH_BF16, "%s: bad dtype %d", who, dtype);
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  SH_REQUIRE(c % ve == 0, "%s: channel count %d not a multiple of %d", who, c, ve);
+  return 0;
+}
+
+int simhand_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int n, int h, int w, int c, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(x && y && idx, "maxpool_fwd: NULL pointer");
+  if (vec_ok(c, dtype, "maxpool_fwd")) return 1;
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  const int64_t total = (int64_t)n * ho * wo * (c / ve);
+  hipStream_t s = (hipStream_t)stream;
+  const double es = dtype == SH_F32 ? 4 : 2;
+  ProfScope ps(SH_PROF_POOL, s, 0, es * ((double)n * h * w * c + (double)n * ho * wo * c) + (double)n * ho * wo * c);
+  SH_DISPATCH(dtype, (maxpool_fwd_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)x, (float*)y, idx, n, h, w, c, ho, wo)),
+              (maxpool_fwd_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, idx, n, h, w, c, ho, wo)));
+  return check_launch("maxpool_fwd");
+}
+
+int simhand_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int n, int h, int w, int c, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(dy && idx && dx, "maxpool_bwd: NULL pointer");
+  if (vec_ok(c, dtype, "maxpool_bwd")) return 1;
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  const int64_t total = (int64_t)n * h * w * (c / ve);
+  hipStream_t s = (hipStream_t)stream;
+  const double es = dtype == SH_F32 ? 4 : 2;
+  ProfScope ps(SH_PROF_POOL, s, 0, es * ((double)n * h * w * c + (double)n * ho * wo * c) + (double)n * ho * wo * c);
+  SH_DISPATCH(dtype, (maxpool_bwd_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)dy, idx, (float*)dx, n, h, w, c, ho, wo)),
+              (maxpool_bwd_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)dy, idx, (bf16_t*)dx, n, h, w, c, ho, wo)));
+  return check_launch("maxpool_bwd");
+}
+
+int simhand_avgpool_fwd(const void* x, void* y, int n, int hw, int c, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(x && y, "avgpool_fwd: NULL pointer");
+  if (vec_ok(c, dtype, "avgpool_fwd")) return 1;
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_POOL, s, 0, (double)n * hw * c * (dtype == SH_F32 ? 4 : 2));
+  const int64_t total = (int64_t)n * (c / ve);
+  SH_DISPATCH(dtype, (avgpool_fwd_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)x, (float*)y, n, hw, c)),
+              (avgpool_fwd_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, n, hw, c)));
+  return check_launch("avgpool_fwd");
+}
+
+int simhand_avgpool_bwd(const void* dy, void* dx, int n, int hw, int c, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(dy && dx, "avgpool_bwd: NULL pointer");
+  if (vec_ok(c, dtype, "avgpool_bwd")) return 1;
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_POOL, s, 0, (double)n * hw * c * (dtype == SH_F32 ? 4 : 2));
+  const int64_t total = (int64_t)n * hw * (c / ve);
+  SH_DISPATCH(dtype, (avgpool_bwd_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)dy, (float*)dx, n, hw, c)),
+              (avgpool_bwd_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)dy, (bf16_t*)dx, n, hw, c)));
+  return check_launch("avgpool_bwd");
+}
+
+int simhand_im2col_nchw_f32(const float* x, void* col, int n, int cin, int h, int w, int r, int s, int stride, int pad, int k_pad,
+                            int dtype, sh_stream_t stream) {
+  SH_REQUIRE(x && col, "im2col: NULL pointer");
+  if (vec_ok(k_pad, dtype, "im2col")) return 1;
+  SH_REQUIRE(k_pad >= r * s * cin, "im2col: k_pad=%d < r*s*cin=%d", k_pad, r * s * cin);
+  const int ho = (h + 2 * pad - r) / stride + 1, wo = (w + 2 * pad - s) / stride + 1;
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  const int64_t total = (int64_t)n * ho * wo * (k_pad / ve);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_MISC, st, 0, (double)n * ho * wo * k_pad * (dtype == SH_F32 ? 4 : 2) + (double)n * cin * h * w * 4);
+  SH_DISPATCH(dtype, (im2col_nchw_kernel<float><<<stream_grid(total), 256, 0, st>>>(x, (float*)col, n, cin, h, w, r, s, stride, pad, ho, wo, k_pad)),
+              (im2col_nchw_kernel<bf16_t><<<stream_grid(total), 256, 0, st>>>(x, (bf16_t*)col, n, cin, h, w, r, s, stride, pad, ho, wo, k_pad)));
+  return check_launch("im2col");
+}
+
+int simhand_nchw_f32_to_nhwc(const float* src, void* dst, int n, int c, int h, int w, int c_pad, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(src && dst && c_pad >= c, "nchw_to_nhwc: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = (int64_t)n * h * w * c_pad;
+  ProfScope ps(SH_PROF_MISC, s, 0, (double)total * 6);
+  SH_DISPATCH(dtype, (nchw_to_nhwc_kernel<float><<<stream_grid(total), 256, 0, s>>>(src, (float*)dst, n, c, h, w, c_pad)),
+              (nchw_to_nhwc_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>(src, (bf16_t*)dst, n, c, h, w, c_pad)));
+  return check_launch("nchw_to_nhwc");
+}
+
+int simhand_oihw_f32_to_krsc(const float* src, void* dst, int k, int c, int r, int s, int k_pad, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(src && dst && k_pad >= c * r * s, "oihw_to_krsc: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)k * k_pad;
+  ProfScope ps(SH_PROF_MISC, st, 0, (double)total * 6);
+  SH_DISPATCH(dtype, (oihw_to_krsc_kernel<float><<<stream_grid(total), 256, 0, st>>>(src, (float*)dst, k, c, r, s, k_pad)),
+              (oihw_to_krsc_kernel<bf16_t><<<stream_grid(total), 256, 0, st>>>(src, (bf16_t*)dst, k, c, r, s, k_pad)));
+  return check_launch("oihw_to_krsc");
+}
+
+int simhand_oihw_f32_to_crsk(const float* src, void* dst, int k, int c, int r, int s, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(src && dst, "oihw_to_crsk: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)k * c * r * s;
+  ProfScope ps(SH_PROF_MISC, st, 0, (double)total * 6);
+  SH_DISPATCH(dtype, (oihw_to_crsk_kernel<float><<<stream_grid(total), 256, 0, st>>>(src, (float*)dst, k, c, r, s)),
+              (oihw_to_crsk_kernel<bf16_t><<<stream_grid(total), 256, 0, st>>>(src, (bf16_t*)dst, k, c, r, s)));
+  return check_launch("oihw_to_crsk");
+}
+
+int simhand_krsc_f32_to_oihw(const float* src, float* dst, int k, int c, int r, int s, int k_pad, sh_stream_t stream) {
+  SH_REQUIRE(src && dst && k_pad >= c * r * s, "krsc_to_oihw: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)k * c * r * s;
+  ProfScope ps(SH_PROF_MISC, st, 0, (double)total * 8);
+  krsc_to_oihw_kernel<<<stream_grid(total), 256, 0, st>>>(src, dst, k, c, r, s, k_pad);
+  return check_launch("krsc_to_oihw");
+}
+
+int simhand_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t count, sh_stream_t stream) {
+  SH_REQUIRE(src && dst && count >= 0, "cast: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_MISC, s, 0, (double)count * 6);
+  if (src_dtype == SH_F32 && dst_dtype == SH_BF16) cast_kernel<float, bf16_t><<<stream_grid(count), 256, 0, s>>>((const float*)src, (bf16_t*)dst, count);
+  else if (src_dtype == SH_BF16 && dst_dtype == SH_F32) cast_kernel<bf16_t, float><<<stream_grid(count), 256, 0, s>>>((const bf16_t*)src, (float*)dst, count);
+  else if (src_dtype == SH_F32 && dst_dtype == SH_F32) cast_kernel<float, float><<<stream_grid(count), 256, 0, s>>>((const float*)src, (float*)dst, count);
+  else if (src_dtype == SH_BF16 && dst_dtype == SH_BF16) cast_kernel<bf16_t, bf16_t><<<stream_grid(count), 256, 0, s>>>((const bf16_t*)src, (bf16_t*)dst, count);
+  else {
+    sh::set_error("cast: bad dtypes %d -> %d", src_dtype, dst_dtype);
+    return 1;
+  }
+  return check_launch("cast");
+}
+
+}  // extern "C"

@@ -1,0 +1,348 @@
+"""Raw (non-autograd) operator layer: torch tensors in, torch tensors out, every
+FLOP in ``libsimhand_hip.so``.  torch only owns memory and the stream.
+
+Layouts: activations NHWC, conv weights KRSC rows ``[cout][k_pad]``; ``dtype``
+is the compute dtype of activations / packed weights (torch.float32 for the
+parity mode, torch.bfloat16 for the MFMA bf16 path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, NtxentParams, check
+
+_DT = {torch.float32: _lib.SH_F32, torch.bfloat16: _lib.SH_BF16}
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise _lib.SimhandHipError("simhand_amd ops need device tensors (there is no CPU path)")
+    if not t.is_contiguous():
+        raise _lib.SimhandHipError("simhand_amd ops need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def _lib_dev():
+    _lib.require_device()
+    return _lib.load()
+
+
+def dt(dtype: torch.dtype) -> int:
+    return _DT[dtype]
+
+
+# --------------------------------------------------------------------------- loss
+class NtxentPlan:
+    """Shapes + flags of one loss evaluation; owns the workspaces."""
+
+    def __init__(self, B: int, b_loc: int, pair_off: int, weight_type: Optional[str], use_wpos: bool, use_wneg: bool,
+                 temperature: float = 0.5, lambda_pos: float = 0.0, lambda_neg: float = 0.0, dim: int = 128):
+        self.p = NtxentParams(B, dim, b_loc, pair_off, _lib.WEIGHT_TYPES[weight_type], int(use_wpos), int(use_wneg),
+                              temperature, lambda_pos or 0.0, lambda_neg or 0.0)
+        self.B, self.N, self.b_loc, self.pair_off, self.rows = B, 2 * B, b_loc, pair_off, 2 * b_loc
+        self.weighted = weight_type not in (None, "none")
+        self.ws_bytes = _lib.load().simhand_ntxent_workspace_bytes(C.byref(self.p))
+        if self.ws_bytes == 0:
+            check(1, "simhand_ntxent_workspace_bytes")
+
+
+def pos_dist(J_all: torch.Tensor, B: int, mode: str, stats: torch.Tensor) -> torch.Tensor:
+    lib = _lib_dev()
+    d = torch.empty(B, dtype=torch.float32, device=J_all.device)
+    check(lib.simhand_pos_dist(_ptr(J_all), B, J_all.shape[1], _lib.DIST_MODES[mode], _ptr(d), _ptr(stats), _stream()), "pos_dist")
+    return d
+
+
+def neg_dist(J_all: torch.Tensor, B: int, mode: str, b_loc: int, pair_off: int, stats: torch.Tensor) -> torch.Tensor:
+    lib = _lib_dev()
+    rows, N = 2 * b_loc, 2 * B
+    D = torch.empty(rows, N, dtype=torch.float32, device=J_all.device)
+    nb = lib.simhand_neg_dist_workspace_bytes(rows, N)
+    ws = torch.empty(nb, dtype=torch.uint8, device=J_all.device)
+    check(lib.simhand_neg_dist(_ptr(J_all), B, J_all.shape[1], _lib.DIST_MODES[mode], b_loc, pair_off, _ptr(D), _ptr(stats),
+                               _ptr(ws), nb, _stream()), "neg_dist")
+    return D
+
+
+def ntxent_fwd(plan: NtxentPlan, Z_all, D_loc, d_pos, stats) -> Tuple[torch.Tensor, torch.Tensor]:
+    lib = _lib_dev()
+    dev = Z_all.device
+    neg = torch.empty(plan.rows, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.simhand_ntxent_fwd(C.byref(plan.p), _ptr(Z_all), _ptr(D_loc), _ptr(d_pos), _ptr(stats), _ptr(neg), _ptr(loss),
+                                 _ptr(ws), plan.ws_bytes, _stream()), "ntxent_fwd")
+    return neg, loss
+
+
+def ntxent_bwd(plan: NtxentPlan, Z_all, D_loc, d_pos, stats, neg_all, dloss) -> torch.Tensor:
+    lib = _lib_dev()
+    dev = Z_all.device
+    dZ = torch.empty(plan.rows, plan.p.dim, dtype=torch.float32, device=dev)
+    ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.simhand_ntxent_bwd(C.byref(plan.p), _ptr(Z_all), _ptr(D_loc), _ptr(d_pos), _ptr(stats), _ptr(neg_all), _ptr(dloss),
+                                 _ptr(dZ), _ptr(ws), plan.ws_bytes, _stream()), "ntxent_bwd")
+    return dZ
+
+
+# ------------------------------------------------------------------ post-process
+def proj_postprocess_fwd(P, jx, jy, angle, hw) -> torch.Tensor:
+    lib = _lib_dev()
+    Z = torch.empty_like(P)
+    check(lib.simhand_proj_postprocess_fwd(_ptr(P), P.shape[0], _ptr(jx), _ptr(jy), _ptr(angle), int(hw[0]), int(hw[1]), _ptr(Z),
+                                           _stream()), "proj_postprocess_fwd")
+    return Z
+
+
+def proj_postprocess_bwd(P, jx, jy, angle, hw, dZ) -> torch.Tensor:
+    lib = _lib_dev()
+    dP = torch.empty_like(P)
+    check(lib.simhand_proj_postprocess_bwd(_ptr(P), P.shape[0], _ptr(jx), _ptr(jy), _ptr(angle), int(hw[0]), int(hw[1]), _ptr(dZ),
+                                           _ptr(dP), _stream()), "proj_postprocess_bwd")
+    return dP
+
+
+def proj_stats(P: torch.Tensor) -> torch.Tensor:
+    """8 batch-mean statistics of one view's raw head output (rows x 128)."""
+    lib = _lib_dev()
+    n = P.shape[0]
+    ws = torch.empty(n, 8, dtype=torch.float32, device=P.device)
+    out = torch.empty(8, dtype=torch.float32, device=P.device)
+    check(lib.simhand_proj_stats(_ptr(P), n, _ptr(ws), _ptr(out), _stream()), "proj_stats")
+    return out
+
+
+# ------------------------------------------------------------------------ conv
+def conv_desc(n, h, w, cin, cout, r, s, stride, pad, dtype: torch.dtype) -> ConvDesc:
+    ho = (h + 2 * pad - r) // stride + 1
+    wo = (w + 2 * pad - s) // stride + 1
+    return ConvDesc(n, h, w, cin, cout, r, s, stride, pad, ho, wo, dt(dtype))
+
+
+def conv2d_fwd(d: ConvDesc, x, w, want_stats: bool = True):
+    lib = _lib_dev()
+    y = torch.empty(d.n, d.ho, d.wo, d.cout, dtype=x.dtype, device=x.device)
+    part = None
+    if want_stats:
+        nblk = lib.simhand_conv2d_fwd_stat_blocks(C.byref(d))
+        part = torch.empty(nblk, 2, d.cout, dtype=torch.float32, device=x.device)
+    check(lib.simhand_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(part), _stream()), "conv2d_fwd")
+    return y, part
+
+
+def conv2d_dgrad(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accumulate: bool = False):
+    lib = _lib_dev()
+    if dx is None:
+        dx = torch.empty(d.n, d.h, d.w, d.cin, dtype=dy.dtype, device=dy.device)
+    check(lib.simhand_conv2d_dgrad(C.byref(d), _ptr(dy), _ptr(wt), _ptr(dx), int(accumulate), _stream()), "conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(d: ConvDesc, x, dy) -> torch.Tensor:
+    """fp32 gradient in KRSC row order [cout][r*s*cin]."""
+    lib = _lib_dev()
+    nb = lib.simhand_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    dw = torch.empty(d.cout, d.r * d.s * d.cin, dtype=torch.float32, device=x.device)
+    check(lib.simhand_conv2d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nb, _stream()), "conv2d_wgrad")
+    return dw
+
+
+def pack_krsc(w_oihw: torch.Tensor, dtype: torch.dtype, k_pad: Optional[int] = None) -> torch.Tensor:
+    lib = _lib_dev()
+    k, c, r, s = w_oihw.shape
+    k_pad = k_pad or c * r * s
+    out = torch.empty(k, k_pad, dtype=dtype, device=w_oihw.device)
+    check(lib.simhand_oihw_f32_to_krsc(_ptr(w_oihw), _ptr(out), k, c, r, s, k_pad, dt(dtype), _stream()), "oihw_to_krsc")
+    return out
+
+
+def pack_crsk(w_oihw: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    lib = _lib_dev()
+    k, c, r, s = w_oihw.shape
+    out = torch.empty(c, r * s * k, dtype=dtype, device=w_oihw.device)
+    check(lib.simhand_oihw_f32_to_crsk(_ptr(w_oihw), _ptr(out), k, c, r, s, dt(dtype), _stream()), "oihw_to_crsk")
+    return out
+
+
+def unpack_krsc_grad(dw: torch.Tensor, shape, k_pad: Optional[int] = None) -> torch.Tensor:
+    lib = _lib_dev()
+    k, c, r, s = shape
+    k_pad = k_pad or c * r * s
+    out = torch.empty(k, c, r, s, dtype=torch.float32, device=dw.device)
+    check(lib.simhand_krsc_f32_to_oihw(_ptr(dw), _ptr(out), k, c, r, s, k_pad, _stream()), "krsc_to_oihw")
+    return out
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    lib = _lib_dev()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib.simhand_cast(_ptr(x), dt(x.dtype), _ptr(out), dt(dtype), x.numel(), _stream()), "cast")
+    return out
+
+
+def im2col_nchw(x: torch.Tensor, r, s, stride, pad, k_pad, dtype) -> torch.Tensor:
+    lib = _lib_dev()
+    n, c, h, w = x.shape
+    ho = (h + 2 * pad - r) // stride + 1
+    wo = (w + 2 * pad - s) // stride + 1
+    col = torch.empty(n, ho, wo, k_pad, dtype=dtype, device=x.device)
+    check(lib.simhand_im2col_nchw_f32(_ptr(x), _ptr(col), n, c, h, w, r, s, stride, pad, k_pad, dt(dtype), _stream()), "im2col")
+    return col
+
+
+def nchw_to_nhwc(x: torch.Tensor, dtype, c_pad: Optional[int] = None) -> torch.Tensor:
+    lib = _lib_dev()
+    n, c, h, w = x.shape
+    c_pad = c_pad or c
+    out = torch.empty(n, h, w, c_pad, dtype=dtype, device=x.device)
+    check(lib.simhand_nchw_f32_to_nhwc(_ptr(x), _ptr(out), n, c, h, w, c_pad, dt(dtype), _stream()), "nchw_to_nhwc")
+    return out
+
+
+# -------------------------------------------------------------------------- BN
+class BNState:
+    """Per-call statistics of one train-mode BatchNorm (all fp32, length C)."""
+
+    __slots__ = ("mean", "invstd", "scale", "shift")
+
+    def __init__(self, c: int, device):
+        buf = torch.empty(4, c, dtype=torch.float32, device=device)
+        self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_partial_stats(y: torch.Tensor, m: int, c: int) -> torch.Tensor:
+    lib = _lib_dev()
+    nblk = lib.simhand_bn_stat_blocks(m, c)
+    part = torch.empty(nblk, 2, c, dtype=torch.float32, device=y.device)
+    check(lib.simhand_bn_partial_stats(_ptr(y), m, c, dt(y.dtype), _ptr(part), _stream()), "bn_partial_stats")
+    return part
+
+
+def bn_finalize(part: torch.Tensor, m: int, c: int, gamma, beta, running_mean, running_var, nbt, pre_bias=None,
+                eps: float = 1e-5, momentum: float = 0.1) -> BNState:
+    lib = _lib_dev()
+    st = BNState(c, part.device)
+    nblk = part.shape[0]
+    nb = lib.simhand_bn_finalize_workspace_bytes(nblk, c)
+    ws = torch.empty(nb, dtype=torch.uint8, device=part.device)
+    check(lib.simhand_bn_finalize(_ptr(part), nblk, m, c, _ptr(gamma), _ptr(beta), _ptr(pre_bias), eps, momentum,
+                                  _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(st.mean), _ptr(st.invstd),
+                                  _ptr(st.scale), _ptr(st.shift), _ptr(ws), nb, _stream()), "bn_finalize")
+    return st
+
+
+def bn_apply(y, st: BNState, m: int, c: int, relu: bool, residual=None, out=None) -> torch.Tensor:
+    lib = _lib_dev()
+    a = torch.empty_like(y) if out is None else out
+    check(lib.simhand_bn_apply(_ptr(y), _ptr(st.scale), _ptr(st.shift), _ptr(residual), int(relu), _ptr(a), m, c, dt(y.dtype),
+                               _stream()), "bn_apply")
+    return a
+
+
+def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_dres: bool):
+    """Returns (dy, dres or None, dgamma, dbeta)."""
+    lib = _lib_dev()
+    dev = y.device
+    nblk = lib.simhand_bn_stat_blocks(m, c)
+    part = torch.empty(nblk, 2, c, dtype=torch.float32, device=dev)
+    check(lib.simhand_bn_bwd_partial(_ptr(da), _ptr(a if relu else None), _ptr(y), _ptr(st.mean), _ptr(st.invstd), int(relu), m, c,
+                                     dt(y.dtype), _ptr(part), _stream()), "bn_bwd_partial")
+    dg = torch.empty(c, dtype=torch.float32, device=dev)
+    db = torch.empty(c, dtype=torch.float32, device=dev)
+    check(lib.simhand_bn_bwd_finalize(_ptr(part), nblk, c, _ptr(dg), _ptr(db), _stream()), "bn_bwd_finalize")
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_dres else None
+    check(lib.simhand_bn_bwd_apply(_ptr(da), _ptr(a if relu else None), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(dg),
+                                   _ptr(db), int(relu), _ptr(dy), _ptr(dres), m, c, dt(y.dtype), _stream()), "bn_bwd_apply")
+    return dy, dres, dg, db
+
+
+# ------------------------------------------------------------------------ pools
+def maxpool_fwd(x: torch.Tensor):
+    lib = _lib_dev()
+    n, h, w, c = x.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty(n, ho, wo, c, dtype=x.dtype, device=x.device)
+    idx = torch.empty(n, ho, wo, c, dtype=torch.uint8, device=x.device)
+    check(lib.simhand_maxpool3x3s2_fwd(_ptr(x), _ptr(y), _ptr(idx), n, h, w, c, dt(x.dtype), _stream()), "maxpool_fwd")
+    return y, idx
+
+
+def maxpool_bwd(dy: torch.Tensor, idx: torch.Tensor, in_shape) -> torch.Tensor:
+    lib = _lib_dev()
+    n, h, w, c = in_shape
+    dx = torch.empty(n, h, w, c, dtype=dy.dtype, device=dy.device)
+    check(lib.simhand_maxpool3x3s2_bwd(_ptr(dy), _ptr(idx), _ptr(dx), n, h, w, c, dt(dy.dtype), _stream()), "maxpool_bwd")
+    return dx
+
+
+def avgpool_fwd(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib_dev()
+    n, h, w, c = x.shape
+    y = torch.empty(n, c, dtype=x.dtype, device=x.device)
+    check(lib.simhand_avgpool_fwd(_ptr(x), _ptr(y), n, h * w, c, dt(x.dtype), _stream()), "avgpool_fwd")
+    return y
+
+
+def avgpool_bwd(dy: torch.Tensor, in_shape) -> torch.Tensor:
+    lib = _lib_dev()
+    n, h, w, c = in_shape
+    dx = torch.empty(n, h, w, c, dtype=dy.dtype, device=dy.device)
+    check(lib.simhand_avgpool_bwd(_ptr(dy), _ptr(dx), n, h * w, c, dt(dy.dtype), _stream()), "avgpool_bwd")
+    return dx
+
+
+def colsum(x: torch.Tensor, m: int, c: int) -> torch.Tensor:
+    lib = _lib_dev()
+    nblk = lib.simhand_bn_stat_blocks(m, c)
+    part = torch.empty((2 * nblk + 1) * c, dtype=torch.float32, device=x.device)
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(lib.simhand_colsum(_ptr(x), m, c, dt(x.dtype), _ptr(part), _ptr(out), _stream()), "colsum")
+    return out
+
+
+# -------------------------------------------------------------------- optimizer
+def lars_adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, weight_decay: float, use_lars: bool,
+                   betas=(0.9, 0.999), adam_eps: float = 1e-8, lars_eta: float = 0.02, lars_eps: float = 1e-8,
+                   lars_clip: bool = True) -> None:
+    lib = _lib_dev()
+    n = param.numel()
+    nblk = max(1, min(256, (n + 4095) // 4096))
+    pp = gp = None
+    if use_lars:
+        pp = torch.empty(nblk, dtype=torch.float32, device=param.device)
+        gp = torch.empty(nblk, dtype=torch.float32, device=param.device)
+        check(lib.simhand_sumsq_partial(_ptr(param), n, _ptr(pp), nblk, _stream()), "sumsq_partial")
+        check(lib.simhand_sumsq_partial(_ptr(grad), n, _ptr(gp), nblk, _stream()), "sumsq_partial")
+    check(lib.simhand_lars_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, _ptr(pp), _ptr(gp), nblk, lr,
+                                     betas[0], betas[1], adam_eps, weight_decay, lars_eta, lars_eps, int(lars_clip), int(use_lars),
+                                     step, _stream()), "lars_adam_step")
+
+
+# --------------------------------------------------------------------- profiler
+def prof_enable(on: bool) -> None:
+    _lib.load().simhand_prof_enable(int(on))
+
+
+def prof_reset() -> None:
+    _lib.load().simhand_prof_reset()
+
+
+def prof_collect() -> dict:
+    lib = _lib.load()
+    n = len(_lib.PROF_CLASSES)
+    ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+    cnt = (C.c_int64 * n)()
+    check(lib.simhand_prof_collect(ms, fl, by, cnt), "prof_collect")
+    return {name: {"ms": ms[i], "flops": fl[i], "bytes": by[i], "count": cnt[i]} for i, name in enumerate(_lib.PROF_CLASSES)}

@@ -1,0 +1,50 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU and exports
+every symbol include/simhand_hip.h declares; the product package has no CPU compute path."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "simhand_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(simhand_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from simhand_amd import _lib
+
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/simhand_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.simhand_abi_version() == 1
+
+
+def test_compute_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from simhand_amd import _lib, ops
+
+    with pytest.raises(_lib.SimhandHipError):
+        ops.proj_stats(torch.zeros(4, 128))
+    with pytest.raises(_lib.SimhandHipError):
+        _lib.require_device()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "simhand_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+                assert "/root/reference" not in src, f"{f} touches the reference tree"

@@ -1,0 +1,234 @@
+"""GPU parity of the backbone operators through the C ABI against torch's ATen CPU ops
+(the arithmetic oracle for conv / BN / pool / linear -- torchvision itself is not vendored
+in the reference).  fp32 mode: exact-f32 MFMA, tolerance 2e-5 of max |ref|;
+bf16 mode: inputs are rounded to bf16 first on both sides, fp32 accumulate, output rounded
+to bf16 -> tolerance 1e-2 of max |ref| (one bf16 ulp = 2^-8 relative).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1e-2
+
+
+def _rnd(t, dtype):
+    return t.to(dtype).float()
+
+
+def _check(got, want, tol, tag):
+    scale = want.abs().max().item()
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale + 1e-6, f"{tag}: err {err:.3e} scale {scale:.3e}"
+
+
+CONV_SHAPES = [
+    # n, h, w, cin, cout, k, stride, pad
+    (2, 14, 14, 64, 64, 1, 1, 0),
+    (2, 14, 14, 64, 256, 1, 1, 0),
+    (3, 9, 9, 128, 128, 3, 1, 1),
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (2, 16, 16, 128, 128, 3, 2, 1),
+    (2, 15, 15, 64, 128, 3, 2, 1),   # odd spatial, ragged M
+    (2, 16, 16, 256, 512, 1, 2, 0),  # downsample shortcut
+    (5, 7, 7, 512, 64, 1, 1, 0),     # M = 245 (not a tile multiple)
+    (70, 1, 1, 512, 512, 1, 1, 0),   # Linear as 1x1 conv
+    (70, 1, 1, 512, 128, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv_fwd_dgrad_wgrad(shape, dtype):
+    from simhand_amd import ops
+
+    n, h, w, cin, cout, k, stride, pad = shape
+    g = torch.Generator().manual_seed(hash(shape) % 10000)
+    x = _rnd(torch.randn(n, cin, h, w, generator=g), dtype)
+    wt = _rnd(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k), dtype)
+    x.requires_grad_(True)
+    wt.requires_grad_(True)
+    y = F.conv2d(x, wt, stride=stride, padding=pad)
+    dy = _rnd(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+
+    d = ops.conv_desc(n, h, w, cin, cout, k, k, stride, pad, dtype)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    wd = ops.pack_krsc(wt.detach().to(DEV), dtype)
+    wtd = ops.pack_crsk(wt.detach().to(DEV), dtype)
+    yd, part = ops.conv2d_fwd(d, xd, wd, want_stats=True)
+    _check(yd.float().cpu().permute(0, 3, 1, 2), y.detach(), _tol(dtype), "fwd")
+    # fused BN partial statistics of the fp32 accumulators
+    m = n * d.ho * d.wo
+    s1 = part[:, 0].sum(0).cpu() / m
+    s2 = part[:, 1].sum(0).cpu() / m
+    yf = y.detach().permute(0, 2, 3, 1).reshape(m, cout)
+    _check(s1, yf.mean(0), 1e-2 if dtype == torch.bfloat16 else 1e-4, "stat mean")
+    _check(s2, (yf * yf).mean(0), 1e-2 if dtype == torch.bfloat16 else 1e-4, "stat sumsq")
+
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    dxd = ops.conv2d_dgrad(d, dyd, wtd)
+    _check(dxd.float().cpu().permute(0, 3, 1, 2), x.grad, _tol(dtype), "dgrad")
+    # accumulate form: dx += result
+    base = _rnd(torch.randn(n, h, w, cin, generator=g), dtype)
+    acc = base.to(DEV).to(dtype).contiguous()
+    ops.conv2d_dgrad(d, dyd, wtd, dx=acc, accumulate=True)
+    _check(acc.float().cpu(), base + x.grad.permute(0, 2, 3, 1), 2 * _tol(dtype), "dgrad accumulate")
+
+    dwd = ops.conv2d_wgrad(d, xd, dyd)
+    dw = ops.unpack_krsc_grad(dwd, (cout, cin, k, k)).cpu()
+    _check(dw, wt.grad, 2e-5 if dtype == torch.float32 else 2e-3, "wgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_transpose_read_matches_scalar_path(dtype):
+    """bf16 wgrad uses ds_read_b64_tr_b16; the scalar-LDS-read build of the same kernel must agree bit for bit."""
+    from simhand_amd import _lib, ops
+
+    n, h, w, cin, cout = 3, 12, 12, 128, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, h, w, cin, generator=g).to(DEV).to(dtype)
+    dy = torch.randn(n, h, w, cout, generator=g).to(DEV).to(dtype)
+    d = ops.conv_desc(n, h, w, cin, cout, 3, 3, 1, 1, dtype)
+    lib = _lib.load()
+    try:
+        lib.simhand_wgrad_set_tr(1)
+        a = ops.conv2d_wgrad(d, x, dy).cpu()
+        lib.simhand_wgrad_set_tr(0)
+        b = ops.conv2d_wgrad(d, x, dy).cpu()
+    finally:
+        lib.simhand_wgrad_set_tr(1)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stem_im2col_conv(dtype):
+    """7x7/2 stem = im2col (NCHW fp32 -> [M][192]) + 1x1 GEMM; wgrad through the same lowering."""
+    from simhand_amd import ops
+
+    n, h = 3, 36
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, 3, h, h, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147)
+    xr, wr = _rnd(x, dtype).requires_grad_(True), _rnd(wt, dtype).requires_grad_(True)
+    y = F.conv2d(xr, wr, stride=2, padding=3)
+    dy = _rnd(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    col = ops.im2col_nchw(x.to(DEV), 7, 7, 2, 3, 192, dtype)
+    ho = y.shape[2]
+    d = ops.conv_desc(n, ho, ho, 192, 64, 1, 1, 1, 0, dtype)
+    wd = ops.pack_krsc(wt.to(DEV), dtype, k_pad=192)
+    yd, _ = ops.conv2d_fwd(d, col, wd)
+    _check(yd.float().cpu().permute(0, 3, 1, 2), y.detach(), _tol(dtype), "stem fwd")
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    dwd = ops.conv2d_wgrad(d, col, dyd)
+    dw = ops.unpack_krsc_grad(dwd, (64, 3, 7, 7), k_pad=192).cpu()
+    _check(dw, wr.grad, 2e-5 if dtype == torch.float32 else 2e-3, "stem wgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,c,relu,res", [(300, 64, True, False), (1000, 256, True, True), (77, 512, False, False),
+                                          (4096, 2048, True, True), (50, 128, False, True)])
+def test_batchnorm_fwd_bwd(m, c, relu, res, dtype):
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(m + c)
+    y = _rnd(torch.randn(m, c, generator=g) * 2 + 0.5, dtype).requires_grad_(True)
+    r = _rnd(torch.randn(m, c, generator=g), dtype).requires_grad_(True) if res else None
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(c, generator=g) * 0.1).requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    out = F.batch_norm(y, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    if res:
+        out = out + r
+    if relu:
+        out = F.relu(out)
+    da = _rnd(torch.randn(m, c, generator=g), dtype)
+    out.backward(da)
+
+    yd = y.detach().to(DEV).to(dtype)
+    part = ops.bn_partial_stats(yd, m, c)
+    rmd, rvd = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    st = ops.bn_finalize(part, m, c, gamma.detach().to(DEV), beta.detach().to(DEV), rmd, rvd, nbt)
+    rd = r.detach().to(DEV).to(dtype) if res else None
+    a = ops.bn_apply(yd, st, m, c, relu, rd)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    _check(a.float().cpu(), out.detach(), tol, "bn fwd")
+    _check(rmd.cpu(), rm, 1e-5, "running_mean")
+    _check(rvd.cpu(), rv, 1e-5, "running_var")
+    assert nbt.item() == 1
+    dad = da.to(DEV).to(dtype)
+    dy, dres, dg, db = ops.bn_backward(dad, a, yd, st, gamma.detach().to(DEV), m, c, relu, want_dres=res)
+    _check(dy.float().cpu(), y.grad, 1e-4 if dtype == torch.float32 else 2e-2, "bn dy")
+    _check(dg.cpu(), gamma.grad, 1e-4 if dtype == torch.float32 else 2e-2, "dgamma")
+    _check(db.cpu(), beta.grad, 1e-4 if dtype == torch.float32 else 2e-2, "dbeta")
+    if res:
+        _check(dres.float().cpu(), r.grad, tol, "dres")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pools(dtype):
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    x = F.relu(_rnd(torch.randn(3, 64, 13, 13, generator=g), dtype)).requires_grad_(True)  # relu -> ties at 0
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = _rnd(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    yd, idx = ops.maxpool_fwd(xd)
+    assert torch.equal(yd.float().cpu().permute(0, 3, 1, 2), y.detach())
+    dxd = ops.maxpool_bwd(dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype), idx, xd.shape)
+    _check(dxd.float().cpu().permute(0, 3, 1, 2), x.grad, 1e-6 if dtype == torch.float32 else 1e-2, "maxpool bwd")
+
+    x2 = _rnd(torch.randn(4, 128, 7, 7, generator=g), dtype).requires_grad_(True)
+    y2 = F.adaptive_avg_pool2d(x2, 1).flatten(1)
+    d2 = _rnd(torch.randn(y2.shape, generator=g), dtype)
+    y2.backward(d2)
+    x2d = x2.detach().permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    y2d = ops.avgpool_fwd(x2d)
+    _check(y2d.float().cpu(), y2.detach(), 1e-6 if dtype == torch.float32 else 1e-2, "avgpool")
+    dx2 = ops.avgpool_bwd(d2.to(DEV).to(dtype), x2d.shape)
+    _check(dx2.float().cpu().permute(0, 3, 1, 2), x2.grad, 1e-6 if dtype == torch.float32 else 1e-2, "avgpool bwd")
+
+
+def test_colsum_and_cast():
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(333, 512, generator=g)
+    out = ops.colsum(x.to(DEV), 333, 512).cpu()
+    _check(out, x.sum(0), 1e-5, "colsum")
+    xb = ops.cast(x.to(DEV), torch.bfloat16)
+    assert torch.equal(xb.cpu(), x.to(torch.bfloat16))
+
+
+def test_lars_adam_step_matches_restated_pl_bolts():
+    """pl_bolts 0.2.2 LARSWrapper(Adam) -- parity unpinned (library not vendored); checked against the
+    restatement in oracle/optim.py built on torch.optim.Adam."""
+    from oracle.optim import LARSWrapperOracle
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    p0 = torch.randn(1000, generator=g)
+    for wd, use_lars in ((1e-6, True), (0.0, True), (1e-6, False)):
+        p = torch.nn.Parameter(p0.clone())
+        adam = torch.optim.Adam([{"params": [p], "weight_decay": wd}], lr=3.2e-3)
+        opt = LARSWrapperOracle(adam) if use_lars else adam
+        pd = p0.clone().to(DEV)
+        m = torch.zeros_like(pd)
+        v = torch.zeros_like(pd)
+        for t in range(1, 4):
+            grad = torch.randn(1000, generator=g) * 0.01
+            p.grad = grad.clone()
+            opt.step()
+            ops.lars_adam_step(pd, grad.to(DEV), m, v, t, 3.2e-3, wd, use_lars)
+            _check(pd.cpu(), p.detach(), 1e-5, f"step {t} wd={wd} lars={use_lars}")
