@@ -39,7 +39,8 @@ enum sh_dist_mode {
   SH_DIST_W_O_ABS = 2,/* pos: ||mean_j d||_2   ; neg: ||mean_xy d||_2 over joints    :219-222,:241-244 */
   SH_DIST_L2 = 3      /* plain L2 over F features (the *_with_pca variants :264-301) */
 };
-enum sh_weight_type { SH_W_NONE = 0, SH_W_LINEAR = 1, SH_W_NONLINEAR = 2 };
+enum sh_weight_type { SH_W_NONE = 0, SH_W_LINEAR = 1, SH_W_NONLINEAR = 2,
+                      SH_W_EXPLICIT = 3 /* D_loc / d_pos already hold the weights (functional surface) */ };
 
 int simhand_abi_version(void);
 const char* simhand_last_error(void);
@@ -81,6 +82,12 @@ int simhand_neg_dist(const float* J_all, int B, int F, int dist_mode, int b_loc,
                      float* D_loc /*[rows_loc][N]*/, double* stats /*[8]*/,
                      void* workspace, size_t workspace_bytes, sh_stream_t stream);
 
+/* explicit weights w = f(dist) as returned by get_weights_linear / get_weights_nonlinear
+ * (src/models/utils.py:235,:259,:321,:344): positive != 0 uses stats[3..5], else stats[0..2];
+ * mean_count = number of entries the mean runs over (B, resp. N*N). */
+int simhand_weights_from_dist(const float* dist, int64_t count, int weight_type, const double* stats, int positive,
+                              double mean_count, float lambda, float* weights, sh_stream_t stream);
+
 typedef struct sh_ntxent_params {
   int B;            /* global pairs; N = 2B */
   int dim;          /* projection width, must be 128 (output_dim of *_config.json) */
@@ -114,10 +121,20 @@ int simhand_ntxent_bwd(const sh_ntxent_params* p, const float* Z_all, const floa
  *   jitter_x/jitter_y: int64 [N] or NULL (flag "crop" off); angle: float64 [N]
  *   degrees or NULL (flag "rotate" off) -- dtypes as collated.
  * =========================================================================== */
+enum sh_pp_flags {
+  SH_PP_NORM_IN = 1,        /* F.normalize before the un-warp  (simhand_w_model.py:57-58) */
+  SH_PP_NORM_OUT = 2,       /* F.normalize after the un-warp   (simhand_w_model.py:92-93) */
+  SH_PP_ANGLE_AS_GIVEN = 4  /* angle[] is rotate_encoding's own argument (already negated by the caller) */
+};
+#define SH_PP_FUSED (SH_PP_NORM_IN | SH_PP_NORM_OUT)
+/* translation: either raw collated jitters (int64; the kernel applies -(j / float(size))) or the ready
+ * factors translate_x/translate_y that translate_encodings() receives (fp32) -- never both. */
 int simhand_proj_postprocess_fwd(const float* P /*[N][128]*/, int N, const int64_t* jitter_x, const int64_t* jitter_y,
-                                 const double* angle, int img_h, int img_w, float* Z /*[N][128]*/, sh_stream_t stream);
+                                 const float* translate_x, const float* translate_y, const double* angle,
+                                 int img_h, int img_w, int flags, float* Z /*[N][128]*/, sh_stream_t stream);
 int simhand_proj_postprocess_bwd(const float* P, int N, const int64_t* jitter_x, const int64_t* jitter_y,
-                                 const double* angle, int img_h, int img_w, const float* dZ, float* dP, sh_stream_t stream);
+                                 const float* translate_x, const float* translate_y, const double* angle,
+                                 int img_h, int img_w, int flags, const float* dZ, float* dP, sh_stream_t stream);
 /* out[8] = batch means of per-row {x_mean,x_median,x_min,x_max,y_mean,y_median,y_min,y_max}; row_ws [N][8] */
 int simhand_proj_stats(const float* P, int N, float* row_ws, float* out, sh_stream_t stream);
 
@@ -175,6 +192,9 @@ int simhand_bn_finalize(const float* partial, int nblk, int64_t m, int c, const 
                         const float* pre_bias, float eps, float momentum, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
                         void* workspace, size_t workspace_bytes, sh_stream_t stream);
+/* eval mode (model.eval(), validation_step): scale/shift from the running statistics */
+int simhand_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                            int c, float* scale, float* shift, sh_stream_t stream);
 /* a = act(y*scale + shift (+ residual)), act = relu if relu != 0 */
 int simhand_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, int relu,
                      void* a, int64_t m, int c, int dtype, sh_stream_t stream);

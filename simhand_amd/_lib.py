@@ -17,7 +17,9 @@ LIB_PATH = os.path.join(_HERE, "libsimhand_hip.so")
 # enums of include/simhand_hip.h
 SH_F32, SH_BF16 = 0, 1
 DIST_MODES = {"mpjpe": 0, "w_abs": 1, "w_o_abs": 2, "l2": 3}
-WEIGHT_TYPES = {None: 0, "none": 0, "linear": 1, "non_linear": 2}
+WEIGHT_TYPES = {None: 0, "none": 0, "linear": 1, "non_linear": 2, "explicit": 3}
+PP_NORM_IN, PP_NORM_OUT, PP_ANGLE_AS_GIVEN = 1, 2, 4
+PP_FUSED = 3
 PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn", "pool", "loss", "misc")
 
 
@@ -58,11 +60,12 @@ SIGNATURES = {
     "simhand_pos_dist": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "simhand_neg_dist_workspace_bytes": (_S, [_I, _I]),
     "simhand_neg_dist": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _S, _P]),
-    "simhand_ntxent_workspace_bytes": (_S, [C.POINTER(NtxentParams)]),
+    "simhand_weights_from_dist": (_I, [_P, _L, _I, _P, _I, C.c_double, _F, _P, _P]),
+    "simhand_ntxent_workspace_bytes":(_S, [C.POINTER(NtxentParams)]),
     "simhand_ntxent_fwd": (_I, [C.POINTER(NtxentParams), _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_ntxent_bwd": (_I, [C.POINTER(NtxentParams), _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
-    "simhand_proj_postprocess_fwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P]),
-    "simhand_proj_postprocess_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "simhand_proj_postprocess_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "simhand_proj_postprocess_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "simhand_proj_stats": (_I, [_P, _I, _P, _P, _P]),
     "simhand_conv2d_fwd_stat_blocks": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
@@ -80,6 +83,7 @@ SIGNATURES = {
     "simhand_bn_partial_stats": (_I, [_P, _L, _I, _I, _P, _P]),
     "simhand_bn_finalize_workspace_bytes": (_S, [_I, _I]),
     "simhand_bn_finalize": (_I, [_P, _I, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "simhand_bn_eval_params": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "simhand_bn_apply": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P]),
     "simhand_bn_bwd_partial": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P]),
     "simhand_bn_bwd_finalize": (_I, [_P, _I, _I, _P, _P, _P]),

@@ -143,6 +143,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   }
 }
 
+__global__ __launch_bounds__(256) void bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ rm, const float* __restrict__ rv, float eps, int c,
+                                                             float* __restrict__ scale, float* __restrict__ shift) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  const float sc = (gamma ? gamma[ch] : 1.0f) / sqrtf(rv[ch] + eps);
+  scale[ch] = sc;
+  shift[ch] = (beta ? beta[ch] : 0.0f) - rm[ch] * sc;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const T* __restrict__ res, int relu,
@@ -315,6 +325,13 @@ int simhand_bn_finalize(const float* partial, int nblk, int64_t m, int c, const 
   bn_finalize_kernel<<<ceil_div(c, 256), 256, 0, s>>>((const double*)workspace, nchunk, m, c, gamma, beta, pre_bias, eps, momentum,
                                                        running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift);
   return check_launch("bn_finalize");
+}
+
+int simhand_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                            int c, float* scale, float* shift, sh_stream_t stream) {
+  SH_REQUIRE(running_mean && running_var && scale && shift, "bn_eval_params: NULL pointer");
+  bn_eval_params_kernel<<<ceil_div(c, 256), 256, 0, (hipStream_t)stream>>>(gamma, beta, running_mean, running_var, eps, c, scale, shift);
+  return check_launch("bn_eval_params");
 }
 
 int simhand_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, int relu, void* a, int64_t m,

@@ -39,6 +39,7 @@ struct Weighting {
   float dmax, dmin, mu, lambda;
 };
 __device__ __forceinline__ float weight_of(float d, const Weighting& w) {
+  if (w.wtype == SH_W_EXPLICIT) return d;
   if (w.wtype == SH_W_LINEAR) return (w.dmax - d) / (w.dmax - w.dmin);  // utils.py:235,:259 (no epsilon: NaN if flat)
   return 1.0f / (1.0f + expf(w.lambda * (d - w.mu)));                   // utils.py:321,:344
 }
@@ -465,13 +466,26 @@ __global__ __launch_bounds__(256) void ntxent_bwd_finalize_kernel(LossArgs a, co
   *reinterpret_cast<float4*>(dZ + (size_t)lrow * kDim + c4 * 4) = o;
 }
 
+// explicit weight tensors for the functional surface (get_weights_* return values)
+__global__ __launch_bounds__(256) void weights_from_dist_kernel(const float* __restrict__ d, long long count, int wtype,
+                                                                const double* __restrict__ stats, int which, double mean_count,
+                                                                float lambda, float* __restrict__ w) {
+  Weighting q;
+  q.wtype = wtype;
+  q.dmax = (float)stats[which ? 3 : 0];
+  q.dmin = (float)stats[which ? 4 : 1];
+  q.mu = (float)(stats[which ? 5 : 2] / mean_count);
+  q.lambda = lambda;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) w[i] = weight_of(d[i], q);
+}
+
 static int make_args(const sh_ntxent_params* p, LossArgs* a) {
   SH_REQUIRE(p != nullptr, "ntxent: params is NULL");
   SH_REQUIRE(p->dim == kDim, "ntxent: projection width %d unsupported (kernel is built for output_dim = 128)", p->dim);
   SH_REQUIRE(p->B >= 1 && p->b_loc >= 1 && p->pair_off >= 0 && p->pair_off + p->b_loc <= p->B,
              "ntxent: bad row partition B=%d b_loc=%d pair_off=%d", p->B, p->b_loc, p->pair_off);
   SH_REQUIRE(p->temperature > 0.f, "ntxent: temperature must be > 0");
-  SH_REQUIRE(p->weight_type >= SH_W_NONE && p->weight_type <= SH_W_NONLINEAR, "ntxent: bad weight_type %d", p->weight_type);
+  SH_REQUIRE(p->weight_type >= SH_W_NONE && p->weight_type <= SH_W_EXPLICIT, "ntxent: bad weight_type %d", p->weight_type);
   a->map = {p->B, p->b_loc, p->pair_off};
   a->N = 2 * p->B;
   const int rb = ceil_div(2 * p->b_loc, 64);
@@ -534,6 +548,17 @@ int simhand_neg_dist(const float* J_all, int B, int F, int dist_mode, int b_loc,
   if (check_launch("neg_dist")) return 1;
   dist_stats_reduce_kernel<<<1, 1024, 0, s>>>(partial, (int)(grid.x * grid.y), stats);
   return check_launch("neg_dist_reduce");
+}
+
+int simhand_weights_from_dist(const float* dist, int64_t count, int weight_type, const double* stats, int positive,
+                              double mean_count, float lambda, float* weights, sh_stream_t stream) {
+  SH_REQUIRE(dist && stats && weights && count >= 1, "weights_from_dist: bad arguments");
+  SH_REQUIRE(weight_type == SH_W_LINEAR || weight_type == SH_W_NONLINEAR, "weights_from_dist: bad weight_type %d", weight_type);
+  int64_t g = (count + 255) / 256;
+  if (g > 4096) g = 4096;
+  ProfScope ps(SH_PROF_LOSS, (hipStream_t)stream, 0, (double)count * 8);
+  weights_from_dist_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>(dist, count, weight_type, stats, positive, mean_count, lambda, weights);
+  return check_launch("weights_from_dist");
 }
 
 size_t simhand_ntxent_workspace_bytes(const sh_ntxent_params* p) {

@@ -20,21 +20,38 @@ struct RowXform {
   float ux, uy;        // after translate + rotate (before second normalize)
   float a, b;          // cos, sin of theta (fp32-rounded like the reference's rot_mat)
   float n2, d2;        // ||u||, max(||u||, eps)
+  float n1;            // ||p||
 };
 
-__device__ __forceinline__ RowXform row_forward(float px, float py, int row, const int64_t* jx, const int64_t* jy,
-                                                const double* angle, int img_h, int img_w) {
+struct PPArgs {
+  const int64_t* jx;   // raw collated jitters (int64) or null
+  const int64_t* jy;
+  const float* tx;     // OR: ready translation factors (translate_encodings' arguments) or null
+  const float* ty;
+  const double* angle; // degrees or null
+  int img_h, img_w;
+  int flags;           // SH_PP_* bits
+};
+
+__device__ __forceinline__ RowXform row_forward(float px, float py, int row, const PPArgs& a) {
   RowXform r;
-  const float n1 = sqrtf(wave_sum(px * px + py * py));
-  const float d1 = fmaxf(n1, kNormEps);
-  r.inv_d1 = 1.0f / d1;
-  r.qx = px / d1;
-  r.qy = py / d1;
+  r.inv_d1 = 1.0f;
+  r.qx = px;
+  r.qy = py;
+  r.n1 = 1.0f;
+  if (a.flags & SH_PP_NORM_IN) {
+    const float n1 = sqrtf(wave_sum(px * px + py * py));
+    const float d1 = fmaxf(n1, kNormEps);
+    r.n1 = n1;
+    r.inv_d1 = 1.0f / d1;
+    r.qx = px / d1;
+    r.qy = py / d1;
+  }
   float x = r.qx, y = r.qy;
-  if (jx != nullptr) {
+  if (a.jx != nullptr || a.tx != nullptr) {
     // -(jitter / float(size)) * (max - min), simhand_w_model.py:68-83, utils.py:674-682
-    const float tx = -((float)jx[row] / (float)img_h);
-    const float ty = -((float)jy[row] / (float)img_w);
+    const float tx = a.tx ? a.tx[row] : -((float)a.jx[row] / (float)a.img_h);
+    const float ty = a.ty ? a.ty[row] : -((float)a.jy[row] / (float)a.img_w);
     const float rx = wave_max(x) - wave_min(x);
     const float ry = wave_max(y) - wave_min(y);
     x += tx * rx;
@@ -42,9 +59,10 @@ __device__ __forceinline__ RowXform row_forward(float px, float py, int row, con
   }
   r.a = 1.0f;
   r.b = 0.0f;
-  if (angle != nullptr) {
+  if (a.angle != nullptr) {
     // theta = (-angle) * pi / 180 in float64 (collated dtype), matrix rounded to fp32: utils.py:622-631
-    const double th = (-angle[row]) * 3.141592653589793 / 180.0;
+    const double deg = (a.flags & SH_PP_ANGLE_AS_GIVEN) ? a.angle[row] : -a.angle[row];
+    const double th = deg * 3.141592653589793 / 180.0;
     const double alpha = cos(th), beta = sin(th);
     const float cx = wave_sum(x) / 64.0f;
     const float cy = wave_sum(y) / 64.0f;
@@ -59,37 +77,37 @@ __device__ __forceinline__ RowXform row_forward(float px, float py, int row, con
   }
   r.ux = x;
   r.uy = y;
-  r.n2 = sqrtf(wave_sum(x * x + y * y));
-  r.d2 = fmaxf(r.n2, kNormEps);
+  r.n2 = 1.0f;
+  r.d2 = 1.0f;
+  if (a.flags & SH_PP_NORM_OUT) {
+    r.n2 = sqrtf(wave_sum(x * x + y * y));
+    r.d2 = fmaxf(r.n2, kNormEps);
+  }
   return r;
 }
 
-__global__ __launch_bounds__(256) void postprocess_fwd_kernel(const float* __restrict__ P, int N,
-                                                              const int64_t* __restrict__ jx, const int64_t* __restrict__ jy,
-                                                              const double* __restrict__ angle, int img_h, int img_w,
+__global__ __launch_bounds__(256) void postprocess_fwd_kernel(const float* __restrict__ P, int N, PPArgs a,
                                                               float* __restrict__ Z) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= N) return;
   const float2 p = *reinterpret_cast<const float2*>(P + (size_t)row * 128 + 2 * lane);
-  const RowXform r = row_forward(p.x, p.y, row, jx, jy, angle, img_h, img_w);
+  const RowXform r = row_forward(p.x, p.y, row, a);
   *reinterpret_cast<float2*>(Z + (size_t)row * 128 + 2 * lane) = make_float2(r.ux / r.d2, r.uy / r.d2);
 }
 
-__global__ __launch_bounds__(256) void postprocess_bwd_kernel(const float* __restrict__ P, int N,
-                                                              const int64_t* __restrict__ jx, const int64_t* __restrict__ jy,
-                                                              const double* __restrict__ angle, int img_h, int img_w,
+__global__ __launch_bounds__(256) void postprocess_bwd_kernel(const float* __restrict__ P, int N, PPArgs a,
                                                               const float* __restrict__ dZ, float* __restrict__ dP) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= N) return;
   const float2 p = *reinterpret_cast<const float2*>(P + (size_t)row * 128 + 2 * lane);
   const float2 g = *reinterpret_cast<const float2*>(dZ + (size_t)row * 128 + 2 * lane);
-  const RowXform r = row_forward(p.x, p.y, row, jx, jy, angle, img_h, img_w);
+  const RowXform r = row_forward(p.x, p.y, row, a);
   // second normalize: z = u / d2
   const float zx = r.ux / r.d2, zy = r.uy / r.d2;
   float dux = g.x / r.d2, duy = g.y / r.d2;
-  if (r.n2 > kNormEps) {
+  if ((a.flags & SH_PP_NORM_OUT) && r.n2 > kNormEps) {
     const float dot = wave_sum(zx * g.x + zy * g.y);
     dux -= zx * dot / r.d2;
     duy -= zy * dot / r.d2;
@@ -99,8 +117,7 @@ __global__ __launch_bounds__(256) void postprocess_bwd_kernel(const float* __res
   const float dqy = r.b * dux + r.a * duy;
   // first normalize: q = p / d1
   float dpx = dqx * r.inv_d1, dpy = dqy * r.inv_d1;
-  const float n1sq = wave_sum(p.x * p.x + p.y * p.y);
-  if (sqrtf(n1sq) > kNormEps) {
+  if ((a.flags & SH_PP_NORM_IN) && r.n1 > kNormEps) {
     const float dot = wave_sum(r.qx * dqx + r.qy * dqy);
     dpx -= r.qx * dot * r.inv_d1;
     dpy -= r.qy * dot * r.inv_d1;
@@ -164,28 +181,37 @@ using namespace sh;
 
 extern "C" {
 
-static int pp_check(const void* a, const void* b, int N, const int64_t* jx, const int64_t* jy, int h, int w, const char* who) {
+static int pp_make(const void* a, const void* b, int N, const int64_t* jx, const int64_t* jy, const float* tx, const float* ty,
+                   const double* angle, int h, int w, int flags, PPArgs* out, const char* who) {
   SH_REQUIRE(a && b, "%s: NULL pointer", who);
   SH_REQUIRE(N >= 1, "%s: N must be >= 1", who);
   SH_REQUIRE((jx == nullptr) == (jy == nullptr), "%s: jitter_x and jitter_y must both be given or both NULL", who);
-  SH_REQUIRE(h > 0 && w > 0, "%s: bad image size %dx%d", who, h, w);
+  SH_REQUIRE((tx == nullptr) == (ty == nullptr), "%s: translate_x and translate_y must both be given or both NULL", who);
+  SH_REQUIRE(!(jx && tx), "%s: give raw jitters OR ready translation factors, not both", who);
+  SH_REQUIRE(!jx || (h > 0 && w > 0), "%s: bad image size %dx%d", who, h, w);
+  out->jx = jx; out->jy = jy; out->tx = tx; out->ty = ty; out->angle = angle;
+  out->img_h = h; out->img_w = w; out->flags = flags;
   return 0;
 }
 
-int simhand_proj_postprocess_fwd(const float* P, int N, const int64_t* jitter_x, const int64_t* jitter_y, const double* angle,
-                                 int img_h, int img_w, float* Z, sh_stream_t stream) {
-  if (pp_check(P, Z, N, jitter_x, jitter_y, img_h, img_w, "proj_postprocess_fwd")) return 1;
+int simhand_proj_postprocess_fwd(const float* P, int N, const int64_t* jitter_x, const int64_t* jitter_y, const float* translate_x,
+                                 const float* translate_y, const double* angle, int img_h, int img_w, int flags, float* Z,
+                                 sh_stream_t stream) {
+  PPArgs a;
+  if (pp_make(P, Z, N, jitter_x, jitter_y, translate_x, translate_y, angle, img_h, img_w, flags, &a, "proj_postprocess_fwd")) return 1;
   ProfScope ps(SH_PROF_MISC, (hipStream_t)stream, 0, (double)N * 128 * 8);
-  postprocess_fwd_kernel<<<ceil_div(N, 4), 256, 0, (hipStream_t)stream>>>(P, N, jitter_x, jitter_y, angle, img_h, img_w, Z);
+  postprocess_fwd_kernel<<<ceil_div(N, 4), 256, 0, (hipStream_t)stream>>>(P, N, a, Z);
   return check_launch("proj_postprocess_fwd");
 }
 
-int simhand_proj_postprocess_bwd(const float* P, int N, const int64_t* jitter_x, const int64_t* jitter_y, const double* angle,
-                                 int img_h, int img_w, const float* dZ, float* dP, sh_stream_t stream) {
-  if (pp_check(P, dP, N, jitter_x, jitter_y, img_h, img_w, "proj_postprocess_bwd")) return 1;
+int simhand_proj_postprocess_bwd(const float* P, int N, const int64_t* jitter_x, const int64_t* jitter_y, const float* translate_x,
+                                 const float* translate_y, const double* angle, int img_h, int img_w, int flags, const float* dZ,
+                                 float* dP, sh_stream_t stream) {
+  PPArgs a;
+  if (pp_make(P, dP, N, jitter_x, jitter_y, translate_x, translate_y, angle, img_h, img_w, flags, &a, "proj_postprocess_bwd")) return 1;
   SH_REQUIRE(dZ, "proj_postprocess_bwd: dZ is NULL");
   ProfScope ps(SH_PROF_MISC, (hipStream_t)stream, 0, (double)N * 128 * 12);
-  postprocess_bwd_kernel<<<ceil_div(N, 4), 256, 0, (hipStream_t)stream>>>(P, N, jitter_x, jitter_y, angle, img_h, img_w, dZ, dP);
+  postprocess_bwd_kernel<<<ceil_div(N, 4), 256, 0, (hipStream_t)stream>>>(P, N, a, dZ, dP);
   return check_launch("proj_postprocess_bwd");
 }
 

@@ -1,0 +1,79 @@
+"""One-process-per-GPU data parallelism over RCCL (replaces the reference's
+single-process nn.DataParallel, src/experiments/main.py:152-163).
+
+* ``init_from_env`` -- reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun) and
+  initialises ``torch.distributed`` (backend "nccl" == RCCL on ROCm; "gloo" on CPU tests).
+* ``allreduce_gradients`` -- bucketed SUM all-reduce of parameter gradients.  The loss is
+  already normalised by the GLOBAL row count N and every rank back-propagates only
+  through its own rows, so the per-rank gradients ADD up to the single-process
+  gradient (no division by world size).  Buckets default to 64 MiB: xGMI rings are
+  per-link bound (about 153 GB/s), a ResNet-50's 98.5 MB of fp32 gradients is two
+  buckets, each about 0.7 ms on the wire.
+* ``shard_pairs`` -- contiguous pair ranges per rank (both views of a pair stay together).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+HSA_IPC_ENV = "HSA_ENABLE_IPC_MODE_LEGACY"
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+    """Returns (rank, local_rank, world_size); no-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault(HSA_IPC_ENV, "0")  # dmabuf IPC only on this pool
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_pairs(global_pairs: int, rank: int, world: int) -> Tuple[int, int]:
+    """(first pair, number of pairs) of this rank; the global batch must divide evenly
+    (the loss kernel's row map assumes equal shards)."""
+    if global_pairs % world:
+        raise ValueError(f"global batch {global_pairs} is not divisible by world size {world}")
+    b = global_pairs // world
+    return rank * b, b
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20) -> None:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    grads: List[torch.Tensor] = [p.grad for p in params if p.grad is not None]
+    bucket: List[torch.Tensor] = []
+    size = 0
+    pending = []
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        pending.append((work, flat, bucket))
+        bucket, size = [], 0
+
+    for g in reversed(grads):  # reverse registration order ~ order of production in backward
+        bucket.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            flush()
+    flush()
+    for work, flat, bucket_ in pending:
+        work.wait()
+        off = 0
+        for g in bucket_:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n

@@ -1,0 +1,182 @@
+"""Minimal stand-ins for the pytorch_lightning 1.8 pieces the reference's hot
+path touches (pytorch_lightning is not installed in this image and is not part
+of the hot path): ``LightningModule`` (nn.Module + ``log`` /
+``save_hyperparameters`` / ``trainer``), ``seed_everything``,
+``ModelCheckpoint`` (monitor / mode / save_top_k / filename template of
+src/experiments/main.py:143-149) and a ``Trainer`` whose ``fit`` runs the
+training_step -> backward -> optimizer/scheduler step loop with one process
+per GPU (RCCL) instead of the reference's ``strategy="dp"``.
+"""
+from __future__ import annotations
+
+import os
+import random
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+def seed_everything(seed: int) -> int:
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    os.environ["PL_GLOBAL_SEED"] = str(seed)
+    return seed
+
+
+class LightningModule(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+        self.trainer: Optional["Trainer"] = None
+        self.logged: Dict[str, Any] = {}
+        self.hparams: Dict[str, Any] = {}
+
+    def log(self, name: str, value, *a, **k) -> None:
+        self.logged[name] = value
+
+    def save_hyperparameters(self, *a, **k) -> None:
+        cfg = getattr(self, "config", None)
+        if cfg is not None:
+            self.hparams = {"config": dict(cfg)}
+
+
+class ModelCheckpoint:
+    """monitor='contrastive_loss', mode='min', save_top_k, filename template
+    with {epoch:02d} and {contrastive_loss:.6f} (main.py:143-149).  Files are
+    Lightning-style dicts: state_dict, hyper_parameters, optimizer_states,
+    lr_schedulers, epoch, global_step."""
+
+    def __init__(self, save_top_k: int = 3, monitor: str = "contrastive_loss", mode: str = "min",
+                 filename: Optional[str] = None, dirpath: Optional[str] = None):
+        self.save_top_k, self.monitor, self.mode = save_top_k, monitor, mode
+        self.filename = filename or "{epoch:02d}"
+        self.dirpath = dirpath
+        self.best_model_path = ""
+        self.kept: List = []  # (score, path)
+
+    def format_name(self, epoch: int, metrics: Dict[str, float]) -> str:
+        name = self.filename
+        name = name.replace("{epoch:02d}", f"epoch={epoch:02d}")
+        for k, v in metrics.items():
+            name = name.replace("{" + k + ":.6f}", f"{k}={v:.6f}")
+        return name + ".ckpt"
+
+    def on_epoch_end(self, trainer: "Trainer", module: LightningModule, epoch: int, metrics: Dict[str, float]) -> None:
+        if self.save_top_k == 0 or self.monitor not in metrics or trainer.global_rank != 0:
+            return
+        score = metrics[self.monitor]
+        key = score if self.mode == "min" else -score
+        if self.save_top_k > 0 and len(self.kept) >= self.save_top_k and key >= max(s for s, _ in self.kept):
+            return
+        os.makedirs(self.dirpath, exist_ok=True)
+        path = os.path.join(self.dirpath, self.format_name(epoch, metrics))
+        torch.save(trainer.checkpoint_dict(module, epoch), path)
+        self.kept.append((key, path))
+        self.kept.sort(key=lambda t: t[0])
+        while self.save_top_k > 0 and len(self.kept) > self.save_top_k:
+            _, drop = self.kept.pop()
+            if os.path.exists(drop):
+                os.remove(drop)
+        self.best_model_path = self.kept[0][1]
+
+
+class Trainer:
+    """fit loop for the contrastive step classes.  precision: 32 -> fp32 kernels,
+    "bf16" / 16 -> bf16 MFMA kernels (the reference's fp16 AMP has no GradScaler
+    equivalent here: bf16 keeps the fp32 exponent range, master weights stay fp32)."""
+
+    def __init__(self, max_epochs: int = 1, precision=32, callbacks: Optional[list] = None, log_every_n_steps: int = 5,
+                 default_root_dir: str = ".", max_steps: int = -1, logger=None, **_ignored):
+        self.max_epochs, self.precision, self.callbacks = max_epochs, precision, callbacks or []
+        self.log_every_n_steps, self.default_root_dir, self.max_steps = log_every_n_steps, default_root_dir, max_steps
+        self.global_step = 0
+        self.current_epoch = 0
+        self.history: List[Dict[str, float]] = []
+        self.optimizers: list = []
+        self.schedulers: list = []
+
+    @property
+    def world_size(self) -> int:
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    @property
+    def global_rank(self) -> int:
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+    @property
+    def compute_dtype(self) -> torch.dtype:
+        return torch.float32 if str(self.precision) == "32" else torch.bfloat16
+
+    def checkpoint_dict(self, module: LightningModule, epoch: int) -> dict:
+        return {
+            "epoch": epoch, "global_step": self.global_step, "pytorch-lightning_version": "1.8.0-compatible",
+            "state_dict": module.state_dict(), "hyper_parameters": module.hparams,
+            "optimizer_states": [o.state_dict() for o in self.optimizers],
+            "lr_schedulers": [s["scheduler"].state_dict() for s in self.schedulers],
+        }
+
+    def fit(self, model: LightningModule, train_dataloaders=None, val_dataloaders=None, ckpt_path: Optional[str] = None):
+        from .dist import allreduce_gradients
+
+        model.trainer = self
+        if hasattr(model, "set_compute_dtype"):
+            model.set_compute_dtype(self.compute_dtype)
+        device = torch.device("cuda", torch.cuda.current_device())
+        model.to(device)
+        model.setup("fit")
+        opts, scheds = model.configure_optimizers()
+        self.optimizers, self.schedulers = opts, scheds
+        start_epoch = 0
+        if ckpt_path:
+            ck = torch.load(ckpt_path, map_location=device)
+            model.load_state_dict(ck["state_dict"])
+            for o, s in zip(opts, ck.get("optimizer_states", [])):
+                o.load_state_dict(s)
+            for s, st in zip(scheds, ck.get("lr_schedulers", [])):
+                s["scheduler"].load_state_dict(st)
+            start_epoch, self.global_step = ck.get("epoch", -1) + 1, ck.get("global_step", 0)
+        for cb in self.callbacks:
+            if isinstance(cb, ModelCheckpoint) and cb.dirpath is None:
+                cb.dirpath = os.path.join(self.default_root_dir, "checkpoints")
+        model.train()
+        for epoch in range(start_epoch, self.max_epochs):
+            self.current_epoch = epoch
+            outputs = []
+            for batch_idx, batch in enumerate(train_dataloaders):
+                batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                out = model.training_step(batch, batch_idx)
+                loss = out["loss"]
+                for o in opts:
+                    o.zero_grad(set_to_none=True)
+                loss.backward()
+                if self.world_size > 1:
+                    allreduce_gradients(model.parameters())
+                for o in opts:
+                    o.step()
+                for s in scheds:
+                    if s.get("interval", "epoch") == "step":
+                        s["scheduler"].step()
+                self.global_step += 1
+                outputs.append({k: v.detach() for k, v in out.items() if torch.is_tensor(v)})
+                if self.global_rank == 0 and self.global_step % self.log_every_n_steps == 0:
+                    print(f"epoch {epoch} step {self.global_step} contrastive_loss {float(loss):.6f}", flush=True)
+                if 0 < self.max_steps <= self.global_step:
+                    break
+            model.training_epoch_end(outputs)
+            metrics = {k: float(v) for k, v in model.train_metrics_epoch.items()}
+            metrics["contrastive_loss"] = metrics.get("loss", float("nan"))
+            self.history.append(metrics)
+            for cb in self.callbacks:
+                if hasattr(cb, "on_epoch_end"):
+                    cb.on_epoch_end(self, model, epoch, metrics)
+            for s in scheds:
+                if s.get("interval", "epoch") == "epoch":
+                    s["scheduler"].step()
+            if 0 < self.max_steps <= self.global_step:
+                break
+        return self

@@ -1,0 +1,86 @@
+"""Optimizer + schedule of src/models/base_model.py:59-106 ("next" row 8f-1):
+Adam wrapped by pl_bolts' LARSWrapper, LinearWarmupCosineAnnealingLR stepped per
+optimizer step.  pl_bolts 0.2.2 is not vendored by the reference nor installed
+here -- semantics restated from its published source, PARITY UNPINNED (checked
+against the restatement in oracle/optim.py).  The parameter update itself is one
+fused HIP launch per tensor (``simhand_lars_adam_step``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable
+
+import torch
+
+from .. import ops
+
+
+class LARSAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr) optionally wrapped like LARSWrapper(eta=0.02, clip=True, eps=1e-8)."""
+
+    def __init__(self, params: Iterable, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 lars: bool = True, lars_eta: float = 0.02, lars_eps: float = 1e-8, lars_clip: bool = True):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, lars=lars, lars_eta=lars_eta,
+                        lars_eps=lars_eps, lars_clip=lars_clip)
+        super().__init__(params, defaults)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                ops.lars_adam_step(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"],
+                                   group["weight_decay"], group["lars"], group["betas"], group["eps"], group["lars_eta"],
+                                   group["lars_eps"], group["lars_clip"])
+
+
+class LinearWarmupCosineAnnealingLR:
+    """Closed form of pl_bolts' scheduler (warmup_start_lr -> base over
+    ``warmup_epochs`` steps, then half-cosine to eta_min at ``max_epochs``)."""
+
+    def __init__(self, optimizer, warmup_epochs: int, max_epochs: int, warmup_start_lr: float = 0.0, eta_min: float = 0.0):
+        self.optimizer, self.warmup_epochs, self.max_epochs = optimizer, warmup_epochs, max_epochs
+        self.warmup_start_lr, self.eta_min = warmup_start_lr, eta_min
+        self.base_lrs = [g["lr"] for g in optimizer.param_groups]
+        self.last_epoch = 0
+        self._apply()
+
+    def lr_at(self, t: int, base: float) -> float:
+        if t < self.warmup_epochs:
+            if self.warmup_epochs <= 1:
+                return base
+            return self.warmup_start_lr + t * (base - self.warmup_start_lr) / (self.warmup_epochs - 1)
+        span = max(1, self.max_epochs - self.warmup_epochs)
+        return self.eta_min + 0.5 * (base - self.eta_min) * (1 + math.cos(math.pi * (t - self.warmup_epochs) / span))
+
+    def _apply(self):
+        for g, b in zip(self.optimizer.param_groups, self.base_lrs):
+            g["lr"] = self.lr_at(self.last_epoch, b)
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch, "base_lrs": self.base_lrs}
+
+    def load_state_dict(self, s):
+        self.last_epoch, self.base_lrs = s["last_epoch"], s["base_lrs"]
+        self._apply()
+
+
+class CosineAnnealingLR(LinearWarmupCosineAnnealingLR):
+    """torch.optim.lr_scheduler.CosineAnnealingLR(T_max) closed form (optimizer='adam' branch, base_model.py:101-102)."""
+
+    def __init__(self, optimizer, T_max: int):
+        super().__init__(optimizer, 0, T_max, 0.0, 0.0)

@@ -1,0 +1,308 @@
+"""Encoder: ``ResNetModel`` with the reference's interface, executed by HIP kernels.
+
+Mirrors src/models/resnet_model.py:6-58 of the reference (``features`` =
+Sequential(conv1, bn1, relu, maxpool, layer1..4, AdaptiveAvgPool2d(1)) indexed
+0..8, unused ``final_layer`` = Linear(C, 64); ``forward`` returns the flattened
+(N, C) embedding in mode "pretraining") on top of a torchvision-v1.5-style
+ResNet-18/34/50/101/152 (torchvision 0.13.1 is not vendored by the reference;
+structure restated from its published definition).  The nn.Conv2d /
+nn.BatchNorm2d modules below are PARAMETER CONTAINERS ONLY (state_dict keys,
+init, optimizer param groups): their ``forward`` is never called.  All
+arithmetic runs in ``ResNetEngine`` through the C ABI:
+
+  stem  : im2col (NCHW fp32 -> [M][192]) -> MFMA GEMM (+fused BN partial sums)
+          -> BN finalize -> BN-apply+ReLU -> MaxPool(3,2,1)
+  block : conv (implicit GEMM, fused BN partial sums) -> BN finalize ->
+          BN-apply(+ReLU)(+residual) ...
+  tail  : global average pool -> fp32 (N, C)
+
+and the hand-written backward (BN bwd -> wgrad + dgrad per conv, residual
+gradients merged by the dgrad epilogue's accumulate flag).  Activations are
+NHWC in the compute dtype (fp32 parity mode or bf16), weights are re-packed
+OIHW fp32 -> KRSC / CRSK compute dtype when the parameter version changes.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from .. import ops
+
+STEM_KPAD = 192  # 7*7*3 = 147 padded to a multiple of 64 (one bf16 k-step)
+
+
+# --------------------------------------------------------------------------
+# parameter containers with torchvision's module / key names
+# --------------------------------------------------------------------------
+def _conv(cin, cout, k, stride=1, pad=0) -> nn.Conv2d:
+    return nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = _conv(inplanes, planes, 3, stride, 1)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU()
+        self.conv2 = _conv(planes, planes, 3, 1, 1)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def units(self):
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2)]
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = _conv(inplanes, planes, 1)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = _conv(planes, planes, 3, stride, 1)  # v1.5: stride on the 3x3
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = _conv(planes, planes * 4, 1)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU()
+        self.downsample = downsample
+
+    def units(self):
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+
+
+_SPECS = {"18": (BasicBlock, [2, 2, 2, 2]), "34": (BasicBlock, [3, 4, 6, 3]), "50": (Bottleneck, [3, 4, 6, 3]),
+          "101": (Bottleneck, [3, 4, 23, 3]), "152": (Bottleneck, [3, 8, 36, 3])}
+
+
+class _Backbone(nn.Module):
+    """Same construction order as torchvision's ResNet so a given torch seed
+    yields the same initial weights."""
+
+    def __init__(self, size: str):
+        super().__init__()
+        if size not in _SPECS:
+            raise NotImplementedError(size)
+        block, layers = _SPECS[size]
+        self.inplanes = 64
+        self.conv1 = _conv(3, 64, 7, 2, 3)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU()
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make(block, 64, layers[0], 1)
+        self.layer2 = self._make(block, 128, layers[1], 2)
+        self.layer3 = self._make(block, 256, layers[2], 2)
+        self.layer4 = self._make(block, 512, layers[3], 2)
+        self.fc = nn.Linear(512 * block.expansion, 1000)  # replaced by the wrapper; kept for init-stream parity
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1.0)
+                nn.init.constant_(m.bias, 0.0)
+
+    def _make(self, block, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            down = nn.Sequential(_conv(self.inplanes, planes * block.expansion, 1, stride), nn.BatchNorm2d(planes * block.expansion))
+        mods = [block(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            mods.append(block(self.inplanes, planes))
+        return nn.Sequential(*mods)
+
+
+# --------------------------------------------------------------------------
+# engine
+# --------------------------------------------------------------------------
+class _Packed:
+    __slots__ = ("krsc", "crsk", "version")
+
+
+class _Unit:
+    """Saved tensors of one conv+BN unit for the backward pass."""
+    __slots__ = ("conv", "bn", "desc", "x", "y", "a", "st", "relu", "stem")
+
+
+class ResNetEngine:
+    def __init__(self, features: nn.Sequential, dtype: torch.dtype = torch.float32):
+        self.features = features
+        self.dtype = dtype
+        self._packs: Dict[int, _Packed] = {}
+
+    # -- weights -------------------------------------------------------------
+    def _pack(self, conv: nn.Conv2d, need_t: bool, k_pad: Optional[int] = None) -> _Packed:
+        w = conv.weight
+        p = self._packs.get(id(w))
+        ver = (w._version, w.data_ptr(), self.dtype)
+        if p is None or p.version != ver:
+            p = _Packed()
+            p.krsc = ops.pack_krsc(w.detach(), self.dtype, k_pad)
+            p.crsk = None
+            p.version = ver
+            self._packs[id(w)] = p
+        if need_t and p.crsk is None:
+            p.crsk = ops.pack_crsk(w.detach(), self.dtype)
+        return p
+
+    # -- forward ---------------------------------------------------------------
+    def _bn(self, bn: nn.BatchNorm2d, part, m, c, training):
+        if training:
+            return ops.bn_finalize(part, m, c, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                   bn.num_batches_tracked, None, bn.eps, bn.momentum)
+        return ops.bn_eval_state(c, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+
+    def _conv_bn(self, conv, bn, x, relu, residual, training, save: Optional[list], need_dgrad=True):
+        n, h, w, cin = x.shape
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        d = ops.conv_desc(n, h, w, cin, conv.out_channels, k, k, s, p, self.dtype)
+        pk = self._pack(conv, need_t=save is not None and need_dgrad)
+        y, part = ops.conv2d_fwd(d, x, pk.krsc, want_stats=training)
+        m = n * d.ho * d.wo
+        st = self._bn(bn, part, m, conv.out_channels, training)
+        a = ops.bn_apply(y, st, m, conv.out_channels, relu, residual)
+        if save is not None:
+            u = _Unit()
+            u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv, bn, d, x, y, a, st, relu, False
+            save.append(u)
+        return a
+
+    def forward(self, images: Tensor, training: bool, want_ctx: bool):
+        f = self.features
+        conv1, bn1 = f[0], f[1]
+        n, _, h, w = images.shape
+        ctx: Optional[dict] = {"units": [], "blocks": []} if want_ctx else None
+        # stem: im2col + GEMM
+        col = ops.im2col_nchw(images, 7, 7, 2, 3, STEM_KPAD, self.dtype)
+        ho, wo = col.shape[1], col.shape[2]
+        d = ops.conv_desc(n, ho, wo, STEM_KPAD, 64, 1, 1, 1, 0, self.dtype)
+        pk = self._pack(conv1, need_t=False, k_pad=STEM_KPAD)
+        y, part = ops.conv2d_fwd(d, col, pk.krsc, want_stats=training)
+        m = n * ho * wo
+        st = self._bn(bn1, part, m, 64, training)
+        a = ops.bn_apply(y, st, m, 64, True, None)
+        x, idx = ops.maxpool_fwd(a)
+        if want_ctx:
+            u = _Unit()
+            u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv1, bn1, d, col, y, a, st, True, True
+            ctx["stem"] = u
+            ctx["pool_idx"] = idx
+            ctx["pool_in_shape"] = tuple(a.shape)
+        for li in (4, 5, 6, 7):
+            for blk in f[li]:
+                saved: Optional[list] = [] if want_ctx else None
+                inp = x
+                units = blk.units()
+                t = inp
+                for conv, bn in units[:-1]:
+                    t = self._conv_bn(conv, bn, t, True, None, training, saved)
+                idn = inp
+                dsaved: Optional[list] = [] if want_ctx else None
+                if blk.downsample is not None:
+                    idn = self._conv_bn(blk.downsample[0], blk.downsample[1], inp, False, None, training, dsaved)
+                conv, bn = units[-1]
+                x = self._conv_bn(conv, bn, t, True, idn, training, saved)
+                if want_ctx:
+                    ctx["blocks"].append((saved, dsaved[0] if dsaved else None))
+        enc = ops.avgpool_fwd(x)
+        if want_ctx:
+            ctx["last_shape"] = tuple(x.shape)
+        out = enc if enc.dtype == torch.float32 else ops.cast(enc, torch.float32)
+        return out, ctx
+
+    # -- backward --------------------------------------------------------------
+    def _unit_bwd(self, u: _Unit, da, grads: dict, want_dres: bool, need_dx: bool, dx_into=None):
+        """BN bwd -> wgrad (+ dgrad).  Returns (dx or None, dres or None)."""
+        d = u.desc
+        m = d.n * d.ho * d.wo
+        c = d.cout
+        dy, dres, dg, db = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, want_dres)
+        grads[u.bn.weight] = dg
+        grads[u.bn.bias] = db
+        dw = ops.conv2d_wgrad(d, u.x, dy)
+        w = u.conv.weight
+        grads[w] = ops.unpack_krsc_grad(dw, tuple(w.shape), STEM_KPAD if u.stem else None)
+        dx = None
+        if need_dx:
+            pk = self._pack(u.conv, need_t=True)
+            if dx_into is not None:
+                dx = ops.conv2d_dgrad(d, dy, pk.crsk, dx=dx_into, accumulate=True)
+            else:
+                dx = ops.conv2d_dgrad(d, dy, pk.crsk)
+        return dx, dres
+
+    def backward(self, ctx: dict, d_enc: Tensor) -> Dict[nn.Parameter, Tensor]:
+        grads: Dict[nn.Parameter, Tensor] = {}
+        g = d_enc.contiguous() if d_enc.dtype == self.dtype else ops.cast(d_enc.contiguous(), self.dtype)
+        dz = ops.avgpool_bwd(g, ctx["last_shape"])
+        for saved, ds in reversed(ctx["blocks"]):
+            last = saved[-1]
+            # out = relu(bn(conv(t)) + idn): dres is the gradient of the identity branch
+            dt_, dres = self._unit_bwd(last, dz, grads, want_dres=True, need_dx=True)
+            for u in reversed(saved[1:-1]):
+                dt_, _ = self._unit_bwd(u, dt_, grads, False, True)
+            first = saved[0]
+            if ds is not None:
+                dx, _ = self._unit_bwd(ds, dres, grads, False, True)
+                dz, _ = self._unit_bwd(first, dt_, grads, False, True, dx_into=dx)
+            else:
+                dz, _ = self._unit_bwd(first, dt_, grads, False, True, dx_into=dres)
+            saved.clear()
+        da = ops.maxpool_bwd(dz, ctx["pool_idx"], ctx["pool_in_shape"])
+        self._unit_bwd(ctx["stem"], da, grads, False, need_dx=False)
+        return grads
+
+
+class _EncoderFn(torch.autograd.Function):
+    """One autograd node for the whole backbone; params are passed so autograd
+    routes their gradients, the engine does the work."""
+
+    @staticmethod
+    def forward(ctx, images, engine, training, grad_mode, *params):
+        need = grad_mode and any(p.requires_grad for p in params)
+        if need and not training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the training step")
+        enc, ectx = engine.forward(images.contiguous(), training, need)
+        ctx.engine, ctx.ectx, ctx.params = engine, ectx, params
+        return enc
+
+    @staticmethod
+    def backward(ctx, d_enc):
+        grads = ctx.engine.backward(ctx.ectx, d_enc)
+        ctx.ectx = None
+        return (None, None, None, None) + tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
+
+
+class ResNetModel(nn.Module):
+    """Reference-compatible wrapper (src/models/resnet_model.py:6-58).
+
+    ``config.model.backend_model`` in {"resnet18",...,"resnet152"};
+    ``config.model.pretrained`` is accepted but ImageNet weights are not
+    fetched (no network): seeded random init, as in the parity oracle.
+    The reference's per-forward ``print(self.features)`` (:49) is dropped."""
+
+    def __init__(self, config, mode: str = "", compute_dtype: torch.dtype = torch.float32):
+        super().__init__()
+        self.mode = mode
+        name = config.model.backend_model.lower()
+        if not name.startswith("resnet") or name[6:] not in _SPECS:
+            raise NotImplementedError(name)
+        m = _Backbone(name[6:])
+        self.features = nn.Sequential(m.conv1, m.bn1, m.relu, m.maxpool, m.layer1, m.layer2, m.layer3, m.layer4,
+                                      nn.AdaptiveAvgPool2d((1, 1)))
+        self.final_layer = nn.Sequential(nn.Linear(m.fc.in_features, 21 * 3 + 1))
+        self.out_features = m.fc.in_features
+        self.engine = ResNetEngine(self.features, compute_dtype)
+
+    def set_compute_dtype(self, dtype: torch.dtype) -> None:
+        self.engine = ResNetEngine(self.features, dtype)
+
+    def forward(self, x: Tensor) -> Tensor:
+        if self.mode != "pretraining":
+            raise NotImplementedError("only mode='pretraining' (the contrastive hot path) is built; "
+                                      "the supervised 2.5D head is out of scope (SURVEY 2 #5)")
+        params = [p for p in self.features.parameters()]
+        return _EncoderFn.apply(x, self.engine, self.training, torch.is_grad_enabled(), *params)

@@ -74,6 +74,15 @@ def neg_dist(J_all: torch.Tensor, B: int, mode: str, b_loc: int, pair_off: int, 
     return D
 
 
+def weights_from_dist(dist: torch.Tensor, weight_type: str, stats: torch.Tensor, positive: bool, mean_count: float,
+                      lam: float = 0.0) -> torch.Tensor:
+    lib = _lib_dev()
+    w = torch.empty_like(dist)
+    check(lib.simhand_weights_from_dist(_ptr(dist), dist.numel(), _lib.WEIGHT_TYPES[weight_type], _ptr(stats), int(positive),
+                                        float(mean_count), float(lam or 0.0), _ptr(w), _stream()), "weights_from_dist")
+    return w
+
+
 def ntxent_fwd(plan: NtxentPlan, Z_all, D_loc, d_pos, stats) -> Tuple[torch.Tensor, torch.Tensor]:
     lib = _lib_dev()
     dev = Z_all.device
@@ -96,19 +105,19 @@ def ntxent_bwd(plan: NtxentPlan, Z_all, D_loc, d_pos, stats, neg_all, dloss) -> 
 
 
 # ------------------------------------------------------------------ post-process
-def proj_postprocess_fwd(P, jx, jy, angle, hw) -> torch.Tensor:
+def proj_postprocess_fwd(P, jx, jy, angle, hw, flags: int = _lib.PP_FUSED, tx=None, ty=None) -> torch.Tensor:
     lib = _lib_dev()
     Z = torch.empty_like(P)
-    check(lib.simhand_proj_postprocess_fwd(_ptr(P), P.shape[0], _ptr(jx), _ptr(jy), _ptr(angle), int(hw[0]), int(hw[1]), _ptr(Z),
-                                           _stream()), "proj_postprocess_fwd")
+    check(lib.simhand_proj_postprocess_fwd(_ptr(P), P.shape[0], _ptr(jx), _ptr(jy), _ptr(tx), _ptr(ty), _ptr(angle), int(hw[0]),
+                                           int(hw[1]), flags, _ptr(Z), _stream()), "proj_postprocess_fwd")
     return Z
 
 
-def proj_postprocess_bwd(P, jx, jy, angle, hw, dZ) -> torch.Tensor:
+def proj_postprocess_bwd(P, jx, jy, angle, hw, dZ, flags: int = _lib.PP_FUSED, tx=None, ty=None) -> torch.Tensor:
     lib = _lib_dev()
     dP = torch.empty_like(P)
-    check(lib.simhand_proj_postprocess_bwd(_ptr(P), P.shape[0], _ptr(jx), _ptr(jy), _ptr(angle), int(hw[0]), int(hw[1]), _ptr(dZ),
-                                           _ptr(dP), _stream()), "proj_postprocess_bwd")
+    check(lib.simhand_proj_postprocess_bwd(_ptr(P), P.shape[0], _ptr(jx), _ptr(jy), _ptr(tx), _ptr(ty), _ptr(angle), int(hw[0]),
+                                           int(hw[1]), flags, _ptr(dZ), _ptr(dP), _stream()), "proj_postprocess_bwd")
     return dP
 
 
@@ -239,6 +248,14 @@ def bn_finalize(part: torch.Tensor, m: int, c: int, gamma, beta, running_mean, r
     check(lib.simhand_bn_finalize(_ptr(part), nblk, m, c, _ptr(gamma), _ptr(beta), _ptr(pre_bias), eps, momentum,
                                   _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(st.mean), _ptr(st.invstd),
                                   _ptr(st.scale), _ptr(st.shift), _ptr(ws), nb, _stream()), "bn_finalize")
+    return st
+
+
+def bn_eval_state(c: int, gamma, beta, running_mean, running_var, eps: float = 1e-5) -> BNState:
+    lib = _lib_dev()
+    st = BNState(c, running_mean.device)
+    check(lib.simhand_bn_eval_params(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), eps, c, _ptr(st.scale),
+                                     _ptr(st.shift), _stream()), "bn_eval_params")
     return st
 
 

@@ -1,0 +1,53 @@
+"""Test helper: make gradient parity immune to ReLU-kink flips.
+
+An activation within an fp32 ulp of zero can land on either side of the ReLU kink under a different
+(equally valid) summation order, which perturbs every upstream gradient by ~1e-3..1e-2.  To compare
+gradients to round-off anyway, the HIP forward's ReLU masks are recorded and imposed on the oracle:
+its ReLU modules return ``input * mask`` (same value wherever both sides agree, identical routing of
+the gradient everywhere)."""
+import contextlib
+
+import torch
+
+
+@contextlib.contextmanager
+def record_hip_relu_masks(store: list):
+    from simhand_amd import ops
+
+    orig = ops.bn_apply
+
+    def bn_apply(y, st, m, c, relu, residual=None, out=None):
+        a = orig(y, st, m, c, relu, residual, out)
+        if relu:
+            store.append((a > 0).cpu())
+        return a
+
+    ops.bn_apply = bn_apply
+    try:
+        yield store
+    finally:
+        ops.bn_apply = orig
+
+
+@contextlib.contextmanager
+def impose_relu_masks(oracle_model: torch.nn.Module, masks: list):
+    """masks: NHWC (or (N,C)) boolean tensors in forward call order."""
+    it = iter(masks)
+    flips = []
+
+    def hook(mod, inp, out):
+        m = next(it)
+        x = inp[0]
+        if x.dim() == 4:
+            m = m.reshape(x.shape[0], x.shape[2], x.shape[3], x.shape[1]).permute(0, 3, 1, 2)
+        else:
+            m = m.reshape(x.shape)
+        flips.append(int(((x > 0) != m).sum()))
+        return x * m.to(x.dtype)
+
+    handles = [mod.register_forward_hook(hook) for mod in oracle_model.modules() if isinstance(mod, torch.nn.ReLU)]
+    try:
+        yield flips
+    finally:
+        for h in handles:
+            h.remove()

@@ -1,0 +1,255 @@
+"""End-to-end GPU parity of the training step (encoder + head + post-process + weighted
+NT-Xent, forward and backward) through the reference-shaped classes:
+  * against the golden outputs of the reference's own HandCLR_W / PeCLR_W / SimCLR
+    training_step (tests/golden/step_rn18.*), and
+  * against the CPU oracle run live on the same seeded weights and batch.
+
+Tolerances.  Loss and embeddings: 1e-3 relative fp32 (the north-star bar; observed ~1e-6).
+Gradients: a ReLU sits behind every BatchNorm, so an activation within one fp32 ulp of zero can
+take a different side of the kink under a different (equally valid) summation order; one such
+flip perturbs every gradient upstream of it by ~1e-3..1e-2 (measured: the oracle's own fp32 vs
+fp64 gradients differ by up to 3e-2 relative on ResNet-50 at these tiny batches).  Hence:
+the plain comparison only requires relative L2 <= 3e-2 per tensor, and the strict comparison
+imposes the HIP forward's ReLU masks on the oracle (tests/_kink.py), after which every gradient
+tensor must agree to round-off: median <= 1e-4, max <= 2e-3 relative L2 (1e-2 for ResNet-50,
+whose 53 BatchNorms at 8 images amplify round-off).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import step as orc
+from tests._kink import impose_relu_masks, record_hip_relu_masks
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+AUG = ["color_jitter", "crop", "random_crop", "resize", "rotate"]
+CASES = {
+    "HandCLR_W": ("simhand_w", dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg")),
+    "PeCLR_W": ("peclr_w", dict(weight_type="non_linear", diff_type="w_abs", pos_neg="neg")),
+    "SimCLR": ("simclr", dict()),
+}
+
+
+def _config(size, wcfg):
+    from simhand_amd.host.config import edict
+
+    return edict(resnet_size=size, projection_head_input_dim=2048, projection_head_hidden_dim=512, output_dim=128,
+                 augmentation=list(AUG), joints_type="augmented", use_pca=False, non_linear_lambda_pos=5.0,
+                 non_linear_lambda_neg=0.05, lr=1e-4, opt_weight_decay=1e-6, warmup_epochs=10, num_of_mini_batch=1,
+                 optimizer="LARS", batch_size=8, num_samples=64, **wcfg)
+
+
+def _product(cname, size, wcfg, oracle_model, dtype=torch.float32):
+    from simhand_amd.host import unsupervised
+
+    model = getattr(unsupervised, cname)(_config(size, wcfg), None, "train")
+    missing = model.load_state_dict(oracle_model.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.set_compute_dtype(dtype)
+    return model.to(DEV).train()
+
+
+def _to_dev(batch):
+    return {k: v.to(DEV) for k, v in batch.items()}
+
+
+def _grad_errors(model, oracle_model):
+    """per-tensor relative L2 error; BN-cancelled biases (analytically zero gradient) compared absolutely."""
+    og = dict(oracle_model.named_parameters())
+    errs = {}
+    for k, p in model.named_parameters():
+        want = og[k].grad
+        if want is None:
+            assert p.grad is None, f"{k}: reference has no grad (encoder.final_layer is unused)"
+            continue
+        assert p.grad is not None, k
+        got = p.grad.cpu()
+        if want.abs().max() < 1e-6:
+            assert got.abs().max() < 1e-5, k
+            continue
+        errs[k] = ((got - want).norm() / want.norm()).item()
+    return errs
+
+
+def _check_grads(model, oracle_model, median_tol, max_tol):
+    errs = _grad_errors(model, oracle_model)
+    vals = sorted(errs.values())
+    med = vals[len(vals) // 2]
+    worst = max(errs, key=errs.get)
+    assert med <= median_tol, f"median grad error {med:.3e}"
+    assert errs[worst] <= max_tol, f"{worst}: grad error {errs[worst]:.3e}"
+    for k in ("projection_head.3.weight", "projection_head.1.weight"):
+        assert errs[k] <= 2e-3, (k, errs[k])
+    return errs
+
+
+@pytest.mark.parametrize("cname", list(CASES))
+def test_step_rn18_matches_reference_golden_and_oracle(golden_dir, cname):
+    exp, wcfg = CASES[cname]
+    meta = json.load(open(os.path.join(golden_dir, "step_rn18.json")))[cname]
+    arrays = np.load(os.path.join(golden_dir, "step_rn18.npz"))
+    b, size, seed = meta["B"], meta["size"], meta["seed"]
+    batch = orc.synthetic_batch(b, size=size, seed=seed)
+    torch.manual_seed(seed)
+    om = orc.StepOracle(exp, "18", AUG, lambda_pos=5.0, lambda_neg=0.05, **wcfg).train()
+    # same torch seed + construction order as the reference run that produced the golden
+    with torch.no_grad():
+        checksum = float(sum(p.double().abs().sum() for p in om.parameters()))
+    assert abs(checksum - meta["param_checksum"]) < 1e-6 * meta["param_checksum"]
+    model = _product(cname, "18", wcfg, om)
+    assert list(model.state_dict().keys()) == meta["state_dict_keys"]
+    out = model.training_step(_to_dev(batch), 0)
+    loss = out["loss"]
+    loss.backward()
+    # (1) the reference's own numbers
+    assert abs(loss.item() - meta["loss"]) <= 1e-3 * abs(meta["loss"]), (loss.item(), meta["loss"])
+    assert sorted(out.keys()) == meta["metric_keys"]
+    assert sorted(model.logged.keys()) == meta["logged"]
+    assert sorted(model.plot_params.keys()) == meta["plot_params_keys"]
+    for k, v in meta["metrics"].items():
+        assert abs(float(out[k]) - v) <= 1e-3 * abs(v) + 1e-5, (k, float(out[k]), v)
+    gw = dict(model.named_parameters())
+    want = arrays[f"{cname}.dW_head3"]
+    got = gw["projection_head.3.weight"].grad.cpu().numpy()
+    assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()
+    want = arrays[f"{cname}.dW_stem"]
+    got = gw["encoder.features.0.weight"].grad.cpu().numpy()
+    assert np.linalg.norm(got - want) <= 3e-2 * np.linalg.norm(want)
+    rel = sorted(abs(gw[k].grad.norm().item() - v) / v for k, v in meta["grad_norms"].items() if v > 1e-6)
+    assert rel[len(rel) // 2] <= 1e-4 and rel[-1] <= 3e-2, (rel[len(rel) // 2], rel[-1])
+    assert sorted(k for k, p in gw.items() if p.grad is None) == sorted(meta["no_grad"])
+    # (2) the oracle, tensor by tensor
+    lo = om.contrastive_step(batch)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) <= 1e-4 * abs(lo.item())
+    _check_grads(model, om, 1e-2, 3e-2)
+    # (3) with the HIP forward's ReLU masks imposed on the oracle the kink ambiguity is gone:
+    #     every gradient tensor must agree to round-off
+    model.zero_grad()
+    om.zero_grad()
+    masks = []
+    with record_hip_relu_masks(masks):
+        loss2 = model.training_step(_to_dev(batch), 0)["loss"]
+    loss2.backward()
+    with impose_relu_masks(om, masks) as flips:
+        lo2 = om.contrastive_step(batch)
+    lo2.backward()
+    assert sum(flips) <= 20, flips
+    _check_grads(model, om, 1e-4, 2e-3)
+    # BatchNorm running statistics follow torch's update rule
+    osd, msd = om.state_dict(), model.state_dict()
+    for k in osd:
+        if "running" in k or "tracked" in k:
+            assert torch.allclose(msd[k].cpu().float(), osd[k].float(), rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.parametrize("size,b,img,max_tol", [("50", 4, 128, 1e-2), ("18", 6, 96, 2e-3), ("34", 4, 96, 2e-3)])
+def test_step_other_backbones_against_oracle(size, b, img, max_tol):
+    """Bottleneck / BasicBlock variants, ragged tile counts; embeddings to 1e-3."""
+    exp, wcfg = CASES["HandCLR_W"]
+    batch = orc.synthetic_batch(b, size=img, seed=21)
+    torch.manual_seed(3)
+    om = orc.StepOracle(exp, size, AUG, **wcfg).train()
+    model = _product("HandCLR_W", size, wcfg, om)
+    dev_batch = _to_dev(batch)
+    masks = []
+    with record_hip_relu_masks(masks):
+        loss = model.training_step(dev_batch, 0)["loss"]
+    loss.backward()
+    with impose_relu_masks(om, masks) as flips:
+        lo = om.contrastive_step(batch)
+    lo.backward()
+    # a few near-zero activations per million may change side; more would mean a real bug
+    assert sum(flips) <= max(20, 1e-5 * sum(m.numel() for m in masks)), flips
+    assert abs(loss.item() - lo.item()) <= 1e-3 * abs(lo.item()), (loss.item(), lo.item())
+    with torch.no_grad():
+        model.train()
+        z1, z2 = model.get_transformed_projections(dev_batch)  # second pass: same batch statistics
+    z = torch.cat((z1, z2)).cpu()
+    assert (z - om.last["z"].detach()).abs().max() <= 1e-3 * om.last["z"].abs().max()
+    _check_grads(model, om, 1e-3 if size == "50" else 1e-4, max_tol)
+
+
+def test_step_bf16_tracks_fp32():
+    """bf16 MFMA path (the benchmarked configuration): same step, loss within 2e-2 relative of the
+    fp32 oracle and gradient direction preserved (cosine > 0.98 on the projection head)."""
+    exp, wcfg = CASES["HandCLR_W"]
+    batch = orc.synthetic_batch(8, size=64, seed=9)
+    torch.manual_seed(4)
+    om = orc.StepOracle(exp, "18", AUG, **wcfg).train()
+    model = _product("HandCLR_W", "18", wcfg, om, dtype=torch.bfloat16)
+    loss = model.training_step(_to_dev(batch), 0)["loss"]
+    loss.backward()
+    lo = om.contrastive_step(batch)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) <= 2e-2 * abs(lo.item()), (loss.item(), lo.item())
+    g = dict(model.named_parameters())["projection_head.3.weight"].grad.cpu().flatten()
+    w = dict(om.named_parameters())["projection_head.3.weight"].grad.flatten()
+    cos = torch.dot(g, w) / (g.norm() * w.norm())
+    assert cos > 0.98, cos
+
+
+def test_eval_mode_forward_uses_running_stats():
+    exp, wcfg = CASES["HandCLR_W"]
+    batch = orc.synthetic_batch(4, size=64, seed=2)
+    torch.manual_seed(8)
+    om = orc.StepOracle(exp, "18", AUG, **wcfg)
+    om.train()
+    om.contrastive_step(batch)  # move the running stats away from their init
+    model = _product("HandCLR_W", "18", wcfg, om)
+    om.eval()
+    model.eval()
+    with torch.no_grad():
+        want = om.contrastive_step(batch)
+    got = model.validation_step(_to_dev(batch), 0)["loss"]
+    assert abs(got.item() - want.item()) <= 1e-3 * abs(want.item())
+    with torch.no_grad():
+        out = model(batch["transformed_image1"].to(DEV))
+        enc, p = om.embed(batch["transformed_image1"])
+    assert torch.allclose(out["embedding"].cpu(), enc, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(out["projection"].cpu(), p, rtol=1e-3, atol=1e-4)
+
+
+def test_functional_surface_matches_reference_golden(golden_dir):
+    """vanila_* / get_weights_* / translate_encodings / rotate_encoding with the reference's signatures."""
+    from simhand_amd.host import model_utils as mu
+
+    g = np.load(os.path.join(golden_dir, "loss_B8.npz"))
+    z1 = torch.from_numpy(g["z1"]).to(DEV).requires_grad_(True)
+    z2 = torch.from_numpy(g["z2"]).to(DEV).requires_grad_(True)
+    j1, j2 = torch.from_numpy(g["j1"]).to(DEV), torch.from_numpy(g["j2"]).to(DEV)
+    for diff in ("mpjpe", "w_abs", "w_o_abs"):
+        wp, wn = mu.get_weights_linear(j1, j2, diff)
+        np.testing.assert_allclose(wp.cpu().numpy(), g[f"wpos.{diff}.linear"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(wn.cpu().numpy(), g[f"wneg.{diff}.linear"], rtol=1e-5, atol=1e-6)
+        wp2, wn2 = mu.get_weights_nonlinear(j1, j2, 5.0, 0.05, diff)
+        np.testing.assert_allclose(wp2.cpu().numpy(), g[f"wpos.{diff}.non_linear"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(wn2.cpu().numpy(), g[f"wneg.{diff}.non_linear"], rtol=1e-5, atol=1e-6)
+    wp, wn = mu.get_weights_linear(j1, j2, "mpjpe")
+    for fn, args, tag in ((mu.vanila_weights_contrastive_loss, (wp, wn), "pos_neg"), (mu.vanila_pos_weights_contrastive_loss, (wp,), "pos"),
+                          (mu.vanila_neg_weights_contrastive_loss, (wn,), "neg")):
+        z1.grad = z2.grad = None
+        loss = fn(z1, z2, *args)
+        loss.backward()
+        want = float(g[f"loss.mpjpe.linear.{tag}"])
+        assert abs(loss.item() - want) <= 1e-5 * abs(want)
+        assert np.abs(z1.grad.cpu().numpy() - g[f"dz1.mpjpe.linear.{tag}"]).max() <= 1e-4 * np.abs(g[f"dz1.mpjpe.linear.{tag}"]).max() + 1e-7
+    loss = mu.vanila_contrastive_loss(z1, z2)
+    assert abs(loss.item() - float(g["loss.simclr"])) <= 1e-5 * float(g["loss.simclr"])
+    # translate / rotate as separate calls, composed like the reference composes them
+    pg = np.load(os.path.join(golden_dir, "postprocess.npz"))
+    P = torch.from_numpy(pg["head_out"]).to(DEV)
+    n = P.shape[0]
+    q = mu.normalize(P).view(n, -1, 2)
+    jx = torch.from_numpy(np.concatenate((pg["jitter_x_1"], pg["jitter_x_2"]))).to(DEV)
+    jy = torch.from_numpy(np.concatenate((pg["jitter_y_1"], pg["jitter_y_2"]))).to(DEV)
+    ang = torch.from_numpy(np.concatenate((pg["angle_1"], pg["angle_2"]))).to(DEV)
+    hw = pg["image_hw"]
+    q = mu.translate_encodings(q, -(jx / float(hw[0])), -(jy / float(hw[1])), None)
+    q = mu.rotate_encoding(q, -ang, None)
+    z = mu.normalize(q.reshape(n, -1))
+    np.testing.assert_allclose(z.cpu().numpy(), pg["z.crop_rotate"], rtol=1e-5, atol=1e-6)
