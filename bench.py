@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""Headline benchmark: hand-image-pairs/s of the SiMHand contrastive training step.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1] / [2]): ResNet-50 `handclr_w`, bf16 MFMA kernels, per-GPU batch
+1024 pairs of synthetic 224x224x3 images (2048 images per GPU), linear MPJPE weighting, crop+rotate
+un-warp, global negatives over all ranks (weak scaling: global batch = 1024 * N).  One step = forward,
+backward, gradient all-reduce (N > 1) and the LARS/Adam update -- nothing is skipped or cached.
+Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel class (the implicit-GEMM
+convolutions), measured live with HIP events on the launch stream inside the timed region;
+`cpu_baseline` is the CPU oracle (a port of the reference step, validated against the reference's
+golden vectors) timed on this host on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+F32_PEAK_TFLOPS = 157.3
+AUG = ["color_jitter", "crop", "random_crop", "resize", "rotate"]
+TRAIN_GFLOP_PER_PAIR = {"18": 21.77, "50": 49.06, "152": 138.15}  # BASELINE.md section 3 (@224)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--per-gpu-batch", type=int, default=1024, help="pairs per GPU (BASELINE config: 1024)")
+    ap.add_argument("--resnet", default="50", choices=["18", "34", "50", "101", "152"])
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "32"])
+    ap.add_argument("--experiment", default="handclr_w", choices=["handclr_w", "peclr_w", "simclr"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def make_model(args, world):
+    from simhand_amd.host import unsupervised
+    from simhand_amd.host.config import edict
+
+    wcfg = dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg") if args.experiment != "simclr" else {}
+    cfg = edict(resnet_size=args.resnet, projection_head_input_dim=2048, projection_head_hidden_dim=512, output_dim=128,
+                augmentation=list(AUG), joints_type="augmented", use_pca=False, lr=1e-4, opt_weight_decay=1e-6,
+                warmup_epochs=10, num_of_mini_batch=1, optimizer="LARS", batch_size=args.per_gpu_batch * world,
+                num_samples=1_000_000, **wcfg)
+    cls = {"handclr_w": unsupervised.HandCLR_W, "peclr_w": unsupervised.PeCLR_W, "simclr": unsupervised.SimCLR}[args.experiment]
+    torch.manual_seed(5)
+    model = cls(cfg, None, "train")
+    model.set_compute_dtype(torch.bfloat16 if args.precision == "bf16" else torch.float32)
+    return model
+
+
+def device_batch(b, size, seed, device):
+    """SURVEY 8d synthetic batch, generated directly on the device (same distributions as
+    oracle.step.synthetic_batch; values differ because the generator is the device's)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    j1 = torch.rand(b, 21, 3, generator=g, device=device) * size
+    j1[:, :, 2] = 1.0
+    j2 = j1.clone()
+    j2[:, :, :2] += torch.randn(b, 21, 2, generator=g, device=device) * 8.0
+    ri = lambda lo, hi: torch.randint(lo, hi, (b,), generator=g, device=device)  # noqa: E731
+    return {
+        "transformed_image1": torch.randn(b, 3, size, size, generator=g, device=device),
+        "transformed_image2": torch.randn(b, 3, size, size, generator=g, device=device),
+        "joints1_aug": j1, "joints2_aug": j2, "joints1_ori": j1 / size, "joints2_ori": j2 / size,
+        "angle_1": ri(-45, 46).to(torch.float64), "angle_2": ri(-45, 46).to(torch.float64),
+        "jitter_x_1": -ri(0, 15), "jitter_x_2": -ri(0, 15), "jitter_y_1": -ri(0, 15), "jitter_y_2": -ri(0, 15),
+    }
+
+
+def cpu_baseline(args):
+    """The oracle (CPU port of the reference step, torch fp32) on all host cores, bounded sample."""
+    from oracle import step as orc
+    from oracle.optim import LARSWrapperOracle
+
+    b = args.cpu_pairs
+    torch.manual_seed(5)
+    wcfg = dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg") if args.experiment != "simclr" else {}
+    exp = {"handclr_w": "simhand_w", "peclr_w": "peclr_w", "simclr": "simclr"}[args.experiment]
+    model = orc.StepOracle(exp, args.resnet, AUG, **wcfg).train()
+    adam = torch.optim.Adam(model.parameters(), lr=3.2e-3, weight_decay=1e-6)
+    opt = LARSWrapperOracle(adam)
+    batch = orc.synthetic_batch(b, size=args.image_size, seed=5)
+    cores = torch.get_num_threads()
+    times = []
+    for i in range(3):
+        t0 = time.perf_counter()
+        adam.zero_grad(set_to_none=True)
+        loss = model.contrastive_step(batch)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = min(times[1:])
+    return {"value": b / t, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"oracle.StepOracle ResNet-{args.resnet} {args.experiment} fp32, {b} pairs of {args.image_size}x{args.image_size}, "
+                      f"fwd+bwd+LARS/Adam, best of 2 steps after 1 warm-up ({t * 1e3:.0f} ms/step)"}
+
+
+def main():
+    args = parse()
+    from simhand_amd import _lib, ops
+    from simhand_amd.host import dist as shdist
+
+    rank, local, world = shdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    _lib.require_device()
+    device = torch.device("cuda", local)
+    model = make_model(args, world).to(device).train()
+
+    class _T:
+        max_epochs, world_size = 100, world
+
+    model.trainer = _T()
+    model.setup("fit")
+    (opt,), (sched,) = model.configure_optimizers()
+    batch = device_batch(args.per_gpu_batch, args.image_size, 5 + rank, device)
+    params = [p for p in model.parameters()]
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        out = model.training_step(batch, i)
+        out["loss"].backward()
+        shdist.allreduce_gradients(params)
+        opt.step()
+        sched["scheduler"].step()
+        return out["loss"]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for i in range(args.warmup):
+        loss = step(i)
+    barrier()
+    ops.prof_reset()
+    ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.prof_enable(False)
+    prof = ops.prof_collect()
+    final_loss = float(loss)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t)
+
+    if rank == 0:
+        global_pairs = args.per_gpu_batch * world
+        value = global_pairs * args.steps / elapsed
+        conv = {k: prof[k] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")}
+        dom = max(conv, key=lambda k: conv[k]["ms"])
+        d = conv[dom]
+        peak = BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else F32_PEAK_TFLOPS
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        all_conv_flops = sum(v["flops"] for v in conv.values())
+        all_conv_ms = sum(v["ms"] for v in conv.values())
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived, filled from rocprofv3 --pmc passes
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get(dom)
+        res = {
+            "metric": "hand-image-pairs/sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"ResNet-{args.resnet} {args.experiment} contrastive step (fwd+bwd+allreduce+LARS/Adam), "
+                                   f"{args.per_gpu_batch} pairs/GPU of 2x{args.image_size}x{args.image_size}x3, linear MPJPE weighting, "
+                                   f"crop+rotate un-warp, global negatives",
+                       "global_batch": global_pairs, "per_gpu_batch": args.per_gpu_batch, "image_size": args.image_size,
+                       "parallelism": f"dp{world}", "loss": final_loss},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": traffic, "launches": d["count"], "avg_launch_ms": d["ms"] / max(1, d["count"]),
+                         "all_conv_tflops": all_conv_flops / (all_conv_ms * 1e-3) / 1e12 if all_conv_ms > 0 else 0.0,
+                         "step_tflops_per_gpu": TRAIN_GFLOP_PER_PAIR.get(args.resnet, 0.0) * (args.image_size / 224.0) ** 2
+                                                * args.per_gpu_batch * args.steps / elapsed / 1e3},
+            "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

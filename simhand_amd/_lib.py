@@ -11,6 +11,11 @@ import ctypes as C
 import os
 import threading
 
+# torch ships its own HIP runtime (torch/lib/libamdhip64.so); it must be the first one mapped into the
+# process, otherwise torch.cuda later reports "No HIP GPUs are available".  Importing torch before the
+# CDLL below guarantees that order; libsimhand_hip.so then binds to the already-loaded runtime by soname.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsimhand_hip.so")
 

@@ -1,0 +1,219 @@
+"""CPU: host-side logic that needs no kernel launch -- CLI / config surface against the values captured
+from the reference's own parser (tests/golden/cli.json), model registry, state_dict keys, weight-decay
+split quirk, LR schedule / LARS restatement, checkpoint naming, and the gloo world-size-2 runs of the
+sharded loss and gradient all-reduce (with the test-side kernel stand-in of tests/_cpu_kernels.py)."""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def cli(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "cli.json")))
+
+
+@pytest.mark.parametrize("name", ["handclr_w", "peclr_w", "simclr_w"])
+def test_cli_surface_matches_reference_parser(cli, name):
+    from simhand_amd.host import config as C
+    from simhand_amd.host import experiments_utils as eu
+    from simhand_amd.host.config import edict, read_json
+
+    ref = cli[name]
+    args = eu.get_general_args("x", ref["argv"])
+    got = {k: v for k, v in vars(args).items() if k not in eu.BUILD_ONLY_FLAGS}
+    assert got == ref["args"]
+    train_param = eu.update_train_params(args, edict(read_json(C.TRAINING_CONFIG_PATH)))
+    assert json.loads(json.dumps(train_param)) == ref["train_param"]
+    model_param = edict(read_json(eu.model_config_path(name)))
+    model_param = eu.update_model_params(model_param, args, 1000000, train_param)
+    model_param.augmentation = [k for k, v in train_param.augmentation_flags.items() if v]
+    assert json.loads(json.dumps(model_param)) == ref["model_param"]
+    assert eu.prepare_name(f"{args.experiment_type}_", train_param) == ref["experiment_name"]
+
+
+def test_weight_flag_assertions():
+    from simhand_amd.host import experiments_utils as eu
+    from simhand_amd.host.config import edict
+
+    tp = edict(batch_size=8, accumulate_grad_batches=1)
+    for bad in (["--weight_type", "cubic", "--joints_type", "augmented", "--diff_type", "mpjpe", "--pos_neg", "pos"],
+                ["--weight_type", "non_linear", "--joints_type", "augmented", "--diff_type", "mpjpe", "--pos_neg", "pos",
+                 "--non_linear_lambda_pos", "3.0", "--non_linear_lambda_neg", "0.05"]):
+        with pytest.raises(AssertionError):
+            eu.update_model_params(edict(), eu.get_general_args("x", bad), 10, tp)
+
+
+def test_registry(cli):
+    from simhand_amd.host import experiments_utils as eu
+
+    for key, cls in cli["get_model"].items():
+        got = eu.get_model(key)
+        if key == "handclr_w":  # unreachable in the reference (falls off the if-chain) -> alias here
+            assert cls is None and got.__name__ == "HandCLR_W"
+        elif cls in ("SiMHand_W", "HandCLR_W"):
+            assert got.__name__ == "HandCLR_W"
+        elif cls in ("SiMHand_VIS", "HandCLR_VIS"):
+            assert got.__name__ == "HandCLR_VIS"
+        else:
+            assert got.__name__ == cls, key
+    assert eu.get_model("nope") is None
+    with pytest.raises(ValueError):
+        eu.model_config_path("supervised")
+
+
+def _cfg(size="18", **kw):
+    from simhand_amd.host.config import edict
+
+    base = dict(resnet_size=size, projection_head_input_dim=2048, projection_head_hidden_dim=512, output_dim=128, augmentation=[],
+                lr=1e-4, opt_weight_decay=1e-6, warmup_epochs=10, num_of_mini_batch=1, optimizer="LARS", batch_size=128, num_samples=12800,
+                weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg", joints_type="augmented", use_pca=False)
+    base.update(kw)
+    return edict(base)
+
+
+def test_state_dict_keys_and_seeded_init_match_oracle(golden_dir):
+    from oracle import step as orc
+    from simhand_amd.host import unsupervised
+
+    meta = json.load(open(os.path.join(golden_dir, "step_rn18.json")))["HandCLR_W"]
+    torch.manual_seed(5)
+    m = unsupervised.HandCLR_W(_cfg("18"), None, "train")
+    assert list(m.state_dict().keys()) == meta["state_dict_keys"]
+    with torch.no_grad():
+        assert float(sum(p.double().abs().sum() for p in m.parameters())) == pytest.approx(meta["param_checksum"], rel=1e-9)
+    torch.manual_seed(7)
+    a = unsupervised.PeCLR_W(_cfg("50"), None, "train").state_dict()
+    torch.manual_seed(7)
+    b = orc.StepOracle("peclr_w", "50").state_dict()
+    assert list(a.keys()) == list(b.keys()) and all(torch.equal(a[k], b[k]) for k in a)
+    assert a["projection_head.0.weight"].shape == (512, 2048) and a["encoder.final_layer.0.weight"].shape == (64, 2048)
+
+
+def test_weight_decay_split_quirk_and_optimizer_setup():
+    from oracle.optim import exclude_from_wt_decay
+    from simhand_amd.host import unsupervised
+
+    m = unsupervised.HandCLR_W(_cfg("18"), None, "train")
+    names = [n for n, _ in m.named_parameters()]
+    groups = m.exclude_from_wt_decay(m.named_parameters(), 1e-6)
+    decay, no_decay = exclude_from_wt_decay(names)
+    assert len(groups[0]["params"]) == len(decay) and len(groups[1]["params"]) == len(no_decay)
+    assert "encoder.features.1.weight" in decay          # stem BN weight is NOT matched by "bn" -> decayed (quirk kept)
+    assert "encoder.features.4.0.bn1.weight" in no_decay
+    assert "encoder.features.5.0.downsample.1.weight" in decay and "encoder.features.5.0.downsample.1.bias" in no_decay
+
+    class T:
+        max_epochs, world_size = 50, 1
+
+    m.trainer = T()
+    m.setup("fit")
+    assert m.train_iters_per_epoch == 100
+    (opt,), (sch,) = m.configure_optimizers()
+    assert sch["interval"] == "step"
+    assert opt.defaults["lr"] == pytest.approx(1e-4 * math.sqrt(1024))
+    assert opt.param_groups[0]["lr"] == 0.0  # warmup_start_lr = 0 at step 0
+    s = sch["scheduler"]
+    assert s.warmup_epochs == 1000 and s.max_epochs == 5000
+
+
+def test_lr_schedule_matches_restated_pl_bolts():
+    from oracle.optim import linear_warmup_cosine_lr
+    from simhand_amd.host.optim import LinearWarmupCosineAnnealingLR
+
+    class FakeOpt:
+        param_groups = [{"lr": 3.2e-3}]
+
+    s = LinearWarmupCosineAnnealingLR(FakeOpt(), warmup_epochs=10, max_epochs=100)
+    for t in range(0, 100):
+        assert FakeOpt.param_groups[0]["lr"] == pytest.approx(linear_warmup_cosine_lr(t, 3.2e-3, 10, 100), abs=1e-12)
+        s.step()
+    assert linear_warmup_cosine_lr(9, 3.2e-3, 10, 100) == pytest.approx(3.2e-3)
+    assert linear_warmup_cosine_lr(100, 3.2e-3, 10, 100) == pytest.approx(0.0, abs=1e-12)
+
+
+def test_checkpoint_filename_template():
+    from simhand_amd.host.lightning import ModelCheckpoint
+
+    ck = ModelCheckpoint(save_top_k=3, monitor="contrastive_loss", mode="min",
+                         filename="handclr_w_pretrain_{epoch:02d}_train_['ego4d-1m']_bs_8.0_1024_lr_3.2e-03_{contrastive_loss:.6f}")
+    assert ck.format_name(7, {"contrastive_loss": 6.123456789}) == \
+        "handclr_w_pretrain_epoch=07_train_['ego4d-1m']_bs_8.0_1024_lr_3.2e-03_contrastive_loss=6.123457.ckpt"
+
+
+def test_sharding_helpers():
+    from simhand_amd.host.dist import shard_pairs
+
+    assert shard_pairs(8192, 3, 8) == (3072, 1024)
+    with pytest.raises(ValueError):
+        shard_pairs(10, 0, 4)
+
+
+def test_main_requires_synthetic_and_rejects_unknown_models(monkeypatch):
+    from simhand_amd.host import main as M
+
+    with pytest.raises(ValueError):
+        M.main(["--experiment_type", "supervised", "--synthetic"])
+    with pytest.raises(SystemExit):
+        M.main(["--experiment_type", "handclr_w", "-sources", "ego4d", "-batch_size", "8"])
+
+
+WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from simhand_amd.host import dist as shdist
+from simhand_amd.host.dist_loss import LossConfig, ShardedNtxent
+from tests import _cpu_kernels
+from oracle import step as orc
+rank, local, world = shdist.init_from_env("gloo")
+B = 12
+g = torch.Generator().manual_seed(3)
+z1 = torch.nn.functional.normalize(torch.randn(B, 128, generator=g)); z2 = torch.nn.functional.normalize(torch.randn(B, 128, generator=g))
+j1 = torch.rand(B, 21, 2, generator=g) * 224; j2 = j1 + torch.randn(B, 21, 2, generator=g) * 8
+off, b = shdist.shard_pairs(B, rank, world)
+for wt, diff, mode in (("linear", "mpjpe", "pos_neg"), ("non_linear", "w_abs", "neg"), (None, "mpjpe", "pos_neg"), ("linear", "w_o_abs", "pos")):
+    cfg = LossConfig(weight_type=wt, diff_type=diff, use_wpos=wt is not None and mode in ("pos_neg", "pos"),
+                     use_wneg=wt is not None and mode in ("pos_neg", "neg"), lambda_pos=2.5, lambda_neg=0.01, kernels=_cpu_kernels)
+    zl = torch.cat((z1[off:off + b], z2[off:off + b])).clone().requires_grad_(True)
+    jl = torch.cat((j1[off:off + b], j2[off:off + b])).reshape(2 * b, -1)
+    loss = ShardedNtxent.apply(zl, jl if wt else None, cfg, None, None, None)
+    loss.backward()
+    wp = wn = None
+    if wt == "linear": wp, wn = orc.weights_linear(j1, j2, diff)
+    if wt == "non_linear": wp, wn = orc.weights_nonlinear(j1, j2, 2.5, 0.01, diff)
+    if mode == "pos": wn = None
+    if mode == "neg": wp = None
+    a, c = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+    want = orc.ntxent(a, c, wp, wn); want.backward()
+    assert abs(loss.item() - want.item()) < 1e-5 * abs(want.item()), (rank, wt, loss.item(), want.item())
+    gw = torch.cat((a.grad[off:off + b], c.grad[off:off + b]))
+    assert (zl.grad - gw).abs().max() < 1e-4 * gw.abs().max() + 1e-7, (rank, wt)
+# gradient all-reduce: per-rank gradients ADD to the single-process gradient
+p = [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(3, 2))]
+p[0].grad = torch.full((5,), float(rank + 1)); p[1].grad = torch.full((3, 2), 10.0 * (rank + 1))
+shdist.allreduce_gradients(p, bucket_bytes=16)
+tot = sum(range(1, world + 1))
+assert torch.equal(p[0].grad, torch.full((5,), float(tot))) and torch.equal(p[1].grad, torch.full((3, 2), 10.0 * tot))
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_loss_and_grad_allreduce_gloo_world2(tmp_path):
+    """world_size 2 over gloo on CPU: sharded loss (+ its backward) == single-process oracle on the global batch."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+        assert f"rank {r} ok" in o
