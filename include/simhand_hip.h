@@ -198,14 +198,17 @@ int simhand_bn_eval_params(const float* gamma, const float* beta, const float* r
 /* a = act(y*scale + shift (+ residual)), act = relu if relu != 0 */
 int simhand_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, int relu,
                      void* a, int64_t m, int c, int dtype, sh_stream_t stream);
-/* backward: g = da * (a > 0 if relu); partial [simhand_bn_stat_blocks][2][C] sums of g and g*xhat;
- * finalize -> dbeta, dgamma; apply: dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), dres (optional) = g */
-int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const float* mean, const float* invstd, int relu,
-                           int64_t m, int c, int dtype, float* partial, sh_stream_t stream);
+/* backward: g = da * [relu input > 0]; partial [simhand_bn_stat_blocks][2][C] sums of g and g*xhat;
+ * finalize -> dbeta, dgamma; apply: dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), dres (optional) = g.
+ * relu: 0 = none, 1 = mask from the stored activation a (units with a residual add),
+ *       2 = mask recomputed from y*scale+shift (no residual; a is not read at all). */
+int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const float* mean, const float* invstd,
+                           const float* scale, const float* shift, int relu, int64_t m, int c, int dtype, float* partial,
+                           sh_stream_t stream);
 int simhand_bn_bwd_finalize(const float* partial, int nblk, int c, float* dgamma, float* dbeta, sh_stream_t stream);
 int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const float* mean, const float* invstd,
-                         const float* gamma, const float* dgamma, const float* dbeta, int relu,
-                         void* dy, void* dres, int64_t m, int c, int dtype, sh_stream_t stream);
+                         const float* gamma, const float* dgamma, const float* dbeta, const float* scale, const float* shift,
+                         int relu, void* dy, void* dres, int64_t m, int c, int dtype, sh_stream_t stream);
 
 /* pooling (NHWC): MaxPool2d(3, stride 2, pad 1) (idx = winning tap 0..8 per output element, uint8)
  * and AdaptiveAvgPool2d(1) */

@@ -90,9 +90,9 @@ SIGNATURES = {
     "simhand_bn_finalize": (_I, [_P, _I, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_bn_eval_params": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "simhand_bn_apply": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P]),
-    "simhand_bn_bwd_partial": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P]),
+    "simhand_bn_bwd_partial": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P]),
     "simhand_bn_bwd_finalize": (_I, [_P, _I, _I, _P, _P, _P]),
-    "simhand_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P]),
+    "simhand_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P]),
     "simhand_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "simhand_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "simhand_avgpool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),

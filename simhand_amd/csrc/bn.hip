@@ -153,46 +153,82 @@ __global__ __launch_bounds__(256) void bn_eval_params_kernel(const float* __rest
   shift[ch] = (beta ? beta[ch] : 0.0f) - rm[ch] * sc;
 }
 
+// Streaming kernels: a thread owns ONE 16-B channel vector (its per-channel coefficients live in
+// registers for the whole launch) and walks rows; lanes run along the channel axis first so a wave
+// covers whole contiguous rows (coalesced), blocks split the row range.
+struct RowWalk {
+  int cv, rl, span, rowlanes;
+  int64_t r0, r1;
+};
+template <int VE>
+__device__ __forceinline__ RowWalk row_walk(int64_t m, int c) {
+  RowWalk w;
+  const int cvecs = c / VE;
+  w.span = cvecs < 256 ? cvecs : 256;
+  w.rowlanes = 256 / w.span;
+  w.cv = threadIdx.x % w.span;
+  w.rl = threadIdx.x / w.span;
+  const int64_t per = (m + gridDim.x - 1) / gridDim.x;
+  w.r0 = (int64_t)blockIdx.x * per;
+  w.r1 = w.r0 + per < m ? w.r0 + per : m;
+  return w;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const T* __restrict__ res, int relu,
-                                                       T* __restrict__ a, int64_t nvec, int cvecs) {
+                                                       T* __restrict__ a, int64_t m, int c) {
   constexpr int VE = Vec16<T>::N;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % cvecs);
-    float v[VE], o[VE];
-    Vec16<T>::load(y + i * VE, v);
+  const RowWalk w = row_walk<VE>(m, c);
+  if (w.rl >= w.rowlanes) return;
+  for (int cv = w.cv; cv < c / VE; cv += w.span) {
+    float sc[VE], sh[VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) o[e] = v[e] * scale[cv * VE + e] + shift[cv * VE + e];
-    if (res) {
-      float r[VE];
-      Vec16<T>::load(res + i * VE, r);
-#pragma unroll
-      for (int e = 0; e < VE; ++e) o[e] += r[e];
+    for (int e = 0; e < VE; ++e) {
+      sc[e] = scale[cv * VE + e];
+      sh[e] = shift[cv * VE + e];
     }
-    if (relu) {
+    for (int64_t r = w.r0 + w.rl; r < w.r1; r += w.rowlanes) {
+      const int64_t off = r * c + cv * VE;
+      float v[VE], o[VE];
+      Vec16<T>::load(y + off, v);
 #pragma unroll
-      for (int e = 0; e < VE; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+      for (int e = 0; e < VE; ++e) o[e] = v[e] * sc[e] + sh[e];
+      if (res) {
+        float q[VE];
+        Vec16<T>::load(res + off, q);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) o[e] += q[e];
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+      }
+      Vec16<T>::store(a + off, o);
     }
-    Vec16<T>::store(a + i * VE, o);
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ da, const T* __restrict__ a,
                                                              const T* __restrict__ y, const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd, int relu, int64_t m, int c,
-                                                             int rows_per_blk, float* __restrict__ partial) {
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             int relu, int64_t m, int c, int rows_per_blk,
+                                                             float* __restrict__ partial) {
   constexpr int VE = Vec16<T>::N;
   column_reduce<T>(m, c, rows_per_blk, partial, [&](int64_t r, int cv, float(&s1)[VE], float(&s2)[VE]) {
     float g[VE], yy[VE];
     Vec16<T>::load(da + r * c + cv * VE, g);
     Vec16<T>::load(y + r * c + cv * VE, yy);
-    if (relu) {
+    if (relu == 1) {
       float aa[VE];
       Vec16<T>::load(a + r * c + cv * VE, aa);
 #pragma unroll
       for (int e = 0; e < VE; ++e) g[e] = aa[e] > 0.f ? g[e] : 0.f;
+    } else if (relu == 2) {  // no residual: the ReLU input is recomputed from y (same fp32 expression as bn_apply)
+#pragma unroll
+      for (int e = 0; e < VE; ++e) g[e] = yy[e] * scale[cv * VE + e] + shift[cv * VE + e] > 0.f ? g[e] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
@@ -233,30 +269,45 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const T* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                           int relu, T* __restrict__ dy, T* __restrict__ dres, int64_t nvec,
-                                                           int cvecs, float inv_m) {
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           int relu, T* __restrict__ dy, T* __restrict__ dres, int64_t m, int c,
+                                                           float inv_m) {
   constexpr int VE = Vec16<T>::N;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % cvecs);
-    float g[VE], yy[VE], o[VE];
-    Vec16<T>::load(da + i * VE, g);
-    Vec16<T>::load(y + i * VE, yy);
-    if (relu) {
-      float aa[VE];
-      Vec16<T>::load(a + i * VE, aa);
-#pragma unroll
-      for (int e = 0; e < VE; ++e) g[e] = aa[e] > 0.f ? g[e] : 0.f;
-    }
+  const RowWalk w = row_walk<VE>(m, c);
+  if (w.rl >= w.rowlanes) return;
+  for (int cv = w.cv; cv < c / VE; cv += w.span) {
+    // dy = A*(g - k2) - xhat*k3 with xhat = (y - mu)*is ; A = gamma*is, k2 = dbeta/M, k3 = A*dgamma/M
+    float mu[VE], is[VE], A[VE], k2[VE], k3[VE], sc[VE], sh[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
       const int ch = cv * VE + e;
-      const float is = invstd[ch];
-      const float xh = (yy[e] - mean[ch]) * is;
-      const float gm = gamma ? gamma[ch] : 1.0f;
-      o[e] = gm * is * (g[e] - dbeta[ch] * inv_m - xh * dgamma[ch] * inv_m);
+      mu[e] = mean[ch];
+      is[e] = invstd[ch];
+      A[e] = (gamma ? gamma[ch] : 1.0f) * is[e];
+      k2[e] = dbeta[ch] * inv_m;
+      k3[e] = A[e] * dgamma[ch] * inv_m;
+      sc[e] = relu == 2 ? scale[ch] : 0.f;
+      sh[e] = relu == 2 ? shift[ch] : 0.f;
     }
-    Vec16<T>::store(dy + i * VE, o);
-    if (dres) Vec16<T>::store(dres + i * VE, g);
+    for (int64_t r = w.r0 + w.rl; r < w.r1; r += w.rowlanes) {
+      const int64_t off = r * c + cv * VE;
+      float g[VE], yy[VE], o[VE];
+      Vec16<T>::load(da + off, g);
+      Vec16<T>::load(y + off, yy);
+      if (relu == 1) {
+        float aa[VE];
+        Vec16<T>::load(a + off, aa);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) g[e] = aa[e] > 0.f ? g[e] : 0.f;
+      } else if (relu == 2) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) g[e] = yy[e] * sc[e] + sh[e] > 0.f ? g[e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < VE; ++e) o[e] = A[e] * (g[e] - k2[e]) - (yy[e] - mu[e]) * is[e] * k3[e];
+      Vec16<T>::store(dy + off, o);
+      if (dres) Vec16<T>::store(dres + off, g);
+    }
   }
 }
 
@@ -270,6 +321,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 #pragma unroll
     for (int e = 0; e < VE; ++e) s1[e] += v[e];
   });
+}
+
+// blocks for the row-walking kernels: >= ~8 rows per row lane, at most 8 blocks per CU
+static inline int row_grid(int64_t m, int cvecs) {
+  const int span = cvecs < 256 ? cvecs : 256;
+  const int rowlanes = 256 / span;
+  int64_t g = (m + (int64_t)rowlanes * 8 - 1) / ((int64_t)rowlanes * 8);
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
 }
 
 static inline int stream_grid(int64_t nvec) {
@@ -339,29 +400,32 @@ int simhand_bn_apply(const void* y, const float* scale, const float* shift, cons
   SH_REQUIRE(y && scale && shift && a, "bn_apply: NULL pointer");
   const int ve = dtype == SH_F32 ? 4 : 8;
   SH_REQUIRE(c % ve == 0, "bn_apply: c=%d not a multiple of %d", c, ve);
-  const int64_t nvec = m * c / ve;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (residual ? 3 : 2));
+  const int grid = row_grid(m, c / ve);
   if (dtype == SH_F32)
-    bn_apply_kernel<float><<<stream_grid(nvec), 256, 0, s>>>((const float*)y, scale, shift, (const float*)residual, relu, (float*)a, nvec, c / ve);
+    bn_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)y, scale, shift, (const float*)residual, relu, (float*)a, m, c);
   else
-    bn_apply_kernel<bf16_t><<<stream_grid(nvec), 256, 0, s>>>((const bf16_t*)y, scale, shift, (const bf16_t*)residual, relu, (bf16_t*)a, nvec, c / ve);
+    bn_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)y, scale, shift, (const bf16_t*)residual, relu, (bf16_t*)a, m, c);
   return check_launch("bn_apply");
 }
 
-int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const float* mean, const float* invstd, int relu,
-                           int64_t m, int c, int dtype, float* partial, sh_stream_t stream) {
+int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const float* mean, const float* invstd,
+                           const float* scale, const float* shift, int relu, int64_t m, int c, int dtype, float* partial,
+                           sh_stream_t stream) {
   SH_REQUIRE(da && y && mean && invstd && partial, "bn_bwd_partial: NULL pointer");
-  SH_REQUIRE(!relu || a, "bn_bwd_partial: relu mask needs the activation output");
+  SH_REQUIRE(relu >= 0 && relu <= 2, "bn_bwd_partial: relu mode %d", relu);
+  SH_REQUIRE(relu != 1 || a, "bn_bwd_partial: relu mode 1 needs the activation output");
+  SH_REQUIRE(relu != 2 || (scale && shift), "bn_bwd_partial: relu mode 2 needs scale/shift");
   SH_REQUIRE(c % (dtype == SH_F32 ? 4 : 8) == 0, "bn_bwd_partial: c=%d not a multiple of the 16-B vector", c);
   int rpb, nblk;
   col_plan(m, &rpb, &nblk);
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (relu ? 3 : 2));
+  ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (relu == 1 ? 3 : 2));
   if (dtype == SH_F32)
-    bn_bwd_partial_kernel<float><<<nblk, 256, 0, s>>>((const float*)da, (const float*)a, (const float*)y, mean, invstd, relu, m, c, rpb, partial);
+    bn_bwd_partial_kernel<float><<<nblk, 256, 0, s>>>((const float*)da, (const float*)a, (const float*)y, mean, invstd, scale, shift, relu, m, c, rpb, partial);
   else
-    bn_bwd_partial_kernel<bf16_t><<<nblk, 256, 0, s>>>((const bf16_t*)da, (const bf16_t*)a, (const bf16_t*)y, mean, invstd, relu, m, c, rpb, partial);
+    bn_bwd_partial_kernel<bf16_t><<<nblk, 256, 0, s>>>((const bf16_t*)da, (const bf16_t*)a, (const bf16_t*)y, mean, invstd, scale, shift, relu, m, c, rpb, partial);
   return check_launch("bn_bwd_partial");
 }
 
@@ -374,22 +438,24 @@ int simhand_bn_bwd_finalize(const float* partial, int nblk, int c, float* dgamma
 }
 
 int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const float* mean, const float* invstd, const float* gamma,
-                         const float* dgamma, const float* dbeta, int relu, void* dy, void* dres, int64_t m, int c, int dtype,
-                         sh_stream_t stream) {
+                         const float* dgamma, const float* dbeta, const float* scale, const float* shift, int relu, void* dy,
+                         void* dres, int64_t m, int c, int dtype, sh_stream_t stream) {
   SH_REQUIRE(da && y && mean && invstd && dgamma && dbeta && dy, "bn_bwd_apply: NULL pointer");
-  SH_REQUIRE(!relu || a, "bn_bwd_apply: relu mask needs the activation output");
+  SH_REQUIRE(relu >= 0 && relu <= 2, "bn_bwd_apply: relu mode %d", relu);
+  SH_REQUIRE(relu != 1 || a, "bn_bwd_apply: relu mode 1 needs the activation output");
+  SH_REQUIRE(relu != 2 || (scale && shift), "bn_bwd_apply: relu mode 2 needs scale/shift");
   const int ve = dtype == SH_F32 ? 4 : 8;
   SH_REQUIRE(c % ve == 0, "bn_bwd_apply: c=%d not a multiple of %d", c, ve);
-  const int64_t nvec = m * c / ve;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (3 + (relu ? 1 : 0) + (dres ? 1 : 0)));
+  ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (3 + (relu == 1 ? 1 : 0) + (dres ? 1 : 0)));
   const float inv_m = (float)(1.0 / (double)m);
+  const int grid = row_grid(m, c / ve);
   if (dtype == SH_F32)
-    bn_bwd_apply_kernel<float><<<stream_grid(nvec), 256, 0, s>>>((const float*)da, (const float*)a, (const float*)y, mean, invstd, gamma, dgamma, dbeta,
-                                                               relu, (float*)dy, (float*)dres, nvec, c / ve, inv_m);
+    bn_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)da, (const float*)a, (const float*)y, mean, invstd, gamma, dgamma, dbeta, scale,
+                                                    shift, relu, (float*)dy, (float*)dres, m, c, inv_m);
   else
-    bn_bwd_apply_kernel<bf16_t><<<stream_grid(nvec), 256, 0, s>>>((const bf16_t*)da, (const bf16_t*)a, (const bf16_t*)y, mean, invstd, gamma, dgamma,
-                                                                dbeta, relu, (bf16_t*)dy, (bf16_t*)dres, nvec, c / ve, inv_m);
+    bn_bwd_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)da, (const bf16_t*)a, (const bf16_t*)y, mean, invstd, gamma, dgamma, dbeta,
+                                                     scale, shift, relu, (bf16_t*)dy, (bf16_t*)dres, m, c, inv_m);
   return check_launch("bn_bwd_apply");
 }
 

@@ -124,7 +124,7 @@ class _Packed:
 
 class _Unit:
     """Saved tensors of one conv+BN unit for the backward pass."""
-    __slots__ = ("conv", "bn", "desc", "x", "y", "a", "st", "relu", "stem")
+    __slots__ = ("conv", "bn", "desc", "x", "y", "a", "st", "relu", "stem", "has_res")
 
 
 class ResNetEngine:
@@ -167,6 +167,7 @@ class ResNetEngine:
         if save is not None:
             u = _Unit()
             u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv, bn, d, x, y, a, st, relu, False
+            u.has_res = residual is not None
             save.append(u)
         return a
 
@@ -188,6 +189,7 @@ class ResNetEngine:
         if want_ctx:
             u = _Unit()
             u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv1, bn1, d, col, y, a, st, True, True
+            u.has_res = False
             ctx["stem"] = u
             ctx["pool_idx"] = idx
             ctx["pool_in_shape"] = tuple(a.shape)
@@ -219,7 +221,8 @@ class ResNetEngine:
         d = u.desc
         m = d.n * d.ho * d.wo
         c = d.cout
-        dy, dres, dg, db = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, want_dres)
+        dy, dres, dg, db = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, want_dres,
+                                           mask_from_y=u.relu and not u.has_res)
         grads[u.bn.weight] = dg
         grads[u.bn.bias] = db
         dw = ops.conv2d_wgrad(d, u.x, dy)

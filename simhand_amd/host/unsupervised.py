@@ -64,7 +64,7 @@ class _HeadFn(torch.autograd.Function):
         dp = dp.contiguous()
         dw2 = ops.conv2d_wgrad(d2, a, dp)
         da = ops.conv2d_dgrad(d2, dp, ops.pack_crsk(w2.detach().view(*w2.shape, 1, 1), torch.float32))
-        dh, _, dgamma, dbeta = ops.bn_backward(da, a, h, st, gamma.detach(), n, hdim, True, False)
+        dh, _, dgamma, dbeta = ops.bn_backward(da, a, h, st, gamma.detach(), n, hdim, True, False, mask_from_y=True)
         db1 = ops.colsum(dh, n, hdim)
         dw1 = ops.conv2d_wgrad(d1, enc, dh)
         denc = ops.conv2d_dgrad(d1, dh, ops.pack_crsk(w1.detach().view(*w1.shape, 1, 1), torch.float32))

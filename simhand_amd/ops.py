@@ -267,21 +267,24 @@ def bn_apply(y, st: BNState, m: int, c: int, relu: bool, residual=None, out=None
     return a
 
 
-def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_dres: bool):
-    """Returns (dy, dres or None, dgamma, dbeta)."""
+def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_dres: bool, mask_from_y: bool = False):
+    """Returns (dy, dres or None, dgamma, dbeta).  mask_from_y: the unit had no residual add, so the ReLU mask is
+    recomputed from y (the stored activation is not read)."""
     lib = _lib_dev()
     dev = y.device
+    mode = 0 if not relu else (2 if mask_from_y else 1)
     nblk = lib.simhand_bn_stat_blocks(m, c)
     part = torch.empty(nblk, 2, c, dtype=torch.float32, device=dev)
-    check(lib.simhand_bn_bwd_partial(_ptr(da), _ptr(a if relu else None), _ptr(y), _ptr(st.mean), _ptr(st.invstd), int(relu), m, c,
+    aa = a if mode == 1 else None
+    check(lib.simhand_bn_bwd_partial(_ptr(da), _ptr(aa), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift), mode, m, c,
                                      dt(y.dtype), _ptr(part), _stream()), "bn_bwd_partial")
     dg = torch.empty(c, dtype=torch.float32, device=dev)
     db = torch.empty(c, dtype=torch.float32, device=dev)
     check(lib.simhand_bn_bwd_finalize(_ptr(part), nblk, c, _ptr(dg), _ptr(db), _stream()), "bn_bwd_finalize")
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
-    check(lib.simhand_bn_bwd_apply(_ptr(da), _ptr(a if relu else None), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(dg),
-                                   _ptr(db), int(relu), _ptr(dy), _ptr(dres), m, c, dt(y.dtype), _stream()), "bn_bwd_apply")
+    check(lib.simhand_bn_bwd_apply(_ptr(da), _ptr(aa), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(dg), _ptr(db),
+                                   _ptr(st.scale), _ptr(st.shift), mode, _ptr(dy), _ptr(dres), m, c, dt(y.dtype), _stream()), "bn_bwd_apply")
     return dy, dres, dg, db
 
 
