@@ -9,15 +9,21 @@
 //   forward : m = output pixel, A = x at (ho*stride - pad + r, wo*stride - pad + s), n = cout
 //   dgrad   : m = input pixel,  A = dy at ((hi + pad - r)/stride, ...) when divisible, n = cin,
 //             Wt = weights permuted to [cin][r][s][cout]
+//   dgrad, stride 2: input pixels are split into the 4 (h%2, w%2) parity classes; a class only
+//             visits the taps whose parity can reach it (9 tap-visits in total instead of 36;
+//             for 1x1/2 three classes have no tap at all and are just zero-filled).
 // Tile: 128 (m) x BN (n) x 128 BYTES of k per step (64 bf16 / 32 fp32), 4 waves as 2x2, each
 // wave 64 x BN/2 from 16x16 MFMA tiles.  Both operands are k-contiguous rows of 128 B, staged
-// global -> VGPR -> LDS (register staging keeps per-row halo masking and, later, the fused
+// global -> VGPR -> LDS (register staging keeps per-row halo masking and, later, a fused
 // BN-apply+ReLU prologue possible), double-buffered with one barrier per k-step.  LDS rows
 // are XOR-swizzled at 16-B granularity (chunk ^= (row>>1)&7) so every ds_read_b128 lane
 // group covers 16 distinct 16-B slots of the 256-B bank row (conflict-free).
 // The MFMA is issued "swapped" (weights as the A operand) so a lane ends up with 4
-// consecutive output channels of one pixel: 8-B (bf16) / 16-B (fp32) stores, and the
-// per-channel BatchNorm partial sums reduce over lanes with 4 xor-shuffles.
+// consecutive output channels of one pixel; the per-channel BatchNorm partial sums reduce
+// over lanes with 4 xor-shuffles.  The output tile is then staged through LDS ([pixel][channel],
+// padded rows) and written as whole rows with 16-B stores: every 64-lane store instruction
+// covers complete 128/256-B lines (the direct 8-B-per-lane epilogue was store-issue bound on the
+// wide 1x1 layers).
 // Block ids are remapped so all n-tiles of an m-tile run on one XCD (shared L2 for A rows).
 #include "common.h"
 
@@ -28,7 +34,7 @@ struct IgemmArgs {
   const void* w;      // [Ng][taps][Ca]
   void* out;          // [Mg][Ng]
   float* bn_partial;  // [m_tiles][2][Ng] or null
-  long long Mg;       // destination pixels
+  long long Mg;       // destination pixels (per parity class when classes == 4)
   int Ng;             // destination channels
   int Ca;             // source channels
   int R, S, stride, pad;
@@ -36,6 +42,8 @@ struct IgemmArgs {
   int Hs, Ws;         // source spatial size
   int accumulate;
   int m_tiles, n_tiles;
+  int classes;        // 1, or 4 = stride-2 dgrad parity classes
+  int Hq, Wq;         // class grid (ceil(Hd/2), ceil(Wd/2)) when classes == 4
 };
 
 template <typename T> struct Mma;
@@ -69,13 +77,54 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+__device__ __forceinline__ unsigned add_bf16x2(unsigned a, unsigned b) {
+  const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
+  const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+// destination pixel of GEMM row m (parity classes: m runs over the class grid Hq x Wq)
+struct Pixel {
+  int img, hd, wd;
+  bool ok;
+};
+struct PixelMap {
+  long long Mg;
+  int Hd, Wd, Hq, Wq, ph, pw;
+  bool par;
+};
+__device__ __forceinline__ Pixel decode_pixel(const PixelMap& q, long long m) {
+  Pixel r;
+  r.ok = m < q.Mg;
+  const long long mm = r.ok ? m : 0;
+  if (q.par) {
+    const int hwq = q.Hq * q.Wq;
+    r.img = (int)(mm / hwq);
+    const int rem = (int)(mm - (long long)r.img * hwq);
+    const int hq = rem / q.Wq, wq = rem - hq * q.Wq;
+    r.hd = 2 * hq + q.ph;
+    r.wd = 2 * wq + q.pw;
+    r.ok = r.ok && r.hd < q.Hd && r.wd < q.Wd;
+  } else {
+    const int hw = q.Hd * q.Wd;
+    r.img = (int)(mm / hw);
+    const int rem = (int)(mm - (long long)r.img * hw);
+    r.hd = rem / q.Wd;
+    r.wd = rem - r.hd * q.Wd;
+  }
+  return r;
+}
+
 template <typename T, bool DGRAD, int BN>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
   constexpr int KE = 128 / (int)sizeof(T);  // elements of k per step
   constexpr int VE = 16 / (int)sizeof(T);   // elements per 16-B chunk
   constexpr int NB = BN / 32;               // B chunks per thread per step
   constexpr int NI = BN / 32;               // 16-wide n tiles per wave
-  __shared__ __attribute__((aligned(16))) char smem[2 * 128 * 128 + 2 * BN * 128];
+  constexpr int OUT_STRIDE = BN * (int)sizeof(T) + 16;  // staged output row (bytes), padded against bank conflicts
+  constexpr int TILE_BYTES = 2 * 128 * 128 + 2 * BN * 128;
+  constexpr int OUT_BYTES = 128 * OUT_STRIDE;
+  __shared__ __attribute__((aligned(16))) char smem[TILE_BYTES > OUT_BYTES ? TILE_BYTES : OUT_BYTES];
   char* sA = smem;
   char* sB = smem + 2 * 128 * 128;
 
@@ -83,11 +132,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  int logical = xcd_remap(blockIdx.x, gridDim.x);
+  // order [m_tile][class][n_tile]: every XCD range holds all 4 parity classes (their work differs: 1/2/2/4
+  // taps for 3x3, 1/0/0/0 for 1x1), and the n-tiles of one m-tile stay adjacent
   const int n_tile = logical % p.n_tiles;
-  const int m_tile = logical / p.n_tiles;
+  logical /= p.n_tiles;
+  const int cls = logical % p.classes;  // 0 unless classes == 4
+  const int m_tile = logical / p.classes;
+  const int ph = cls >> 1, pw = cls & 1;
   const long long m0 = (long long)m_tile * 128;
   const int n0 = n_tile * BN;
+  const bool par = DGRAD && p.classes == 4;
+
+  const PixelMap pm{p.Mg, p.Hd, p.Wd, p.Hq, p.Wq, ph, pw, par};
 
   // ---- per-thread loader state: 4 A rows (tid/8 + 32 i), chunk tid%8 --------------------
   const int chunk = tid & 7;
@@ -95,38 +152,39 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
   long long a_img[4];  // element offset of the image in the source tensor
   int a_h[4], a_w[4];  // fwd: hs0/ws0 = hd*stride - pad ; dgrad: hd + pad / wd + pad
   bool a_ok[4];
-  const int hw_d = p.Hd * p.Wd;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const long long m = m0 + lrow + 32 * i;
-    a_ok[i] = m < p.Mg;
-    const long long mm = a_ok[i] ? m : 0;
-    const int img = (int)(mm / hw_d);
-    const int rem = (int)(mm - (long long)img * hw_d);
-    const int hd = rem / p.Wd, wd = rem - hd * p.Wd;
-    a_img[i] = (long long)img * p.Hs * p.Ws * p.Ca;
+    const Pixel px = decode_pixel(pm, m0 + lrow + 32 * i);
+    a_ok[i] = px.ok;
+    a_img[i] = (long long)px.img * p.Hs * p.Ws * p.Ca;
     if (DGRAD) {
-      a_h[i] = hd + p.pad;
-      a_w[i] = wd + p.pad;
+      a_h[i] = px.hd + p.pad;
+      a_w[i] = px.wd + p.pad;
     } else {
-      a_h[i] = hd * p.stride - p.pad;
-      a_w[i] = wd * p.stride - p.pad;
+      a_h[i] = px.hd * p.stride - p.pad;
+      a_w[i] = px.wd * p.stride - p.pad;
     }
   }
   const T* __restrict__ asrc = reinterpret_cast<const T*>(p.a);
   const T* __restrict__ wsrc = reinterpret_cast<const T*>(p.w);
-  const int taps = p.R * p.S;
   const int csteps = p.Ca / KE;
-  const int nk = taps * csteps;
-  const long long wrow = (long long)taps * p.Ca;  // elements per weight row
+  // tap enumeration: all R x S taps, or (parity classes) only those with (hd + pad - r) even
+  const int r0 = par ? ((ph + p.pad) & 1) : 0, s0 = par ? ((pw + p.pad) & 1) : 0;
+  const int rstep = par ? 2 : 1;
+  const int ntr = par ? (p.R - r0 + 1) / 2 : p.R;
+  const int nts = par ? (p.S - s0 + 1) / 2 : p.S;
+  const int nk = (ntr > 0 && nts > 0) ? ntr * nts * csteps : 0;
+  const long long wrow = (long long)p.R * p.S * p.Ca;  // elements per weight row
 
-  uint4 ra[4], rb[NB];
-  auto load_step = [&](int ks) {
-    const int tap = ks / csteps;
-    const int c0 = (ks - tap * csteps) * KE + chunk * VE;
-    const int r = tap / p.S, s = tap - r * p.S;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
+  // staging registers as named scalars: an array here ends up in scratch / promoted to LDS (hipcc 7.2)
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2 = make_uint4(0, 0, 0, 0), rb3 = make_uint4(0, 0, 0, 0);
+  auto load_step = [&](int ks) __attribute__((always_inline)) {
+    const int t = ks / csteps;
+    const int c0 = (ks - t * csteps) * KE + chunk * VE;
+    const int tr = t / nts, ts = t - tr * nts;
+    const int r = r0 + rstep * tr, s = s0 + rstep * ts;
+    const int tap = r * p.S + s;
+    auto load_a = [&](int i) __attribute__((always_inline)) -> uint4 {
       int hs, ws;
       bool ok = a_ok[i];
       if (DGRAD) {
@@ -147,26 +205,39 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
       ok = ok && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (ok) v = *reinterpret_cast<const uint4*>(asrc + a_img[i] + ((long long)hs * p.Ws + ws) * p.Ca + c0);
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
+      return v;
+    };
+    auto load_b = [&](int i) __attribute__((always_inline)) -> uint4 {
       const int n = n0 + lrow + 32 * i;  // always < Ng (Ng % BN == 0)
-      rb[i] = *reinterpret_cast<const uint4*>(wsrc + (long long)n * wrow + (long long)tap * p.Ca + c0);
+      return *reinterpret_cast<const uint4*>(wsrc + (long long)n * wrow + (long long)tap * p.Ca + c0);
+    };
+    ra0 = load_a(0);
+    ra1 = load_a(1);
+    ra2 = load_a(2);
+    ra3 = load_a(3);
+    rb0 = load_b(0);
+    rb1 = load_b(1);
+    if (NB == 4) {
+      rb2 = load_b(2);
+      rb3 = load_b(3);
     }
   };
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf) __attribute__((always_inline)) {
     char* dA = sA + buf * (128 * 128);
     char* dB = sB + buf * (BN * 128);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    auto put = [&](char* base, int i, const uint4& v) __attribute__((always_inline)) {
       const int row = lrow + 32 * i;
-      *reinterpret_cast<uint4*>(dA + row * 128 + swz(row, chunk) * 16) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int row = lrow + 32 * i;
-      *reinterpret_cast<uint4*>(dB + row * 128 + swz(row, chunk) * 16) = rb[i];
+      *reinterpret_cast<uint4*>(base + row * 128 + swz(row, chunk) * 16) = v;
+    };
+    put(dA, 0, ra0);
+    put(dA, 1, ra1);
+    put(dA, 2, ra2);
+    put(dA, 3, ra3);
+    put(dB, 0, rb0);
+    put(dB, 1, rb1);
+    if (NB == 4) {
+      put(dB, 2, rb2);
+      put(dB, 3, rb3);
     }
   };
 
@@ -176,8 +247,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  load_step(0);
-  store_step(0);
+  if (nk > 0) {
+    load_step(0);
+    store_step(0);
+  }
   __syncthreads();
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
@@ -201,42 +274,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds pixel (wm*64 + mi*16 + li), channels n0 + wn*BN/2 + ni*16 + 4g + r
-  T* __restrict__ out = reinterpret_cast<T*>(p.out);
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const long long m = m0 + wm * 64 + mi * 16 + li;
-    if (m < p.Mg) {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        T* dst = out + m * p.Ng + n0 + wn * (BN / 2) + ni * 16 + 4 * g;
-        float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-        if (sizeof(T) == 4) {
-          float4* d4 = reinterpret_cast<float4*>(dst);
-          if (p.accumulate) {
-            const float4 o = *d4;
-            v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-          }
-          *d4 = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          uint2* d2 = reinterpret_cast<uint2*>(dst);
-          if (p.accumulate) {
-            const uint2 o = *d2;
-            v[0] += __uint_as_float(o.x << 16);
-            v[1] += __uint_as_float(o.x & 0xffff0000u);
-            v[2] += __uint_as_float(o.y << 16);
-            v[3] += __uint_as_float(o.y & 0xffff0000u);
-          }
-          uint2 w;
-          w.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-          w.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-          *d2 = w;
-        }
-      }
-    }
-  }
-
-  // ---- fused BatchNorm partial statistics of the fp32 accumulators ------------------------
+  // ---- fused BatchNorm partial statistics of the fp32 accumulators (registers -> LDS -> global) ----
+  // lane holds pixel (wm*64 + mi*16 + li), channels wn*BN/2 + ni*16 + 4g + r
   if (p.bn_partial != nullptr) {
     float* red = reinterpret_cast<float*>(smem);  // [2 (wm)][2][BN]; tiles are dead (loop ended with a barrier)
 #pragma unroll
@@ -268,12 +307,61 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
       const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c];
       p.bn_partial[((long long)m_tile * 2 + which) * p.Ng + n0 + c] = v;
     }
+    __syncthreads();
+  }
+
+  // ---- epilogue: stage the tile as [pixel][channel] in LDS, then whole-row 16-B stores ----------
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    char* orow = smem + (wm * 64 + mi * 16 + li) * OUT_STRIDE;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int ch = wn * (BN / 2) + ni * 16 + 4 * g;
+      if (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(orow + ch * 4) = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+      } else {
+        uint2 w;
+        w.x = (unsigned)f32_to_bf16(acc[mi][ni][0]) | ((unsigned)f32_to_bf16(acc[mi][ni][1]) << 16);
+        w.y = (unsigned)f32_to_bf16(acc[mi][ni][2]) | ((unsigned)f32_to_bf16(acc[mi][ni][3]) << 16);
+        *reinterpret_cast<uint2*>(orow + ch * 2) = w;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int CPR = BN * (int)sizeof(T) / 16;  // 16-B chunks per output row
+    constexpr int RPI = 256 / CPR;                 // rows covered per pass
+    const int oc = tid % CPR, orow0 = tid / CPR;
+    T* __restrict__ out = reinterpret_cast<T*>(p.out);
+#pragma unroll 4
+    for (int row = orow0; row < 128; row += RPI) {
+      const Pixel px = decode_pixel(pm, m0 + row);
+      if (!px.ok) continue;
+      const long long pix = par ? ((long long)px.img * p.Hd + px.hd) * p.Wd + px.wd : m0 + row;
+      T* dst = out + pix * p.Ng + n0 + oc * VE;
+      uint4 v = *reinterpret_cast<const uint4*>(smem + row * OUT_STRIDE + oc * 16);
+      if (p.accumulate) {
+        const uint4 o = *reinterpret_cast<const uint4*>(dst);
+        if (sizeof(T) == 4) {
+          v.x = __float_as_uint(__uint_as_float(v.x) + __uint_as_float(o.x));
+          v.y = __float_as_uint(__uint_as_float(v.y) + __uint_as_float(o.y));
+          v.z = __float_as_uint(__uint_as_float(v.z) + __uint_as_float(o.z));
+          v.w = __float_as_uint(__uint_as_float(v.w) + __uint_as_float(o.w));
+        } else {
+          v.x = add_bf16x2(v.x, o.x);
+          v.y = add_bf16x2(v.y, o.y);
+          v.z = add_bf16x2(v.z, o.z);
+          v.w = add_bf16x2(v.w, o.w);
+        }
+      }
+      *reinterpret_cast<uint4*>(dst) = v;
+    }
   }
 }
 
 template <typename T, bool DGRAD>
 static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
-  const int nblk = a.m_tiles * a.n_tiles;
+  const int nblk = a.classes * a.m_tiles * a.n_tiles;
   if (a.Ng % 128 == 0) {
     igemm_kernel<T, DGRAD, 128><<<nblk, 256, 0, s>>>(a);
   } else {
@@ -316,6 +404,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
   a.R = d->r; a.S = d->s; a.stride = d->stride; a.pad = d->pad;
   a.Hd = d->ho; a.Wd = d->wo; a.Hs = d->h; a.Ws = d->w;
   a.accumulate = 0;
+  a.classes = 1; a.Hq = a.Wq = 0;
   a.m_tiles = ceil_div(a.Mg, 128);
   a.n_tiles = a.Ng % 128 == 0 ? a.Ng / 128 : a.Ng / 64;
   const double flops = 2.0 * (double)a.Mg * d->cout * d->cin * d->r * d->s;
@@ -333,17 +422,26 @@ int simhand_conv2d_dgrad(const sh_conv_desc* d, const void* dy, const void* wt, 
   SH_REQUIRE(d->cin % 64 == 0, "conv2d_dgrad: cin=%d must be a multiple of 64", d->cin);
   IgemmArgs a;
   a.a = dy; a.w = wt; a.out = dx; a.bn_partial = nullptr;
-  a.Mg = (long long)d->n * d->h * d->w;
   a.Ng = d->cin; a.Ca = d->cout;
   a.R = d->r; a.S = d->s; a.stride = d->stride; a.pad = d->pad;
   a.Hd = d->h; a.Wd = d->w; a.Hs = d->ho; a.Ws = d->wo;
   a.accumulate = accumulate;
+  if (d->stride == 2) {
+    a.classes = 4;
+    a.Hq = (d->h + 1) / 2;
+    a.Wq = (d->w + 1) / 2;
+    a.Mg = (long long)d->n * a.Hq * a.Wq;
+  } else {
+    a.classes = 1;
+    a.Hq = a.Wq = 0;
+    a.Mg = (long long)d->n * d->h * d->w;
+  }
   a.m_tiles = ceil_div(a.Mg, 128);
   a.n_tiles = a.Ng % 128 == 0 ? a.Ng / 128 : a.Ng / 64;
   const long long mo = (long long)d->n * d->ho * d->wo;
   const double flops = 2.0 * (double)mo * d->cout * d->cin * d->r * d->s;
   const double es = d->dtype == SH_F32 ? 4 : 2;
-  const double bytes = es * ((double)a.Mg * d->cin * (accumulate ? 2 : 1) + (double)mo * d->cout + (double)d->cout * d->cin * d->r * d->s);
+  const double bytes = es * ((double)d->n * d->h * d->w * d->cin * (accumulate ? 2 : 1) + (double)mo * d->cout + (double)d->cout * d->cin * d->r * d->s);
   ProfScope ps(SH_PROF_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
   return d->dtype == SH_F32 ? launch_igemm<float, true>(a, (hipStream_t)stream) : launch_igemm<bf16_t, true>(a, (hipStream_t)stream);
 }

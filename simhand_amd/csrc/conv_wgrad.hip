@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   const unsigned hw = (unsigned)(p.Ho * p.Wo);
 
   uint4 ra[NA], rb[NBL];
-  auto load_step = [&](int ks) {
+  auto load_step = [&](int ks) __attribute__((always_inline)) {
     const long long base = pix_begin + (long long)ks * KP;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
       rb[i] = v;
     }
   };
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf) __attribute__((always_inline)) {
     char* dA = sA + buf * (KP * SA);
     char* dB = sB + buf * (KP * SB);
 #pragma unroll
