@@ -181,8 +181,8 @@ def main():
         all_conv_ms = sum(v["ms"] for v in conv.values())
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived, filled from rocprofv3 --pmc passes
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get(dom)
+        if os.path.exists(tf):  # bytes per launch of that kernel class from the committed rocprofv3 --pmc passes
+            traffic = (json.load(open(tf)).get(dom) or {}).get("bytes_per_launch")
         res = {
             "metric": "hand-image-pairs/sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",

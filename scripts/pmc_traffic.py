@@ -1,0 +1,34 @@
+"""HBM traffic per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KB units).
+FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for 16-B-per-lane coalesced reads on
+gfx950; WRITE_SIZE is taken as reported (uncalibrated).  usage: pmc_traffic.py fetch.db write.db out.md out.json"""
+import json, re, sqlite3, sys
+
+def load(path):
+    cur = sqlite3.connect(path).cursor()
+    out = {}
+    for name, cnt, tot in cur.execute("select name, count(*), sum(counter_value) from pmc_events group by name"):
+        out[re.sub(r"\(.*", "", name)] = (cnt, tot)
+    return out
+
+f, w = load(sys.argv[1]), load(sys.argv[2])
+rows = []
+for k in f:
+    cnt, fk = f[k]
+    wk = w.get(k, (cnt, 0.0))[1]
+    rd, wr = 2.0 * fk * 1024, wk * 1024
+    rows.append((rd + wr, k, cnt, rd, wr))
+rows.sort(reverse=True)
+lines = ["| kernel | launches | HBM read GB (2xFETCH_SIZE) | HBM write GB (WRITE_SIZE) | bytes / launch (MB) |", "|---|---|---|---|---|"]
+for tot, k, cnt, rd, wr in rows[:25]:
+    lines.append(f"| {k[:90]} | {cnt} | {rd/1e9:.2f} | {wr/1e9:.2f} | {tot/cnt/1e6:.1f} |")
+lines.append(f"\nall kernels: read {sum(r[3] for r in rows)/1e9:.1f} GB, write {sum(r[4] for r in rows)/1e9:.1f} GB over the profiled run (2 steps: 1 warm-up + 1 timed)")
+open(sys.argv[3], "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+cls = {"conv_fwd": "igemm_kernel<unsigned short, false", "conv_dgrad": "igemm_kernel<unsigned short, true", "conv_wgrad": "wgrad_kernel<unsigned short"}
+out = {}
+for c, pat in cls.items():
+    sel = [r for r in rows if pat in r[1]]
+    n = sum(r[2] for r in sel)
+    out[c] = {"bytes_per_launch": sum(r[0] for r in sel) / max(1, n), "launches_profiled": n,
+              "read_bytes": sum(r[3] for r in sel), "write_bytes": sum(r[4] for r in sel)}
+json.dump(out, open(sys.argv[4], "w"), indent=1)
