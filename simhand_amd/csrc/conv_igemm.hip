@@ -29,6 +29,27 @@
 
 namespace sh {
 
+// 32-bit division by an invariant divisor (host-precomputed), n < 2^31
+struct FastDiv {
+  unsigned d, mul, shr;
+};
+static FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d ? d : 1;
+  if (f.d == 1) {
+    f.mul = 0;
+    f.shr = 0;
+    return f;
+  }
+  unsigned lg = 31 - __builtin_clz(f.d);
+  if (f.d & (f.d - 1)) lg += 1;
+  const unsigned pw = 31 + lg;
+  f.mul = (unsigned)(((1ull << pw) + f.d - 1) / f.d);
+  f.shr = pw - 32;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr); }
+
 struct IgemmArgs {
   const void* a;      // source activations (x or dy), NHWC
   const void* w;      // [Ng][taps][Ca]
@@ -44,6 +65,8 @@ struct IgemmArgs {
   int m_tiles, n_tiles;
   int classes;        // 1, or 4 = stride-2 dgrad parity classes
   int Hq, Wq;         // class grid (ceil(Hd/2), ceil(Wd/2)) when classes == 4
+  FastDiv div_hw;     // pixel-grid size (Hd*Wd, or Hq*Wq with parity classes)
+  FastDiv div_w;      // grid width (Wd or Wq)
 };
 
 template <typename T> struct Mma;
@@ -88,32 +111,6 @@ struct Pixel {
   int img, hd, wd;
   bool ok;
 };
-struct PixelMap {
-  long long Mg;
-  int Hd, Wd, Hq, Wq, ph, pw;
-  bool par;
-};
-__device__ __forceinline__ Pixel decode_pixel(const PixelMap& q, long long m) {
-  Pixel r;
-  r.ok = m < q.Mg;
-  const long long mm = r.ok ? m : 0;
-  if (q.par) {
-    const int hwq = q.Hq * q.Wq;
-    r.img = (int)(mm / hwq);
-    const int rem = (int)(mm - (long long)r.img * hwq);
-    const int hq = rem / q.Wq, wq = rem - hq * q.Wq;
-    r.hd = 2 * hq + q.ph;
-    r.wd = 2 * wq + q.pw;
-    r.ok = r.ok && r.hd < q.Hd && r.wd < q.Wd;
-  } else {
-    const int hw = q.Hd * q.Wd;
-    r.img = (int)(mm / hw);
-    const int rem = (int)(mm - (long long)r.img * hw);
-    r.hd = rem / q.Wd;
-    r.wd = rem - r.hd * q.Wd;
-  }
-  return r;
-}
 
 template <typename T, bool DGRAD, int BN>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
@@ -140,104 +137,114 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
   const int cls = logical % p.classes;  // 0 unless classes == 4
   const int m_tile = logical / p.classes;
   const int ph = cls >> 1, pw = cls & 1;
-  const long long m0 = (long long)m_tile * 128;
+  const unsigned m0 = (unsigned)m_tile * 128u;  // Mg < 2^31 (checked on the host)
   const int n0 = n_tile * BN;
   const bool par = DGRAD && p.classes == 4;
 
-  const PixelMap pm{p.Mg, p.Hd, p.Wd, p.Hq, p.Wq, ph, pw, par};
-
-  // ---- per-thread loader state: 4 A rows (tid/8 + 32 i), chunk tid%8 --------------------
-  const int chunk = tid & 7;
-  const int lrow = tid >> 3;
-  long long a_img[4];  // element offset of the image in the source tensor
-  int a_h[4], a_w[4];  // fwd: hs0/ws0 = hd*stride - pad ; dgrad: hd + pad / wd + pad
-  bool a_ok[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const Pixel px = decode_pixel(pm, m0 + lrow + 32 * i);
-    a_ok[i] = px.ok;
-    a_img[i] = (long long)px.img * p.Hs * p.Ws * p.Ca;
-    if (DGRAD) {
-      a_h[i] = px.hd + p.pad;
-      a_w[i] = px.wd + p.pad;
+  auto decode = [&](unsigned m) __attribute__((always_inline)) -> Pixel {
+    Pixel r;
+    r.ok = m < (unsigned)p.Mg;
+    const unsigned mm = r.ok ? m : 0u;
+    const unsigned img = fdiv(mm, p.div_hw);
+    const unsigned rem = mm - img * p.div_hw.d;
+    const unsigned hq = fdiv(rem, p.div_w);
+    const unsigned wq = rem - hq * p.div_w.d;
+    r.img = (int)img;
+    if (par) {
+      r.hd = 2 * (int)hq + ph;
+      r.wd = 2 * (int)wq + pw;
+      r.ok = r.ok && r.hd < p.Hd && r.wd < p.Wd;
     } else {
-      a_h[i] = px.hd * p.stride - p.pad;
-      a_w[i] = px.wd * p.stride - p.pad;
+      r.hd = (int)hq;
+      r.wd = (int)wq;
     }
-  }
-  const T* __restrict__ asrc = reinterpret_cast<const T*>(p.a);
-  const T* __restrict__ wsrc = reinterpret_cast<const T*>(p.w);
-  const int csteps = p.Ca / KE;
-  // tap enumeration: all R x S taps, or (parity classes) only those with (hd + pad - r) even
+    return r;
+  };
+
+  // tap enumeration: all R x S taps, or (parity classes) only those with (hd + pad - r) even.
+  // Source pixel of tap (tr, ts): (h0 + dh*tr, w0 + dh*ts) with dh = +1 (forward) / -1 (dgrad).
   const int r0 = par ? ((ph + p.pad) & 1) : 0, s0 = par ? ((pw + p.pad) & 1) : 0;
   const int rstep = par ? 2 : 1;
   const int ntr = par ? (p.R - r0 + 1) / 2 : p.R;
   const int nts = par ? (p.S - s0 + 1) / 2 : p.S;
+  const int csteps = p.Ca / KE;
   const int nk = (ntr > 0 && nts > 0) ? ntr * nts * csteps : 0;
-  const long long wrow = (long long)p.R * p.S * p.Ca;  // elements per weight row
+  constexpr int dh = DGRAD ? -1 : 1;
 
+  // ---- per-thread loader state: 4 A rows (tid/8 + 32 i), chunk tid%8 --------------------
+  const int chunk = tid & 7;
+  const int lrow = tid >> 3;
+  const T* __restrict__ asrc = reinterpret_cast<const T*>(p.a);
+  const T* __restrict__ wsrc = reinterpret_cast<const T*>(p.w);
+  const T* pa0; const T* pa1; const T* pa2; const T* pa3;   // row base at tap (0,0), channel chunk 0
+  int h00, h01, h02, h03, w00, w01, w02, w03;              // source coords at tap (0,0); h = -2^20 for dead rows
+  auto init_row = [&](int i, const T*& pa, int& h0, int& w0) __attribute__((always_inline)) {
+    const Pixel px = decode(m0 + lrow + 32 * i);
+    if (DGRAD) {
+      h0 = par ? (px.hd + p.pad - r0) >> 1 : px.hd + p.pad;
+      w0 = par ? (px.wd + p.pad - s0) >> 1 : px.wd + p.pad;
+    } else {
+      h0 = px.hd * p.stride - p.pad;
+      w0 = px.wd * p.stride - p.pad;
+    }
+    pa = asrc + ((long long)px.img * p.Hs * p.Ws + (long long)h0 * p.Ws + w0) * p.Ca + chunk * VE;
+    if (!px.ok) h0 = -(1 << 20);  // fails every bounds test below
+  };
+  init_row(0, pa0, h00, w00);
+  init_row(1, pa1, h01, w01);
+  init_row(2, pa2, h02, w02);
+  init_row(3, pa3, h03, w03);
+  const long long wrow = (long long)p.R * p.S * p.Ca;  // elements per weight row
+  const T* pb0 = wsrc + (long long)(n0 + lrow) * wrow + chunk * VE;  // rows n0 + lrow + 32 i (always < Ng)
+  const long long wrow32 = 32 * wrow;
+  // LDS store offsets of this thread's rows (identical for the A and B tiles)
+  const int st0 = (lrow + 0) * 128 + swz(lrow + 0, chunk) * 16, st1 = (lrow + 32) * 128 + swz(lrow + 32, chunk) * 16;
+  const int st2 = (lrow + 64) * 128 + swz(lrow + 64, chunk) * 16, st3 = (lrow + 96) * 128 + swz(lrow + 96, chunk) * 16;
+
+  // iteration state of the NEXT load (wave-uniform)
+  int l_cs = 0, l_tr = 0, l_ts = 0;
   // staging registers as named scalars: an array here ends up in scratch / promoted to LDS (hipcc 7.2)
   uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2 = make_uint4(0, 0, 0, 0), rb3 = make_uint4(0, 0, 0, 0);
-  auto load_step = [&](int ks) __attribute__((always_inline)) {
-    const int t = ks / csteps;
-    const int c0 = (ks - t * csteps) * KE + chunk * VE;
-    const int tr = t / nts, ts = t - tr * nts;
-    const int r = r0 + rstep * tr, s = s0 + rstep * ts;
-    const int tap = r * p.S + s;
-    auto load_a = [&](int i) __attribute__((always_inline)) -> uint4 {
-      int hs, ws;
-      bool ok = a_ok[i];
-      if (DGRAD) {
-        const int th = a_h[i] - r, tw = a_w[i] - s;
-        if (p.stride == 2) {
-          ok = ok && ((th | tw) & 1) == 0;
-          hs = th >> 1;
-          ws = tw >> 1;
-        } else {
-          hs = th;
-          ws = tw;
-        }
-        ok = ok && th >= 0 && tw >= 0;
-      } else {
-        hs = a_h[i] + r;
-        ws = a_w[i] + s;
-      }
-      ok = ok && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+  auto load_step = [&]() __attribute__((always_inline)) {
+    const int hoff = dh * l_tr, woff = dh * l_ts;
+    const int aoff = (hoff * p.Ws + woff) * p.Ca + l_cs * KE;                              // elements, |.| < 2^31
+    const int boff = ((r0 + rstep * l_tr) * p.S + (s0 + rstep * l_ts)) * p.Ca + l_cs * KE;
+    auto load_a = [&](const T* pa, int h0, int w0) __attribute__((always_inline)) -> uint4 {
+      const bool ok = (unsigned)(h0 + hoff) < (unsigned)p.Hs && (unsigned)(w0 + woff) < (unsigned)p.Ws;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *reinterpret_cast<const uint4*>(asrc + a_img[i] + ((long long)hs * p.Ws + ws) * p.Ca + c0);
+      if (ok) v = *reinterpret_cast<const uint4*>(pa + aoff);
       return v;
     };
-    auto load_b = [&](int i) __attribute__((always_inline)) -> uint4 {
-      const int n = n0 + lrow + 32 * i;  // always < Ng (Ng % BN == 0)
-      return *reinterpret_cast<const uint4*>(wsrc + (long long)n * wrow + (long long)tap * p.Ca + c0);
-    };
-    ra0 = load_a(0);
-    ra1 = load_a(1);
-    ra2 = load_a(2);
-    ra3 = load_a(3);
-    rb0 = load_b(0);
-    rb1 = load_b(1);
+    ra0 = load_a(pa0, h00, w00);
+    ra1 = load_a(pa1, h01, w01);
+    ra2 = load_a(pa2, h02, w02);
+    ra3 = load_a(pa3, h03, w03);
+    rb0 = *reinterpret_cast<const uint4*>(pb0 + boff);
+    rb1 = *reinterpret_cast<const uint4*>(pb0 + wrow32 + boff);
     if (NB == 4) {
-      rb2 = load_b(2);
-      rb3 = load_b(3);
+      rb2 = *reinterpret_cast<const uint4*>(pb0 + 2 * wrow32 + boff);
+      rb3 = *reinterpret_cast<const uint4*>(pb0 + 3 * wrow32 + boff);
+    }
+    if (++l_cs == csteps) {
+      l_cs = 0;
+      if (++l_ts == nts) {
+        l_ts = 0;
+        ++l_tr;
+      }
     }
   };
   auto store_step = [&](int buf) __attribute__((always_inline)) {
     char* dA = sA + buf * (128 * 128);
     char* dB = sB + buf * (BN * 128);
-    auto put = [&](char* base, int i, const uint4& v) __attribute__((always_inline)) {
-      const int row = lrow + 32 * i;
-      *reinterpret_cast<uint4*>(base + row * 128 + swz(row, chunk) * 16) = v;
-    };
-    put(dA, 0, ra0);
-    put(dA, 1, ra1);
-    put(dA, 2, ra2);
-    put(dA, 3, ra3);
-    put(dB, 0, rb0);
-    put(dB, 1, rb1);
+    *reinterpret_cast<uint4*>(dA + st0) = ra0;
+    *reinterpret_cast<uint4*>(dA + st1) = ra1;
+    *reinterpret_cast<uint4*>(dA + st2) = ra2;
+    *reinterpret_cast<uint4*>(dA + st3) = ra3;
+    *reinterpret_cast<uint4*>(dB + st0) = rb0;
+    *reinterpret_cast<uint4*>(dB + st1) = rb1;
     if (NB == 4) {
-      put(dB, 2, rb2);
-      put(dB, 3, rb3);
+      *reinterpret_cast<uint4*>(dB + st2) = rb2;
+      *reinterpret_cast<uint4*>(dB + st3) = rb3;
     }
   };
 
@@ -248,23 +255,27 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) {
-    load_step(0);
+    load_step();
     store_step(0);
   }
   __syncthreads();
+  // fragment offsets: rows differ by multiples of 16 -> one swizzle key per lane
+  const int fkey = (li >> 1) & 7;
+  const int fo0 = ((0 + g) ^ fkey) * 16, fo1 = ((4 + g) ^ fkey) * 16;
+  const int fa_base = (wm * 64 + li) * 128, fb_base = (wn * (BN / 2) + li) * 128;
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
-    if (ks + 1 < nk) load_step(ks + 1);  // global loads in flight under the MFMAs
-    const char* cA = sA + buf * (128 * 128) + (wm * 64 + li) * 128;
-    const char* cB = sB + buf * (BN * 128) + (wn * (BN / 2) + li) * 128;
+    if (ks + 1 < nk) load_step();  // global loads in flight under the MFMAs
+    const char* cA = sA + buf * (128 * 128) + fa_base;
+    const char* cB = sB + buf * (BN * 128) + fb_base;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       uint4 fa[4], fb[NI];
-      const int c = (4 * kk + g) ^ ((li >> 1) & 7);  // rows differ by multiples of 16 -> same swizzle key
+      const int fo = kk == 0 ? fo0 : fo1;
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) fa[mi] = *reinterpret_cast<const uint4*>(cA + mi * 16 * 128 + c * 16);
+      for (int mi = 0; mi < 4; ++mi) fa[mi] = *reinterpret_cast<const uint4*>(cA + mi * 16 * 128 + fo);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) fb[ni] = *reinterpret_cast<const uint4*>(cB + ni * 16 * 128 + c * 16);
+      for (int ni = 0; ni < NI; ++ni) fb[ni] = *reinterpret_cast<const uint4*>(cB + ni * 16 * 128 + fo);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -335,9 +346,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
     T* __restrict__ out = reinterpret_cast<T*>(p.out);
 #pragma unroll 4
     for (int row = orow0; row < 128; row += RPI) {
-      const Pixel px = decode_pixel(pm, m0 + row);
-      if (!px.ok) continue;
-      const long long pix = par ? ((long long)px.img * p.Hd + px.hd) * p.Wd + px.wd : m0 + row;
+      long long pix = (long long)m0 + row;
+      if (par) {
+        const Pixel px = decode(m0 + row);
+        if (!px.ok) continue;
+        pix = ((long long)px.img * p.Hd + px.hd) * p.Wd + px.wd;
+      } else if (pix >= p.Mg) {
+        continue;
+      }
       T* dst = out + pix * p.Ng + n0 + oc * VE;
       uint4 v = *reinterpret_cast<const uint4*>(smem + row * OUT_STRIDE + oc * 16);
       if (p.accumulate) {
@@ -405,6 +421,9 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
   a.Hd = d->ho; a.Wd = d->wo; a.Hs = d->h; a.Ws = d->w;
   a.accumulate = 0;
   a.classes = 1; a.Hq = a.Wq = 0;
+  SH_REQUIRE(a.Mg < (1ll << 31) - 256, "conv2d_fwd: %lld output pixels exceed the 2^31 index range", a.Mg);
+  a.div_hw = make_fastdiv((unsigned)(a.Hd * a.Wd));
+  a.div_w = make_fastdiv((unsigned)a.Wd);
   a.m_tiles = ceil_div(a.Mg, 128);
   a.n_tiles = a.Ng % 128 == 0 ? a.Ng / 128 : a.Ng / 64;
   const double flops = 2.0 * (double)a.Mg * d->cout * d->cin * d->r * d->s;
@@ -436,6 +455,9 @@ int simhand_conv2d_dgrad(const sh_conv_desc* d, const void* dy, const void* wt, 
     a.Hq = a.Wq = 0;
     a.Mg = (long long)d->n * d->h * d->w;
   }
+  SH_REQUIRE(a.Mg < (1ll << 31) - 256, "conv2d_dgrad: %lld pixels exceed the 2^31 index range", a.Mg);
+  a.div_hw = make_fastdiv((unsigned)(a.classes == 4 ? a.Hq * a.Wq : a.Hd * a.Wd));
+  a.div_w = make_fastdiv((unsigned)(a.classes == 4 ? a.Wq : a.Wd));
   a.m_tiles = ceil_div(a.Mg, 128);
   a.n_tiles = a.Ng % 128 == 0 ? a.Ng / 128 : a.Ng / 64;
   const long long mo = (long long)d->n * d->ho * d->wo;
