@@ -106,6 +106,16 @@ __device__ __forceinline__ unsigned add_bf16x2(unsigned a, unsigned b) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
 
+// sum over the 16 lanes of a DPP row (lanes sharing lane>>4), result in every lane: four row_ror
+// rotations on the VALU instead of ds_bpermute shuffles through the LDS crossbar
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+
 // destination pixel of GEMM row m (parity classes: m runs over the class grid Hq x Wq)
 struct Pixel {
   int img, hd, wd;
@@ -300,11 +310,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
           s1 += v;
           s2 += v * v;
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          s1 += __shfl_xor(s1, o);
-          s2 += __shfl_xor(s2, o);
-        }
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
         if (li == 0) {
           const int c = wn * (BN / 2) + ni * 16 + 4 * g + r;
           red[(wm * 2 + 0) * BN + c] = s1;
