@@ -157,9 +157,14 @@ typedef struct sh_conv_desc {
  * bn_partial [nblk_m][2][cout] fp32 with nblk_m = simhand_conv2d_fwd_stat_blocks(). */
 int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d);
 int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void* y, float* bn_partial, sh_stream_t stream);
-/* dx = conv_transpose(dy, w).  wt = weights permuted to [Cin][R][S][Cout] (simhand_permute_krsc_to_crsk).
+/* dx = conv_transpose(dy, w).  wt = weights permuted to [Cin][R][S][Cout] (simhand_oihw_f32_to_crsk).
  * accumulate != 0: dx += result (residual branch merge). */
 int simhand_conv2d_dgrad(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, sh_stream_t stream);
+/* identity-block merge without materialising the ReLU-masked residual gradient:
+ * dx = conv_transpose(dy, w) + res_grad * [bit of res_mask]  (res_grad = gradient of the block output,
+ * res_mask = the block output's ReLU bit mask from simhand_bn_apply; both laid out like dx). */
+int simhand_conv2d_dgrad_masked_residual(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, const void* res_grad,
+                                         const uint8_t* res_mask, sh_stream_t stream);
 /* dw (fp32, KRSC) = sum over output pixels of dy (x) patches(x); deterministic two-stage split-K */
 size_t simhand_conv2d_wgrad_workspace_bytes(const sh_conv_desc* d);
 int simhand_conv2d_wgrad(const sh_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, sh_stream_t stream);
@@ -195,13 +200,16 @@ int simhand_bn_finalize(const float* partial, int nblk, int64_t m, int c, const 
 /* eval mode (model.eval(), validation_step): scale/shift from the running statistics */
 int simhand_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                             int c, float* scale, float* shift, sh_stream_t stream);
-/* a = act(y*scale + shift (+ residual)), act = relu if relu != 0 */
+/* a = act(y*scale + shift (+ residual)), act = relu if relu != 0.  relu_mask (or NULL): [M][C/VE] bytes, bit e of
+ * byte (row, cv) = element (row, cv*VE + e) passed the ReLU (VE = 8 for bf16, 4 for fp32) -- lets the backward of
+ * units with a residual add read 1 bit instead of the stored activation. */
 int simhand_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, int relu,
-                     void* a, int64_t m, int c, int dtype, sh_stream_t stream);
+                     void* a, uint8_t* relu_mask, int64_t m, int c, int dtype, sh_stream_t stream);
 /* backward: g = da * [relu input > 0]; partial [simhand_bn_stat_blocks][2][C] sums of g and g*xhat;
  * finalize -> dbeta, dgamma; apply: dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), dres (optional) = g.
  * relu: 0 = none, 1 = mask from the stored activation a (units with a residual add),
- *       2 = mask recomputed from y*scale+shift (no residual; a is not read at all). */
+ *       2 = mask recomputed from y*scale+shift (no residual; a is not read at all),
+ *       3 = `a` points to the bit mask written by simhand_bn_apply (residual units). */
 int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const float* mean, const float* invstd,
                            const float* scale, const float* shift, int relu, int64_t m, int c, int dtype, float* partial,
                            sh_stream_t stream);

@@ -75,6 +75,7 @@ SIGNATURES = {
     "simhand_conv2d_fwd_stat_blocks": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "simhand_conv2d_dgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),
+    "simhand_conv2d_dgrad_masked_residual": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "simhand_conv2d_wgrad_workspace_bytes": (_S, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _S, _P]),
     "simhand_wgrad_set_tr": (_I, [_I]),
@@ -89,7 +90,7 @@ SIGNATURES = {
     "simhand_bn_finalize_workspace_bytes": (_S, [_I, _I]),
     "simhand_bn_finalize": (_I, [_P, _I, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_bn_eval_params": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
-    "simhand_bn_apply": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P]),
+    "simhand_bn_apply": (_I, [_P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P]),
     "simhand_bn_bwd_partial": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P]),
     "simhand_bn_bwd_finalize": (_I, [_P, _I, _I, _P, _P, _P]),
     "simhand_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P]),

@@ -177,10 +177,11 @@ __device__ __forceinline__ RowWalk row_walk(int64_t m, int c) {
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const T* __restrict__ res, int relu,
-                                                       T* __restrict__ a, int64_t m, int c) {
+                                                       T* __restrict__ a, uint8_t* __restrict__ mask, int64_t m, int c) {
   constexpr int VE = Vec16<T>::N;
   const RowWalk w = row_walk<VE>(m, c);
   if (w.rl >= w.rowlanes) return;
+  const int cvecs = c / VE;
   for (int cv = w.cv; cv < c / VE; cv += w.span) {
     float sc[VE], sh[VE];
 #pragma unroll
@@ -201,6 +202,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
         for (int e = 0; e < VE; ++e) o[e] += q[e];
       }
       if (relu) {
+        if (mask) {  // 1 bit per element (bit e = channel cv*VE + e passed the ReLU): the backward reads this, not `a`
+          unsigned bits = 0;
+#pragma unroll
+          for (int e = 0; e < VE; ++e) bits |= (o[e] > 0.f ? 1u : 0u) << e;
+          mask[r * cvecs + cv] = (uint8_t)bits;
+        }
 #pragma unroll
         for (int e = 0; e < VE; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
       }
@@ -229,6 +236,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
     } else if (relu == 2) {  // no residual: the ReLU input is recomputed from y (same fp32 expression as bn_apply)
 #pragma unroll
       for (int e = 0; e < VE; ++e) g[e] = yy[e] * scale[cv * VE + e] + shift[cv * VE + e] > 0.f ? g[e] : 0.f;
+    } else if (relu == 3) {  // residual unit: 1-bit mask written by bn_apply (`a` points to it)
+      const unsigned bits = reinterpret_cast<const uint8_t*>(a)[r * (c / VE) + cv];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) g[e] = (bits >> e) & 1u ? g[e] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
@@ -302,6 +313,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       } else if (relu == 2) {
 #pragma unroll
         for (int e = 0; e < VE; ++e) g[e] = yy[e] * sc[e] + sh[e] > 0.f ? g[e] : 0.f;
+      } else if (relu == 3) {
+        const unsigned bits = reinterpret_cast<const uint8_t*>(a)[r * (c / VE) + cv];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) g[e] = (bits >> e) & 1u ? g[e] : 0.f;
       }
 #pragma unroll
       for (int e = 0; e < VE; ++e) o[e] = A[e] * (g[e] - k2[e]) - (yy[e] - mu[e]) * is[e] * k3[e];
@@ -395,18 +410,19 @@ int simhand_bn_eval_params(const float* gamma, const float* beta, const float* r
   return check_launch("bn_eval_params");
 }
 
-int simhand_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, int relu, void* a, int64_t m,
-                     int c, int dtype, sh_stream_t stream) {
+int simhand_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, int relu, void* a,
+                     uint8_t* relu_mask, int64_t m, int c, int dtype, sh_stream_t stream) {
   SH_REQUIRE(y && scale && shift && a, "bn_apply: NULL pointer");
+  SH_REQUIRE(!relu_mask || relu, "bn_apply: a ReLU mask is only produced with relu != 0");
   const int ve = dtype == SH_F32 ? 4 : 8;
   SH_REQUIRE(c % ve == 0, "bn_apply: c=%d not a multiple of %d", c, ve);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (residual ? 3 : 2));
   const int grid = row_grid(m, c / ve);
   if (dtype == SH_F32)
-    bn_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)y, scale, shift, (const float*)residual, relu, (float*)a, m, c);
+    bn_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)y, scale, shift, (const float*)residual, relu, (float*)a, relu_mask, m, c);
   else
-    bn_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)y, scale, shift, (const bf16_t*)residual, relu, (bf16_t*)a, m, c);
+    bn_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)y, scale, shift, (const bf16_t*)residual, relu, (bf16_t*)a, relu_mask, m, c);
   return check_launch("bn_apply");
 }
 
@@ -414,8 +430,8 @@ int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const f
                            const float* scale, const float* shift, int relu, int64_t m, int c, int dtype, float* partial,
                            sh_stream_t stream) {
   SH_REQUIRE(da && y && mean && invstd && partial, "bn_bwd_partial: NULL pointer");
-  SH_REQUIRE(relu >= 0 && relu <= 2, "bn_bwd_partial: relu mode %d", relu);
-  SH_REQUIRE(relu != 1 || a, "bn_bwd_partial: relu mode 1 needs the activation output");
+  SH_REQUIRE(relu >= 0 && relu <= 3, "bn_bwd_partial: relu mode %d", relu);
+  SH_REQUIRE((relu != 1 && relu != 3) || a, "bn_bwd_partial: relu modes 1 / 3 need the activation output / its bit mask");
   SH_REQUIRE(relu != 2 || (scale && shift), "bn_bwd_partial: relu mode 2 needs scale/shift");
   SH_REQUIRE(c % (dtype == SH_F32 ? 4 : 8) == 0, "bn_bwd_partial: c=%d not a multiple of the 16-B vector", c);
   int rpb, nblk;
@@ -441,8 +457,8 @@ int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const flo
                          const float* dgamma, const float* dbeta, const float* scale, const float* shift, int relu, void* dy,
                          void* dres, int64_t m, int c, int dtype, sh_stream_t stream) {
   SH_REQUIRE(da && y && mean && invstd && dgamma && dbeta && dy, "bn_bwd_apply: NULL pointer");
-  SH_REQUIRE(relu >= 0 && relu <= 2, "bn_bwd_apply: relu mode %d", relu);
-  SH_REQUIRE(relu != 1 || a, "bn_bwd_apply: relu mode 1 needs the activation output");
+  SH_REQUIRE(relu >= 0 && relu <= 3, "bn_bwd_apply: relu mode %d", relu);
+  SH_REQUIRE((relu != 1 && relu != 3) || a, "bn_bwd_apply: relu modes 1 / 3 need the activation output / its bit mask");
   SH_REQUIRE(relu != 2 || (scale && shift), "bn_bwd_apply: relu mode 2 needs scale/shift");
   const int ve = dtype == SH_F32 ? 4 : 8;
   SH_REQUIRE(c % ve == 0, "bn_bwd_apply: c=%d not a multiple of %d", c, ve);

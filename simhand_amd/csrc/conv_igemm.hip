@@ -61,7 +61,9 @@ struct IgemmArgs {
   int R, S, stride, pad;
   int Hd, Wd;         // destination spatial size
   int Hs, Ws;         // source spatial size
-  int accumulate;
+  int accumulate;     // 0: store, 1: out += result, 2: out = result + res_grad * bit(res_mask)
+  const void* res_grad;        // accumulate == 2: gradient of the block output, laid out like out
+  const unsigned char* res_mask; // accumulate == 2: its ReLU bit mask [pixel][Ng / VE]
   int m_tiles, n_tiles;
   int classes;        // 1, or 4 = stride-2 dgrad parity classes
   int Hq, Wq;         // class grid (ceil(Hd/2), ceil(Wd/2)) when classes == 4
@@ -363,7 +365,26 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
       }
       T* dst = out + pix * p.Ng + n0 + oc * VE;
       uint4 v = *reinterpret_cast<const uint4*>(smem + row * OUT_STRIDE + oc * 16);
-      if (p.accumulate) {
+      if (p.accumulate == 2) {
+        // identity-branch gradient g = res_grad * relu_mask, merged here instead of being materialised
+        const uint4 o = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res_grad) + pix * p.Ng + n0 + oc * VE);
+        const unsigned bits = p.res_mask[pix * (p.Ng / VE) + n0 / VE + oc];
+        if (sizeof(T) == 4) {
+          v.x = __float_as_uint(__uint_as_float(v.x) + ((bits & 1u) ? __uint_as_float(o.x) : 0.f));
+          v.y = __float_as_uint(__uint_as_float(v.y) + ((bits & 2u) ? __uint_as_float(o.y) : 0.f));
+          v.z = __float_as_uint(__uint_as_float(v.z) + ((bits & 4u) ? __uint_as_float(o.z) : 0.f));
+          v.w = __float_as_uint(__uint_as_float(v.w) + ((bits & 8u) ? __uint_as_float(o.w) : 0.f));
+        } else {
+          const unsigned m0w = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
+          const unsigned m1w = ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
+          const unsigned m2w = ((bits & 16u) ? 0x0000ffffu : 0u) | ((bits & 32u) ? 0xffff0000u : 0u);
+          const unsigned m3w = ((bits & 64u) ? 0x0000ffffu : 0u) | ((bits & 128u) ? 0xffff0000u : 0u);
+          v.x = add_bf16x2(v.x, o.x & m0w);
+          v.y = add_bf16x2(v.y, o.y & m1w);
+          v.z = add_bf16x2(v.z, o.z & m2w);
+          v.w = add_bf16x2(v.w, o.w & m3w);
+        }
+      } else if (p.accumulate) {
         const uint4 o = *reinterpret_cast<const uint4*>(dst);
         if (sizeof(T) == 4) {
           v.x = __float_as_uint(__uint_as_float(v.x) + __uint_as_float(o.x));
@@ -426,7 +447,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
   a.Ng = d->cout; a.Ca = d->cin;
   a.R = d->r; a.S = d->s; a.stride = d->stride; a.pad = d->pad;
   a.Hd = d->ho; a.Wd = d->wo; a.Hs = d->h; a.Ws = d->w;
-  a.accumulate = 0;
+  a.accumulate = 0; a.res_grad = nullptr; a.res_mask = nullptr;
   a.classes = 1; a.Hq = a.Wq = 0;
   SH_REQUIRE(a.Mg < (1ll << 31) - 256, "conv2d_fwd: %lld output pixels exceed the 2^31 index range", a.Mg);
   a.div_hw = make_fastdiv((unsigned)(a.Hd * a.Wd));
@@ -440,7 +461,8 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
   return d->dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 
-int simhand_conv2d_dgrad(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, sh_stream_t stream) {
+static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
+                      const unsigned char* res_mask, sh_stream_t stream) {
   if (check_desc(d, "conv2d_dgrad")) return 1;
   SH_REQUIRE(dy && wt && dx, "conv2d_dgrad: NULL pointer");
   const int ke = d->dtype == SH_F32 ? 32 : 64;
@@ -451,7 +473,7 @@ int simhand_conv2d_dgrad(const sh_conv_desc* d, const void* dy, const void* wt, 
   a.Ng = d->cin; a.Ca = d->cout;
   a.R = d->r; a.S = d->s; a.stride = d->stride; a.pad = d->pad;
   a.Hd = d->h; a.Wd = d->w; a.Hs = d->ho; a.Ws = d->wo;
-  a.accumulate = accumulate;
+  a.accumulate = accumulate; a.res_grad = res_grad; a.res_mask = res_mask;
   if (d->stride == 2) {
     a.classes = 4;
     a.Hq = (d->h + 1) / 2;
@@ -473,6 +495,16 @@ int simhand_conv2d_dgrad(const sh_conv_desc* d, const void* dy, const void* wt, 
   const double bytes = es * ((double)d->n * d->h * d->w * d->cin * (accumulate ? 2 : 1) + (double)mo * d->cout + (double)d->cout * d->cin * d->r * d->s);
   ProfScope ps(SH_PROF_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
   return d->dtype == SH_F32 ? launch_igemm<float, true>(a, (hipStream_t)stream) : launch_igemm<bf16_t, true>(a, (hipStream_t)stream);
+}
+
+int simhand_conv2d_dgrad(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, sh_stream_t stream) {
+  return dgrad_impl(d, dy, wt, dx, accumulate ? 1 : 0, nullptr, nullptr, stream);
+}
+
+int simhand_conv2d_dgrad_masked_residual(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, const void* res_grad,
+                                         const uint8_t* res_mask, sh_stream_t stream) {
+  SH_REQUIRE(res_grad && res_mask, "conv2d_dgrad_masked_residual: NULL pointer");
+  return dgrad_impl(d, dy, wt, dx, 2, res_grad, res_mask, stream);
 }
 
 }  // extern "C"

@@ -124,7 +124,7 @@ class _Packed:
 
 class _Unit:
     """Saved tensors of one conv+BN unit for the backward pass."""
-    __slots__ = ("conv", "bn", "desc", "x", "y", "a", "st", "relu", "stem", "has_res")
+    __slots__ = ("conv", "bn", "desc", "x", "y", "a", "st", "relu", "stem", "has_res", "mask")
 
 
 class ResNetEngine:
@@ -163,11 +163,16 @@ class ResNetEngine:
         y, part = ops.conv2d_fwd(d, x, pk.krsc, want_stats=training)
         m = n * d.ho * d.wo
         st = self._bn(bn, part, m, conv.out_channels, training)
-        a = ops.bn_apply(y, st, m, conv.out_channels, relu, residual)
+        mask = None
+        if save is not None and residual is not None and relu:
+            a, mask = ops.bn_apply(y, st, m, conv.out_channels, relu, residual, want_mask=True)
+        else:
+            a = ops.bn_apply(y, st, m, conv.out_channels, relu, residual)
         if save is not None:
             u = _Unit()
             u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv, bn, d, x, y, a, st, relu, False
             u.has_res = residual is not None
+            u.mask = mask
             save.append(u)
         return a
 
@@ -190,6 +195,7 @@ class ResNetEngine:
             u = _Unit()
             u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv1, bn1, d, col, y, a, st, True, True
             u.has_res = False
+            u.mask = None
             ctx["stem"] = u
             ctx["pool_idx"] = idx
             ctx["pool_in_shape"] = tuple(a.shape)
@@ -216,26 +222,28 @@ class ResNetEngine:
         return out, ctx
 
     # -- backward --------------------------------------------------------------
-    def _unit_bwd(self, u: _Unit, da, grads: dict, want_dres: bool, need_dx: bool, dx_into=None):
-        """BN bwd -> wgrad (+ dgrad).  Returns (dx or None, dres or None)."""
+    def _unit_bwd(self, u: _Unit, da, grads: dict, need_dx: bool, dx_into=None, relu_mask=None, res_grad=None, res_mask=None):
+        """BN bwd -> wgrad (+ dgrad).  relu_mask: bit mask that gates `da` (residual units: their own output mask;
+        downsample branch: the block output's mask).  res_grad/res_mask: merge the identity-branch gradient
+        res_grad * bit(res_mask) into dx inside the dgrad epilogue.  Returns dx or None."""
         d = u.desc
         m = d.n * d.ho * d.wo
         c = d.cout
-        dy, dres, dg, db = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, want_dres,
-                                           mask_from_y=u.relu and not u.has_res)
+        dy, _, dg, db = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, False,
+                                        mask_from_y=u.relu and not u.has_res, relu_mask=relu_mask)
         grads[u.bn.weight] = dg
         grads[u.bn.bias] = db
         dw = ops.conv2d_wgrad(d, u.x, dy)
         w = u.conv.weight
         grads[w] = ops.unpack_krsc_grad(dw, tuple(w.shape), STEM_KPAD if u.stem else None)
-        dx = None
-        if need_dx:
-            pk = self._pack(u.conv, need_t=True)
-            if dx_into is not None:
-                dx = ops.conv2d_dgrad(d, dy, pk.crsk, dx=dx_into, accumulate=True)
-            else:
-                dx = ops.conv2d_dgrad(d, dy, pk.crsk)
-        return dx, dres
+        if not need_dx:
+            return None
+        pk = self._pack(u.conv, need_t=True)
+        if res_grad is not None:
+            return ops.conv2d_dgrad_masked_residual(d, dy, pk.crsk, res_grad, res_mask)
+        if dx_into is not None:
+            return ops.conv2d_dgrad(d, dy, pk.crsk, dx=dx_into, accumulate=True)
+        return ops.conv2d_dgrad(d, dy, pk.crsk)
 
     def backward(self, ctx: dict, d_enc: Tensor) -> Dict[nn.Parameter, Tensor]:
         grads: Dict[nn.Parameter, Tensor] = {}
@@ -243,19 +251,19 @@ class ResNetEngine:
         dz = ops.avgpool_bwd(g, ctx["last_shape"])
         for saved, ds in reversed(ctx["blocks"]):
             last = saved[-1]
-            # out = relu(bn(conv(t)) + idn): dres is the gradient of the identity branch
-            dt_, dres = self._unit_bwd(last, dz, grads, want_dres=True, need_dx=True)
+            # out = relu(bn(conv(t)) + idn): the gradient of both branches is dz gated by the output's ReLU mask
+            dt_ = self._unit_bwd(last, dz, grads, True, relu_mask=last.mask)
             for u in reversed(saved[1:-1]):
-                dt_, _ = self._unit_bwd(u, dt_, grads, False, True)
+                dt_ = self._unit_bwd(u, dt_, grads, True)
             first = saved[0]
             if ds is not None:
-                dx, _ = self._unit_bwd(ds, dres, grads, False, True)
-                dz, _ = self._unit_bwd(first, dt_, grads, False, True, dx_into=dx)
+                dx = self._unit_bwd(ds, dz, grads, True, relu_mask=last.mask)
+                dz = self._unit_bwd(first, dt_, grads, True, dx_into=dx)
             else:
-                dz, _ = self._unit_bwd(first, dt_, grads, False, True, dx_into=dres)
+                dz = self._unit_bwd(first, dt_, grads, True, res_grad=dz, res_mask=last.mask)
             saved.clear()
         da = ops.maxpool_bwd(dz, ctx["pool_idx"], ctx["pool_in_shape"])
-        self._unit_bwd(ctx["stem"], da, grads, False, need_dx=False)
+        self._unit_bwd(ctx["stem"], da, grads, need_dx=False)
         return grads
 
 

@@ -157,6 +157,15 @@ def conv2d_dgrad(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accumul
     return dx
 
 
+def conv2d_dgrad_masked_residual(d: ConvDesc, dy, wt, res_grad, res_mask) -> torch.Tensor:
+    """dx = dgrad(dy) + res_grad * relu-bit(res_mask): identity-block merge without a materialised residual gradient."""
+    lib = _lib_dev()
+    dx = torch.empty(d.n, d.h, d.w, d.cin, dtype=dy.dtype, device=dy.device)
+    check(lib.simhand_conv2d_dgrad_masked_residual(C.byref(d), _ptr(dy), _ptr(wt), _ptr(dx), _ptr(res_grad), _ptr(res_mask), _stream()),
+          "conv2d_dgrad_masked_residual")
+    return dx
+
+
 def conv2d_wgrad(d: ConvDesc, x, dy) -> torch.Tensor:
     """fp32 gradient in KRSC row order [cout][r*s*cin]."""
     lib = _lib_dev()
@@ -259,23 +268,32 @@ def bn_eval_state(c: int, gamma, beta, running_mean, running_var, eps: float = 1
     return st
 
 
-def bn_apply(y, st: BNState, m: int, c: int, relu: bool, residual=None, out=None) -> torch.Tensor:
+def bn_apply(y, st: BNState, m: int, c: int, relu: bool, residual=None, out=None, want_mask: bool = False):
+    """a = act(y*scale + shift (+ residual)).  want_mask: also return the ReLU bit mask ([m][c/VE] uint8) that the
+    backward of a residual unit reads instead of the activation."""
     lib = _lib_dev()
     a = torch.empty_like(y) if out is None else out
-    check(lib.simhand_bn_apply(_ptr(y), _ptr(st.scale), _ptr(st.shift), _ptr(residual), int(relu), _ptr(a), m, c, dt(y.dtype),
-                               _stream()), "bn_apply")
-    return a
+    mask = None
+    if want_mask:
+        ve = 4 if y.dtype == torch.float32 else 8
+        mask = torch.empty(m, c // ve, dtype=torch.uint8, device=y.device)
+    check(lib.simhand_bn_apply(_ptr(y), _ptr(st.scale), _ptr(st.shift), _ptr(residual), int(relu), _ptr(a), _ptr(mask), m, c,
+                               dt(y.dtype), _stream()), "bn_apply")
+    return (a, mask) if want_mask else a
 
 
-def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_dres: bool, mask_from_y: bool = False):
+def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_dres: bool, mask_from_y: bool = False,
+                relu_mask=None):
     """Returns (dy, dres or None, dgamma, dbeta).  mask_from_y: the unit had no residual add, so the ReLU mask is
-    recomputed from y (the stored activation is not read)."""
+    recomputed from y (the stored activation is not read).  relu_mask: bit mask from bn_apply(want_mask=True) --
+    g = da * bit, whatever `relu` says about this unit's own activation (used for residual units and for the
+    downsample branch, whose incoming gradient is the block output's masked gradient)."""
     lib = _lib_dev()
     dev = y.device
-    mode = 0 if not relu else (2 if mask_from_y else 1)
+    mode = 3 if relu_mask is not None else (0 if not relu else (2 if mask_from_y else 1))
     nblk = lib.simhand_bn_stat_blocks(m, c)
     part = torch.empty(nblk, 2, c, dtype=torch.float32, device=dev)
-    aa = a if mode == 1 else None
+    aa = relu_mask if mode == 3 else (a if mode == 1 else None)
     check(lib.simhand_bn_bwd_partial(_ptr(da), _ptr(aa), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift), mode, m, c,
                                      dt(y.dtype), _ptr(part), _stream()), "bn_bwd_partial")
     dg = torch.empty(c, dtype=torch.float32, device=dev)

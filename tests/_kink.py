@@ -16,11 +16,12 @@ def record_hip_relu_masks(store: list):
 
     orig = ops.bn_apply
 
-    def bn_apply(y, st, m, c, relu, residual=None, out=None):
-        a = orig(y, st, m, c, relu, residual, out)
+    def bn_apply(y, st, m, c, relu, residual=None, out=None, **kw):
+        res = orig(y, st, m, c, relu, residual, out, **kw)
+        a = res[0] if isinstance(res, tuple) else res
         if relu:
             store.append((a > 0).cpu())
-        return a
+        return res
 
     ops.bn_apply = bn_apply
     try:

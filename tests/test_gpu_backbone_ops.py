@@ -172,6 +172,34 @@ def test_batchnorm_fwd_bwd(m, c, relu, res, dtype):
     _check(db.cpu(), beta.grad, 1e-4 if dtype == torch.float32 else 2e-2, "dbeta")
     if res:
         _check(dres.float().cpu(), r.grad, tol, "dres")
+    if relu and res:
+        # same backward from the 1-bit ReLU mask written by bn_apply (the stored activation is not read)
+        a2, mask = ops.bn_apply(yd, st, m, c, relu, rd, want_mask=True)
+        assert torch.equal(a2, a)
+        dy2, _, dg2, db2 = ops.bn_backward(dad, None, yd, st, gamma.detach().to(DEV), m, c, relu, False, relu_mask=mask)
+        assert torch.equal(dy2, dy) and torch.equal(dg2, dg) and torch.equal(db2, db)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dgrad_masked_residual_merge(dtype):
+    """dx = dgrad(dy) + res_grad * relu_bit: identity-block gradient merge inside the dgrad epilogue."""
+    from simhand_amd import ops
+
+    n, h, cin, cout = 3, 10, 128, 64
+    g = torch.Generator().manual_seed(4)
+    wt = _rnd(torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin), dtype)
+    dy = _rnd(torch.randn(n, cout, h, h, generator=g), dtype)
+    res_grad = _rnd(torch.randn(n, h, h, cin, generator=g), dtype)
+    act = _rnd(torch.randn(n * h * h, cin, generator=g), dtype)  # pre-ReLU values of the block output
+    want = torch.nn.grad.conv2d_input((n, cin, h, h), wt, dy).permute(0, 2, 3, 1) + res_grad * (act > 0).view(n, h, h, cin)
+    d = ops.conv_desc(n, h, h, cin, cout, 1, 1, 1, 0, dtype)
+    st = ops.BNState(cin, DEV)
+    st.scale.fill_(1.0)
+    st.shift.fill_(0.0)
+    _, mask = ops.bn_apply(act.to(DEV).to(dtype), st, n * h * h, cin, True, None, want_mask=True)
+    dx = ops.conv2d_dgrad_masked_residual(d, dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype), ops.pack_crsk(wt.to(DEV), dtype),
+                                          res_grad.to(DEV).to(dtype).contiguous(), mask)
+    _check(dx.float().cpu(), want, 2 * _tol(dtype), "masked residual dgrad")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
