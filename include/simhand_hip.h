@@ -179,7 +179,8 @@ int simhand_oihw_f32_to_krsc(const float* src, void* dst, int k, int c, int r, i
 int simhand_oihw_f32_to_crsk(const float* src, void* dst, int k, int c, int r, int s, int dtype, sh_stream_t stream);
 int simhand_krsc_f32_to_oihw(const float* src, float* dst, int k, int c, int r, int s, int k_pad, sh_stream_t stream);
 int simhand_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t count, sh_stream_t stream);
-/* stem lowering: NCHW fp32 images -> [n*ho*wo][k_pad] patch matrix, column (r*S+s)*cin+c, zero padded.
+/* stem lowering: NCHW fp32 images -> [n*ho*wo][k_pad] patch matrix, column (c*R + r)*S + s (the OIHW
+ * flattening of the filter, so the weight matrix is W.view(cout, cin*R*S) row-padded to k_pad), zero padded.
  * The 7x7/2 stem then runs as a 1x1 conv with cin = k_pad through conv2d_fwd / conv2d_wgrad. */
 int simhand_im2col_nchw_f32(const float* x, void* col, int n, int cin, int h, int w, int r, int s, int stride, int pad,
                             int k_pad, int dtype, sh_stream_t stream);

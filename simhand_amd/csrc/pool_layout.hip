@@ -139,32 +139,37 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ 
 }
 
 // ---- im2col for small-cin convolutions (the stem): NCHW fp32 image -> [N*Ho*Wo][k_pad] ----------
-// column k = (r*S + s)*Cin + c (KRSC flattening), zero-filled for k >= R*S*Cin and for the halo
-template <typename T>
+// column k = (c*R + r)*S + s  (= the OIHW flattening of the filter, so the weight matrix is the parameter
+// itself, row-padded), zero-filled for k >= Cin*R*S and for the halo.  RS > 0: compile-time R = S = RS
+// (the divisions become multiply-shifts; the 7x7 stem), RS = 0: runtime R, S.
+template <typename T, int RS>
 __global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restrict__ x, T* __restrict__ col, int n, int cin, int h,
-                                                          int w, int R, int S, int stride, int pad, int ho, int wo, int k_pad) {
+                                                          int w, int Rr, int Sr, int stride, int pad, int ho, int wo, int k_pad) {
   constexpr int VE = Vec16<T>::N;
-  const int kvecs = k_pad / VE;
+  const int R = RS > 0 ? RS : Rr, S = RS > 0 ? RS : Sr;
+  const unsigned kvecs = (unsigned)(k_pad / VE);
   const int kreal = R * S * cin;
-  const int64_t total = (int64_t)n * ho * wo * kvecs;
+  const unsigned hw_o = (unsigned)(ho * wo);
+  const int64_t total = (int64_t)n * hw_o * kvecs;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int kv = (int)(i % kvecs);
-    int64_t t = i / kvecs;
-    const int ow = (int)(t % wo);
-    t /= wo;
-    const int oh = (int)(t % ho);
-    const int img = (int)(t / ho);
+    const unsigned pixrow = (unsigned)(i / kvecs);          // < 2^31 (checked on the host)
+    const int kv = (int)((unsigned)i - pixrow * kvecs);
+    const unsigned img = pixrow / hw_o;
+    const unsigned rem = pixrow - img * hw_o;
+    const int oh = (int)(rem / (unsigned)wo), ow = (int)(rem - (unsigned)oh * (unsigned)wo);
+    const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+    const float* __restrict__ ximg = x + (int64_t)img * cin * h * w;
     float v[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
       const int k = kv * VE + e;
       float val = 0.f;
       if (k < kreal) {
-        const int c = k % cin;
-        const int rs = k / cin;
-        const int s = rs % S, r = rs / S;
-        const int ih = oh * stride - pad + r, iw = ow * stride - pad + s;
-        if ((unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w) val = x[(((int64_t)img * cin + c) * h + ih) * w + iw];
+        const int c = k / (R * S);
+        const int rs = k - c * (R * S);
+        const int r = rs / S, s2 = rs - r * S;
+        const int ih = ih0 + r, iw = iw0 + s2;
+        if ((unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w) val = ximg[(c * h + ih) * w + iw];
       }
       v[e] = val;
     }
@@ -323,8 +328,14 @@ int simhand_im2col_nchw_f32(const float* x, void* col, int n, int cin, int h, in
   const int64_t total = (int64_t)n * ho * wo * (k_pad / ve);
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(SH_PROF_MISC, st, 0, (double)n * ho * wo * k_pad * (dtype == SH_F32 ? 4 : 2) + (double)n * cin * h * w * 4);
-  SH_DISPATCH(dtype, (im2col_nchw_kernel<float><<<stream_grid(total), 256, 0, st>>>(x, (float*)col, n, cin, h, w, r, s, stride, pad, ho, wo, k_pad)),
-              (im2col_nchw_kernel<bf16_t><<<stream_grid(total), 256, 0, st>>>(x, (bf16_t*)col, n, cin, h, w, r, s, stride, pad, ho, wo, k_pad)));
+  SH_REQUIRE((int64_t)n * ho * wo < (1ll << 31), "im2col: %lld output pixels exceed the 2^31 index range", (long long)n * ho * wo);
+  if (r == 7 && s == 7) {
+    SH_DISPATCH(dtype, (im2col_nchw_kernel<float, 7><<<stream_grid(total), 256, 0, st>>>(x, (float*)col, n, cin, h, w, r, s, stride, pad, ho, wo, k_pad)),
+                (im2col_nchw_kernel<bf16_t, 7><<<stream_grid(total), 256, 0, st>>>(x, (bf16_t*)col, n, cin, h, w, r, s, stride, pad, ho, wo, k_pad)));
+  } else {
+    SH_DISPATCH(dtype, (im2col_nchw_kernel<float, 0><<<stream_grid(total), 256, 0, st>>>(x, (float*)col, n, cin, h, w, r, s, stride, pad, ho, wo, k_pad)),
+                (im2col_nchw_kernel<bf16_t, 0><<<stream_grid(total), 256, 0, st>>>(x, (bf16_t*)col, n, cin, h, w, r, s, stride, pad, ho, wo, k_pad)));
+  }
   return check_launch("im2col");
 }
 

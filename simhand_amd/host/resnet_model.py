@@ -140,7 +140,10 @@ class ResNetEngine:
         ver = (w._version, w.data_ptr(), self.dtype)
         if p is None or p.version != ver:
             p = _Packed()
-            p.krsc = ops.pack_krsc(w.detach(), self.dtype, k_pad)
+            if k_pad is not None:  # stem: the im2col columns follow the OIHW flattening -> plain row-padded copy
+                p.krsc = ops.pack_krsc(w.detach().view(w.shape[0], -1, 1, 1), self.dtype, k_pad)
+            else:
+                p.krsc = ops.pack_krsc(w.detach(), self.dtype)
             p.crsk = None
             p.version = ver
             self._packs[id(w)] = p
@@ -235,7 +238,10 @@ class ResNetEngine:
         grads[u.bn.bias] = db
         dw = ops.conv2d_wgrad(d, u.x, dy)
         w = u.conv.weight
-        grads[w] = ops.unpack_krsc_grad(dw, tuple(w.shape), STEM_KPAD if u.stem else None)
+        if u.stem:
+            grads[w] = ops.unpack_krsc_grad(dw, (w.shape[0], w[0].numel(), 1, 1), STEM_KPAD).view_as(w)
+        else:
+            grads[w] = ops.unpack_krsc_grad(dw, tuple(w.shape))
         if not need_dx:
             return None
         pk = self._pack(u.conv, need_t=True)

@@ -124,12 +124,12 @@ def test_stem_im2col_conv(dtype):
     col = ops.im2col_nchw(x.to(DEV), 7, 7, 2, 3, 192, dtype)
     ho = y.shape[2]
     d = ops.conv_desc(n, ho, ho, 192, 64, 1, 1, 1, 0, dtype)
-    wd = ops.pack_krsc(wt.to(DEV), dtype, k_pad=192)
+    wd = ops.pack_krsc(wt.to(DEV).view(64, 147, 1, 1), dtype, k_pad=192)  # columns follow the OIHW flattening
     yd, _ = ops.conv2d_fwd(d, col, wd)
     _check(yd.float().cpu().permute(0, 3, 1, 2), y.detach(), _tol(dtype), "stem fwd")
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
     dwd = ops.conv2d_wgrad(d, col, dyd)
-    dw = ops.unpack_krsc_grad(dwd, (64, 3, 7, 7), k_pad=192).cpu()
+    dw = ops.unpack_krsc_grad(dwd, (64, 147, 1, 1), k_pad=192).view(64, 3, 7, 7).cpu()
     _check(dw, wr.grad, 2e-5 if dtype == torch.float32 else 2e-3, "stem wgrad")
 
 
