@@ -29,7 +29,11 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault(HSA_IPC_ENV, "0")  # dmabuf IPC only on this pool
     if torch.cuda.is_available():
-        torch.cuda.set_device(local)
+        # SIMHAND_SHARE_GPU=1 (tests only): several ranks on one device, which RCCL refuses -> gloo
+        share = os.environ.get("SIMHAND_SHARE_GPU") == "1"
+        torch.cuda.set_device(local % torch.cuda.device_count() if share else local)
+        if share:
+            backend = backend or "gloo"
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
