@@ -19,11 +19,10 @@
 // are XOR-swizzled at 16-B granularity (chunk ^= (row>>1)&7) so every ds_read_b128 lane
 // group covers 16 distinct 16-B slots of the 256-B bank row (conflict-free).
 // The MFMA is issued "swapped" (weights as the A operand) so a lane ends up with 4
-// consecutive output channels of one pixel; the per-channel BatchNorm partial sums reduce
-// over lanes with 4 xor-shuffles.  The output tile is then staged through LDS ([pixel][channel],
-// padded rows) and written as whole rows with 16-B stores: every 64-lane store instruction
-// covers complete 128/256-B lines (the direct 8-B-per-lane epilogue was store-issue bound on the
-// wide 1x1 layers).
+// output channels of one pixel, and the weight rows are fed to the MFMA tiles in a permuted order
+// so that those are 4*NI CONSECUTIVE channels (32 B bf16 / 64 B fp32 per lane and pixel): the epilogue
+// stores 16-B vectors straight from registers (no LDS staging, no extra barriers), and the per-channel
+// BatchNorm partial sums reduce over the 16 pixel lanes with four DPP row rotations.
 // Block ids are remapped so all n-tiles of an m-tile run on one XCD (shared L2 for A rows).
 #include "common.h"
 
@@ -130,10 +129,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
   constexpr int VE = 16 / (int)sizeof(T);   // elements per 16-B chunk
   constexpr int NB = BN / 32;               // B chunks per thread per step
   constexpr int NI = BN / 32;               // 16-wide n tiles per wave
-  constexpr int OUT_STRIDE = BN * (int)sizeof(T) + 16;  // staged output row (bytes), padded against bank conflicts
   constexpr int TILE_BYTES = 2 * 128 * 128 + 2 * BN * 128;
-  constexpr int OUT_BYTES = 128 * OUT_STRIDE;
-  __shared__ __attribute__((aligned(16))) char smem[TILE_BYTES > OUT_BYTES ? TILE_BYTES : OUT_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[TILE_BYTES];
   char* sA = smem;
   char* sB = smem + 2 * 128 * 128;
 
@@ -209,9 +206,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
   const long long wrow = (long long)p.R * p.S * p.Ca;  // elements per weight row
   const T* pb0 = wsrc + (long long)(n0 + lrow) * wrow + chunk * VE;  // rows n0 + lrow + 32 i (always < Ng)
   const long long wrow32 = 32 * wrow;
-  // LDS store offsets of this thread's rows (identical for the A and B tiles)
+  // LDS store offsets of this thread's rows.  The B (weight) tile uses its own swizzle key because its rows are
+  // read in a permuted order (see the fragment offsets below).
   const int st0 = (lrow + 0) * 128 + swz(lrow + 0, chunk) * 16, st1 = (lrow + 32) * 128 + swz(lrow + 32, chunk) * 16;
   const int st2 = (lrow + 64) * 128 + swz(lrow + 64, chunk) * 16, st3 = (lrow + 96) * 128 + swz(lrow + 96, chunk) * 16;
+  // bf16: rows are read 8q + t (q, t = 0..3) apart -> key from bits 1 and 3..4; fp32: natural row order
+  auto key_b = [](int row) __attribute__((always_inline)) -> int {
+    return sizeof(T) == 2 ? (((row >> 1) & 1) | (((row >> 3) & 3) << 1)) : ((row >> 1) & 7);
+  };
+  // weight row (within this wave's half) fed to MFMA tile ni, operand row m -- and therefore the output channel of
+  // accumulator register r = m & 3 of lane group g = m >> 2.  bf16: (ni>>1)*32 + g*8 + (ni&1)*4 + r, so the 8 bf16 of
+  // tiles (2j, 2j+1) form ONE 16-B vector and the four lane groups cover 64 contiguous bytes per pixel and store
+  // instruction.  fp32: ni*16 + 4g + r (the natural order already gives 16 B per lane, 64 B per pixel).
+  auto chan_of = [](int ni, int m) __attribute__((always_inline)) -> int {
+    return sizeof(T) == 2 ? ((ni >> 1) * 32 + (m >> 2) * 8 + (ni & 1) * 4 + (m & 3)) : (ni * 16 + m);
+  };
+  const int sb0 = (lrow + 0) * 128 + (chunk ^ key_b(lrow + 0)) * 16, sb1 = (lrow + 32) * 128 + (chunk ^ key_b(lrow + 32)) * 16;
+  const int sb2 = (lrow + 64) * 128 + (chunk ^ key_b(lrow + 64)) * 16, sb3 = (lrow + 96) * 128 + (chunk ^ key_b(lrow + 96)) * 16;
 
   // iteration state of the NEXT load (wave-uniform)
   int l_cs = 0, l_tr = 0, l_ts = 0;
@@ -252,11 +263,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
     *reinterpret_cast<uint4*>(dA + st1) = ra1;
     *reinterpret_cast<uint4*>(dA + st2) = ra2;
     *reinterpret_cast<uint4*>(dA + st3) = ra3;
-    *reinterpret_cast<uint4*>(dB + st0) = rb0;
-    *reinterpret_cast<uint4*>(dB + st1) = rb1;
+    *reinterpret_cast<uint4*>(dB + sb0) = rb0;
+    *reinterpret_cast<uint4*>(dB + sb1) = rb1;
     if (NB == 4) {
-      *reinterpret_cast<uint4*>(dB + st2) = rb2;
-      *reinterpret_cast<uint4*>(dB + st3) = rb3;
+      *reinterpret_cast<uint4*>(dB + sb2) = rb2;
+      *reinterpret_cast<uint4*>(dB + sb3) = rb3;
     }
   };
 
@@ -271,15 +282,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
     store_step(0);
   }
   __syncthreads();
-  // fragment offsets: rows differ by multiples of 16 -> one swizzle key per lane
+  // A fragment offsets: rows differ by multiples of 16 -> one swizzle key per lane
   const int fkey = (li >> 1) & 7;
   const int fo0 = ((0 + g) ^ fkey) * 16, fo1 = ((4 + g) ^ fkey) * 16;
-  const int fa_base = (wm * 64 + li) * 128, fb_base = (wn * (BN / 2) + li) * 128;
+  const int fa_base = (wm * 64 + li) * 128;
+  // B fragment rows follow chan_of(): the epilogue stores 16-B vectors per lane straight from registers
+  // (no LDS staging, no extra barriers) and every store instruction covers whole 64-B sectors.
+  int fbo0[NI], fbo1[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int rowb = wn * (BN / 2) + chan_of(ni, li);
+    fbo0[ni] = rowb * 128 + ((0 + g) ^ key_b(rowb)) * 16;
+    fbo1[ni] = rowb * 128 + ((4 + g) ^ key_b(rowb)) * 16;
+  }
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
     if (ks + 1 < nk) load_step();  // global loads in flight under the MFMAs
     const char* cA = sA + buf * (128 * 128) + fa_base;
-    const char* cB = sB + buf * (BN * 128) + fb_base;
+    const char* cB = sB + buf * (BN * 128);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       uint4 fa[4], fb[NI];
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) fa[mi] = *reinterpret_cast<const uint4*>(cA + mi * 16 * 128 + fo);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) fb[ni] = *reinterpret_cast<const uint4*>(cB + ni * 16 * 128 + fo);
+      for (int ni = 0; ni < NI; ++ni) fb[ni] = *reinterpret_cast<const uint4*>(cB + (kk == 0 ? fbo0[ni] : fbo1[ni]));
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -298,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
   }
 
   // ---- fused BatchNorm partial statistics of the fp32 accumulators (registers -> LDS -> global) ----
-  // lane holds pixel (wm*64 + mi*16 + li), channels wn*BN/2 + ni*16 + 4g + r
+  // lane holds pixel (wm*64 + mi*16 + li), channels wn*BN/2 + chan_of(ni, 4g + r)
   if (p.bn_partial != nullptr) {
     float* red = reinterpret_cast<float*>(smem);  // [2 (wm)][2][BN]; tiles are dead (loop ended with a barrier)
 #pragma unroll
@@ -315,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
         s1 = row16_sum(s1);
         s2 = row16_sum(s2);
         if (li == 0) {
-          const int c = wn * (BN / 2) + ni * 16 + 4 * g + r;
+          const int c = wn * (BN / 2) + chan_of(ni, 4 * g + r);
           red[(wm * 2 + 0) * BN + c] = s1;
           red[(wm * 2 + 1) * BN + c] = s2;
         }
@@ -327,78 +347,76 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
       const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c];
       p.bn_partial[((long long)m_tile * 2 + which) * p.Ng + n0 + c] = v;
     }
-    __syncthreads();
   }
 
-  // ---- epilogue: stage the tile as [pixel][channel] in LDS, then whole-row 16-B stores ----------
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    char* orow = smem + (wm * 64 + mi * 16 + li) * OUT_STRIDE;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int ch = wn * (BN / 2) + ni * 16 + 4 * g;
-      if (sizeof(T) == 4) {
-        *reinterpret_cast<float4*>(orow + ch * 4) = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
-      } else {
-        uint2 w;
-        w.x = (unsigned)f32_to_bf16(acc[mi][ni][0]) | ((unsigned)f32_to_bf16(acc[mi][ni][1]) << 16);
-        w.y = (unsigned)f32_to_bf16(acc[mi][ni][2]) | ((unsigned)f32_to_bf16(acc[mi][ni][3]) << 16);
-        *reinterpret_cast<uint2*>(orow + ch * 2) = w;
-      }
-    }
-  }
-  __syncthreads();
+  // ---- epilogue: 16-B vectors straight from registers; chunk j of lane group g = channels j*4*VE + g*VE .. ----
   {
-    constexpr int CPR = BN * (int)sizeof(T) / 16;  // 16-B chunks per output row
-    constexpr int RPI = 256 / CPR;                 // rows covered per pass
-    const int oc = tid % CPR, orow0 = tid / CPR;
+    constexpr int NCH = 4 * NI / VE;  // 16-B chunks per lane per pixel
     T* __restrict__ out = reinterpret_cast<T*>(p.out);
-#pragma unroll 4
-    for (int row = orow0; row < 128; row += RPI) {
-      long long pix = (long long)m0 + row;
+    const int ch0 = n0 + wn * (BN / 2) + g * VE;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const unsigned mrow = m0 + wm * 64 + mi * 16 + li;
+      long long pix = (long long)mrow;
+      bool ok = pix < p.Mg;
       if (par) {
-        const Pixel px = decode(m0 + row);
-        if (!px.ok) continue;
+        const Pixel px = decode(mrow);
+        ok = px.ok;
         pix = ((long long)px.img * p.Hd + px.hd) * p.Wd + px.wd;
-      } else if (pix >= p.Mg) {
-        continue;
       }
-      T* dst = out + pix * p.Ng + n0 + oc * VE;
-      uint4 v = *reinterpret_cast<const uint4*>(smem + row * OUT_STRIDE + oc * 16);
-      if (p.accumulate == 2) {
-        // identity-branch gradient g = res_grad * relu_mask, merged here instead of being materialised
-        const uint4 o = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res_grad) + pix * p.Ng + n0 + oc * VE);
-        const unsigned bits = p.res_mask[pix * (p.Ng / VE) + n0 / VE + oc];
+      if (!ok) continue;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        uint4 v;
         if (sizeof(T) == 4) {
-          v.x = __float_as_uint(__uint_as_float(v.x) + ((bits & 1u) ? __uint_as_float(o.x) : 0.f));
-          v.y = __float_as_uint(__uint_as_float(v.y) + ((bits & 2u) ? __uint_as_float(o.y) : 0.f));
-          v.z = __float_as_uint(__uint_as_float(v.z) + ((bits & 4u) ? __uint_as_float(o.z) : 0.f));
-          v.w = __float_as_uint(__uint_as_float(v.w) + ((bits & 8u) ? __uint_as_float(o.w) : 0.f));
+          v.x = __float_as_uint(acc[mi][j][0]);
+          v.y = __float_as_uint(acc[mi][j][1]);
+          v.z = __float_as_uint(acc[mi][j][2]);
+          v.w = __float_as_uint(acc[mi][j][3]);
         } else {
-          const unsigned m0w = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
-          const unsigned m1w = ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
-          const unsigned m2w = ((bits & 16u) ? 0x0000ffffu : 0u) | ((bits & 32u) ? 0xffff0000u : 0u);
-          const unsigned m3w = ((bits & 64u) ? 0x0000ffffu : 0u) | ((bits & 128u) ? 0xffff0000u : 0u);
-          v.x = add_bf16x2(v.x, o.x & m0w);
-          v.y = add_bf16x2(v.y, o.y & m1w);
-          v.z = add_bf16x2(v.z, o.z & m2w);
-          v.w = add_bf16x2(v.w, o.w & m3w);
+          const f32x4 lo = acc[mi][(2 * j) % NI], hi = acc[mi][(2 * j + 1) % NI];
+          v.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
+          v.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
+          v.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
+          v.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
         }
-      } else if (p.accumulate) {
-        const uint4 o = *reinterpret_cast<const uint4*>(dst);
-        if (sizeof(T) == 4) {
-          v.x = __float_as_uint(__uint_as_float(v.x) + __uint_as_float(o.x));
-          v.y = __float_as_uint(__uint_as_float(v.y) + __uint_as_float(o.y));
-          v.z = __float_as_uint(__uint_as_float(v.z) + __uint_as_float(o.z));
-          v.w = __float_as_uint(__uint_as_float(v.w) + __uint_as_float(o.w));
-        } else {
-          v.x = add_bf16x2(v.x, o.x);
-          v.y = add_bf16x2(v.y, o.y);
-          v.z = add_bf16x2(v.z, o.z);
-          v.w = add_bf16x2(v.w, o.w);
+        const int ch = ch0 + j * 4 * VE;
+        T* dst = out + pix * p.Ng + ch;
+        if (p.accumulate == 2) {
+          // identity-branch gradient g = res_grad * relu_mask, merged here instead of being materialised
+          const uint4 o = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res_grad) + pix * p.Ng + ch);
+          const unsigned bits = p.res_mask[pix * (p.Ng / VE) + ch / VE];
+          if (sizeof(T) == 4) {
+            v.x = __float_as_uint(__uint_as_float(v.x) + ((bits & 1u) ? __uint_as_float(o.x) : 0.f));
+            v.y = __float_as_uint(__uint_as_float(v.y) + ((bits & 2u) ? __uint_as_float(o.y) : 0.f));
+            v.z = __float_as_uint(__uint_as_float(v.z) + ((bits & 4u) ? __uint_as_float(o.z) : 0.f));
+            v.w = __float_as_uint(__uint_as_float(v.w) + ((bits & 8u) ? __uint_as_float(o.w) : 0.f));
+          } else {
+            const unsigned m0w = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
+            const unsigned m1w = ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
+            const unsigned m2w = ((bits & 16u) ? 0x0000ffffu : 0u) | ((bits & 32u) ? 0xffff0000u : 0u);
+            const unsigned m3w = ((bits & 64u) ? 0x0000ffffu : 0u) | ((bits & 128u) ? 0xffff0000u : 0u);
+            v.x = add_bf16x2(v.x, o.x & m0w);
+            v.y = add_bf16x2(v.y, o.y & m1w);
+            v.z = add_bf16x2(v.z, o.z & m2w);
+            v.w = add_bf16x2(v.w, o.w & m3w);
+          }
+        } else if (p.accumulate) {
+          const uint4 o = *reinterpret_cast<const uint4*>(dst);
+          if (sizeof(T) == 4) {
+            v.x = __float_as_uint(__uint_as_float(v.x) + __uint_as_float(o.x));
+            v.y = __float_as_uint(__uint_as_float(v.y) + __uint_as_float(o.y));
+            v.z = __float_as_uint(__uint_as_float(v.z) + __uint_as_float(o.z));
+            v.w = __float_as_uint(__uint_as_float(v.w) + __uint_as_float(o.w));
+          } else {
+            v.x = add_bf16x2(v.x, o.x);
+            v.y = add_bf16x2(v.y, o.y);
+            v.z = add_bf16x2(v.z, o.z);
+            v.w = add_bf16x2(v.w, o.w);
+          }
         }
+        *reinterpret_cast<uint4*>(dst) = v;
       }
-      *reinterpret_cast<uint4*>(dst) = v;
     }
   }
 }
