@@ -177,6 +177,48 @@ __global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restric
   }
 }
 
+// 7x7 / stride 2 / pad 3 / cin 3 stem, k_pad = 192: the gather runs with LANES ALONG THE OUTPUT ROW (adjacent lanes read
+// addresses 8 B apart: a wave touches 4-5 cache lines per load instead of 64), the [64 pixel][192] tile is transposed
+// through LDS (odd dword row stride -> conflict-free 2/4-B writes) and leaves as whole 384/768-B rows of 16-B stores.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_stem7_kernel(const float* __restrict__ x, T* __restrict__ col, int n, int h, int w,
+                                                           int ho, int wo) {
+  constexpr int KP = 192, KR = 147, TP = 64;
+  constexpr int ROW_DW = KP * (int)sizeof(T) / 4 + 1;  // odd -> lanes (= pixels) hit distinct banks
+  __shared__ unsigned tile[TP * ROW_DW];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long npix = (long long)n * ho * wo;
+  const long long p0 = (long long)blockIdx.x * TP;
+  const long long pp = p0 + lane;
+  const bool pok = pp < npix;
+  const unsigned pr = (unsigned)(pok ? pp : 0);
+  const unsigned hw_o = (unsigned)(ho * wo);
+  const unsigned img = pr / hw_o;
+  const unsigned rem = pr - img * hw_o;
+  const int oh = (int)(rem / (unsigned)wo), ow = (int)(rem - (unsigned)oh * (unsigned)wo);
+  const int ih0 = oh * 2 - 3, iw0 = ow * 2 - 3;
+  const float* __restrict__ ximg = x + (long long)img * 3 * h * w;
+  T* trow = reinterpret_cast<T*>(tile + lane * ROW_DW);
+  for (int k = wv; k < KP; k += 4) {  // k is wave-uniform: (c, r, s) are scalars
+    float val = 0.f;
+    if (k < KR) {
+      const int c = k / 49, rs = k - c * 49, r = rs / 7, s2 = rs - r * 7;
+      const int ih = ih0 + r, iw = iw0 + s2;
+      if (pok && (unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w) val = ximg[(c * h + ih) * w + iw];
+    }
+    Elem<T>::store(trow + k, val);
+  }
+  __syncthreads();
+  constexpr int CPR = KP * (int)sizeof(T) / 16;  // 16-B chunks per row
+  for (int id = threadIdx.x; id < TP * CPR; id += 256) {
+    const int pix = id / CPR, ch = id - pix * CPR;
+    if (p0 + pix >= npix) continue;
+    const unsigned* src = tile + pix * ROW_DW + ch * 4;
+    const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(col) + ((p0 + pix) * CPR + ch) * 16) = v;
+  }
+}
+
 // ---- weights: OIHW fp32 -> [K][k_pad] (KRSC rows, zero padded) / [C][R][S][K] ; and back ---------------
 template <typename T>
 __global__ __launch_bounds__(256) void oihw_to_krsc_kernel(const float* __restrict__ src, T* __restrict__ dst, int k, int c, int r,
@@ -329,7 +371,11 @@ int simhand_im2col_nchw_f32(const float* x, void* col, int n, int cin, int h, in
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(SH_PROF_MISC, st, 0, (double)n * ho * wo * k_pad * (dtype == SH_F32 ? 4 : 2) + (double)n * cin * h * w * 4);
   SH_REQUIRE((int64_t)n * ho * wo < (1ll << 31), "im2col: %lld output pixels exceed the 2^31 index range", (long long)n * ho * wo);
-  if (r == 7 && s == 7) {
+  if (r == 7 && s == 7 && cin == 3 && stride == 2 && pad == 3 && k_pad == 192) {
+    const int grid = (int)(((int64_t)n * ho * wo + 63) / 64);
+    SH_DISPATCH(dtype, (im2col_stem7_kernel<float><<<grid, 256, 0, st>>>(x, (float*)col, n, h, w, ho, wo)),
+                (im2col_stem7_kernel<bf16_t><<<grid, 256, 0, st>>>(x, (bf16_t*)col, n, h, w, ho, wo)));
+  } else if (r == 7 && s == 7) {
     SH_DISPATCH(dtype, (im2col_nchw_kernel<float, 7><<<stream_grid(total), 256, 0, st>>>(x, (float*)col, n, cin, h, w, r, s, stride, pad, ho, wo, k_pad)),
                 (im2col_nchw_kernel<bf16_t, 7><<<stream_grid(total), 256, 0, st>>>(x, (bf16_t*)col, n, cin, h, w, r, s, stride, pad, ho, wo, k_pad)));
   } else {
