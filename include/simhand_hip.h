@@ -240,6 +240,26 @@ int simhand_lars_adam_step(float* param, const float* grad, float* exp_avg, floa
                            float lr, float beta1, float beta2, float adam_eps, float weight_decay,
                            float lars_eta, float lars_eps, int lars_clip, int use_lars, int step, sh_stream_t stream);
 
+/* Multi-tensor form: the whole parameter list in two launches.  `tensors` (n_tensors records) and `chunks`
+ * (n_chunks pairs {tensor index, chunk index inside that tensor}, a chunk = simhand_opt_chunk_elems() consecutive
+ * elements, tensors in table order so that a tensor's chunks are first_chunk .. first_chunk+n_chunks-1) are DEVICE
+ * arrays; bc1 = 1-beta1^step and bc2_sqrt = sqrt(1-beta2^step) are computed by the caller per tensor.
+ * norm_partials: 2*n_chunks floats of scratch. */
+typedef struct sh_opt_tensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t count;
+  int32_t first_chunk, n_chunks;
+  float lr, weight_decay, bc1, bc2_sqrt;
+  int32_t use_lars, reserved;
+} sh_opt_tensor;
+int simhand_opt_chunk_elems(void);
+int simhand_lars_adam_multi(const sh_opt_tensor* tensors, int n_tensors, const int32_t* chunks, int n_chunks, float* norm_partials,
+                            float beta1, float beta2, float adam_eps, float lars_eta, float lars_eps, int lars_clip,
+                            int64_t total_elems, sh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

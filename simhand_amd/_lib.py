@@ -100,6 +100,8 @@ SIGNATURES = {
     "simhand_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "simhand_colsum": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "simhand_sumsq_partial": (_I, [_P, _L, _P, _I, _P]),
+    "simhand_opt_chunk_elems": (_I, []),
+    "simhand_lars_adam_multi": (_I, [_P, _I, _P, _I, _P, _F, _F, _F, _F, _F, _I, _L, _P]),
     "simhand_lars_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P]),
 }
 

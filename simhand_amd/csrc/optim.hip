@@ -60,6 +60,89 @@ __global__ __launch_bounds__(256) void lars_adam_kernel(float* __restrict__ para
   }
 }
 
+// ---- multi-tensor form: the whole parameter list in two launches (norm partials, update) --------------------------------
+// A chunk is OPT_CHUNK consecutive elements of one tensor; the chunk table and the tensor table live in device memory.
+constexpr int OPT_CHUNK = 16384;
+
+__global__ __launch_bounds__(256) void opt_norms_kernel(const sh_opt_tensor* __restrict__ tensors, const int2* __restrict__ chunks,
+                                                        float* __restrict__ p_part, float* __restrict__ g_part) {
+  __shared__ float red[8];
+  const int2 ck = chunks[blockIdx.x];
+  const sh_opt_tensor t = tensors[ck.x];
+  float ps = 0.f, gs = 0.f;
+  if (t.use_lars) {
+    const int64_t off = (int64_t)ck.y * OPT_CHUNK;
+    const int n = (int)((t.count - off) < OPT_CHUNK ? (t.count - off) : OPT_CHUNK);
+    const float* __restrict__ p = t.param + off;
+    const float* __restrict__ g = t.grad + off;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const float a = p[i], b = g[i];
+      ps += a * a;
+      gs += b * b;
+    }
+  }
+  ps = wave_sum(ps);
+  gs = wave_sum(gs);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = ps;
+    red[4 + (threadIdx.x >> 6)] = gs;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    p_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    g_part[blockIdx.x] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+
+__global__ __launch_bounds__(256) void opt_update_kernel(const sh_opt_tensor* __restrict__ tensors, const int2* __restrict__ chunks,
+                                                         const float* __restrict__ p_part, const float* __restrict__ g_part,
+                                                         float beta1, float beta2, float adam_eps, float lars_eta, float lars_eps,
+                                                         int lars_clip) {
+  __shared__ float coef[2];
+  const int2 ck = chunks[blockIdx.x];
+  const sh_opt_tensor t = tensors[ck.x];
+  if (threadIdx.x == 0) {
+    float scale = 1.0f, wd = t.weight_decay;
+    if (t.use_lars) {
+      double ps = 0.0, gs = 0.0;
+      for (int i = 0; i < t.n_chunks; ++i) {  // fixed order: deterministic
+        ps += (double)p_part[t.first_chunk + i];
+        gs += (double)g_part[t.first_chunk + i];
+      }
+      const float pn = (float)sqrt(ps), gn = (float)sqrt(gs);
+      if (pn != 0.f && gn != 0.f) {
+        float l = lars_eta * pn / (gn + pn * t.weight_decay + lars_eps);
+        if (lars_clip) l = fminf(l / t.lr, 1.0f);
+        scale = l;
+      } else {
+        wd = 0.f;
+      }
+    }
+    coef[0] = scale;
+    coef[1] = wd;
+  }
+  __syncthreads();
+  const float scale = coef[0], wd = coef[1];
+  const int64_t off = (int64_t)ck.y * OPT_CHUNK;
+  const int n = (int)((t.count - off) < OPT_CHUNK ? (t.count - off) : OPT_CHUNK);
+  float* __restrict__ param = t.param + off;
+  const float* __restrict__ grad = t.grad + off;
+  float* __restrict__ exp_avg = t.exp_avg + off;
+  float* __restrict__ exp_avg_sq = t.exp_avg_sq + off;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float p = param[i];
+    float g = grad[i];
+    if (t.use_lars) g = (g + wd * p) * scale;
+    else g = g + wd * p;
+    const float m = beta1 * exp_avg[i] + (1.0f - beta1) * g;
+    const float v = beta2 * exp_avg_sq[i] + (1.0f - beta2) * g * g;
+    exp_avg[i] = m;
+    exp_avg_sq[i] = v;
+    const float denom = sqrtf(v) / t.bc2_sqrt + adam_eps;
+    param[i] = p - (t.lr / t.bc1) * (m / denom);
+  }
+}
+
 }  // namespace sh
 
 using namespace sh;
@@ -90,6 +173,21 @@ int simhand_lars_adam_step(float* param, const float* grad, float* exp_avg, floa
                                                             beta1, beta2, adam_eps, weight_decay, lars_eta, lars_eps, lars_clip, use_lars,
                                                             bc1, bc2_sqrt);
   return check_launch("lars_adam_step");
+}
+
+int simhand_opt_chunk_elems(void) { return OPT_CHUNK; }
+
+int simhand_lars_adam_multi(const sh_opt_tensor* tensors, int n_tensors, const int32_t* chunks, int n_chunks, float* norm_partials,
+                            float beta1, float beta2, float adam_eps, float lars_eta, float lars_eps, int lars_clip,
+                            int64_t total_elems, sh_stream_t stream) {
+  SH_REQUIRE(tensors && chunks && norm_partials, "lars_adam_multi: NULL pointer");
+  SH_REQUIRE(n_tensors >= 1 && n_chunks >= 1, "lars_adam_multi: empty tables");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_MISC, st, 0, (double)total_elems * 36);
+  opt_norms_kernel<<<n_chunks, 256, 0, st>>>(tensors, (const int2*)chunks, norm_partials, norm_partials + n_chunks);
+  opt_update_kernel<<<n_chunks, 256, 0, st>>>(tensors, (const int2*)chunks, norm_partials, norm_partials + n_chunks, beta1, beta2,
+                                              adam_eps, lars_eta, lars_eps, lars_clip);
+  return check_launch("lars_adam_multi");
 }
 
 }  // extern "C"

@@ -2,14 +2,16 @@
 Adam wrapped by pl_bolts' LARSWrapper, LinearWarmupCosineAnnealingLR stepped per
 optimizer step.  pl_bolts 0.2.2 is not vendored by the reference nor installed
 here -- semantics restated from its published source, PARITY UNPINNED (checked
-against the restatement in oracle/optim.py).  The parameter update itself is one
-fused HIP launch per tensor (``simhand_lars_adam_step``).
+against the restatement in oracle/optim.py).  The whole parameter list is updated
+by two HIP launches (``simhand_lars_adam_multi``: norm partials, then the fused
+LARS+Adam update); ``multi_tensor=False`` keeps one launch group per tensor.
 """
 from __future__ import annotations
 
 import math
 from typing import Iterable
 
+import numpy as np
 import torch
 
 from .. import ops
@@ -19,26 +21,61 @@ class LARSAdam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr) optionally wrapped like LARSWrapper(eta=0.02, clip=True, eps=1e-8)."""
 
     def __init__(self, params: Iterable, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 lars: bool = True, lars_eta: float = 0.02, lars_eps: float = 1e-8, lars_clip: bool = True):
+                 lars: bool = True, lars_eta: float = 0.02, lars_eps: float = 1e-8, lars_clip: bool = True,
+                 multi_tensor: bool = True):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, lars=lars, lars_eta=lars_eta,
                         lars_eps=lars_eps, lars_clip=lars_clip)
         super().__init__(params, defaults)
+        self.multi_tensor = multi_tensor
+        self._plans = {}
+
+    def _state(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st
 
     @torch.no_grad()
     def step(self, closure=None):
+        if not self.multi_tensor:
+            for group in self.param_groups:
+                for p in group["params"]:
+                    if p.grad is None:
+                        continue
+                    st = self._state(p)
+                    st["step"] += 1
+                    ops.lars_adam_step(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"],
+                                       group["weight_decay"], group["lars"], group["betas"], group["eps"], group["lars_eta"],
+                                       group["lars_eps"], group["lars_clip"])
+            return
+        # groups that share the kernel-wide constants go out together: the whole list in two launches
+        buckets = {}
         for group in self.param_groups:
+            key = (tuple(group["betas"]), group["eps"], group["lars_eta"], group["lars_eps"], bool(group["lars_clip"]))
             for p in group["params"]:
-                if p.grad is None:
-                    continue
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                if p.grad is not None:
+                    buckets.setdefault(key, []).append((group, p))
+        for key, items in buckets.items():
+            betas, eps, eta, leps, clip = key
+            pkey = (key, tuple(id(p) for _, p in items))
+            plan = self._plans.get(pkey)
+            if plan is None:
+                plan = self._plans[pkey] = ops.LarsAdamPlan([p.numel() for _, p in items], items[0][1].device)
+            rec = np.zeros(len(items), dtype=ops.OPT_TENSOR_DTYPE)
+            keep = []  # contiguous gradient copies must outlive the launch
+            for i, (group, p) in enumerate(items):
+                st = self._state(p)
                 st["step"] += 1
-                ops.lars_adam_step(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"],
-                                   group["weight_decay"], group["lars"], group["betas"], group["eps"], group["lars_eta"],
-                                   group["lars_eps"], group["lars_clip"])
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                keep.append(g)
+                t = st["step"]
+                rec[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                          plan.first[i], plan.nchunks[i], group["lr"], group["weight_decay"],
+                          np.float32(1.0) - np.float32(betas[0]) ** np.float32(t),
+                          np.sqrt(np.float32(1.0) - np.float32(betas[1]) ** np.float32(t)), int(bool(group["lars"])), 0)
+            ops.lars_adam_multi(plan, rec, betas, eps, eta, leps, clip)  # same stream as the producers of `keep`
 
 
 class LinearWarmupCosineAnnealingLR:

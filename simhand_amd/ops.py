@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -366,6 +367,42 @@ def lars_adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, weigh
     check(lib.simhand_lars_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, _ptr(pp), _ptr(gp), nblk, lr,
                                      betas[0], betas[1], adam_eps, weight_decay, lars_eta, lars_eps, int(lars_clip), int(use_lars),
                                      step, _stream()), "lars_adam_step")
+
+
+OPT_TENSOR_DTYPE = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("count", "<i8"),
+                             ("first_chunk", "<i4"), ("n_chunks", "<i4"), ("lr", "<f4"), ("weight_decay", "<f4"), ("bc1", "<f4"),
+                             ("bc2_sqrt", "<f4"), ("use_lars", "<i4"), ("reserved", "<i4")])  # == sh_opt_tensor
+
+
+class LarsAdamPlan:
+    """Chunk table (device, built once per parameter list) for ``lars_adam_multi``."""
+
+    def __init__(self, counts, device):
+        lib = _lib_dev()
+        ch = lib.simhand_opt_chunk_elems()
+        self.counts = [int(c) for c in counts]
+        self.first, self.nchunks, pairs = [], [], []
+        for t, c in enumerate(self.counts):
+            k = max(1, (c + ch - 1) // ch)
+            self.first.append(len(pairs))
+            self.nchunks.append(k)
+            pairs.extend((t, j) for j in range(k))
+        self.n_chunks = len(pairs)
+        self.total = sum(self.counts)
+        self.chunks = torch.tensor(pairs, dtype=torch.int32).reshape(-1, 2).contiguous().to(device)
+        self.partials = torch.empty(2 * self.n_chunks, dtype=torch.float32, device=device)
+
+
+def lars_adam_multi(plan: LarsAdamPlan, records: "np.ndarray", betas=(0.9, 0.999), adam_eps: float = 1e-8, lars_eta: float = 0.02,
+                    lars_eps: float = 1e-8, lars_clip: bool = True) -> None:
+    """records: OPT_TENSOR_DTYPE array, one per tensor of the plan (device pointers as integers)."""
+    lib = _lib_dev()
+    assert records.dtype == OPT_TENSOR_DTYPE and len(records) == len(plan.counts)
+    host = torch.from_numpy(records.view(np.uint8)).pin_memory()  # caching host allocator: safe to reuse across async copies
+    table = host.to(plan.chunks.device, non_blocking=True)
+    check(lib.simhand_lars_adam_multi(_ptr(table), len(records), _ptr(plan.chunks), plan.n_chunks, _ptr(plan.partials), betas[0],
+                                      betas[1], adam_eps, lars_eta, lars_eps, int(lars_clip), plan.total, _stream()),
+          "lars_adam_multi")
 
 
 # --------------------------------------------------------------------- profiler

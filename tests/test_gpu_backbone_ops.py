@@ -260,3 +260,41 @@ def test_lars_adam_step_matches_restated_pl_bolts():
             opt.step()
             ops.lars_adam_step(pd, grad.to(DEV), m, v, t, 3.2e-3, wd, use_lars)
             _check(pd.cpu(), p.detach(), 1e-5, f"step {t} wd={wd} lars={use_lars}")
+
+
+def test_lars_adam_multi_tensor_matches_per_tensor_and_oracle():
+    """The two-launch multi-tensor update (simhand_lars_adam_multi) against the per-tensor launches and the restated
+    pl_bolts oracle: tensors larger than one chunk, a ragged tail, a zero-gradient tensor (LARS skips it), and an
+    excluded (no LARS, no decay) group -- base_model.py:59-106 exclude_from_wt_decay."""
+    from oracle.optim import LARSWrapperOracle
+    from simhand_amd.host.optim import LARSAdam
+
+    g = torch.Generator().manual_seed(4)
+    shapes = [(40000,), (64, 3, 7, 7), (16384,), (16385,), (5,), (128,)]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+
+    def make(dev):
+        ps = [torch.nn.Parameter(x.clone().to(dev)) for x in init]
+        return ps, [{"params": ps[:4], "weight_decay": 1e-6}, {"params": ps[4:], "weight_decay": 0.0}]
+
+    pc, groups_c = make("cpu")
+    adam = torch.optim.Adam(groups_c, lr=3.2e-3)
+    oracle = LARSWrapperOracle(adam)
+    pm, groups_m = make(DEV)
+    ps_, groups_s = make(DEV)
+    for gr in (groups_m, groups_s):
+        gr[0]["lars"], gr[1]["lars"] = True, True
+    multi = LARSAdam(groups_m, lr=3.2e-3, multi_tensor=True)
+    single = LARSAdam(groups_s, lr=3.2e-3, multi_tensor=False)
+    for t in range(3):
+        grads = [torch.randn(*s, generator=g) * 0.01 for s in shapes]
+        grads[2].zero_()  # zero gradient norm: LARS leaves this tensor's gradient untouched
+        for lst, dev in ((pc, "cpu"), (pm, DEV), (ps_, DEV)):
+            for p, gr in zip(lst, grads):
+                p.grad = gr.clone().to(dev)
+        oracle.step()
+        multi.step()
+        single.step()
+        for i, (a, b, c) in enumerate(zip(pm, ps_, pc)):
+            _check(a.detach().cpu(), b.detach().cpu(), 1e-6, f"multi vs single, tensor {i} step {t}")
+            _check(a.detach().cpu(), c.detach(), 1e-5, f"multi vs oracle, tensor {i} step {t}")
