@@ -13,6 +13,7 @@ from typing import Iterable
 
 import numpy as np
 import torch
+from torch.autograd.graph import increment_version
 
 from .. import ops
 
@@ -49,6 +50,7 @@ class LARSAdam(torch.optim.Optimizer):
                     ops.lars_adam_step(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"],
                                        group["weight_decay"], group["lars"], group["betas"], group["eps"], group["lars_eta"],
                                        group["lars_eps"], group["lars_clip"])
+                    increment_version(p)  # the kernel wrote through the raw pointer: packed-weight caches key on _version
             return
         # groups that share the kernel-wide constants go out together: the whole list in two launches
         buckets = {}
@@ -76,6 +78,8 @@ class LARSAdam(torch.optim.Optimizer):
                           np.float32(1.0) - np.float32(betas[0]) ** np.float32(t),
                           np.sqrt(np.float32(1.0) - np.float32(betas[1]) ** np.float32(t)), int(bool(group["lars"])), 0)
             ops.lars_adam_multi(plan, rec, betas, eps, eta, leps, clip)  # same stream as the producers of `keep`
+            # the kernels wrote through raw pointers: tell torch, the packed-weight caches key on _version
+            increment_version([p for _, p in items])
 
 
 class LinearWarmupCosineAnnealingLR:

@@ -253,3 +253,65 @@ def test_functional_surface_matches_reference_golden(golden_dir):
     q = mu.rotate_encoding(q, -ang, None)
     z = mu.normalize(q.reshape(n, -1))
     np.testing.assert_allclose(z.cpu().numpy(), pg["z.crop_rotate"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("multi", [True, False])
+def test_optimizer_step_reaches_the_next_forward(multi):
+    """The LARS/Adam kernels write parameters through raw pointers; the engine's packed (KRSC/CRSK, compute-dtype)
+    weight copies must be rebuilt for the next forward.  After training steps, the live model must produce the
+    embeddings of a fresh model loaded from its own state_dict, and the loss trajectory must track the oracle's
+    (base_model.py:59-106 optimizer, main.py fit loop)."""
+    from oracle.optim import LARSWrapperOracle
+    from simhand_amd.host import unsupervised
+
+    exp, wcfg = CASES["HandCLR_W"]
+    torch.manual_seed(3)
+    om = orc.StepOracle(exp, "18", AUG, lambda_pos=5.0, lambda_neg=0.05, **wcfg).train()
+    model = _product("HandCLR_W", "18", wcfg, om)
+
+    class _T:
+        max_epochs, world_size = 100, 1
+
+    model.trainer = _T()
+    model.setup("fit")
+    (opt,), _ = model.configure_optimizers()
+    opt.multi_tensor = multi
+    lr = 3.2e-3  # the warm-up schedule starts at 0: pin the rate the reference reaches after warm-up (1e-4 * sqrt(1024))
+    for g in opt.param_groups:
+        g["lr"] = lr
+    assert len(opt.param_groups) == 2
+    names = dict(model.named_parameters())
+    onames = dict(om.named_parameters())
+    ogroups = [{"params": [onames[k] for k, p in names.items() if any(p is q for q in g["params"])],
+                "weight_decay": g["weight_decay"]} for g in opt.param_groups]
+    adam = torch.optim.Adam(ogroups, lr=lr)
+    oopt = LARSWrapperOracle(adam)
+    batch = orc.synthetic_batch(6, size=64, seed=9)
+    dbatch = _to_dev(batch)
+    losses, olosses = [], []
+    for i in range(3):
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(dbatch, i)["loss"]
+        loss.backward()
+        opt.step()
+        adam.zero_grad(set_to_none=True)
+        lo = om.contrastive_step(batch)
+        lo.backward()
+        oopt.step()
+        losses.append(loss.item())
+        olosses.append(lo.item())
+    # Adam's first steps move every element by ~lr * sign(g): near-zero gradients can take either sign, so the
+    # trajectories agree only loosely -- but they must move, and together
+    assert abs(losses[0] - olosses[0]) <= 1e-4 * abs(olosses[0])
+    assert abs(losses[2] - losses[0]) > 1e-3 * abs(losses[0]), losses
+    for a, b in zip(losses, olosses):
+        assert abs(a - b) <= 2e-2 * abs(b), (losses, olosses)
+    fresh = getattr(unsupervised, "HandCLR_W")(_config("18", wcfg), None, "train")
+    fresh.load_state_dict(model.state_dict(), strict=True)
+    fresh = fresh.to(DEV).eval()
+    model.eval()
+    with torch.no_grad():
+        img = dbatch["transformed_image1"]
+        a = model.get_encodings(img) if hasattr(model, "get_encodings") else model.encoder(img)
+        b = fresh.get_encodings(img) if hasattr(fresh, "get_encodings") else fresh.encoder(img)
+    assert torch.equal(a, b), (a - b).abs().max().item()
