@@ -168,6 +168,10 @@ int simhand_conv2d_dgrad_masked_residual(const sh_conv_desc* d, const void* dy, 
 /* dw (fp32, KRSC) = sum over output pixels of dy (x) patches(x); deterministic two-stage split-K */
 size_t simhand_conv2d_wgrad_workspace_bytes(const sh_conv_desc* d);
 int simhand_conv2d_wgrad(const sh_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, sh_stream_t stream);
+/* Same, but the split-K reduction writes the gradient directly in the reference's nn.Conv2d.weight.grad layout
+ * OIHW fp32 [cout][c_real][r][s]; c_real <= cin drops zero-padded input channels (the im2col'd stem: cin = 192
+ * columns, c_real = 147 = 3*7*7 -> exactly weight.grad.view(64, 147)). */
+int simhand_conv2d_wgrad_oihw(const sh_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int c_real, void* workspace, size_t workspace_bytes, sh_stream_t stream);
 
 /* test hook: bf16 wgrad LDS transpose path (1 = ds_read_b64_tr_b16 [default], 0 = scalar LDS reads) */
 int simhand_wgrad_set_tr(int on);

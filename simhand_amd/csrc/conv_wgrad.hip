@@ -263,16 +263,60 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
       }
 }
 
+// Second pass of the deterministic split-K: sums the `splitk` partial [Cout][R*S][Cin] matrices in a fixed order.
+// SL threads share one float4 column group (split k = lane, lane+SL, ...; LDS tree in fixed order), so that short
+// outputs with many splits (64x64 1x1: 1536 splits of 16 KB) still fill the chip.  `c_real > 0` writes the result in
+// OIHW order [Cout][c_real][R][S] (the layout of the reference's nn.Conv2d.weight.grad), dropping padded channels.
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, long long count, int splitk,
-                                                           float* __restrict__ dw) {
-  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= count) return;
+                                                           float* __restrict__ dw, int cin, int rs, int c_real) {
+  constexpr int COLS = 256 / SL;
+  __shared__ float4 red[SL > 1 ? 256 : 1];
+  const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+  const long long i = ((long long)blockIdx.x * COLS + col) * 4;
   float4 s = make_float4(0, 0, 0, 0);
-  for (int k = 0; k < splitk; ++k) {
-    const float4 v = *reinterpret_cast<const float4*>(part + (long long)k * count + i);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  if (i < count)
+    for (int k = sl; k < splitk; k += SL) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (long long)k * count + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  if (SL > 1) {
+    red[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int h = SL / 2; h >= 1; h >>= 1) {
+      if (sl < h) {
+        const float4 o = red[threadIdx.x + h * COLS];
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        red[threadIdx.x] = s;
+      }
+      __syncthreads();
+    }
+    if (sl != 0) return;
   }
-  *reinterpret_cast<float4*>(dw + i) = s;
+  if (i >= count) return;
+  if (c_real <= 0) {
+    *reinterpret_cast<float4*>(dw + i) = s;
+    return;
+  }
+  const long long row = i / cin;  // = k * rs + tap
+  const int c = (int)(i - row * cin);
+  const long long k = row / rs;
+  const int tap = (int)(row - k * rs);
+  const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (c + j < c_real) dw[(k * c_real + c + j) * rs + tap] = v[j];
+}
+
+static void launch_reduce(const float* part, long long count, int splitk, float* dw, int cin, int rs, int c_real, hipStream_t s) {
+  const long long groups = count / 4;
+  if (splitk <= 4)
+    wgrad_reduce_kernel<1><<<ceil_div(groups, 256), 256, 0, s>>>(part, count, splitk, dw, cin, rs, c_real);
+  else if (splitk <= 32 || groups >= 16384)
+    wgrad_reduce_kernel<4><<<ceil_div(groups, 64), 256, 0, s>>>(part, count, splitk, dw, cin, rs, c_real);
+  else
+    wgrad_reduce_kernel<16><<<ceil_div(groups, 16), 256, 0, s>>>(part, count, splitk, dw, cin, rs, c_real);
 }
 
 static int g_use_tr = 1;
@@ -313,8 +357,8 @@ size_t simhand_conv2d_wgrad_workspace_bytes(const sh_conv_desc* d) {
   return (size_t)sk * d->cout * d->cin * d->r * d->s * sizeof(float);
 }
 
-int simhand_conv2d_wgrad(const sh_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
-                         sh_stream_t stream) {
+static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, float* dw, int c_real, void* workspace,
+                      size_t workspace_bytes, sh_stream_t stream) {
   SH_REQUIRE(d != nullptr, "conv2d_wgrad: desc is NULL");
   SH_REQUIRE(x && dy && dw && workspace, "conv2d_wgrad: NULL pointer");
   SH_REQUIRE(d->dtype == SH_F32 || d->dtype == SH_BF16, "conv2d_wgrad: bad dtype %d", d->dtype);
@@ -357,8 +401,20 @@ int simhand_conv2d_wgrad(const sh_conv_desc* d, const void* x, const void* dy, f
 #undef SH_WG
   if (check_launch("conv2d_wgrad")) return 1;
   const long long count = (long long)d->cout * d->cin * d->r * d->s;
-  wgrad_reduce_kernel<<<ceil_div(count / 4, 256), 256, 0, s>>>(a.part, count, a.splitk, dw);
+  launch_reduce(a.part, count, a.splitk, dw, d->cin, d->r * d->s, c_real, s);
   return check_launch("conv2d_wgrad reduce");
+}
+
+int simhand_conv2d_wgrad(const sh_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
+                         sh_stream_t stream) {
+  return wgrad_impl(d, x, dy, dw, 0, workspace, workspace_bytes, stream);
+}
+
+int simhand_conv2d_wgrad_oihw(const sh_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int c_real, void* workspace,
+                              size_t workspace_bytes, sh_stream_t stream) {
+  SH_REQUIRE(d != nullptr, "conv2d_wgrad_oihw: desc is NULL");
+  SH_REQUIRE(c_real >= 1 && c_real <= d->cin, "conv2d_wgrad_oihw: c_real=%d outside [1, cin=%d]", c_real, d->cin);
+  return wgrad_impl(d, x, dy, dw_oihw, c_real, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -236,12 +236,8 @@ class ResNetEngine:
                                         mask_from_y=u.relu and not u.has_res, relu_mask=relu_mask)
         grads[u.bn.weight] = dg
         grads[u.bn.bias] = db
-        dw = ops.conv2d_wgrad(d, u.x, dy)
         w = u.conv.weight
-        if u.stem:
-            grads[w] = ops.unpack_krsc_grad(dw, (w.shape[0], w[0].numel(), 1, 1), STEM_KPAD).view_as(w)
-        else:
-            grads[w] = ops.unpack_krsc_grad(dw, tuple(w.shape))
+        grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))  # split-K reduce writes weight.grad's layout
         if not need_dx:
             return None
         pk = self._pack(u.conv, need_t=True)

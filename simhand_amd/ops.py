@@ -177,6 +177,18 @@ def conv2d_wgrad(d: ConvDesc, x, dy) -> torch.Tensor:
     return dw
 
 
+def conv2d_wgrad_oihw(d: ConvDesc, x, dy, shape) -> torch.Tensor:
+    """fp32 gradient directly in the nn.Conv2d.weight.grad layout `shape` = (cout, c, r, s); for the im2col'd stem
+    `d` is the 1x1 descriptor over the padded columns and shape = (64, 3, 7, 7) (147 real columns)."""
+    lib = _lib_dev()
+    nb = lib.simhand_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    dw = torch.empty(shape, dtype=torch.float32, device=x.device)
+    c_real = dw[0].numel() // (d.r * d.s)
+    check(lib.simhand_conv2d_wgrad_oihw(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), c_real, _ptr(ws), nb, _stream()), "conv2d_wgrad_oihw")
+    return dw
+
+
 def pack_krsc(w_oihw: torch.Tensor, dtype: torch.dtype, k_pad: Optional[int] = None) -> torch.Tensor:
     lib = _lib_dev()
     k, c, r, s = w_oihw.shape

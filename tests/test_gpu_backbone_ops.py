@@ -85,6 +85,8 @@ def test_conv_fwd_dgrad_wgrad(shape, dtype):
     dwd = ops.conv2d_wgrad(d, xd, dyd)
     dw = ops.unpack_krsc_grad(dwd, (cout, cin, k, k)).cpu()
     _check(dw, wt.grad, 2e-5 if dtype == torch.float32 else 2e-3, "wgrad")
+    # the reduce pass can write weight.grad's OIHW layout itself: same sums, bit for bit
+    assert torch.equal(ops.conv2d_wgrad_oihw(d, xd, dyd, (cout, cin, k, k)).cpu(), dw)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -131,6 +133,7 @@ def test_stem_im2col_conv(dtype):
     dwd = ops.conv2d_wgrad(d, col, dyd)
     dw = ops.unpack_krsc_grad(dwd, (64, 147, 1, 1), k_pad=192).view(64, 3, 7, 7).cpu()
     _check(dw, wr.grad, 2e-5 if dtype == torch.float32 else 2e-3, "stem wgrad")
+    assert torch.equal(ops.conv2d_wgrad_oihw(d, col, dyd, (64, 3, 7, 7)).cpu(), dw)  # drops the 45 padded columns
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
