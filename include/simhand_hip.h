@@ -157,6 +157,18 @@ typedef struct sh_conv_desc {
  * bn_partial [nblk_m][2][cout] fp32 with nblk_m = simhand_conv2d_fwd_stat_blocks(). */
 int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d);
 int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void* y, float* bn_partial, sh_stream_t stream);
+/* Direct 7x7 / stride 2 / pad 3 / 3 -> 64 stem (torchvision ResNet conv1, src/models/resnet_model.py:13-26) without an
+ * im2col matrix.  simhand_stem_pad_input repacks the NCHW fp32 image batch to zero-padded NHWC4
+ * xp [n][hp][wp][4] (dtype elements; geometry from simhand_stem_geometry: hp = h + 8, wp = roundup8(w + 8),
+ * input pixel (ih, iw) at (ih + 3, iw + 3)); simhand_stem_pack_weights lays the OIHW fp32 [64][3][7][7] filter out as
+ * [64][256] (column r*32 + tap*4 + c).  fwd: y [n*ho*wo][64] (+ BN partials [ceil(n*ho*wo/128)][2][64] if non-NULL);
+ * wgrad: dw_oihw fp32 [64][3][7][7] from xp and dy [n*ho*wo][64], deterministic split-K through `workspace`. */
+int simhand_stem_geometry(int h, int w, int* hp, int* wp, int* ho, int* wo);
+int simhand_stem_pad_input(const float* x_nchw, void* xp, int n, int h, int w, int dtype, sh_stream_t stream);
+int simhand_stem_pack_weights(const float* w_oihw, void* wp, int dtype, sh_stream_t stream);
+int simhand_stem_conv_fwd(const void* xp, const void* wp, void* y, float* bn_partial, int n, int h, int w, int dtype, sh_stream_t stream);
+size_t simhand_stem_conv_wgrad_workspace_bytes(int n, int h, int w, int dtype);
+int simhand_stem_conv_wgrad(const void* xp, const void* dy, float* dw_oihw, void* workspace, size_t workspace_bytes, int n, int h, int w, int dtype, sh_stream_t stream);
 /* dx = conv_transpose(dy, w).  wt = weights permuted to [Cin][R][S][Cout] (simhand_oihw_f32_to_crsk).
  * accumulate != 0: dx += result (residual branch merge). */
 int simhand_conv2d_dgrad(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, sh_stream_t stream);

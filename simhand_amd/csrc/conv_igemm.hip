@@ -68,6 +68,7 @@ struct IgemmArgs {
   int Hq, Wq;         // class grid (ceil(Hd/2), ceil(Wd/2)) when classes == 4
   FastDiv div_hw;     // pixel-grid size (Hd*Wd, or Hq*Wq with parity classes)
   FastDiv div_w;      // grid width (Wd or Wq)
+  int stem_hp, stem_wp;  // > 0: direct 7x7/2 stem from the zero-padded NHWC4 input [N][hp][wp][4] (see stem_fwd below)
 };
 
 template <typename T> struct Mma;
@@ -189,6 +190,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
   int h00, h01, h02, h03, w00, w01, w02, w03;              // source coords at tap (0,0); h = -2^20 for dead rows
   auto init_row = [&](int i, const T*& pa, int& h0, int& w0) __attribute__((always_inline)) {
     const Pixel px = decode(m0 + lrow + 32 * i);
+    if (!DGRAD && p.stem_wp > 0) {
+      // filter row r of output pixel (ho, wo) = 8 taps x 4 channels = 32 contiguous elements at padded (2ho + r, 2wo);
+      // a 128-B k-step is 2 such rows (bf16) or 1 (fp32); the generic tap walk then advances by whole k-steps
+      // (host sets R = k-steps, S = 1, Ca = KE, Ws = wp / 8 so that aoff = l_tr * rows_per_step * wp * 4).
+      constexpr int CPR = 32 / VE;
+      pa = asrc + (((long long)px.img * p.stem_hp + 2 * px.hd) * p.stem_wp + 2 * px.wd) * 4 + (chunk / CPR) * (p.stem_wp * 4) +
+           (chunk % CPR) * VE;
+      h0 = px.ok ? 0 : -(1 << 20);
+      w0 = 0;
+      return;
+    }
     if (DGRAD) {
       h0 = par ? (px.hd + p.pad - r0) >> 1 : px.hd + p.pad;
       w0 = par ? (px.wd + p.pad - s0) >> 1 : px.wd + p.pad;
@@ -467,6 +479,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
   a.Hd = d->ho; a.Wd = d->wo; a.Hs = d->h; a.Ws = d->w;
   a.accumulate = 0; a.res_grad = nullptr; a.res_mask = nullptr;
   a.classes = 1; a.Hq = a.Wq = 0;
+  a.stem_hp = a.stem_wp = 0;
   SH_REQUIRE(a.Mg < (1ll << 31) - 256, "conv2d_fwd: %lld output pixels exceed the 2^31 index range", a.Mg);
   a.div_hw = make_fastdiv((unsigned)(a.Hd * a.Wd));
   a.div_w = make_fastdiv((unsigned)a.Wd);
@@ -477,6 +490,50 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
   const double bytes = es * ((double)d->n * d->h * d->w * d->cin + (double)a.Mg * d->cout + (double)d->cout * d->cin * d->r * d->s);
   ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, flops, bytes);
   return d->dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
+}
+
+// ---- direct 7x7 / stride 2 / pad 3 / 3 -> 64 stem --------------------------------------------------------------------
+// torchvision ResNet conv1 (reference: src/models/resnet_model.py:13-26).  Cin = 3 cannot form a k-contiguous MFMA
+// operand, so the input is first repacked (simhand_stem_pad_input) to zero-padded NHWC4 [N][h+8][wp][4]; then filter
+// row r of an output pixel is ONE contiguous run of 8 taps x 4 channels (tap 7 and channel 3 carry zero weights) and
+// the stem is a K = 8 rows x 32 = 256 GEMM read straight from that buffer: no im2col matrix (9.9 GB at 2048 x 224^2).
+int simhand_stem_geometry(int h, int w, int* hp, int* wp, int* ho, int* wo) {
+  SH_REQUIRE(h >= 1 && w >= 1 && hp && wp && ho && wo, "stem_geometry: bad arguments");
+  *ho = (h + 6 - 7) / 2 + 1;
+  *wo = (w + 6 - 7) / 2 + 1;
+  *hp = h + 8;
+  *wp = (w + 8 + 7) / 8 * 8;
+  return 0;
+}
+
+int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_partial, int n, int h, int w, int dtype,
+                          sh_stream_t stream) {
+  SH_REQUIRE(xp && wp_ && y, "stem_conv_fwd: NULL pointer");
+  SH_REQUIRE(dtype == SH_F32 || dtype == SH_BF16, "stem_conv_fwd: bad dtype %d", dtype);
+  SH_REQUIRE(n >= 1, "stem_conv_fwd: bad shape");
+  int hp, wp, ho, wo;
+  if (simhand_stem_geometry(h, w, &hp, &wp, &ho, &wo)) return 1;
+  const int ke = dtype == SH_F32 ? 32 : 64;
+  IgemmArgs a;
+  a.a = xp; a.w = wp_; a.out = y; a.bn_partial = bn_partial;
+  a.Mg = (long long)n * ho * wo;
+  a.Ng = 64; a.Ca = ke;
+  a.R = 256 / ke; a.S = 1; a.stride = 1; a.pad = 0;
+  a.Hd = ho; a.Wd = wo; a.Hs = a.R + 1; a.Ws = wp / 8;
+  a.accumulate = 0; a.res_grad = nullptr; a.res_mask = nullptr;
+  a.classes = 1; a.Hq = a.Wq = 0;
+  a.stem_hp = hp; a.stem_wp = wp;
+  SH_REQUIRE(a.Mg < (1ll << 31) - 256, "stem_conv_fwd: %lld output pixels exceed the 2^31 index range", a.Mg);
+  SH_REQUIRE((long long)n * hp * wp * 4 < (1ll << 40), "stem_conv_fwd: input too large");
+  a.div_hw = make_fastdiv((unsigned)(ho * wo));
+  a.div_w = make_fastdiv((unsigned)wo);
+  a.m_tiles = ceil_div(a.Mg, 128);
+  a.n_tiles = 1;
+  const double flops = 2.0 * (double)a.Mg * 64 * 147;
+  const double es = dtype == SH_F32 ? 4 : 2;
+  const double bytes = es * ((double)n * hp * wp * 4 + (double)a.Mg * 64 + 64.0 * 256);
+  ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, flops, bytes);
+  return dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 
 static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
@@ -492,6 +549,7 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   a.R = d->r; a.S = d->s; a.stride = d->stride; a.pad = d->pad;
   a.Hd = d->h; a.Wd = d->w; a.Hs = d->ho; a.Ws = d->wo;
   a.accumulate = accumulate; a.res_grad = res_grad; a.res_mask = res_mask;
+  a.stem_hp = a.stem_wp = 0;
   if (d->stride == 2) {
     a.classes = 4;
     a.Hq = (d->h + 1) / 2;

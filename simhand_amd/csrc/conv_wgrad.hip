@@ -57,6 +57,8 @@ struct WgradArgs {
   int mt, nt;           // cout tiles, cin tiles
   FastDiv div_hw, div_w;
   int use_tr;           // bf16: 1 = ds_read_b64_tr_b16, 0 = scalar fallback (self-test)
+  int stem_hp, stem_wp; // > 0: x is the zero-padded NHWC4 stem input [N][hp][wp][4]; Cin = 256 virtual channels
+                        // = 8 filter rows x (8 taps x 4 channels), row r of output pixel (ho, wo) at (2ho + r, 2wo)
 };
 
 __device__ __forceinline__ int xcd_remap_w(int bid, int nblk) {
@@ -108,7 +110,7 @@ __device__ __forceinline__ uint4 frag_bf16_scalar(const char* tile, int stride, 
   return r;
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool STEM = false>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   constexpr int KP = WgCfg<T>::KP;
   constexpr int SA = BM * (int)sizeof(T) + WgCfg<T>::PAD;  // dy tile row stride (bytes)
@@ -166,10 +168,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
         const unsigned rem = mu - img * hw;
         const unsigned ho = fdiv(rem, p.div_w);
         const unsigned wo = rem - ho * (unsigned)p.Wo;
-        const int hs = (int)ho * p.stride - p.pad + fr;
-        const int ws = (int)wo * p.stride - p.pad + fs;
-        if ((unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W)
-          v = *reinterpret_cast<const uint4*>(xs + (((long long)img * p.H + hs) * p.W + ws) * p.Cin + c0 + ch * VE);
+        if constexpr (STEM) {
+          const int vc = c0 + ch * VE;  // virtual channel: filter row vc / 32, element vc % 32 of its 8 x 4 run
+          v = *reinterpret_cast<const uint4*>(xs + (((long long)img * p.stem_hp + 2 * ho + (vc >> 5)) * p.stem_wp + 2 * wo) * 4 +
+                                              (vc & 31));
+        } else {
+          const int hs = (int)ho * p.stride - p.pad + fr;
+          const int ws = (int)wo * p.stride - p.pad + fs;
+          if ((unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W)
+            v = *reinterpret_cast<const uint4*>(xs + (((long long)img * p.H + hs) * p.W + ws) * p.Cin + c0 + ch * VE);
+        }
       }
       rb[i] = v;
     }
@@ -295,8 +303,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (sl != 0) return;
   }
   if (i >= count) return;
-  if (c_real <= 0) {
+  if (c_real == 0) {
     *reinterpret_cast<float4*>(dw + i) = s;
+    return;
+  }
+  if (c_real < 0) {  // direct stem: column r*32 + tap*4 + c of row k -> OIHW [64][3][7][7]; padded columns dropped
+    const long long k = i >> 8;
+    const int col = (int)(i & 255), r = col >> 5, t = (col & 31) >> 2;
+    if (r < 7 && t < 7) {
+      float* o = dw + (k * 3 * 7 + r) * 7 + t;
+      o[0] = s.x;
+      o[49] = s.y;
+      o[98] = s.z;
+    }
     return;
   }
   const long long row = i / cin;  // = k * rs + tap
@@ -358,7 +377,7 @@ size_t simhand_conv2d_wgrad_workspace_bytes(const sh_conv_desc* d) {
 }
 
 static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, float* dw, int c_real, void* workspace,
-                      size_t workspace_bytes, sh_stream_t stream) {
+                      size_t workspace_bytes, sh_stream_t stream, int stem_hp = 0, int stem_wp = 0) {
   SH_REQUIRE(d != nullptr, "conv2d_wgrad: desc is NULL");
   SH_REQUIRE(x && dy && dw && workspace, "conv2d_wgrad: NULL pointer");
   SH_REQUIRE(d->dtype == SH_F32 || d->dtype == SH_BF16, "conv2d_wgrad: bad dtype %d", d->dtype);
@@ -380,14 +399,22 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
   a.div_hw = make_fastdiv((unsigned)(d->ho * d->wo));
   a.div_w = make_fastdiv((unsigned)d->wo);
   a.use_tr = g_use_tr;
+  a.stem_hp = stem_hp; a.stem_wp = stem_wp;
   hipStream_t s = (hipStream_t)stream;
   const int nblk = a.splitk * d->r * d->s * a.mt * a.nt;
-  const double flops = 2.0 * (double)mo * d->cout * d->cin * d->r * d->s;
   const double es = d->dtype == SH_F32 ? 4 : 2;
-  const double bytes = es * ((double)d->n * d->h * d->w * d->cin + (double)mo * d->cout) + 4.0 * d->cout * d->cin * d->r * d->s;
+  double flops = 2.0 * (double)mo * d->cout * d->cin * d->r * d->s;
+  double bytes = es * ((double)d->n * d->h * d->w * d->cin + (double)mo * d->cout) + 4.0 * d->cout * d->cin * d->r * d->s;
+  if (stem_wp > 0) {  // algorithmic figures of the 7x7x3 stem, not of its padded K = 256 lowering
+    flops = 2.0 * (double)mo * 64 * 147;
+    bytes = es * ((double)d->n * stem_hp * stem_wp * 4 + (double)mo * 64) + 4.0 * 64 * 147;
+  }
   ProfScope ps(SH_PROF_CONV_WGRAD, s, flops, bytes);
 #define SH_WG(T, BM, BN) wgrad_kernel<T, BM, BN><<<nblk, 256, 0, s>>>(a)
-  if (d->dtype == SH_F32) {
+  if (stem_wp > 0) {  // cout 64 x 256 virtual channels -> the 64 x 128 tile with the NHWC4 address map
+    if (d->dtype == SH_F32) wgrad_kernel<float, 64, 128, true><<<nblk, 256, 0, s>>>(a);
+    else wgrad_kernel<bf16_t, 64, 128, true><<<nblk, 256, 0, s>>>(a);
+  } else if (d->dtype == SH_F32) {
     if (bm == 128 && bn == 128) SH_WG(float, 128, 128);
     else if (bm == 128) SH_WG(float, 128, 64);
     else if (bn == 128) SH_WG(float, 64, 128);
@@ -415,6 +442,30 @@ int simhand_conv2d_wgrad_oihw(const sh_conv_desc* d, const void* x, const void* 
   SH_REQUIRE(d != nullptr, "conv2d_wgrad_oihw: desc is NULL");
   SH_REQUIRE(c_real >= 1 && c_real <= d->cin, "conv2d_wgrad_oihw: c_real=%d outside [1, cin=%d]", c_real, d->cin);
   return wgrad_impl(d, x, dy, dw_oihw, c_real, workspace, workspace_bytes, stream);
+}
+
+// weight gradient of the direct stem (see simhand_stem_conv_fwd): dw is the OIHW fp32 [64][3][7][7] gradient
+static void stem_wgrad_desc(sh_conv_desc* d, int n, int h, int w, int dtype) {
+  memset(d, 0, sizeof(*d));
+  d->n = n;
+  d->ho = d->h = (h + 6 - 7) / 2 + 1;
+  d->wo = d->w = (w + 6 - 7) / 2 + 1;
+  d->cin = 256; d->cout = 64; d->r = d->s = 1; d->stride = 1; d->pad = 0; d->dtype = dtype;
+}
+
+size_t simhand_stem_conv_wgrad_workspace_bytes(int n, int h, int w, int dtype) {
+  sh_conv_desc d;
+  stem_wgrad_desc(&d, n, h, w, dtype);
+  return simhand_conv2d_wgrad_workspace_bytes(&d);
+}
+
+int simhand_stem_conv_wgrad(const void* xp, const void* dy, float* dw_oihw, void* workspace, size_t workspace_bytes, int n, int h,
+                            int w, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(n >= 1 && h >= 1 && w >= 1, "stem_conv_wgrad: bad shape");
+  sh_conv_desc d;
+  stem_wgrad_desc(&d, n, h, w, dtype);
+  const int hp = h + 8, wp = (w + 8 + 7) / 8 * 8;
+  return wgrad_impl(&d, xp, dy, dw_oihw, -1, workspace, workspace_bytes, stream, hp, wp);
 }
 
 }  // extern "C"

@@ -293,6 +293,45 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 
 using namespace sh;
 
+// ---- direct stem (conv_igemm.hip simhand_stem_conv_fwd): NCHW fp32 -> zero-padded NHWC4 [N][hp][wp][4] ------------------
+// one thread per padded pixel; input pixel (ih, iw) lands at (ih + 3, iw + 3); borders and channel 3 are zeros
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pad_kernel(const float* __restrict__ x, T* __restrict__ xp, int n, int h, int w, int hp,
+                                                       int wp) {
+  const int64_t total = (int64_t)n * hp * wp;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int pw = (int)(i % wp);
+    const int64_t t = i / wp;
+    const int ph = (int)(t % hp);
+    const int64_t img = t / hp;
+    const int ih = ph - 3, iw = pw - 3;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if ((unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w) {
+      const float* src = x + ((img * 3) * h + ih) * (int64_t)w + iw;
+      v0 = src[0];
+      v1 = src[(int64_t)h * w];
+      v2 = src[2 * (int64_t)h * w];
+    }
+    if (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(xp + i * 4) = make_float4(v0, v1, v2, 0.f);
+    } else {
+      uint2 o;
+      o.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+      o.y = (unsigned)f32_to_bf16(v2);
+      *reinterpret_cast<uint2*>(xp + i * 4) = o;
+    }
+  }
+}
+
+// OIHW fp32 [64][3][7][7] -> [64][256]: column r*32 + tap*4 + c (rows r = 7, taps 7 and channel 3 are zeros)
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pack_w_kernel(const float* __restrict__ w, T* __restrict__ wp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 64 * 256) return;
+  const int k = i >> 8, col = i & 255, r = col >> 5, t = (col & 31) >> 2, c = col & 3;
+  Elem<T>::store(wp + i, (r < 7 && t < 7 && c < 3) ? w[((k * 3 + c) * 7 + r) * 7 + t] : 0.f);
+}
+
 #define SH_DISPATCH(dtype, CALL_F32, CALL_BF16) \
   do {                                          \
     if ((dtype) == SH_F32) { CALL_F32; }        \
@@ -383,6 +422,26 @@ int simhand_im2col_nchw_f32(const float* x, void* col, int n, int cin, int h, in
                 (im2col_nchw_kernel<bf16_t, 0><<<stream_grid(total), 256, 0, st>>>(x, (bf16_t*)col, n, cin, h, w, r, s, stride, pad, ho, wo, k_pad)));
   }
   return check_launch("im2col");
+}
+
+int simhand_stem_pad_input(const float* x, void* xp, int n, int h, int w, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(x && xp, "stem_pad_input: NULL pointer");
+  SH_REQUIRE(n >= 1 && h >= 1 && w >= 1, "stem_pad_input: bad shape");
+  const int hp = h + 8, wp = (w + 8 + 7) / 8 * 8;
+  const int64_t total = (int64_t)n * hp * wp;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_MISC, st, 0, (double)total * 4 * (dtype == SH_F32 ? 4 : 2) + (double)n * 3 * h * w * 4);
+  SH_DISPATCH(dtype, (stem_pad_kernel<float><<<stream_grid(total), 256, 0, st>>>(x, (float*)xp, n, h, w, hp, wp)),
+              (stem_pad_kernel<bf16_t><<<stream_grid(total), 256, 0, st>>>(x, (bf16_t*)xp, n, h, w, hp, wp)));
+  return check_launch("stem_pad_input");
+}
+
+int simhand_stem_pack_weights(const float* w_oihw, void* wp, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(w_oihw && wp, "stem_pack_weights: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  SH_DISPATCH(dtype, (stem_pack_w_kernel<float><<<64, 256, 0, st>>>(w_oihw, (float*)wp)),
+              (stem_pack_w_kernel<bf16_t><<<64, 256, 0, st>>>(w_oihw, (bf16_t*)wp)));
+  return check_launch("stem_pack_weights");
 }
 
 int simhand_nchw_f32_to_nhwc(const float* src, void* dst, int n, int c, int h, int w, int c_pad, int dtype, sh_stream_t stream) {

@@ -10,8 +10,8 @@ nn.BatchNorm2d modules below are PARAMETER CONTAINERS ONLY (state_dict keys,
 init, optimizer param groups): their ``forward`` is never called.  All
 arithmetic runs in ``ResNetEngine`` through the C ABI:
 
-  stem  : im2col (NCHW fp32 -> [M][192]) -> MFMA GEMM (+fused BN partial sums)
-          -> BN finalize -> BN-apply+ReLU -> MaxPool(3,2,1)
+  stem  : NCHW fp32 -> zero-padded NHWC4 -> direct 7x7/2 MFMA GEMM, K = 8 filter rows x (8 taps x 4 ch)
+          (+fused BN partial sums; no im2col matrix) -> BN finalize -> BN-apply+ReLU -> MaxPool(3,2,1)
   block : conv (implicit GEMM, fused BN partial sums) -> BN finalize ->
           BN-apply(+ReLU)(+residual) ...
   tail  : global average pool -> fp32 (N, C)
@@ -30,7 +30,6 @@ from torch import Tensor, nn
 
 from .. import ops
 
-STEM_KPAD = 192  # 7*7*3 = 147 padded to a multiple of 64 (one bf16 k-step)
 
 
 # --------------------------------------------------------------------------
@@ -134,14 +133,14 @@ class ResNetEngine:
         self._packs: Dict[int, _Packed] = {}
 
     # -- weights -------------------------------------------------------------
-    def _pack(self, conv: nn.Conv2d, need_t: bool, k_pad: Optional[int] = None) -> _Packed:
+    def _pack(self, conv: nn.Conv2d, need_t: bool, stem: bool = False) -> _Packed:
         w = conv.weight
         p = self._packs.get(id(w))
         ver = (w._version, w.data_ptr(), self.dtype)
         if p is None or p.version != ver:
             p = _Packed()
-            if k_pad is not None:  # stem: the im2col columns follow the OIHW flattening -> plain row-padded copy
-                p.krsc = ops.pack_krsc(w.detach().view(w.shape[0], -1, 1, 1), self.dtype, k_pad)
+            if stem:  # [64][256]: column r*32 + tap*4 + c of the direct stem kernel
+                p.krsc = ops.stem_pack_weights(w.detach(), self.dtype)
             else:
                 p.krsc = ops.pack_krsc(w.detach(), self.dtype)
             p.crsk = None
@@ -184,19 +183,20 @@ class ResNetEngine:
         conv1, bn1 = f[0], f[1]
         n, _, h, w = images.shape
         ctx: Optional[dict] = {"units": [], "blocks": []} if want_ctx else None
-        # stem: im2col + GEMM
-        col = ops.im2col_nchw(images, 7, 7, 2, 3, STEM_KPAD, self.dtype)
-        ho, wo = col.shape[1], col.shape[2]
-        d = ops.conv_desc(n, ho, wo, STEM_KPAD, 64, 1, 1, 1, 0, self.dtype)
-        pk = self._pack(conv1, need_t=False, k_pad=STEM_KPAD)
-        y, part = ops.conv2d_fwd(d, col, pk.krsc, want_stats=training)
+        # stem: direct 7x7/2 conv from the zero-padded NHWC4 copy of the batch (0.9 GB at 2048 x 224^2 -- an im2col
+        # matrix would be 9.9 GB); the same copy feeds the stem's weight gradient
+        xp = ops.stem_pad_input(images.contiguous(), self.dtype)
+        pk = self._pack(conv1, need_t=False, stem=True)
+        y, part = ops.stem_conv_fwd(xp, pk.krsc, h, w, want_stats=training)
+        ho, wo = y.shape[1], y.shape[2]
+        d = ops.conv_desc(n, h, w, 3, 64, 7, 7, 2, 3, self.dtype)  # bookkeeping only (n, h, w, ho, wo, cout)
         m = n * ho * wo
         st = self._bn(bn1, part, m, 64, training)
         a = ops.bn_apply(y, st, m, 64, True, None)
         x, idx = ops.maxpool_fwd(a)
         if want_ctx:
             u = _Unit()
-            u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv1, bn1, d, col, y, a, st, True, True
+            u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv1, bn1, d, xp, y, a, st, True, True
             u.has_res = False
             u.mask = None
             ctx["stem"] = u
@@ -237,7 +237,10 @@ class ResNetEngine:
         grads[u.bn.weight] = dg
         grads[u.bn.bias] = db
         w = u.conv.weight
-        grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))  # split-K reduce writes weight.grad's layout
+        if u.stem:
+            grads[w] = ops.stem_conv_wgrad(u.x, dy, d.h, d.w)
+        else:
+            grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))  # split-K reduce writes weight.grad's layout
         if not need_dx:
             return None
         pk = self._pack(u.conv, need_t=True)

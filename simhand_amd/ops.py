@@ -232,6 +232,55 @@ def im2col_nchw(x: torch.Tensor, r, s, stride, pad, k_pad, dtype) -> torch.Tenso
     return col
 
 
+# ---- direct 7x7/2 stem (no im2col matrix) ----------------------------------------------------------------------------
+def stem_geometry(h: int, w: int):
+    """(hp, wp, ho, wo) of the zero-padded NHWC4 stem input and the conv1 output."""
+    lib = _lib.load()
+    v = [C.c_int() for _ in range(4)]
+    check(lib.simhand_stem_geometry(h, w, *[C.byref(i) for i in v]), "stem_geometry")
+    return tuple(i.value for i in v)
+
+
+def stem_pad_input(x: torch.Tensor, dtype) -> torch.Tensor:
+    """NCHW fp32 [n,3,h,w] -> zero-padded NHWC4 [n,hp,wp,4] in the compute dtype."""
+    lib = _lib_dev()
+    n, c, h, w = x.shape
+    assert c == 3 and x.dtype == torch.float32 and x.is_contiguous()
+    hp, wp, _, _ = stem_geometry(h, w)
+    xp = torch.empty(n, hp, wp, 4, dtype=dtype, device=x.device)
+    check(lib.simhand_stem_pad_input(_ptr(x), _ptr(xp), n, h, w, dt(dtype), _stream()), "stem_pad_input")
+    return xp
+
+
+def stem_pack_weights(w_oihw: torch.Tensor, dtype) -> torch.Tensor:
+    lib = _lib_dev()
+    assert tuple(w_oihw.shape) == (64, 3, 7, 7) and w_oihw.dtype == torch.float32
+    wp = torch.empty(64, 256, dtype=dtype, device=w_oihw.device)
+    check(lib.simhand_stem_pack_weights(_ptr(w_oihw.contiguous()), _ptr(wp), dt(dtype), _stream()), "stem_pack_weights")
+    return wp
+
+
+def stem_conv_fwd(xp: torch.Tensor, wp: torch.Tensor, h: int, w: int, want_stats: bool = True):
+    lib = _lib_dev()
+    n = xp.shape[0]
+    _, _, ho, wo = stem_geometry(h, w)
+    y = torch.empty(n, ho, wo, 64, dtype=xp.dtype, device=xp.device)
+    part = torch.empty((n * ho * wo + 127) // 128, 2, 64, dtype=torch.float32, device=xp.device) if want_stats else None
+    check(lib.simhand_stem_conv_fwd(_ptr(xp), _ptr(wp), _ptr(y), _ptr(part), n, h, w, dt(xp.dtype), _stream()), "stem_conv_fwd")
+    return y, part
+
+
+def stem_conv_wgrad(xp: torch.Tensor, dy: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """fp32 weight.grad [64,3,7,7] of the stem from the padded input and dy [n,ho,wo,64]."""
+    lib = _lib_dev()
+    n = xp.shape[0]
+    nb = lib.simhand_stem_conv_wgrad_workspace_bytes(n, h, w, dt(xp.dtype))
+    ws = torch.empty(nb, dtype=torch.uint8, device=xp.device)
+    dw = torch.empty(64, 3, 7, 7, dtype=torch.float32, device=xp.device)
+    check(lib.simhand_stem_conv_wgrad(_ptr(xp), _ptr(dy), _ptr(dw), _ptr(ws), nb, n, h, w, dt(xp.dtype), _stream()), "stem_conv_wgrad")
+    return dw
+
+
 def nchw_to_nhwc(x: torch.Tensor, dtype, c_pad: Optional[int] = None) -> torch.Tensor:
     lib = _lib_dev()
     n, c, h, w = x.shape

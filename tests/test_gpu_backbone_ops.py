@@ -137,6 +137,39 @@ def test_stem_im2col_conv(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,h,w", [(3, 36, 36), (2, 64, 48), (5, 31, 45), (1, 224, 224)])
+def test_stem_direct_conv(dtype, n, h, w):
+    """7x7/2 stem read straight from the zero-padded NHWC4 input (no im2col matrix): forward, fused BN partial sums and
+    weight gradient against ATen; odd sizes exercise the ragged last tile and the bottom/right halo."""
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147)
+    xr, wr = _rnd(x, dtype).requires_grad_(True), _rnd(wt, dtype).requires_grad_(True)
+    y = F.conv2d(xr, wr, stride=2, padding=3)
+    dy = _rnd(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    hp, wp, ho, wo = ops.stem_geometry(h, w)
+    assert (ho, wo) == tuple(y.shape[2:])
+    xp = ops.stem_pad_input(x.to(DEV), dtype)
+    assert tuple(xp.shape) == (n, hp, wp, 4)
+    ref = torch.zeros(n, hp, wp, 4)
+    ref[:, 3:3 + h, 3:3 + w, :3] = _rnd(x, dtype).permute(0, 2, 3, 1)
+    assert torch.equal(xp.float().cpu(), ref)
+    wpk = ops.stem_pack_weights(wt.to(DEV), dtype)
+    yd, part = ops.stem_conv_fwd(xp, wpk, h, w)
+    _check(yd.float().cpu().permute(0, 3, 1, 2), y.detach(), _tol(dtype), "stem fwd")
+    m = n * ho * wo
+    yf = y.detach().permute(0, 2, 3, 1).reshape(m, 64)
+    _check(part[:, 0].sum(0).cpu() / m, yf.mean(0), 1e-2 if dtype == torch.bfloat16 else 1e-4, "stat mean")
+    _check(part[:, 1].sum(0).cpu() / m, (yf * yf).mean(0), 1e-2 if dtype == torch.bfloat16 else 1e-4, "stat sumsq")
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    dw = ops.stem_conv_wgrad(xp, dyd, h, w).cpu()
+    _check(dw, wr.grad, 2e-5 if dtype == torch.float32 else 2e-3, "stem wgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("m,c,relu,res", [(300, 64, True, False), (1000, 256, True, True), (77, 512, False, False),
                                           (4096, 2048, True, True), (50, 128, False, True)])
 def test_batchnorm_fwd_bwd(m, c, relu, res, dtype):
