@@ -1,0 +1,23 @@
+// Internal interface of conv_1x1.hip (activation-stationary short-K 1x1 GEMM); used by the conv2d entry points.
+#pragma once
+#include "common.h"
+
+namespace sh {
+
+struct Gemm1x1Args {
+  const bf16_t* a;    // [M][K] activations (x, or dy for the data gradient), NHWC rows
+  const bf16_t* w;    // [N][K] weights (KRSC forward, CRSK data gradient)
+  bf16_t* out;        // [M][N]
+  float* bn_partial;  // [ceil(M / rows_per_block)][2][N] or null
+  long long M;
+  int N;
+  int accumulate;     // 0: store, 1: out += result, 2: out = result + res_grad * bit(res_mask)
+  const bf16_t* res_grad;
+  const unsigned char* res_mask;
+};
+
+bool gemm1x1_supported(int k, int n);
+int gemm1x1_rows_per_block(int k);
+int launch_gemm1x1(const Gemm1x1Args& a, int k, hipStream_t s);
+
+}  // namespace sh

@@ -1,0 +1,243 @@
+// Activation-stationary GEMM for the short-K 1x1 convolutions of the bottleneck blocks (bf16, stride 1):
+//   Out[m][n] = sum_k A[m][k] * W[n][k],   K in {64, 128, 256},  N a multiple of 64.
+//
+// Replaces (reference): the 1x1 nn.Conv2d forward / input-gradient of torchvision's Bottleneck inside
+// src/models/resnet_model.py:13-58 (cuDNN there).  Forward: A = x (K = cin), W = KRSC weights, N = cout (the 4x
+// expansions 64->256 ... 256->1024 and the reductions with cin <= 256); dgrad: A = dy (K = cout), W = CRSK, N = cin.
+//
+// These layers are HBM-bound (51-170 FLOP/B against a ~400 FLOP/B ridge) and write up to 4x what they read, so the
+// generic 128x128 tile kernel -- one prologue / k-loop / epilogue latency chain per 32 KB of output -- runs at a
+// third of the HBM roof on them.  Here a block owns 64*MF pixel rows for ALL output channels:
+//   * its A rows are loaded ONCE, straight from global memory into the MFMA operand registers (a lane's 16-B k-slice
+//     is contiguous in the NHWC row): no LDS traffic and no re-reads for A, every A byte crosses HBM exactly once;
+//   * the weights (<= 512 KB, L2-resident) stream through a double-buffered, XOR-swizzled LDS tile of 64 channels x
+//     128 k, one barrier per step, the next tile's global loads in flight under the MFMAs;
+//   * every 64 output channels the accumulators leave through 16-B register stores (64 contiguous bytes per pixel
+//     and store instruction) while the other waves keep the matrix cores busy -- there is no separate epilogue phase.
+// MFMA operands are swapped and the weight rows permuted exactly as in conv_igemm.hip, so a lane owns 8 consecutive
+// channels of a pixel per tile pair; BatchNorm partial sums use DPP row reductions + a double-buffered LDS slab.
+#include "conv_1x1.h"
+
+namespace sh {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16_frag_t;
+
+__device__ __forceinline__ f32x4 mma_bf16(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16_frag_t, a), __builtin_bit_cast(bf16_frag_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float row16_sum_g1(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
+
+__device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
+  const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
+  const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+  return pack_bf16x2(lo, hi);
+}
+
+template <int K, int MF>
+__global__ __launch_bounds__(256, 2) void gemm1x1_kernel(Gemm1x1Args p) {
+  constexpr int KC = K < 128 ? K : 128;   // k elements per weight tile
+  constexpr int KSTEPS = K / KC;          // weight tiles per 64-channel chunk
+  constexpr int KK = KC / 32;             // MFMA k-steps per weight tile
+  constexpr int KF = K / 32;              // A fragments per 16-row group
+  constexpr int CPR = KC / 8;             // 16-B chunks per weight row
+  constexpr int NBL = 64 * CPR / 256;     // staged chunks per thread and step
+  constexpr int ROWB = KC * 2;            // bytes per weight-tile row
+  constexpr int BT = 64 * ROWB;           // bytes per weight tile
+  __shared__ __attribute__((aligned(16))) char sB[2 * BT];
+  __shared__ float red[2][4][2][64];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const long long mbase = (long long)blockIdx.x * (64 * MF) + wave * (16 * MF);
+  const int nch = p.N >> 6, total = nch * KSTEPS;
+
+  // swizzle key of a weight-tile row (rows are read 8q + t apart, q, t = 0..3: see conv_igemm.hip)
+  auto keyb = [](int row) __attribute__((always_inline)) -> int {
+    return CPR == 16 ? ((row & 3) | (((row >> 3) & 3) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 3) << 1));
+  };
+
+  // ---- staging map of this thread: chunks tid + 256 i of the [64][CPR] tile = rows row0 + i*RSTEP, same chunk ---------
+  // (named scalars, not arrays: hipcc 7.2 sends small per-thread arrays that live across the loop to scratch)
+  constexpr int RSTEP = 256 / CPR;
+  const int row0 = tid / CPR, ch0 = tid - row0 * CPR;
+  const int st0 = (row0 + 0 * RSTEP) * ROWB + ((ch0 ^ keyb(row0 + 0 * RSTEP)) * 16);
+  const int st1 = (row0 + 1 * RSTEP) * ROWB + ((ch0 ^ keyb(row0 + 1 * RSTEP)) * 16);
+  const int st2 = (row0 + 2 * RSTEP) * ROWB + ((ch0 ^ keyb(row0 + 2 * RSTEP)) * 16);
+  const int st3 = (row0 + 3 * RSTEP) * ROWB + ((ch0 ^ keyb(row0 + 3 * RSTEP)) * 16);
+  const bf16_t* wsrc0 = p.w + (long long)row0 * K + ch0 * 8;  // chunk i at + i * RSTEP * K elements
+  uint4 rb0, rb1, rb2 = make_uint4(0, 0, 0, 0), rb3 = make_uint4(0, 0, 0, 0);
+#define SH_G1_LOAD(OFF)                                                                         \
+  do {                                                                                          \
+    rb0 = *reinterpret_cast<const uint4*>(wsrc0 + (OFF));                                       \
+    rb1 = *reinterpret_cast<const uint4*>(wsrc0 + (OFF) + 1 * RSTEP * K);                       \
+    if (NBL == 4) {                                                                             \
+      rb2 = *reinterpret_cast<const uint4*>(wsrc0 + (OFF) + 2 * RSTEP * K);                     \
+      rb3 = *reinterpret_cast<const uint4*>(wsrc0 + (OFF) + 3 * RSTEP * K);                     \
+    }                                                                                           \
+  } while (0)
+#define SH_G1_STORE(DST)                                  \
+  do {                                                    \
+    *reinterpret_cast<uint4*>((DST) + st0) = rb0;         \
+    *reinterpret_cast<uint4*>((DST) + st1) = rb1;         \
+    if (NBL == 4) {                                       \
+      *reinterpret_cast<uint4*>((DST) + st2) = rb2;       \
+      *reinterpret_cast<uint4*>((DST) + st3) = rb3;       \
+    }                                                     \
+  } while (0)
+  SH_G1_LOAD(0);
+
+  // ---- A: this wave's 16*MF rows, whole K, straight into MFMA operand registers ----------------------------------------
+  uint4 afr[MF][KF];
+#pragma unroll
+  for (int mi = 0; mi < MF; ++mi) {
+    const long long row = mbase + mi * 16 + li;
+    const bool ok = row < p.M;
+    const bf16_t* pr = p.a + (ok ? row : 0) * K + g * 8;
+#pragma unroll
+    for (int j = 0; j < KF; ++j) afr[mi][j] = ok ? *reinterpret_cast<const uint4*>(pr + j * 32) : make_uint4(0, 0, 0, 0);
+  }
+
+  // ---- fragment read offsets: weight row chan_of(ni, li) = (ni>>1)*32 + (li>>2)*8 + (ni&1)*4 + (li&3); key == li -------
+  const int fkey = CPR == 16 ? li : (((li & 3) >> 1) | ((li >> 2) << 1));
+  int frow[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) frow[ni] = ((ni >> 1) * 32 + (li >> 2) * 8 + (ni & 1) * 4 + (li & 3)) * ROWB;
+  int fo[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) fo[kk] = ((kk * 4 + g) ^ fkey) * 16;
+
+  f32x4 acc[MF][4];
+#pragma unroll
+  for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  SH_G1_STORE(sB);
+  __syncthreads();
+
+  int s = 0;
+  for (int nc = 0; nc < nch; ++nc) {
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks, ++s) {
+      const int buf = s & 1;
+      const bool more = s + 1 < total;
+      if (more) {  // next weight tile: (nc, ks + 1) or (nc + 1, 0)
+        const long long off = ks + 1 < KSTEPS ? (long long)nc * 64 * K + (ks + 1) * KC : (long long)(nc + 1) * 64 * K;
+        SH_G1_LOAD(off);
+      }
+      const char* cB = sB + buf * BT;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        uint4 fb[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) fb[ni] = *reinterpret_cast<const uint4*>(cB + frow[ni] + fo[kk]);
+#pragma unroll
+        for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mma_bf16(fb[ni], afr[mi][ks * KK + kk], acc[mi][ni]);
+      }
+      if (ks == KSTEPS - 1) {
+        const int n0 = nc * 64;
+        // ---- BatchNorm partial sums of the fp32 accumulators: lane holds pixel li of each 16-row group, channels
+        //      chan_of(ni, 4g + r); rows beyond M are exact zeros
+        if (p.bn_partial != nullptr) {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+              for (int mi = 0; mi < MF; ++mi) {
+                const float v = acc[mi][ni][r];
+                s1 += v;
+                s2 += v * v;
+              }
+              s1 = row16_sum_g1(s1);
+              s2 = row16_sum_g1(s2);
+              if (li == 0) {
+                const int c = (ni >> 1) * 32 + g * 8 + (ni & 1) * 4 + r;
+                red[nc & 1][wave][0][c] = s1;
+                red[nc & 1][wave][1][c] = s2;
+              }
+            }
+        }
+        // ---- 64 channels out: two 16-B vectors per lane and pixel (channels n0 + j*32 + g*8 .. +8)
+#pragma unroll
+        for (int mi = 0; mi < MF; ++mi) {
+          const long long row = mbase + mi * 16 + li;
+          if (row < p.M) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
+              uint4 v;
+              v.x = pack_bf16x2(lo[0], lo[1]);
+              v.y = pack_bf16x2(lo[2], lo[3]);
+              v.z = pack_bf16x2(hi[0], hi[1]);
+              v.w = pack_bf16x2(hi[2], hi[3]);
+              const int ch = n0 + j * 32 + g * 8;
+              bf16_t* dst = p.out + row * p.N + ch;
+              if (p.accumulate == 2) {
+                const uint4 o = *reinterpret_cast<const uint4*>(p.res_grad + row * p.N + ch);
+                const unsigned bits = p.res_mask[row * (p.N >> 3) + (ch >> 3)];
+                const unsigned m0w = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
+                const unsigned m1w = ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
+                const unsigned m2w = ((bits & 16u) ? 0x0000ffffu : 0u) | ((bits & 32u) ? 0xffff0000u : 0u);
+                const unsigned m3w = ((bits & 64u) ? 0x0000ffffu : 0u) | ((bits & 128u) ? 0xffff0000u : 0u);
+                v.x = add_bf16x2_g1(v.x, o.x & m0w);
+                v.y = add_bf16x2_g1(v.y, o.y & m1w);
+                v.z = add_bf16x2_g1(v.z, o.z & m2w);
+                v.w = add_bf16x2_g1(v.w, o.w & m3w);
+              } else if (p.accumulate) {
+                const uint4 o = *reinterpret_cast<const uint4*>(dst);
+                v.x = add_bf16x2_g1(v.x, o.x);
+                v.y = add_bf16x2_g1(v.y, o.y);
+                v.z = add_bf16x2_g1(v.z, o.z);
+                v.w = add_bf16x2_g1(v.w, o.w);
+              }
+              *reinterpret_cast<uint4*>(dst) = v;
+            }
+          }
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      if (more) {
+        char* dB = sB + (buf ^ 1) * BT;
+        SH_G1_STORE(dB);
+      }
+      __syncthreads();
+      if (ks == KSTEPS - 1 && p.bn_partial != nullptr && tid < 128) {
+        const int which = tid >> 6, c = tid & 63;
+        const float v = (red[nc & 1][0][which][c] + red[nc & 1][1][which][c]) + (red[nc & 1][2][which][c] + red[nc & 1][3][which][c]);
+        p.bn_partial[((long long)blockIdx.x * 2 + which) * p.N + nc * 64 + c] = v;
+      }
+    }
+  }
+}
+
+#undef SH_G1_LOAD
+#undef SH_G1_STORE
+
+bool gemm1x1_supported(int k, int n) { return (k == 64 || k == 128 || k == 256) && n % 64 == 0 && n >= 64; }
+
+int gemm1x1_rows_per_block(int k) { return k == 256 ? 128 : 256; }
+
+int launch_gemm1x1(const Gemm1x1Args& a, int k, hipStream_t s) {
+  const int rows = gemm1x1_rows_per_block(k);
+  const int nblk = ceil_div(a.M, rows);
+  if (k == 64) gemm1x1_kernel<64, 4><<<nblk, 256, 0, s>>>(a);
+  else if (k == 128) gemm1x1_kernel<128, 4><<<nblk, 256, 0, s>>>(a);
+  else gemm1x1_kernel<256, 2><<<nblk, 256, 0, s>>>(a);
+  return 0;
+}
+
+}  // namespace sh

@@ -25,6 +25,7 @@
 // BatchNorm partial sums reduce over the 16 pixel lanes with four DPP row rotations.
 // Block ids are remapped so all n-tiles of an m-tile run on one XCD (shared L2 for A rows).
 #include "common.h"
+#include "conv_1x1.h"
 
 namespace sh {
 
@@ -457,6 +458,11 @@ static int check_desc(const sh_conv_desc* d, const char* who) {
   return 0;
 }
 
+// short-K stride-1 1x1 layers in bf16 go to the activation-stationary kernel (conv_1x1.hip)
+static bool use_1x1(const sh_conv_desc* d, int k, int n) {
+  return d->dtype == SH_BF16 && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && gemm1x1_supported(k, n);
+}
+
 }  // namespace sh
 
 using namespace sh;
@@ -465,7 +471,8 @@ extern "C" {
 
 int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d) {
   if (!d) return 0;
-  return ceil_div((long long)d->n * d->ho * d->wo, 128);
+  const int rows = use_1x1(d, d->cin, d->cout) ? gemm1x1_rows_per_block(d->cin) : 128;
+  return ceil_div((long long)d->n * d->ho * d->wo, rows);
 }
 
 int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void* y, float* bn_partial, sh_stream_t stream) {
@@ -489,6 +496,13 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
   const double es = d->dtype == SH_F32 ? 4 : 2;
   const double bytes = es * ((double)d->n * d->h * d->w * d->cin + (double)a.Mg * d->cout + (double)d->cout * d->cin * d->r * d->s);
   ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, flops, bytes);
+  if (use_1x1(d, d->cin, d->cout)) {
+    Gemm1x1Args g;
+    g.a = (const bf16_t*)x; g.w = (const bf16_t*)w; g.out = (bf16_t*)y; g.bn_partial = bn_partial;
+    g.M = a.Mg; g.N = d->cout; g.accumulate = 0; g.res_grad = nullptr; g.res_mask = nullptr;
+    launch_gemm1x1(g, d->cin, (hipStream_t)stream);
+    return check_launch("conv2d_fwd (1x1)");
+  }
   return d->dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 
@@ -570,6 +584,13 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   const double es = d->dtype == SH_F32 ? 4 : 2;
   const double bytes = es * ((double)d->n * d->h * d->w * d->cin * (accumulate ? 2 : 1) + (double)mo * d->cout + (double)d->cout * d->cin * d->r * d->s);
   ProfScope ps(SH_PROF_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
+  if (use_1x1(d, d->cout, d->cin)) {
+    Gemm1x1Args g;
+    g.a = (const bf16_t*)dy; g.w = (const bf16_t*)wt; g.out = (bf16_t*)dx; g.bn_partial = nullptr;
+    g.M = a.Mg; g.N = d->cin; g.accumulate = accumulate; g.res_grad = (const bf16_t*)res_grad; g.res_mask = res_mask;
+    launch_gemm1x1(g, d->cout, (hipStream_t)stream);
+    return check_launch("conv2d_dgrad (1x1)");
+  }
   return d->dtype == SH_F32 ? launch_igemm<float, true>(a, (hipStream_t)stream) : launch_igemm<bf16_t, true>(a, (hipStream_t)stream);
 }
 

@@ -41,6 +41,12 @@ CONV_SHAPES = [
     (5, 7, 7, 512, 64, 1, 1, 0),     # M = 245 (not a tile multiple)
     (70, 1, 1, 512, 512, 1, 1, 0),   # Linear as 1x1 conv
     (70, 1, 1, 512, 128, 1, 1, 0),
+    # short-K 1x1 layers (bf16: activation-stationary kernel, conv_1x1.hip), ragged against its 256 / 128-row blocks
+    (3, 13, 13, 128, 512, 1, 1, 0),
+    (2, 20, 20, 256, 1024, 1, 1, 0),
+    (2, 20, 20, 1024, 256, 1, 1, 0),
+    (3, 13, 13, 256, 128, 1, 1, 0),
+    (1, 3, 3, 64, 64, 1, 1, 0),
 ]
 
 
