@@ -156,6 +156,8 @@ typedef struct sh_conv_desc {
  * partial (sum, sum of squares) of the fp32 accumulators per output channel:
  * bn_partial [nblk_m][2][cout] fp32 with nblk_m = simhand_conv2d_fwd_stat_blocks(). */
 int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d);
+/* tuning / test hook of the short-K (cin or cout in {64,128,256}) bf16 stride-1 1x1 kernel: rows per block = 64*mf */
+int simhand_conv1x1_set_rows(int k, int mf);
 int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void* y, float* bn_partial, sh_stream_t stream);
 /* Direct 7x7 / stride 2 / pad 3 / 3 -> 64 stem (torchvision ResNet conv1, src/models/resnet_model.py:13-26) without an
  * im2col matrix.  simhand_stem_pad_input repacks the NCHW fp32 image batch to zero-padded NHWC4

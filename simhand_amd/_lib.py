@@ -78,6 +78,7 @@ SIGNATURES = {
     "simhand_conv2d_dgrad_masked_residual": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "simhand_conv2d_wgrad_workspace_bytes": (_S, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _S, _P]),
+    "simhand_conv1x1_set_rows": (_I, [_I, _I]),
     "simhand_stem_geometry": (_I, [_I, _I, _P, _P, _P, _P]),
     "simhand_stem_pad_input": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "simhand_stem_pack_weights": (_I, [_P, _P, _I, _P]),

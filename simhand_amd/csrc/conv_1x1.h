@@ -18,6 +18,7 @@ struct Gemm1x1Args {
 
 bool gemm1x1_supported(int k, int n);
 int gemm1x1_rows_per_block(int k);
+void gemm1x1_set_mf(int k, int mf);
 int launch_gemm1x1(const Gemm1x1Args& a, int k, hipStream_t s);
 
 }  // namespace sh

@@ -229,14 +229,25 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(Gemm1x1Args p) {
 
 bool gemm1x1_supported(int k, int n) { return (k == 64 || k == 128 || k == 256) && n % 64 == 0 && n >= 64; }
 
-int gemm1x1_rows_per_block(int k) { return k == 256 ? 128 : 256; }
+// rows per block = 64 * MF; tuned per K on MI355X (scripts/conv_bench.py), overridable for experiments
+static int g_mf[3] = {4, 2, 2};  // K = 64, 128, 256
+static int mf_of(int k) { return g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)]; }
+void gemm1x1_set_mf(int k, int mf) { g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)] = mf; }
+
+int gemm1x1_rows_per_block(int k) { return 64 * mf_of(k); }
 
 int launch_gemm1x1(const Gemm1x1Args& a, int k, hipStream_t s) {
-  const int rows = gemm1x1_rows_per_block(k);
-  const int nblk = ceil_div(a.M, rows);
-  if (k == 64) gemm1x1_kernel<64, 4><<<nblk, 256, 0, s>>>(a);
-  else if (k == 128) gemm1x1_kernel<128, 4><<<nblk, 256, 0, s>>>(a);
-  else gemm1x1_kernel<256, 2><<<nblk, 256, 0, s>>>(a);
+  const int mf = mf_of(k);
+  const int nblk = ceil_div(a.M, 64 * mf);
+#define SH_G1(KV, MFV) gemm1x1_kernel<KV, MFV><<<nblk, 256, 0, s>>>(a)
+  if (k == 64) {
+    if (mf == 4) SH_G1(64, 4); else if (mf == 2) SH_G1(64, 2); else SH_G1(64, 1);
+  } else if (k == 128) {
+    if (mf == 4) SH_G1(128, 4); else if (mf == 2) SH_G1(128, 2); else SH_G1(128, 1);
+  } else {
+    if (mf == 2) SH_G1(256, 2); else SH_G1(256, 1);
+  }
+#undef SH_G1
   return 0;
 }
 

@@ -181,6 +181,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
   const int csteps = p.Ca / KE;
   const int nk = (ntr > 0 && nts > 0) ? ntr * nts * csteps : 0;
   constexpr int dh = DGRAD ? -1 : 1;
+  // a parity class no filter tap can reach (three of the four for 1x1/2) contributes zeros: with `out += result`
+  // there is nothing to do -- the shortcut gradient of a stride-2 block is merged after conv1's, touching only 1/4 of dx
+  if (DGRAD && nk == 0 && p.accumulate == 1) return;
 
   // ---- per-thread loader state: 4 A rows (tid/8 + 32 i), chunk tid%8 --------------------
   const int chunk = tid & 7;
@@ -468,6 +471,13 @@ static bool use_1x1(const sh_conv_desc* d, int k, int n) {
 using namespace sh;
 
 extern "C" {
+
+// test / tuning hook: rows per block (64 * mf, mf in {1, 2, 4}; K = 256 supports {1, 2}) of the short-K 1x1 kernel
+int simhand_conv1x1_set_rows(int k, int mf) {
+  SH_REQUIRE((k == 64 || k == 128 || k == 256) && (mf == 1 || mf == 2 || (mf == 4 && k != 256)), "conv1x1_set_rows: bad k=%d mf=%d", k, mf);
+  gemm1x1_set_mf(k, mf);
+  return 0;
+}
 
 int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d) {
   if (!d) return 0;

@@ -262,8 +262,10 @@ class ResNetEngine:
                 dt_ = self._unit_bwd(u, dt_, grads, True)
             first = saved[0]
             if ds is not None:
-                dx = self._unit_bwd(ds, dz, grads, True, relu_mask=last.mask)
-                dz = self._unit_bwd(first, dt_, grads, True, dx_into=dx)
+                # main branch first (plain store), then the shortcut accumulates: for a stride-2 1x1 shortcut the
+                # dgrad kernel then only visits the one parity class its taps can reach (1/4 of dx)
+                dx = self._unit_bwd(first, dt_, grads, True)
+                dz = self._unit_bwd(ds, dz, grads, True, relu_mask=last.mask, dx_into=dx)
             else:
                 dz = self._unit_bwd(first, dt_, grads, True, res_grad=dz, res_mask=last.mask)
             saved.clear()
