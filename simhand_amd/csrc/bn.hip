@@ -92,11 +92,23 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
   int b1 = b0 + kChunk;
   if (b1 > nblk) b1 = nblk;
   double s1 = 0.0, s2 = 0.0;
-  if (ch < c)
-    for (int b = b0 + rl; b < b1; b += 4) {
-      s1 += (double)partial[((int64_t)b * 2 + 0) * c + ch];
-      s2 += (double)partial[((int64_t)b * 2 + 1) * c + ch];
+  if (ch < c) {
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};  // independent chains: loads overlap
+    int b = b0 + rl;
+    for (; b + 12 < b1; b += 16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a1[j] += (double)partial[((int64_t)(b + 4 * j) * 2 + 0) * c + ch];
+        a2[j] += (double)partial[((int64_t)(b + 4 * j) * 2 + 1) * c + ch];
+      }
     }
+    for (; b < b1; b += 4) {
+      a1[0] += (double)partial[((int64_t)b * 2 + 0) * c + ch];
+      a2[0] += (double)partial[((int64_t)b * 2 + 1) * c + ch];
+    }
+    s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+  }
   red[rl][0][cl] = s1;
   red[rl][1][cl] = s2;
   __syncthreads();
@@ -121,9 +133,22 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   if (ch == 0 && nbt) nbt[0] += 1;
   if (ch >= c) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nchunk; ++b) {
-    s1 += lvl2[((int64_t)b * 2 + 0) * c + ch];
-    s2 += lvl2[((int64_t)b * 2 + 1) * c + ch];
+  {
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+    int b = 0;
+    for (; b + 3 < nchunk; b += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a1[j] += lvl2[((int64_t)(b + j) * 2 + 0) * c + ch];
+        a2[j] += lvl2[((int64_t)(b + j) * 2 + 1) * c + ch];
+      }
+    }
+    for (; b < nchunk; ++b) {
+      a1[0] += lvl2[((int64_t)b * 2 + 0) * c + ch];
+      a2[0] += lvl2[((int64_t)b * 2 + 1) * c + ch];
+    }
+    s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
   }
   const double mean = s1 / (double)m;
   double var = s2 / (double)m - mean * mean;  // biased (normalisation) variance
@@ -250,28 +275,38 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
   });
 }
 
-// dbeta = sum g, dgamma = sum g*xhat  (one thread per channel over <= ~2048 partial blocks, 16 row lanes)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int c,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double red[16][2][16];
+// dbeta = sum g, dgamma = sum g*xhat over <= ~2048 partial blocks: 16 channels x 64 row lanes per block, four
+// independent accumulator pairs per thread so the (L2-resident) partial loads overlap instead of forming one
+// dependent chain; fixed summation order (deterministic)
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int c,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double red[64][2][16];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cl;
-  double s1 = 0.0, s2 = 0.0;
-  if (ch < c)
-    for (int b = rl; b < nblk; b += 16) {
-      s1 += (double)partial[((int64_t)b * 2 + 0) * c + ch];
-      s2 += (double)partial[((int64_t)b * 2 + 1) * c + ch];
+  double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+  if (ch < c) {
+    int b = rl;
+    for (; b + 3 * 64 < nblk; b += 4 * 64) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a1[j] += (double)partial[((int64_t)(b + j * 64) * 2 + 0) * c + ch];
+        a2[j] += (double)partial[((int64_t)(b + j * 64) * 2 + 1) * c + ch];
+      }
     }
+    for (; b < nblk; b += 64) {
+      a1[0] += (double)partial[((int64_t)b * 2 + 0) * c + ch];
+      a2[0] += (double)partial[((int64_t)b * 2 + 1) * c + ch];
+    }
+  }
+  double s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
   red[rl][0][cl] = s1;
   red[rl][1][cl] = s2;
   __syncthreads();
-  if (rl == 0 && ch < c) {
-    for (int j = 1; j < 16; ++j) {
-      s1 += red[j][0][cl];
-      s2 += red[j][1][cl];
-    }
-    dbeta[ch] = (float)s1;
-    dgamma[ch] = (float)s2;
+  if (rl < 2 && ch < c) {  // row lane 0 folds the sums, row lane 1 the xhat-weighted sums
+    double t = 0.0;
+    for (int j = 0; j < 64; ++j) t += red[j][rl][cl];
+    if (rl == 0) dbeta[ch] = (float)t;
+    else dgamma[ch] = (float)t;
   }
 }
 
@@ -449,7 +484,7 @@ int simhand_bn_bwd_finalize(const float* partial, int nblk, int c, float* dgamma
   SH_REQUIRE(partial && dgamma && dbeta, "bn_bwd_finalize: NULL pointer");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 0, (double)nblk * 2 * c * 4);
-  bn_bwd_finalize_kernel<<<ceil_div(c, 16), 256, 0, s>>>(partial, nblk, c, dgamma, dbeta);
+  bn_bwd_finalize_kernel<<<ceil_div(c, 16), 1024, 0, s>>>(partial, nblk, c, dgamma, dbeta);
   return check_launch("bn_bwd_finalize");
 }
 
@@ -486,7 +521,7 @@ int simhand_colsum(const void* x, int64_t m, int c, int dtype, float* partial, f
   else colsum_kernel<bf16_t><<<nblk, 256, 0, s>>>((const bf16_t*)x, m, c, rpb, partial);
   if (check_launch("colsum")) return 1;
   // reuse the bwd finalize reducer: "dbeta" slot = sum of s1, "dgamma" slot (s2 = 0) goes to scratch inside partial
-  bn_bwd_finalize_kernel<<<ceil_div(c, 16), 256, 0, s>>>(partial, nblk, c, partial + (int64_t)nblk * 2 * c, out);
+  bn_bwd_finalize_kernel<<<ceil_div(c, 16), 1024, 0, s>>>(partial, nblk, c, partial + (int64_t)nblk * 2 * c, out);
   return check_launch("colsum finalize");
 }
 
