@@ -24,10 +24,12 @@ for tot, k, cnt, rd, wr in rows[:25]:
 lines.append(f"\nall kernels: read {sum(r[3] for r in rows)/1e9:.1f} GB, write {sum(r[4] for r in rows)/1e9:.1f} GB over the profiled run (2 steps: 1 warm-up + 1 timed)")
 open(sys.argv[3], "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
-cls = {"conv_fwd": "igemm_kernel<unsigned short, false", "conv_dgrad": "igemm_kernel<unsigned short, true", "conv_wgrad": "wgrad_kernel<unsigned short"}
+cls = {"conv_fwd": (r"igemm_kernel<unsigned short, false", r"gemm1x1_kernel<\d+, \d+, false"),
+       "conv_dgrad": (r"igemm_kernel<unsigned short, true", r"gemm1x1_kernel<\d+, \d+, true"),
+       "conv_wgrad": (r"wgrad_kernel<unsigned short",)}
 out = {}
-for c, pat in cls.items():
-    sel = [r for r in rows if pat in r[1]]
+for c, pats in cls.items():
+    sel = [r for r in rows if any(re.search(p, r[1]) for p in pats)]
     n = sum(r[2] for r in sel)
     out[c] = {"bytes_per_launch": sum(r[0] for r in sel) / max(1, n), "launches_profiled": n,
               "read_bytes": sum(r[3] for r in sel), "write_bytes": sum(r[4] for r in sel)}

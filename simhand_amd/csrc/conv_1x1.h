@@ -19,6 +19,6 @@ struct Gemm1x1Args {
 bool gemm1x1_supported(int k, int n);
 int gemm1x1_rows_per_block(int k);
 void gemm1x1_set_mf(int k, int mf);
-int launch_gemm1x1(const Gemm1x1Args& a, int k, hipStream_t s);
+int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s);
 
 }  // namespace sh

@@ -42,7 +42,8 @@ __device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
   return pack_bf16x2(lo, hi);
 }
 
-template <int K, int MF>
+// DGRAD selects the epilogue: forward = BatchNorm partial sums + plain store; data gradient = the accumulate modes
+template <int K, int MF, bool DGRAD>
 __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(Gemm1x1Args p) {
   constexpr int KC = K < 128 ? K : 128;   // k elements per weight tile
   constexpr int KSTEPS = K / KC;          // weight tiles per 64-channel chunk
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(Gemm1x1Args p) {
         const int n0 = nc * 64;
         // ---- BatchNorm partial sums of the fp32 accumulators: lane holds pixel li of each 16-row group, channels
         //      chan_of(ni, 4g + r); rows beyond M are exact zeros
-        if (p.bn_partial != nullptr) {
+        if (!DGRAD && p.bn_partial != nullptr) {
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(Gemm1x1Args p) {
               v.w = pack_bf16x2(hi[2], hi[3]);
               const int ch = n0 + j * 32 + g * 8;
               bf16_t* dst = p.out + row * p.N + ch;
-              if (p.accumulate == 2) {
+              if (DGRAD && p.accumulate == 2) {
                 const uint4 o = *reinterpret_cast<const uint4*>(p.res_grad + row * p.N + ch);
                 const unsigned bits = p.res_mask[row * (p.N >> 3) + (ch >> 3)];
                 const unsigned m0w = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(Gemm1x1Args p) {
                 v.y = add_bf16x2_g1(v.y, o.y & m1w);
                 v.z = add_bf16x2_g1(v.z, o.z & m2w);
                 v.w = add_bf16x2_g1(v.w, o.w & m3w);
-              } else if (p.accumulate) {
+              } else if (DGRAD && p.accumulate) {
                 const uint4 o = *reinterpret_cast<const uint4*>(dst);
                 v.x = add_bf16x2_g1(v.x, o.x);
                 v.y = add_bf16x2_g1(v.y, o.y);
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(Gemm1x1Args p) {
         SH_G1_STORE(dB);
       }
       __syncthreads();
-      if (ks == KSTEPS - 1 && p.bn_partial != nullptr && tid < 128) {
+      if (!DGRAD && ks == KSTEPS - 1 && p.bn_partial != nullptr && tid < 128) {
         const int which = tid >> 6, c = tid & 63;
         const float v = (red[nc & 1][0][which][c] + red[nc & 1][1][which][c]) + (red[nc & 1][2][which][c] + red[nc & 1][3][which][c]);
         p.bn_partial[((long long)blockIdx.x * 2 + which) * p.N + nc * 64 + c] = v;
@@ -236,10 +237,14 @@ void gemm1x1_set_mf(int k, int mf) { g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)] = mf
 
 int gemm1x1_rows_per_block(int k) { return 64 * mf_of(k); }
 
-int launch_gemm1x1(const Gemm1x1Args& a, int k, hipStream_t s) {
+int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
   const int mf = mf_of(k);
   const int nblk = ceil_div(a.M, 64 * mf);
-#define SH_G1(KV, MFV) gemm1x1_kernel<KV, MFV><<<nblk, 256, 0, s>>>(a)
+#define SH_G1(KV, MFV)                                               \
+  do {                                                               \
+    if (dgrad) gemm1x1_kernel<KV, MFV, true><<<nblk, 256, 0, s>>>(a); \
+    else gemm1x1_kernel<KV, MFV, false><<<nblk, 256, 0, s>>>(a);      \
+  } while (0)
   if (k == 64) {
     if (mf == 4) SH_G1(64, 4); else if (mf == 2) SH_G1(64, 2); else SH_G1(64, 1);
   } else if (k == 128) {

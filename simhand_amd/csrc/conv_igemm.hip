@@ -510,7 +510,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
     Gemm1x1Args g;
     g.a = (const bf16_t*)x; g.w = (const bf16_t*)w; g.out = (bf16_t*)y; g.bn_partial = bn_partial;
     g.M = a.Mg; g.N = d->cout; g.accumulate = 0; g.res_grad = nullptr; g.res_mask = nullptr;
-    launch_gemm1x1(g, d->cin, (hipStream_t)stream);
+    launch_gemm1x1(g, d->cin, false, (hipStream_t)stream);
     return check_launch("conv2d_fwd (1x1)");
   }
   return d->dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
@@ -598,7 +598,7 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
     Gemm1x1Args g;
     g.a = (const bf16_t*)dy; g.w = (const bf16_t*)wt; g.out = (bf16_t*)dx; g.bn_partial = nullptr;
     g.M = a.Mg; g.N = d->cin; g.accumulate = accumulate; g.res_grad = (const bf16_t*)res_grad; g.res_mask = res_mask;
-    launch_gemm1x1(g, d->cout, (hipStream_t)stream);
+    launch_gemm1x1(g, d->cout, true, (hipStream_t)stream);
     return check_launch("conv2d_dgrad (1x1)");
   }
   return d->dtype == SH_F32 ? launch_igemm<float, true>(a, (hipStream_t)stream) : launch_igemm<bf16_t, true>(a, (hipStream_t)stream);
