@@ -235,8 +235,8 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
   const long long wrow32 = 32 * wrow;
   // LDS store offsets of this thread's rows.  The B (weight) tile uses its own swizzle key because its rows are
   // read in a permuted order (see the fragment offsets below).
-  const int st0 = (lrow + 0) * 128 + swz(lrow + 0, chunk) * 16, st1 = (lrow + 32) * 128 + swz(lrow + 32, chunk) * 16;
-  const int st2 = (lrow + 64) * 128 + swz(lrow + 64, chunk) * 16, st3 = (lrow + 96) * 128 + swz(lrow + 96, chunk) * 16;
+  // rows lrow + 32 i share one swizzle key (the keys only look at row bits 1..4): offsets differ by 32 * 128 bytes
+  const int st0 = lrow * 128 + swz(lrow, chunk) * 16;
   // bf16: rows are read 8q + t (q, t = 0..3) apart -> key from bits 1 and 3..4; fp32: natural row order
   auto key_b = [](int row) __attribute__((always_inline)) -> int {
     return sizeof(T) == 2 ? (((row >> 1) & 1) | (((row >> 3) & 3) << 1)) : ((row >> 1) & 7);
@@ -248,8 +248,7 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
   auto chan_of = [](int ni, int m) __attribute__((always_inline)) -> int {
     return sizeof(T) == 2 ? ((ni >> 1) * 32 + (m >> 2) * 8 + (ni & 1) * 4 + (m & 3)) : (ni * 16 + m);
   };
-  const int sb0 = (lrow + 0) * 128 + (chunk ^ key_b(lrow + 0)) * 16, sb1 = (lrow + 32) * 128 + (chunk ^ key_b(lrow + 32)) * 16;
-  const int sb2 = (lrow + 64) * 128 + (chunk ^ key_b(lrow + 64)) * 16, sb3 = (lrow + 96) * 128 + (chunk ^ key_b(lrow + 96)) * 16;
+  const int sb0 = lrow * 128 + (chunk ^ key_b(lrow)) * 16;
 
   // iteration state of the NEXT load (wave-uniform)
   int l_cs = 0, l_tr = 0, l_ts = 0;
@@ -287,14 +286,14 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
     char* dA = sA + buf * (128 * 128);
     char* dB = sB + buf * (BN * 128);
     *reinterpret_cast<uint4*>(dA + st0) = ra0;
-    *reinterpret_cast<uint4*>(dA + st1) = ra1;
-    *reinterpret_cast<uint4*>(dA + st2) = ra2;
-    *reinterpret_cast<uint4*>(dA + st3) = ra3;
+    *reinterpret_cast<uint4*>(dA + st0 + 32 * 128) = ra1;
+    *reinterpret_cast<uint4*>(dA + st0 + 64 * 128) = ra2;
+    *reinterpret_cast<uint4*>(dA + st0 + 96 * 128) = ra3;
     *reinterpret_cast<uint4*>(dB + sb0) = rb0;
-    *reinterpret_cast<uint4*>(dB + sb1) = rb1;
+    *reinterpret_cast<uint4*>(dB + sb0 + 32 * 128) = rb1;
     if (NB == 4) {
-      *reinterpret_cast<uint4*>(dB + sb2) = rb2;
-      *reinterpret_cast<uint4*>(dB + sb3) = rb3;
+      *reinterpret_cast<uint4*>(dB + sb0 + 64 * 128) = rb2;
+      *reinterpret_cast<uint4*>(dB + sb0 + 96 * 128) = rb3;
     }
   };
 
@@ -311,17 +310,13 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
   __syncthreads();
   // A fragment offsets: rows differ by multiples of 16 -> one swizzle key per lane
   const int fkey = (li >> 1) & 7;
-  const int fo0 = ((0 + g) ^ fkey) * 16, fo1 = ((4 + g) ^ fkey) * 16;
+  const int fo0 = (g ^ fkey) * 16;  // second half of the k-step: chunk 4 + g -> the same offset with bit 6 flipped
   const int fa_base = (wm * 64 + li) * 128;
   // B fragment rows follow chan_of(): the epilogue stores 16-B vectors per lane straight from registers
-  // (no LDS staging, no extra barriers) and every store instruction covers whole 64-B sectors.
-  int fbo0[NI], fbo1[NI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int rowb = wn * (BN / 2) + chan_of(ni, li);
-    fbo0[ni] = rowb * 128 + ((0 + g) ^ key_b(rowb)) * 16;
-    fbo1[ni] = rowb * 128 + ((4 + g) ^ key_b(rowb)) * 16;
-  }
+  // (no LDS staging, no extra barriers) and every store instruction covers whole 64-B sectors.  chan_of(ni, li) =
+  // chan_of(0, li) + a constant whose bits (2 and 5; fp32: 4 and 5) the swizzle key ignores: one offset per lane.
+  const int rowb0 = wn * (BN / 2) + chan_of(0, li);
+  const int fbo = rowb0 * 128 + ((g ^ key_b(rowb0)) * 16);
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = NBUF == 2 ? (ks & 1) : 0;
     if (ks + 1 < nk) load_step();  // global loads in flight under the MFMAs
@@ -330,11 +325,12 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       uint4 fa[4], fb[NI];
-      const int fo = kk == 0 ? fo0 : fo1;
+      const int fo = kk == 0 ? fo0 : (fo0 ^ 64);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) fa[mi] = *reinterpret_cast<const uint4*>(cA + mi * 16 * 128 + fo);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) fb[ni] = *reinterpret_cast<const uint4*>(cB + (kk == 0 ? fbo0[ni] : fbo1[ni]));
+      for (int ni = 0; ni < NI; ++ni)
+        fb[ni] = *reinterpret_cast<const uint4*>(cB + ((kk == 0 ? fbo : (fbo ^ 64)) + (chan_of(ni, 0) - chan_of(0, 0)) * 128));
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
