@@ -179,6 +179,31 @@ int simhand_conv2d_dgrad(const sh_conv_desc* d, const void* dy, const void* wt, 
  * res_mask = the block output's ReLU bit mask from simhand_bn_apply; both laid out like dx). */
 int simhand_conv2d_dgrad_masked_residual(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, const void* res_grad,
                                          const uint8_t* res_mask, sh_stream_t stream);
+/* Data gradient with the BatchNorm-backward partial sums of the PREVIOUS conv+BN unit fused into the epilogue.
+ * The dx this call stores is that unit's incoming gradient da (its raw conv output y has dx's layout), so instead
+ * of a separate simhand_bn_bwd_partial pass (reads da and y) the epilogue reads y once and emits per tile
+ *   partial[blk][0][c] = sum g,  partial[blk][1][c] = sum g * y,   g = da * relu'(.)
+ * relu_mode 0: no ReLU; 2: mask recomputed as y*scale + shift > 0; 3: 1-bit mask written by simhand_bn_apply.
+ * blk runs over simhand_conv2d_dgrad_stat_blocks(d) tiles; finish with simhand_bn_bwd_finalize_raw.
+ * accumulate: 0 store, 1 dx += result, 2 dx = result + res_grad * bit(res_mask) (as the two entry points above).
+ * Replaces (reference): autograd's native_batch_norm_backward reduction after each Conv2d input-gradient in
+ * torchvision's Bottleneck / BasicBlock (src/models/resnet_model.py:13-58). */
+typedef struct sh_bn_bwd_fuse {
+  const void* y;
+  const float* scale;
+  const float* shift;
+  const uint8_t* mask;
+  int32_t relu_mode;
+  float* partial;
+} sh_bn_bwd_fuse;
+int simhand_conv2d_dgrad_stat_blocks(const sh_conv_desc* d);
+/* 1 if the fused form is the faster choice for this layer (callers keep the standalone pass otherwise);
+ * simhand_conv2d_dgrad_fuse_1x1(1) forces it for the short-K 1x1 layers too (tuning hook) */
+int simhand_conv2d_dgrad_fuse_pays(const sh_conv_desc* d);
+int simhand_conv2d_dgrad_fuse_1x1(int on);
+int simhand_conv2d_dgrad_fused(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
+                               const uint8_t* res_mask, const sh_bn_bwd_fuse* fuse, sh_stream_t stream);
+
 /* dw (fp32, KRSC) = sum over output pixels of dy (x) patches(x); deterministic two-stage split-K */
 size_t simhand_conv2d_wgrad_workspace_bytes(const sh_conv_desc* d);
 int simhand_conv2d_wgrad(const sh_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, sh_stream_t stream);
@@ -186,6 +211,9 @@ int simhand_conv2d_wgrad(const sh_conv_desc* d, const void* x, const void* dy, f
  * OIHW fp32 [cout][c_real][r][s]; c_real <= cin drops zero-padded input channels (the im2col'd stem: cin = 192
  * columns, c_real = 147 = 3*7*7 -> exactly weight.grad.view(64, 147)). */
 int simhand_conv2d_wgrad_oihw(const sh_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int c_real, void* workspace, size_t workspace_bytes, sh_stream_t stream);
+
+/* tuning hook: non-temporal (streaming) loads / stores in the BatchNorm passes (1 = on [default]) */
+int simhand_bn_set_nt(int on);
 
 /* test hook: bf16 wgrad LDS transpose path (1 = ds_read_b64_tr_b16 [default], 0 = scalar LDS reads) */
 int simhand_wgrad_set_tr(int on);
@@ -233,6 +261,10 @@ int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const f
                            const float* scale, const float* shift, int relu, int64_t m, int c, int dtype, float* partial,
                            sh_stream_t stream);
 int simhand_bn_bwd_finalize(const float* partial, int nblk, int c, float* dgamma, float* dbeta, sh_stream_t stream);
+/* same for the RAW partial sums of simhand_conv2d_dgrad_fused (sum g, sum g*y):
+ * dbeta = sum g, dgamma = invstd * (sum g*y - mean * sum g), folded in fp64 */
+int simhand_bn_bwd_finalize_raw(const float* partial, int nblk, int c, const float* mean, const float* invstd, float* dgamma,
+                                float* dbeta, sh_stream_t stream);
 int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const float* mean, const float* invstd,
                          const float* gamma, const float* dgamma, const float* dbeta, const float* scale, const float* shift,
                          int relu, void* dy, void* dres, int64_t m, int c, int dtype, sh_stream_t stream);

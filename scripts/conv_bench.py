@@ -26,7 +26,7 @@ def timeit(fn, iters=5):
     return (time.perf_counter() - t0) / iters
 
 tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
-print(f"{'shape':34s} {'GF':>7s} {'MB':>7s} | {'fwd ms':>7s} {'TF/s':>6s} {'GB/s':>6s} | {'dgrad':>7s} {'TF/s':>6s} | {'wgrad':>7s} {'TF/s':>6s} | bound ms (hbm 5TB/s, mfma 1.5PF)")
+print(f"{'shape':34s} {'GF':>7s} {'MB':>7s} | {'fwd ms':>7s} {'TF/s':>6s} {'GB/s':>6s} | {'dgrad':>7s} {'TF/s':>6s} {'+bnsum':>7s} | {'wgrad':>7s} {'TF/s':>6s} | bound ms (hbm 5TB/s, mfma 1.5PF)")
 for (cin, cout, k, s, h), cnt in zip(SHAPES, COUNT):
     pad = k // 2
     d = ops.conv_desc(N, h, h, cin, cout, k, k, s, pad, dtype)
@@ -39,8 +39,15 @@ for (cin, cout, k, s, h), cnt in zip(SHAPES, COUNT):
     tf = timeit(lambda: ops.conv2d_fwd(d, x, wk, True)) if which in ("all", "fwd") else 0
     td = timeit(lambda: ops.conv2d_dgrad(d, dy, wt)) if which in ("all", "dgrad") and cin != 192 else 0
     tw = timeit(lambda: ops.conv2d_wgrad(d, x, dy)) if which in ("all", "wgrad") else 0
-    tot["fwd"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt
+    tdf = 0
+    if which in ("all", "dgrad", "fused") and cin != 192:
+        # dgrad with the previous unit's BN-backward sums fused (mask recomputed from y): +1 read of a dx-sized tensor
+        st = ops.BNState(cin, x.device)
+        st.scale.fill_(1.0); st.shift.fill_(0.0)
+        dxb = torch.empty_like(x)
+        tdf = timeit(lambda: ops.conv2d_dgrad_fused(d, dy, wt, x, st, None, dx=dxb))
+    tot["fwd"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt; tot["dgrad_fused"] = tot.get("dgrad_fused", 0.0) + tdf * cnt
     f = lambda t: f"{t*1e3:7.3f} {flops/t/1e12 if t else 0:6.0f}"
-    print(f"{str((cin,cout,k,s,h))+'x'+str(cnt):34s} {flops/1e9:7.0f} {byts/1e6:7.0f} | {f(tf)} {byts/tf/1e9 if tf else 0:6.0f} | {f(td)} | {f(tw)} | {byts/5e12*1e3:.3f} {flops/1.5e15*1e3:.3f}")
+    print(f"{str((cin,cout,k,s,h))+'x'+str(cnt):34s} {flops/1e9:7.0f} {byts/1e6:7.0f} | {f(tf)} {byts/tf/1e9 if tf else 0:6.0f} | {f(td)} {tdf*1e3:7.3f} | {f(tw)} | {byts/5e12*1e3:.3f} {flops/1.5e15*1e3:.3f}")
     del x, dy
 print("per-step totals (ms):", {k: round(v * 1e3, 2) for k, v in tot.items()})

@@ -40,6 +40,12 @@ class NtxentParams(C.Structure):
     ]
 
 
+class BnBwdFuse(C.Structure):
+    """sh_bn_bwd_fuse (include/simhand_hip.h)."""
+    _fields_ = [("y", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mask", C.c_void_p),
+                ("relu_mode", C.c_int32), ("partial", C.c_void_p)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [
         ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("cin", C.c_int),
@@ -87,6 +93,7 @@ SIGNATURES = {
     "simhand_stem_conv_wgrad": (_I, [_P, _P, _P, _P, _S, _I, _I, _I, _I, _P]),
     "simhand_conv2d_wgrad_oihw": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _S, _P]),
     "simhand_wgrad_set_tr": (_I, [_I]),
+    "simhand_bn_set_nt": (_I, [_I]),
     "simhand_nchw_f32_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "simhand_oihw_f32_to_krsc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "simhand_oihw_f32_to_crsk": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
@@ -101,6 +108,11 @@ SIGNATURES = {
     "simhand_bn_apply": (_I, [_P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P]),
     "simhand_bn_bwd_partial": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P]),
     "simhand_bn_bwd_finalize": (_I, [_P, _I, _I, _P, _P, _P]),
+    "simhand_bn_bwd_finalize_raw": (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
+    "simhand_conv2d_dgrad_stat_blocks": (_I, [C.POINTER(ConvDesc)]),
+    "simhand_conv2d_dgrad_fuse_pays": (_I, [C.POINTER(ConvDesc)]),
+    "simhand_conv2d_dgrad_fuse_1x1": (_I, [_I]),
+    "simhand_conv2d_dgrad_fused": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _P, C.POINTER(BnBwdFuse), _P]),
     "simhand_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P]),
     "simhand_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "simhand_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -199,7 +199,7 @@ __device__ __forceinline__ RowWalk row_walk(int64_t m, int c) {
   return w;
 }
 
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const T* __restrict__ res, int relu,
                                                        T* __restrict__ a, uint8_t* __restrict__ mask, int64_t m, int c) {
@@ -214,15 +214,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
       sc[e] = scale[cv * VE + e];
       sh[e] = shift[cv * VE + e];
     }
-    for (int64_t r = w.r0 + w.rl; r < w.r1; r += w.rowlanes) {
-      const int64_t off = r * c + cv * VE;
-      float v[VE], o[VE];
-      Vec16<T>::load(y + off, v);
+    auto finish = [&](int64_t r, const float(&v)[VE], const float(&q)[VE]) __attribute__((always_inline)) {
+      float o[VE];
 #pragma unroll
       for (int e = 0; e < VE; ++e) o[e] = v[e] * sc[e] + sh[e];
       if (res) {
-        float q[VE];
-        Vec16<T>::load(res + off, q);
 #pragma unroll
         for (int e = 0; e < VE; ++e) o[e] += q[e];
       }
@@ -236,12 +232,33 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 #pragma unroll
         for (int e = 0; e < VE; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
       }
-      Vec16<T>::store(a + off, o);
+      Vec16<T>::template store<NT>(a + r * c + cv * VE, o);
+    };
+    // U rows per trip: all loads are issued before the first dependent use (more bytes in flight per wave)
+    constexpr int U = 4;
+    int64_t r = w.r0 + w.rl;
+    for (; r + (U - 1) * w.rowlanes < w.r1; r += U * w.rowlanes) {
+      float v[U][VE], q[U][VE];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t off = (r + u * w.rowlanes) * c + cv * VE;
+        Vec16<T>::template load<NT>(y + off, v[u]);
+        if (res) Vec16<T>::template load<NT>(res + off, q[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) finish(r + u * w.rowlanes, v[u], q[u]);
+    }
+    for (; r < w.r1; r += w.rowlanes) {
+      float v[VE], q[VE];
+      const int64_t off = r * c + cv * VE;
+      Vec16<T>::template load<NT>(y + off, v);
+      if (res) Vec16<T>::template load<NT>(res + off, q);
+      finish(r, v, q);
     }
   }
 }
 
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ da, const T* __restrict__ a,
                                                              const T* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
@@ -251,8 +268,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
   constexpr int VE = Vec16<T>::N;
   column_reduce<T>(m, c, rows_per_blk, partial, [&](int64_t r, int cv, float(&s1)[VE], float(&s2)[VE]) {
     float g[VE], yy[VE];
-    Vec16<T>::load(da + r * c + cv * VE, g);
-    Vec16<T>::load(y + r * c + cv * VE, yy);
+    Vec16<T>::template load<NT>(da + r * c + cv * VE, g);
+    Vec16<T>::template load<NT>(y + r * c + cv * VE, yy);
     if (relu == 1) {
       float aa[VE];
       Vec16<T>::load(a + r * c + cv * VE, aa);
@@ -279,7 +296,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
 // independent accumulator pairs per thread so the (L2-resident) partial loads overlap instead of forming one
 // dependent chain; fixed summation order (deterministic)
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int c,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               const float* __restrict__ mean = nullptr,
+                                                               const float* __restrict__ invstd = nullptr) {
   __shared__ double red[64][2][16];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cl;
@@ -302,6 +321,18 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   red[rl][0][cl] = s1;
   red[rl][1][cl] = s2;
   __syncthreads();
+  if (mean != nullptr) {  // raw sums (sum g, sum g*y) from the fused dgrad epilogue: sum g*xhat = invstd*(sum g*y - mean*sum g)
+    if (rl == 0 && ch < c) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int j = 0; j < 64; ++j) {
+        t1 += red[j][0][cl];
+        t2 += red[j][1][cl];
+      }
+      dbeta[ch] = (float)t1;
+      dgamma[ch] = (float)((double)invstd[ch] * (t2 - (double)mean[ch] * t1));
+    }
+    return;
+  }
   if (rl < 2 && ch < c) {  // row lane 0 folds the sums, row lane 1 the xhat-weighted sums
     double t = 0.0;
     for (int j = 0; j < 64; ++j) t += red[j][rl][cl];
@@ -310,7 +341,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   }
 }
 
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ da, const T* __restrict__ a,
                                                            const T* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -338,8 +369,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     for (int64_t r = w.r0 + w.rl; r < w.r1; r += w.rowlanes) {
       const int64_t off = r * c + cv * VE;
       float g[VE], yy[VE], o[VE];
-      Vec16<T>::load(da + off, g);
-      Vec16<T>::load(y + off, yy);
+      Vec16<T>::template load<NT>(da + off, g);
+      Vec16<T>::template load<NT>(y + off, yy);
       if (relu == 1) {
         float aa[VE];
         Vec16<T>::load(a + off, aa);
@@ -355,8 +386,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       }
 #pragma unroll
       for (int e = 0; e < VE; ++e) o[e] = A[e] * (g[e] - k2[e]) - (yy[e] - mu[e]) * is[e] * k3[e];
-      Vec16<T>::store(dy + off, o);
-      if (dres) Vec16<T>::store(dres + off, g);
+      Vec16<T>::template store<NT>(dy + off, o);
+      if (dres) Vec16<T>::template store<NT>(dres + off, g);
     }
   }
 }
@@ -390,11 +421,18 @@ static inline int stream_grid(int64_t nvec) {
   return (int)g;
 }
 
+static int g_bn_nt = 1;  // non-temporal loads / stores in the streaming kernels (test hook: simhand_bn_set_nt)
+
 }  // namespace sh
 
 using namespace sh;
 
 extern "C" {
+
+int simhand_bn_set_nt(int on) {
+  g_bn_nt = on ? 1 : 0;
+  return 0;
+}
 
 int simhand_bn_stat_blocks(int64_t m, int c) {
   (void)c;
@@ -454,10 +492,10 @@ int simhand_bn_apply(const void* y, const float* scale, const float* shift, cons
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (residual ? 3 : 2));
   const int grid = row_grid(m, c / ve);
-  if (dtype == SH_F32)
-    bn_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)y, scale, shift, (const float*)residual, relu, (float*)a, relu_mask, m, c);
-  else
-    bn_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)y, scale, shift, (const bf16_t*)residual, relu, (bf16_t*)a, relu_mask, m, c);
+#define SH_BN_APPLY(T, NT) bn_apply_kernel<T, NT><<<grid, 256, 0, s>>>((const T*)y, scale, shift, (const T*)residual, relu, (T*)a, relu_mask, m, c)
+  if (dtype == SH_F32) { if (g_bn_nt) SH_BN_APPLY(float, true); else SH_BN_APPLY(float, false); }
+  else { if (g_bn_nt) SH_BN_APPLY(bf16_t, true); else SH_BN_APPLY(bf16_t, false); }
+#undef SH_BN_APPLY
   return check_launch("bn_apply");
 }
 
@@ -473,10 +511,10 @@ int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const f
   col_plan(m, &rpb, &nblk);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (relu == 1 ? 3 : 2));
-  if (dtype == SH_F32)
-    bn_bwd_partial_kernel<float><<<nblk, 256, 0, s>>>((const float*)da, (const float*)a, (const float*)y, mean, invstd, scale, shift, relu, m, c, rpb, partial);
-  else
-    bn_bwd_partial_kernel<bf16_t><<<nblk, 256, 0, s>>>((const bf16_t*)da, (const bf16_t*)a, (const bf16_t*)y, mean, invstd, scale, shift, relu, m, c, rpb, partial);
+#define SH_BN_BP(T, NT) bn_bwd_partial_kernel<T, NT><<<nblk, 256, 0, s>>>((const T*)da, (const T*)a, (const T*)y, mean, invstd, scale, shift, relu, m, c, rpb, partial)
+  if (dtype == SH_F32) { if (g_bn_nt) SH_BN_BP(float, true); else SH_BN_BP(float, false); }
+  else { if (g_bn_nt) SH_BN_BP(bf16_t, true); else SH_BN_BP(bf16_t, false); }
+#undef SH_BN_BP
   return check_launch("bn_bwd_partial");
 }
 
@@ -486,6 +524,15 @@ int simhand_bn_bwd_finalize(const float* partial, int nblk, int c, float* dgamma
   ProfScope ps(SH_PROF_BN, s, 0, (double)nblk * 2 * c * 4);
   bn_bwd_finalize_kernel<<<ceil_div(c, 16), 1024, 0, s>>>(partial, nblk, c, dgamma, dbeta);
   return check_launch("bn_bwd_finalize");
+}
+
+int simhand_bn_bwd_finalize_raw(const float* partial, int nblk, int c, const float* mean, const float* invstd, float* dgamma,
+                                float* dbeta, sh_stream_t stream) {
+  SH_REQUIRE(partial && mean && invstd && dgamma && dbeta, "bn_bwd_finalize_raw: NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_BN, s, 0, (double)nblk * 2 * c * 4);
+  bn_bwd_finalize_kernel<<<ceil_div(c, 16), 1024, 0, s>>>(partial, nblk, c, dgamma, dbeta, mean, invstd);
+  return check_launch("bn_bwd_finalize_raw");
 }
 
 int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const float* mean, const float* invstd, const float* gamma,
@@ -501,12 +548,10 @@ int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const flo
   ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (3 + (relu == 1 ? 1 : 0) + (dres ? 1 : 0)));
   const float inv_m = (float)(1.0 / (double)m);
   const int grid = row_grid(m, c / ve);
-  if (dtype == SH_F32)
-    bn_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)da, (const float*)a, (const float*)y, mean, invstd, gamma, dgamma, dbeta, scale,
-                                                    shift, relu, (float*)dy, (float*)dres, m, c, inv_m);
-  else
-    bn_bwd_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)da, (const bf16_t*)a, (const bf16_t*)y, mean, invstd, gamma, dgamma, dbeta,
-                                                     scale, shift, relu, (bf16_t*)dy, (bf16_t*)dres, m, c, inv_m);
+#define SH_BN_BA(T, NT) bn_bwd_apply_kernel<T, NT><<<grid, 256, 0, s>>>((const T*)da, (const T*)a, (const T*)y, mean, invstd, gamma, dgamma, dbeta, scale, shift, relu, (T*)dy, (T*)dres, m, c, inv_m)
+  if (dtype == SH_F32) { if (g_bn_nt) SH_BN_BA(float, true); else SH_BN_BA(float, false); }
+  else { if (g_bn_nt) SH_BN_BA(bf16_t, true); else SH_BN_BA(bf16_t, false); }
+#undef SH_BN_BA
   return check_launch("bn_bwd_apply");
 }
 

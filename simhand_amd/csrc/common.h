@@ -59,22 +59,39 @@ template <> struct Elem<bf16_t> {
   __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
-// 16-byte vector of T <-> fp32 lanes
+// 16-byte vector of T <-> fp32 lanes.  NT = non-temporal (streaming) access: the tensors of the BatchNorm / pooling
+// passes are far larger than L2 + Infinity Cache and are touched once per pass.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ uint4 ld16(const void* p) {
+  if (NT) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const uint4*>(p);
+}
+template <bool NT> __device__ __forceinline__ void st16(void* p, const uint4& v) {
+  if (NT) {
+    u32x4_t o = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t*>(p));
+  } else {
+    *reinterpret_cast<uint4*>(p) = v;
+  }
+}
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
   static constexpr int N = 4;
-  __device__ static __forceinline__ void load(const float* p, float (&o)[4]) {
-    float4 v = *reinterpret_cast<const float4*>(p);
-    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  template <bool NT = false> __device__ static __forceinline__ void load(const float* p, float (&o)[4]) {
+    const uint4 v = ld16<NT>(p);
+    o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
   }
-  __device__ static __forceinline__ void store(float* p, const float (&o)[4]) {
-    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  template <bool NT = false> __device__ static __forceinline__ void store(float* p, const float (&o)[4]) {
+    st16<NT>(p, make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])));
   }
 };
 template <> struct Vec16<bf16_t> {
   static constexpr int N = 8;
-  __device__ static __forceinline__ void load(const bf16_t* p, float (&o)[8]) {
-    uint4 v = *reinterpret_cast<const uint4*>(p);
+  template <bool NT = false> __device__ static __forceinline__ void load(const bf16_t* p, float (&o)[8]) {
+    const uint4 v = ld16<NT>(p);
     unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -82,11 +99,11 @@ template <> struct Vec16<bf16_t> {
       o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
   }
-  __device__ static __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
+  template <bool NT = false> __device__ static __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
     unsigned w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16(o[2 * i]) | ((unsigned)f32_to_bf16(o[2 * i + 1]) << 16);
-    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    st16<NT>(p, make_uint4(w[0], w[1], w[2], w[3]));
   }
 };
 

@@ -14,6 +14,13 @@ struct Gemm1x1Args {
   int accumulate;     // 0: store, 1: out += result, 2: out = result + res_grad * bit(res_mask)
   const bf16_t* res_grad;
   const unsigned char* res_mask;
+  // dgrad only: fused BatchNorm-backward partial sums of the previous unit (see sh_bn_bwd_fuse); fy null = off
+  const bf16_t* fy;
+  const float* fscale;
+  const float* fshift;
+  const unsigned char* fmask;
+  int fmode;
+  float* fpartial;    // [ceil(M / rows_per_block)][2][N]
 };
 
 bool gemm1x1_supported(int k, int n);

@@ -43,8 +43,12 @@ __device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
 }
 
 // DGRAD selects the epilogue: forward = BatchNorm partial sums + plain store; data gradient = the accumulate modes
-template <int K, int MF, bool DGRAD>
-__global__ __launch_bounds__(256, 2) void gemm1x1_kernel(Gemm1x1Args p) {
+// FUSE (data gradient only): also emit the previous unit's BatchNorm-backward partial sums (Gemm1x1Args::fy ...)
+template <int K, int MF, bool DGRAD, bool FUSE = false>
+#ifndef SH_G1_FUSE_MINB
+#define SH_G1_FUSE_MINB 3
+#endif
+__global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kernel(Gemm1x1Args p) {
   constexpr int KC = K < 128 ? K : 128;   // k elements per weight tile
   constexpr int KSTEPS = K / KC;          // weight tiles per 64-channel chunk
   constexpr int KK = KC / 32;             // MFMA k-steps per weight tile
@@ -172,54 +176,110 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(Gemm1x1Args p) {
             }
         }
         // ---- 64 channels out: two 16-B vectors per lane and pixel (channels n0 + j*32 + g*8 .. +8)
+        auto store_chunk = [&](int mi, int j, long long row) __attribute__((always_inline)) -> uint4 {
+          const f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
+          uint4 v;
+          v.x = pack_bf16x2(lo[0], lo[1]);
+          v.y = pack_bf16x2(lo[2], lo[3]);
+          v.z = pack_bf16x2(hi[0], hi[1]);
+          v.w = pack_bf16x2(hi[2], hi[3]);
+          const int ch = n0 + j * 32 + g * 8;
+          bf16_t* dst = p.out + row * p.N + ch;
+          if (DGRAD && p.accumulate == 2) {
+            const uint4 o = *reinterpret_cast<const uint4*>(p.res_grad + row * p.N + ch);
+            const unsigned bits = p.res_mask[row * (p.N >> 3) + (ch >> 3)];
+            const unsigned m0w = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
+            const unsigned m1w = ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
+            const unsigned m2w = ((bits & 16u) ? 0x0000ffffu : 0u) | ((bits & 32u) ? 0xffff0000u : 0u);
+            const unsigned m3w = ((bits & 64u) ? 0x0000ffffu : 0u) | ((bits & 128u) ? 0xffff0000u : 0u);
+            v.x = add_bf16x2_g1(v.x, o.x & m0w);
+            v.y = add_bf16x2_g1(v.y, o.y & m1w);
+            v.z = add_bf16x2_g1(v.z, o.z & m2w);
+            v.w = add_bf16x2_g1(v.w, o.w & m3w);
+          } else if (DGRAD && p.accumulate) {
+            const uint4 o = *reinterpret_cast<const uint4*>(dst);
+            v.x = add_bf16x2_g1(v.x, o.x);
+            v.y = add_bf16x2_g1(v.y, o.y);
+            v.z = add_bf16x2_g1(v.z, o.z);
+            v.w = add_bf16x2_g1(v.w, o.w);
+          }
+          *reinterpret_cast<uint4*>(dst) = v;
+          return v;
+        };
+        if (FUSE) {
+          // fused BatchNorm-backward partial sums of the previous unit: the stored gradient is its incoming gradient
+          // da; g = da * relu'(.); per-channel sums of g and g * y over this block's rows (see conv_igemm.hip)
 #pragma unroll
-        for (int mi = 0; mi < MF; ++mi) {
-          const long long row = mbase + mi * 16 + li;
-          if (row < p.M) {
+          for (int j = 0; j < 2; ++j) {
+            const int ch = n0 + j * 32 + g * 8;
+            float sc[8], sh[8], s1[8], s2[8];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
-              uint4 v;
-              v.x = pack_bf16x2(lo[0], lo[1]);
-              v.y = pack_bf16x2(lo[2], lo[3]);
-              v.z = pack_bf16x2(hi[0], hi[1]);
-              v.w = pack_bf16x2(hi[2], hi[3]);
-              const int ch = n0 + j * 32 + g * 8;
-              bf16_t* dst = p.out + row * p.N + ch;
-              if (DGRAD && p.accumulate == 2) {
-                const uint4 o = *reinterpret_cast<const uint4*>(p.res_grad + row * p.N + ch);
-                const unsigned bits = p.res_mask[row * (p.N >> 3) + (ch >> 3)];
-                const unsigned m0w = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
-                const unsigned m1w = ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
-                const unsigned m2w = ((bits & 16u) ? 0x0000ffffu : 0u) | ((bits & 32u) ? 0xffff0000u : 0u);
-                const unsigned m3w = ((bits & 64u) ? 0x0000ffffu : 0u) | ((bits & 128u) ? 0xffff0000u : 0u);
-                v.x = add_bf16x2_g1(v.x, o.x & m0w);
-                v.y = add_bf16x2_g1(v.y, o.y & m1w);
-                v.z = add_bf16x2_g1(v.z, o.z & m2w);
-                v.w = add_bf16x2_g1(v.w, o.w & m3w);
-              } else if (DGRAD && p.accumulate) {
-                const uint4 o = *reinterpret_cast<const uint4*>(dst);
-                v.x = add_bf16x2_g1(v.x, o.x);
-                v.y = add_bf16x2_g1(v.y, o.y);
-                v.z = add_bf16x2_g1(v.z, o.z);
-                v.w = add_bf16x2_g1(v.w, o.w);
+            for (int e = 0; e < 8; ++e) {
+              sc[e] = p.fmode == 2 ? p.fscale[ch + e] : 0.f;
+              sh[e] = p.fmode == 2 ? p.fshift[ch + e] : 0.f;
+              s1[e] = s2[e] = 0.f;
+            }
+#pragma unroll
+            for (int mi = 0; mi < MF; ++mi) {
+              const long long row = mbase + mi * 16 + li;
+              if (row < p.M) {
+                float yy[8];
+                Vec16<bf16_t>::load(p.fy + row * p.N + ch, yy);
+                unsigned bits = 0xffu;
+                if (p.fmode == 3) bits = p.fmask[row * (p.N >> 3) + (ch >> 3)];
+                const uint4 v = store_chunk(mi, j, row);
+                const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                  for (int h = 0; h < 2; ++h) {
+                    const int e = 2 * i + h;
+                    const float gq = h == 0 ? __uint_as_float(w4[i] << 16) : __uint_as_float(w4[i] & 0xffff0000u);
+                    bool on = true;
+                    if (p.fmode == 2) on = yy[e] * sc[e] + sh[e] > 0.f;
+                    else if (p.fmode == 3) on = (bits >> e) & 1u;
+                    const float gv = on ? gq : 0.f;
+                    s1[e] += gv;
+                    s2[e] += gv * yy[e];
+                  }
+                }
               }
-              *reinterpret_cast<uint4*>(dst) = v;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float t1 = row16_sum_g1(s1[e]), t2 = row16_sum_g1(s2[e]);
+              if (li == 0) {
+                const int c = j * 32 + g * 8 + e;
+                red[nc & 1][wave][0][c] = t1;
+                red[nc & 1][wave][1][c] = t2;
+              }
             }
           }
+        } else {
+#pragma unroll
+          for (int mi = 0; mi < MF; ++mi) {
+            const long long row = mbase + mi * 16 + li;
+            if (row < p.M) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j) store_chunk(mi, j, row);
+            }
+          }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
       }
       if (more) {
         char* dB = sB + (buf ^ 1) * BT;
         SH_G1_STORE(dB);
       }
       __syncthreads();
-      if (!DGRAD && ks == KSTEPS - 1 && p.bn_partial != nullptr && tid < 128) {
+      float* stat_out = DGRAD ? (FUSE ? p.fpartial : nullptr) : p.bn_partial;
+      if (ks == KSTEPS - 1 && stat_out != nullptr && tid < 128) {
         const int which = tid >> 6, c = tid & 63;
         const float v = (red[nc & 1][0][which][c] + red[nc & 1][1][which][c]) + (red[nc & 1][2][which][c] + red[nc & 1][3][which][c]);
-        p.bn_partial[((long long)blockIdx.x * 2 + which) * p.N + nc * 64 + c] = v;
+        stat_out[((long long)blockIdx.x * 2 + which) * p.N + nc * 64 + c] = v;
       }
     }
   }
@@ -240,10 +300,11 @@ int gemm1x1_rows_per_block(int k) { return 64 * mf_of(k); }
 int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
   const int mf = mf_of(k);
   const int nblk = ceil_div(a.M, 64 * mf);
-#define SH_G1(KV, MFV)                                               \
-  do {                                                               \
-    if (dgrad) gemm1x1_kernel<KV, MFV, true><<<nblk, 256, 0, s>>>(a); \
-    else gemm1x1_kernel<KV, MFV, false><<<nblk, 256, 0, s>>>(a);      \
+#define SH_G1(KV, MFV)                                                                          \
+  do {                                                                                          \
+    if (dgrad && a.fy != nullptr) gemm1x1_kernel<KV, MFV, true, true><<<nblk, 256, 0, s>>>(a);  \
+    else if (dgrad) gemm1x1_kernel<KV, MFV, true><<<nblk, 256, 0, s>>>(a);                      \
+    else gemm1x1_kernel<KV, MFV, false><<<nblk, 256, 0, s>>>(a);                                \
   } while (0)
   if (k == 64) {
     if (mf == 4) SH_G1(64, 4); else if (mf == 2) SH_G1(64, 2); else SH_G1(64, 1);

@@ -70,6 +70,13 @@ struct IgemmArgs {
   FastDiv div_hw;     // pixel-grid size (Hd*Wd, or Hq*Wq with parity classes)
   FastDiv div_w;      // grid width (Wd or Wq)
   int stem_hp, stem_wp;  // > 0: direct 7x7/2 stem from the zero-padded NHWC4 input [N][hp][wp][4] (see stem_fwd below)
+  // dgrad only: BatchNorm-backward partial sums of the unit whose incoming gradient this call produces (sh_bn_bwd_fuse)
+  const void* fy;              // that unit's raw conv output, laid out like out; null = no fusion
+  const float* fscale;         // fmode 2: ReLU mask recomputed from fy * fscale + fshift > 0
+  const float* fshift;
+  const unsigned char* fmask;  // fmode 3: ReLU bit mask [pixel][Ng / VE]
+  int fmode;
+  float* fpartial;             // [m_tiles * classes][2][Ng]: sum g, sum g * y
 };
 
 template <typename T> struct Mma;
@@ -378,8 +385,8 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
     constexpr int NCH = 4 * NI / VE;  // 16-B chunks per lane per pixel
     T* __restrict__ out = reinterpret_cast<T*>(p.out);
     const int ch0 = n0 + wn * (BN / 2) + g * VE;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    // destination pixel of accumulator row mi (linear NHWC pixel index, or -1)
+    auto pixel_of = [&](int mi) __attribute__((always_inline)) -> long long {
       const unsigned mrow = m0 + wm * 64 + mi * 16 + li;
       long long pix = (long long)mrow;
       bool ok = pix < p.Mg;
@@ -388,58 +395,132 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
         ok = px.ok;
         pix = ((long long)px.img * p.Hd + px.hd) * p.Wd + px.wd;
       }
-      if (!ok) continue;
+      return ok ? pix : -1;
+    };
+    // value of chunk j of row mi after the accumulate mode, as stored
+    auto chunk_out = [&](int mi, int j, long long pix) __attribute__((always_inline)) -> uint4 {
+      uint4 v;
+      if (sizeof(T) == 4) {
+        v.x = __float_as_uint(acc[mi][j % NI][0]);
+        v.y = __float_as_uint(acc[mi][j % NI][1]);
+        v.z = __float_as_uint(acc[mi][j % NI][2]);
+        v.w = __float_as_uint(acc[mi][j % NI][3]);
+      } else {
+        const f32x4 lo = acc[mi][(2 * j) % NI], hi = acc[mi][(2 * j + 1) % NI];
+        v.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
+        v.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
+        v.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
+        v.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
+      }
+      const int ch = ch0 + j * 4 * VE;
+      T* dst = out + pix * p.Ng + ch;
+      if (p.accumulate == 2) {
+        // identity-branch gradient g = res_grad * relu_mask, merged here instead of being materialised
+        const uint4 o = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res_grad) + pix * p.Ng + ch);
+        const unsigned bits = p.res_mask[pix * (p.Ng / VE) + ch / VE];
+        if (sizeof(T) == 4) {
+          v.x = __float_as_uint(__uint_as_float(v.x) + ((bits & 1u) ? __uint_as_float(o.x) : 0.f));
+          v.y = __float_as_uint(__uint_as_float(v.y) + ((bits & 2u) ? __uint_as_float(o.y) : 0.f));
+          v.z = __float_as_uint(__uint_as_float(v.z) + ((bits & 4u) ? __uint_as_float(o.z) : 0.f));
+          v.w = __float_as_uint(__uint_as_float(v.w) + ((bits & 8u) ? __uint_as_float(o.w) : 0.f));
+        } else {
+          const unsigned m0w = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
+          const unsigned m1w = ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
+          const unsigned m2w = ((bits & 16u) ? 0x0000ffffu : 0u) | ((bits & 32u) ? 0xffff0000u : 0u);
+          const unsigned m3w = ((bits & 64u) ? 0x0000ffffu : 0u) | ((bits & 128u) ? 0xffff0000u : 0u);
+          v.x = add_bf16x2(v.x, o.x & m0w);
+          v.y = add_bf16x2(v.y, o.y & m1w);
+          v.z = add_bf16x2(v.z, o.z & m2w);
+          v.w = add_bf16x2(v.w, o.w & m3w);
+        }
+      } else if (p.accumulate) {
+        const uint4 o = *reinterpret_cast<const uint4*>(dst);
+        if (sizeof(T) == 4) {
+          v.x = __float_as_uint(__uint_as_float(v.x) + __uint_as_float(o.x));
+          v.y = __float_as_uint(__uint_as_float(v.y) + __uint_as_float(o.y));
+          v.z = __float_as_uint(__uint_as_float(v.z) + __uint_as_float(o.z));
+          v.w = __float_as_uint(__uint_as_float(v.w) + __uint_as_float(o.w));
+        } else {
+          v.x = add_bf16x2(v.x, o.x);
+          v.y = add_bf16x2(v.y, o.y);
+          v.z = add_bf16x2(v.z, o.z);
+          v.w = add_bf16x2(v.w, o.w);
+        }
+      }
+      *reinterpret_cast<uint4*>(dst) = v;
+      return v;
+    };
+    if (!DGRAD || p.fy == nullptr) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const long long pix = pixel_of(mi);
+        if (pix < 0) continue;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) chunk_out(mi, j, pix);
+      }
+    } else {
+      // Fused BatchNorm-backward partial sums of the PREVIOUS unit: the stored gradient (rounded as stored) is that
+      // unit's incoming gradient da; g = da * relu'(.), sums of g and g * y per channel over this tile's pixels.
+      // Chunk-major order keeps one chunk's coefficients / sums live at a time.
+      float* red = reinterpret_cast<float*>(smem);  // [2 (wm)][2][BN]; tiles are dead (loop ended with a barrier)
+      const T* __restrict__ fy = reinterpret_cast<const T*>(p.fy);
+      long long pixs[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) pixs[mi] = pixel_of(mi);
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {
-        uint4 v;
-        if (sizeof(T) == 4) {
-          v.x = __float_as_uint(acc[mi][j][0]);
-          v.y = __float_as_uint(acc[mi][j][1]);
-          v.z = __float_as_uint(acc[mi][j][2]);
-          v.w = __float_as_uint(acc[mi][j][3]);
-        } else {
-          const f32x4 lo = acc[mi][(2 * j) % NI], hi = acc[mi][(2 * j + 1) % NI];
-          v.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
-          v.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
-          v.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
-          v.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
-        }
         const int ch = ch0 + j * 4 * VE;
-        T* dst = out + pix * p.Ng + ch;
-        if (p.accumulate == 2) {
-          // identity-branch gradient g = res_grad * relu_mask, merged here instead of being materialised
-          const uint4 o = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res_grad) + pix * p.Ng + ch);
-          const unsigned bits = p.res_mask[pix * (p.Ng / VE) + ch / VE];
+        float sc[VE], sh[VE], s1[VE], s2[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          sc[e] = p.fmode == 2 ? p.fscale[ch + e] : 0.f;
+          sh[e] = p.fmode == 2 ? p.fshift[ch + e] : 0.f;
+          s1[e] = s2[e] = 0.f;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const long long pix = pixs[mi];
+          if (pix < 0) continue;
+          float yy[VE], gg[VE];
+          Vec16<T>::load(fy + pix * p.Ng + ch, yy);
+          unsigned bits = 0xffu;
+          if (p.fmode == 3) bits = p.fmask[pix * (p.Ng / VE) + ch / VE];
+          const uint4 v = chunk_out(mi, j, pix);
           if (sizeof(T) == 4) {
-            v.x = __float_as_uint(__uint_as_float(v.x) + ((bits & 1u) ? __uint_as_float(o.x) : 0.f));
-            v.y = __float_as_uint(__uint_as_float(v.y) + ((bits & 2u) ? __uint_as_float(o.y) : 0.f));
-            v.z = __float_as_uint(__uint_as_float(v.z) + ((bits & 4u) ? __uint_as_float(o.z) : 0.f));
-            v.w = __float_as_uint(__uint_as_float(v.w) + ((bits & 8u) ? __uint_as_float(o.w) : 0.f));
+            gg[0] = __uint_as_float(v.x); gg[1] = __uint_as_float(v.y); gg[2] = __uint_as_float(v.z); gg[3] = __uint_as_float(v.w);
           } else {
-            const unsigned m0w = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
-            const unsigned m1w = ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
-            const unsigned m2w = ((bits & 16u) ? 0x0000ffffu : 0u) | ((bits & 32u) ? 0xffff0000u : 0u);
-            const unsigned m3w = ((bits & 64u) ? 0x0000ffffu : 0u) | ((bits & 128u) ? 0xffff0000u : 0u);
-            v.x = add_bf16x2(v.x, o.x & m0w);
-            v.y = add_bf16x2(v.y, o.y & m1w);
-            v.z = add_bf16x2(v.z, o.z & m2w);
-            v.w = add_bf16x2(v.w, o.w & m3w);
+            const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              gg[(2 * i) % VE] = __uint_as_float(w4[i] << 16);
+              gg[(2 * i + 1) % VE] = __uint_as_float(w4[i] & 0xffff0000u);
+            }
           }
-        } else if (p.accumulate) {
-          const uint4 o = *reinterpret_cast<const uint4*>(dst);
-          if (sizeof(T) == 4) {
-            v.x = __float_as_uint(__uint_as_float(v.x) + __uint_as_float(o.x));
-            v.y = __float_as_uint(__uint_as_float(v.y) + __uint_as_float(o.y));
-            v.z = __float_as_uint(__uint_as_float(v.z) + __uint_as_float(o.z));
-            v.w = __float_as_uint(__uint_as_float(v.w) + __uint_as_float(o.w));
-          } else {
-            v.x = add_bf16x2(v.x, o.x);
-            v.y = add_bf16x2(v.y, o.y);
-            v.z = add_bf16x2(v.z, o.z);
-            v.w = add_bf16x2(v.w, o.w);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            bool on = true;
+            if (p.fmode == 2) on = yy[e] * sc[e] + sh[e] > 0.f;
+            else if (p.fmode == 3) on = (bits >> e) & 1u;
+            const float gv = on ? gg[e] : 0.f;
+            s1[e] += gv;
+            s2[e] += gv * yy[e];
           }
         }
-        *reinterpret_cast<uint4*>(dst) = v;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const float t1 = row16_sum(s1[e]), t2 = row16_sum(s2[e]);
+          if (li == 0) {
+            const int c = wn * (BN / 2) + g * VE + j * 4 * VE + e;
+            red[(wm * 2 + 0) * BN + c] = t1;
+            red[(wm * 2 + 1) * BN + c] = t2;
+          }
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * BN) {
+        const int which = tid / BN, c = tid - which * BN;
+        const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c];
+        p.fpartial[(((long long)m_tile * p.classes + cls) * 2 + which) * p.Ng + n0 + c] = v;
       }
     }
   }
@@ -505,6 +586,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
   a.accumulate = 0; a.res_grad = nullptr; a.res_mask = nullptr;
   a.classes = 1; a.Hq = a.Wq = 0;
   a.stem_hp = a.stem_wp = 0;
+  a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr;
   SH_REQUIRE(a.Mg < (1ll << 31) - 256, "conv2d_fwd: %lld output pixels exceed the 2^31 index range", a.Mg);
   a.div_hw = make_fastdiv((unsigned)(a.Hd * a.Wd));
   a.div_w = make_fastdiv((unsigned)a.Wd);
@@ -518,6 +600,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
     Gemm1x1Args g;
     g.a = (const bf16_t*)x; g.w = (const bf16_t*)w; g.out = (bf16_t*)y; g.bn_partial = bn_partial;
     g.M = a.Mg; g.N = d->cout; g.accumulate = 0; g.res_grad = nullptr; g.res_mask = nullptr;
+    g.fy = nullptr; g.fscale = g.fshift = nullptr; g.fmask = nullptr; g.fmode = 0; g.fpartial = nullptr;
     launch_gemm1x1(g, d->cin, false, (hipStream_t)stream);
     return check_launch("conv2d_fwd (1x1)");
   }
@@ -555,6 +638,7 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
   a.accumulate = 0; a.res_grad = nullptr; a.res_mask = nullptr;
   a.classes = 1; a.Hq = a.Wq = 0;
   a.stem_hp = hp; a.stem_wp = wp;
+  a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr;
   SH_REQUIRE(a.Mg < (1ll << 31) - 256, "stem_conv_fwd: %lld output pixels exceed the 2^31 index range", a.Mg);
   SH_REQUIRE((long long)n * hp * wp * 4 < (1ll << 40), "stem_conv_fwd: input too large");
   a.div_hw = make_fastdiv((unsigned)(ho * wo));
@@ -568,8 +652,15 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
   return dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 
+// tiles (= rows of the fused BatchNorm-backward partial buffer) of the data-gradient launch
+static int dgrad_stat_blocks(const sh_conv_desc* d) {
+  if (use_1x1(d, d->cout, d->cin)) return ceil_div((long long)d->n * d->h * d->w, gemm1x1_rows_per_block(d->cout));
+  if (d->stride == 2) return 4 * ceil_div((long long)d->n * ((d->h + 1) / 2) * ((d->w + 1) / 2), 128);
+  return ceil_div((long long)d->n * d->h * d->w, 128);
+}
+
 static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
-                      const unsigned char* res_mask, sh_stream_t stream) {
+                      const unsigned char* res_mask, sh_stream_t stream, const sh_bn_bwd_fuse* fuse = nullptr) {
   if (check_desc(d, "conv2d_dgrad")) return 1;
   SH_REQUIRE(dy && wt && dx, "conv2d_dgrad: NULL pointer");
   const int ke = d->dtype == SH_F32 ? 32 : 64;
@@ -582,6 +673,17 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   a.Hd = d->h; a.Wd = d->w; a.Hs = d->ho; a.Ws = d->wo;
   a.accumulate = accumulate; a.res_grad = res_grad; a.res_mask = res_mask;
   a.stem_hp = a.stem_wp = 0;
+  a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr;
+  if (fuse != nullptr) {
+    SH_REQUIRE(fuse->y && fuse->partial, "conv2d_dgrad_fused: NULL y / partial");
+    SH_REQUIRE(fuse->relu_mode == 0 || fuse->relu_mode == 2 || fuse->relu_mode == 3, "conv2d_dgrad_fused: relu_mode %d", fuse->relu_mode);
+    SH_REQUIRE(fuse->relu_mode != 2 || (fuse->scale && fuse->shift), "conv2d_dgrad_fused: relu_mode 2 needs scale / shift");
+    SH_REQUIRE(fuse->relu_mode != 3 || fuse->mask, "conv2d_dgrad_fused: relu_mode 3 needs the bit mask");
+    // a stride-2 1x1 shortcut that accumulates skips the parity classes no tap reaches: their pixels would be missing
+    SH_REQUIRE(!(accumulate == 1 && d->stride == 2 && d->r == 1), "conv2d_dgrad_fused: not available for an accumulating stride-2 1x1");
+    a.fy = fuse->y; a.fscale = fuse->scale; a.fshift = fuse->shift; a.fmask = fuse->mask; a.fmode = fuse->relu_mode;
+    a.fpartial = fuse->partial;
+  }
   if (d->stride == 2) {
     a.classes = 4;
     a.Hq = (d->h + 1) / 2;
@@ -600,12 +702,14 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   const long long mo = (long long)d->n * d->ho * d->wo;
   const double flops = 2.0 * (double)mo * d->cout * d->cin * d->r * d->s;
   const double es = d->dtype == SH_F32 ? 4 : 2;
-  const double bytes = es * ((double)d->n * d->h * d->w * d->cin * (accumulate ? 2 : 1) + (double)mo * d->cout + (double)d->cout * d->cin * d->r * d->s);
+  const double bytes = es * ((double)d->n * d->h * d->w * d->cin * ((accumulate ? 2 : 1) + (fuse ? 1 : 0)) + (double)mo * d->cout +
+                             (double)d->cout * d->cin * d->r * d->s);
   ProfScope ps(SH_PROF_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
   if (use_1x1(d, d->cout, d->cin)) {
     Gemm1x1Args g;
     g.a = (const bf16_t*)dy; g.w = (const bf16_t*)wt; g.out = (bf16_t*)dx; g.bn_partial = nullptr;
     g.M = a.Mg; g.N = d->cin; g.accumulate = accumulate; g.res_grad = (const bf16_t*)res_grad; g.res_mask = res_mask;
+    g.fy = (const bf16_t*)a.fy; g.fscale = a.fscale; g.fshift = a.fshift; g.fmask = a.fmask; g.fmode = a.fmode; g.fpartial = a.fpartial;
     launch_gemm1x1(g, d->cout, true, (hipStream_t)stream);
     return check_launch("conv2d_dgrad (1x1)");
   }
@@ -620,6 +724,32 @@ int simhand_conv2d_dgrad_masked_residual(const sh_conv_desc* d, const void* dy, 
                                          const uint8_t* res_mask, sh_stream_t stream) {
   SH_REQUIRE(res_grad && res_mask, "conv2d_dgrad_masked_residual: NULL pointer");
   return dgrad_impl(d, dy, wt, dx, 2, res_grad, res_mask, stream);
+}
+
+// 1 when fusing the previous unit's BatchNorm-backward sums into this data gradient is the faster choice: the
+// tile kernel hides the extra read of y behind its other resident blocks; the activation-stationary short-K 1x1
+// kernel would pay the read's latency once per 64-channel chunk (measured 2-3x slower), so those layers keep the
+// standalone simhand_bn_bwd_partial pass unless forced (simhand_conv2d_dgrad_fuse_1x1).
+static int g_fuse_1x1 = 0;
+int simhand_conv2d_dgrad_fuse_1x1(int on) {
+  g_fuse_1x1 = on ? 1 : 0;
+  return 0;
+}
+int simhand_conv2d_dgrad_fuse_pays(const sh_conv_desc* d) {
+  if (!d) return 0;
+  return (!use_1x1(d, d->cout, d->cin) || g_fuse_1x1) ? 1 : 0;
+}
+
+int simhand_conv2d_dgrad_stat_blocks(const sh_conv_desc* d) {
+  if (!d) return 0;
+  return dgrad_stat_blocks(d);
+}
+
+int simhand_conv2d_dgrad_fused(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
+                               const uint8_t* res_mask, const sh_bn_bwd_fuse* fuse, sh_stream_t stream) {
+  SH_REQUIRE(accumulate >= 0 && accumulate <= 2, "conv2d_dgrad_fused: accumulate mode %d", accumulate);
+  SH_REQUIRE(accumulate != 2 || (res_grad && res_mask), "conv2d_dgrad_fused: accumulate 2 needs res_grad / res_mask");
+  return dgrad_impl(d, dy, wt, dx, accumulate, res_grad, res_mask, stream, fuse);
 }
 
 }  // extern "C"

@@ -131,6 +131,8 @@ class ResNetEngine:
         self.features = features
         self.dtype = dtype
         self._packs: Dict[int, _Packed] = {}
+        # BN-backward partial sums of a unit fused into the epilogue of the dgrad that produces its incoming gradient
+        self.fuse_bn_bwd = True
 
     # -- weights -------------------------------------------------------------
     def _pack(self, conv: nn.Conv2d, need_t: bool, stem: bool = False) -> _Packed:
@@ -225,15 +227,19 @@ class ResNetEngine:
         return out, ctx
 
     # -- backward --------------------------------------------------------------
-    def _unit_bwd(self, u: _Unit, da, grads: dict, need_dx: bool, dx_into=None, relu_mask=None, res_grad=None, res_mask=None):
+    def _unit_bwd(self, u: _Unit, da, grads: dict, need_dx: bool, dx_into=None, relu_mask=None, res_grad=None, res_mask=None,
+                  raw_partial=None, prev: Optional[_Unit] = None):
         """BN bwd -> wgrad (+ dgrad).  relu_mask: bit mask that gates `da` (residual units: their own output mask;
         downsample branch: the block output's mask).  res_grad/res_mask: merge the identity-branch gradient
-        res_grad * bit(res_mask) into dx inside the dgrad epilogue.  Returns dx or None."""
+        res_grad * bit(res_mask) into dx inside the dgrad epilogue.  raw_partial: this unit's BN-backward sums
+        already produced by the dgrad that wrote `da`.  prev: the unit whose incoming gradient is the dx computed
+        here -- its BN-backward partial sums are then fused into this dgrad's epilogue.
+        Returns (dx or None, raw partial sums for `prev` or None)."""
         d = u.desc
         m = d.n * d.ho * d.wo
         c = d.cout
         dy, _, dg, db = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, False,
-                                        mask_from_y=u.relu and not u.has_res, relu_mask=relu_mask)
+                                        mask_from_y=u.relu and not u.has_res, relu_mask=relu_mask, raw_partial=raw_partial)
         grads[u.bn.weight] = dg
         grads[u.bn.bias] = db
         w = u.conv.weight
@@ -242,32 +248,43 @@ class ResNetEngine:
         else:
             grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))  # split-K reduce writes weight.grad's layout
         if not need_dx:
-            return None
+            return None, None
         pk = self._pack(u.conv, need_t=True)
+        if prev is not None and self.fuse_bn_bwd and ops.conv2d_dgrad_fuse_pays(d):
+            # prev's incoming gradient = this dx; residual units gate it with their output mask, the others with
+            # the mask recomputed from their own y
+            return ops.conv2d_dgrad_fused(d, dy, pk.crsk, prev.y, prev.st if prev.relu else None, prev.mask if prev.has_res else None,
+                                          dx=dx_into, accumulate=dx_into is not None, res_grad=res_grad, res_mask=res_mask)
         if res_grad is not None:
-            return ops.conv2d_dgrad_masked_residual(d, dy, pk.crsk, res_grad, res_mask)
+            return ops.conv2d_dgrad_masked_residual(d, dy, pk.crsk, res_grad, res_mask), None
         if dx_into is not None:
-            return ops.conv2d_dgrad(d, dy, pk.crsk, dx=dx_into, accumulate=True)
-        return ops.conv2d_dgrad(d, dy, pk.crsk)
+            return ops.conv2d_dgrad(d, dy, pk.crsk, dx=dx_into, accumulate=True), None
+        return ops.conv2d_dgrad(d, dy, pk.crsk), None
 
     def backward(self, ctx: dict, d_enc: Tensor) -> Dict[nn.Parameter, Tensor]:
         grads: Dict[nn.Parameter, Tensor] = {}
         g = d_enc.contiguous() if d_enc.dtype == self.dtype else ops.cast(d_enc.contiguous(), self.dtype)
         dz = ops.avgpool_bwd(g, ctx["last_shape"])
-        for saved, ds in reversed(ctx["blocks"]):
+        dz_part = None  # BN-backward sums of the current block's last unit, when the next block's dgrad produced them
+        blocks = ctx["blocks"]
+        for bi in range(len(blocks) - 1, -1, -1):
+            saved, ds = blocks[bi]
             last = saved[-1]
             # out = relu(bn(conv(t)) + idn): the gradient of both branches is dz gated by the output's ReLU mask
-            dt_ = self._unit_bwd(last, dz, grads, True, relu_mask=last.mask)
-            for u in reversed(saved[1:-1]):
-                dt_ = self._unit_bwd(u, dt_, grads, True)
+            dt_, part = self._unit_bwd(last, dz, grads, True, relu_mask=last.mask, raw_partial=dz_part, prev=saved[-2])
+            for ui in range(len(saved) - 2, 0, -1):
+                dt_, part = self._unit_bwd(saved[ui], dt_, grads, True, raw_partial=part, prev=saved[ui - 1])
             first = saved[0]
             if ds is not None:
                 # main branch first (plain store), then the shortcut accumulates: for a stride-2 1x1 shortcut the
                 # dgrad kernel then only visits the one parity class its taps can reach (1/4 of dx)
-                dx = self._unit_bwd(first, dt_, grads, True)
-                dz = self._unit_bwd(ds, dz, grads, True, relu_mask=last.mask, dx_into=dx)
+                dx, _ = self._unit_bwd(first, dt_, grads, True, raw_partial=part)
+                dz, _ = self._unit_bwd(ds, dz, grads, True, relu_mask=last.mask, dx_into=dx)
+                dz_part = None
             else:
-                dz = self._unit_bwd(first, dt_, grads, True, res_grad=dz, res_mask=last.mask)
+                # identity block: dz of the block below = conv1's dgrad + masked dz; that block's last unit is `prev`
+                below = blocks[bi - 1][0][-1] if bi > 0 else None
+                dz, dz_part = self._unit_bwd(first, dt_, grads, True, res_grad=dz, res_mask=last.mask, raw_partial=part, prev=below)
             saved.clear()
         da = ops.maxpool_bwd(dz, ctx["pool_idx"], ctx["pool_in_shape"])
         self._unit_bwd(ctx["stem"], da, grads, need_dx=False)

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, NtxentParams, check
+from ._lib import BnBwdFuse, ConvDesc, NtxentParams, check
 
 _DT = {torch.float32: _lib.SH_F32, torch.bfloat16: _lib.SH_BF16}
 
@@ -165,6 +165,34 @@ def conv2d_dgrad_masked_residual(d: ConvDesc, dy, wt, res_grad, res_mask) -> tor
     check(lib.simhand_conv2d_dgrad_masked_residual(C.byref(d), _ptr(dy), _ptr(wt), _ptr(dx), _ptr(res_grad), _ptr(res_mask), _stream()),
           "conv2d_dgrad_masked_residual")
     return dx
+
+
+def conv2d_dgrad_fused(d: ConvDesc, dy, wt, prev_y, prev_st: Optional["BNState"], prev_mask, dx: Optional[torch.Tensor] = None,
+                       accumulate: bool = False, res_grad=None, res_mask=None):
+    """Data gradient whose epilogue also emits the BatchNorm-backward partial sums (sum g, sum g*y) of the PREVIOUS
+    conv+BN unit -- the one whose incoming gradient is the dx produced here (prev_y = its raw conv output).
+    prev_mask given: residual unit, ReLU bit mask; else prev_st given: ReLU mask recomputed from prev_y; neither: no
+    ReLU.  Returns (dx, raw_partial) for bn_backward(raw_partial=...)."""
+    lib = _lib_dev()
+    if dx is None:
+        dx = torch.empty(d.n, d.h, d.w, d.cin, dtype=dy.dtype, device=dy.device)
+    nblk = lib.simhand_conv2d_dgrad_stat_blocks(C.byref(d))
+    part = torch.empty(nblk, 2, d.cin, dtype=torch.float32, device=dy.device)
+    f = BnBwdFuse()
+    f.y = _ptr(prev_y)
+    f.mask = _ptr(prev_mask)
+    f.relu_mode = 3 if prev_mask is not None else (2 if prev_st is not None else 0)
+    f.scale = _ptr(prev_st.scale) if f.relu_mode == 2 else None
+    f.shift = _ptr(prev_st.shift) if f.relu_mode == 2 else None
+    f.partial = _ptr(part)
+    mode = 2 if res_grad is not None else int(accumulate)
+    check(lib.simhand_conv2d_dgrad_fused(C.byref(d), _ptr(dy), _ptr(wt), _ptr(dx), mode, _ptr(res_grad), _ptr(res_mask), C.byref(f),
+                                         _stream()), "conv2d_dgrad_fused")
+    return dx, part
+
+
+def conv2d_dgrad_fuse_pays(d: ConvDesc) -> bool:
+    return bool(_lib_dev().simhand_conv2d_dgrad_fuse_pays(C.byref(d)))
 
 
 def conv2d_wgrad(d: ConvDesc, x, dy) -> torch.Tensor:
@@ -345,22 +373,28 @@ def bn_apply(y, st: BNState, m: int, c: int, relu: bool, residual=None, out=None
 
 
 def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_dres: bool, mask_from_y: bool = False,
-                relu_mask=None):
-    """Returns (dy, dres or None, dgamma, dbeta).  mask_from_y: the unit had no residual add, so the ReLU mask is
+                relu_mask=None, raw_partial=None):
+    """Returns (dy, dres or None, dgamma, dbeta).  raw_partial: (sum g, sum g*y) tiles from conv2d_dgrad_fused -- the
+    standalone partial-sum pass is skipped.  mask_from_y: the unit had no residual add, so the ReLU mask is
     recomputed from y (the stored activation is not read).  relu_mask: bit mask from bn_apply(want_mask=True) --
     g = da * bit, whatever `relu` says about this unit's own activation (used for residual units and for the
     downsample branch, whose incoming gradient is the block output's masked gradient)."""
     lib = _lib_dev()
     dev = y.device
     mode = 3 if relu_mask is not None else (0 if not relu else (2 if mask_from_y else 1))
-    nblk = lib.simhand_bn_stat_blocks(m, c)
-    part = torch.empty(nblk, 2, c, dtype=torch.float32, device=dev)
     aa = relu_mask if mode == 3 else (a if mode == 1 else None)
-    check(lib.simhand_bn_bwd_partial(_ptr(da), _ptr(aa), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift), mode, m, c,
-                                     dt(y.dtype), _ptr(part), _stream()), "bn_bwd_partial")
     dg = torch.empty(c, dtype=torch.float32, device=dev)
     db = torch.empty(c, dtype=torch.float32, device=dev)
-    check(lib.simhand_bn_bwd_finalize(_ptr(part), nblk, c, _ptr(dg), _ptr(db), _stream()), "bn_bwd_finalize")
+    if raw_partial is not None:
+        # sums of g and g*y came out of the epilogue of the dgrad that produced `da` (conv2d_dgrad_fused)
+        check(lib.simhand_bn_bwd_finalize_raw(_ptr(raw_partial), raw_partial.shape[0], c, _ptr(st.mean), _ptr(st.invstd), _ptr(dg),
+                                              _ptr(db), _stream()), "bn_bwd_finalize_raw")
+    else:
+        nblk = lib.simhand_bn_stat_blocks(m, c)
+        part = torch.empty(nblk, 2, c, dtype=torch.float32, device=dev)
+        check(lib.simhand_bn_bwd_partial(_ptr(da), _ptr(aa), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift), mode, m, c,
+                                         dt(y.dtype), _ptr(part), _stream()), "bn_bwd_partial")
+        check(lib.simhand_bn_bwd_finalize(_ptr(part), nblk, c, _ptr(dg), _ptr(db), _stream()), "bn_bwd_finalize")
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
     check(lib.simhand_bn_bwd_apply(_ptr(da), _ptr(aa), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(dg), _ptr(db),
