@@ -212,6 +212,10 @@ int simhand_conv2d_wgrad(const sh_conv_desc* d, const void* x, const void* dy, f
  * columns, c_real = 147 = 3*7*7 -> exactly weight.grad.view(64, 147)). */
 int simhand_conv2d_wgrad_oihw(const sh_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int c_real, void* workspace, size_t workspace_bytes, sh_stream_t stream);
 
+/* tuning hook: route the eligible bf16 layers (>= 256 destination channels, long reduction) to the 256x256 LDS-DMA
+ * tile kernel (1 = default); the BN partial-sum block counts above follow the setting */
+int simhand_igemm256_enable(int on);
+
 /* tuning hook: non-temporal (streaming) loads / stores in the BatchNorm passes (1 = on [default]) */
 int simhand_bn_set_nt(int on);
 

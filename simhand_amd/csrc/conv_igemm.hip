@@ -324,28 +324,64 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
   // chan_of(0, li) + a constant whose bits (2 and 5; fp32: 4 and 5) the swizzle key ignores: one offset per lane.
   const int rowb0 = wn * (BN / 2) + chan_of(0, li);
   const int fbo = rowb0 * 128 + ((g ^ key_b(rowb0)) * 16);
+#ifndef SH_ABL
+#define SH_ABL 0
+#endif
+  // SH_ABL (scripts/igemm_ablate.sh only; results are garbage): 1 = no LDS stores, 2 = no global loads, 3 = no MFMA,
+  // 4 = no fragment reads, 5 = no barriers
+#if SH_ABL == 4
+  uint4 fa_c[4], fb_c[NI];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) fa_c[mi] = *reinterpret_cast<const uint4*>(sA + fa_base + mi * 16 * 128 + fo0);
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) fb_c[ni] = *reinterpret_cast<const uint4*>(sB + fbo + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
+#endif
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = NBUF == 2 ? (ks & 1) : 0;
+#if SH_ABL != 2
     if (ks + 1 < nk) load_step();  // global loads in flight under the MFMAs
+#endif
     const char* cA = sA + buf * (128 * 128) + fa_base;
     const char* cB = sB + buf * (BN * 128);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       uint4 fa[4], fb[NI];
       const int fo = kk == 0 ? fo0 : (fo0 ^ 64);
+#if SH_ABL == 4
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fa[mi] = fa_c[mi];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) fb[ni] = fb_c[ni];
+#else
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) fa[mi] = *reinterpret_cast<const uint4*>(cA + mi * 16 * 128 + fo);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
         fb[ni] = *reinterpret_cast<const uint4*>(cB + ((kk == 0 ? fbo : (fbo ^ 64)) + (chan_of(ni, 0) - chan_of(0, 0)) * 128));
+#endif
+#if SH_ABL == 3
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(fa[mi].x), "v"(fa[mi].y), "v"(fa[mi].z), "v"(fa[mi].w));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(fb[ni].x), "v"(fb[ni].y), "v"(fb[ni].z), "v"(fb[ni].w));
+#else
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mma<T>::run(fb[ni], fa[mi], acc[mi][ni]);
+#endif
     }
+#if SH_ABL != 5
     if (NBUF == 1) __syncthreads();  // single buffer: every wave is done reading before the tile is overwritten
+#endif
+#if SH_ABL != 1
     if (ks + 1 < nk) store_step(NBUF == 2 ? (buf ^ 1) : 0);
+#else
+    asm volatile("" ::"v"(ra0.x), "v"(ra1.x), "v"(ra2.x), "v"(ra3.x), "v"(rb0.x), "v"(rb1.x), "v"(rb2.x), "v"(rb3.x));
+#endif
+#if SH_ABL != 5
     __syncthreads();
+#endif
   }
 
   // ---- fused BatchNorm partial statistics of the fp32 accumulators (registers -> LDS -> global) ----
@@ -526,6 +562,377 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
   }
 }
 
+
+// ======================================================================================================================
+// 256 x 256 x 64 tile kernel for the MFMA-bound bf16 layers (destination channels a multiple of 256: the 3x3 layers of
+// stages 3-4, the long-K 1x1 layers).  The 128 x 128 kernel above moves 256 B of operands from L2 per MFMA; this one
+// 128 B, and its operands never pass through registers: every 16-B chunk goes global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4), a whole k-step (64 KB) ahead of its use, into the second of two 64-KB stages.
+//   * 8 waves as 2 (m) x 4 (n), each 128 x 64 = 8 x 4 MFMA tiles (128 accumulator registers), one block per CU;
+//   * a DMA instruction writes 64 lanes x 16 B = 8 consecutive 128-B tile rows; the XOR swizzle of the fragment reads
+//     is applied on the SOURCE side (lane l fetches global chunk (l & 7) ^ key(row)), the LDS image stays lane-linear;
+//   * halo / out-of-range lanes fetch from a 128-B page of zeros instead of being masked;
+//   * per k-step: issue the next step's 8 DMA instructions, s_waitcnt vmcnt(8) (this step has landed), barrier,
+//     64 MFMAs per wave from the current stage, barrier.  No ordinary global loads in the loop.
+// Fragment layout, weight-row permutation and the epilogues are those of igemm_kernel (MI = 8 row tiles per wave).
+__device__ uint4 g_zero_page[8];
+
+template <bool DGRAD>
+__global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
+  typedef bf16_t T;
+  constexpr int KE = 64, VE = 8, BM = 256, BN = 256, MI = 8, NI = 4;
+  constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BN * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  // LDS-DMA as inline asm: hipcc's waitcnt pass makes every ds_read wait for ALL outstanding builtin LDS-DMAs
+  // (s_waitcnt vmcnt(0) right after the barrier), which would drain the prefetch; the asm form is invisible to it and
+  // the loop counts vmcnt by hand.  m0 = LDS byte address of the wave's 1-KB destination.
+  auto dma16 = [](const void* src, unsigned lds_addr) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src));
+  };
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int n_tile = logical % p.n_tiles;
+  logical /= p.n_tiles;
+  const int cls = logical % p.classes;
+  const int m_tile = logical / p.classes;
+  const int ph = cls >> 1, pw = cls & 1;
+  const unsigned m0 = (unsigned)m_tile * (unsigned)BM;
+  const int n0 = n_tile * BN;
+  const bool par = DGRAD && p.classes == 4;
+
+  auto decode = [&](unsigned m) __attribute__((always_inline)) -> Pixel {
+    Pixel r;
+    r.ok = m < (unsigned)p.Mg;
+    const unsigned mm = r.ok ? m : 0u;
+    const unsigned img = fdiv(mm, p.div_hw);
+    const unsigned rem = mm - img * p.div_hw.d;
+    const unsigned hq = fdiv(rem, p.div_w);
+    const unsigned wq = rem - hq * p.div_w.d;
+    r.img = (int)img;
+    if (par) {
+      r.hd = 2 * (int)hq + ph;
+      r.wd = 2 * (int)wq + pw;
+      r.ok = r.ok && r.hd < p.Hd && r.wd < p.Wd;
+    } else {
+      r.hd = (int)hq;
+      r.wd = (int)wq;
+    }
+    return r;
+  };
+
+  const int r0 = par ? ((ph + p.pad) & 1) : 0, s0 = par ? ((pw + p.pad) & 1) : 0;
+  const int rstep = par ? 2 : 1;
+  const int ntr = par ? (p.R - r0 + 1) / 2 : p.R;
+  const int nts = par ? (p.S - s0 + 1) / 2 : p.S;
+  const int csteps = p.Ca / KE;
+  const int nk = (ntr > 0 && nts > 0) ? ntr * nts * csteps : 0;
+  constexpr int dh = DGRAD ? -1 : 1;
+  if (DGRAD && nk == 0 && p.accumulate == 1) return;
+
+  // ---- DMA map: instruction i of wave w fills tile rows i*64 + w*8 .. +8; lane l = row (l >> 3), LDS slot l & 7 ----
+  const int slot = lane & 7;
+  const int lrow = wave * 8 + (lane >> 3);  // 0..63; rows lrow + 64 i share their swizzle keys
+  auto key_b = [](int row) __attribute__((always_inline)) -> int { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); };
+  auto chan_of = [](int ni, int m) __attribute__((always_inline)) -> int {
+    return (ni >> 1) * 32 + (m >> 2) * 8 + (ni & 1) * 4 + (m & 3);
+  };
+  const int chunk_a = slot ^ ((lrow >> 1) & 7);
+  const int chunk_b = slot ^ key_b(lrow);
+  const T* __restrict__ asrc = reinterpret_cast<const T*>(p.a);
+  const T* __restrict__ wsrc = reinterpret_cast<const T*>(p.w);
+  const char* zsrc = reinterpret_cast<const char*>(g_zero_page) + slot * 16;
+  const T* pa0; const T* pa1; const T* pa2; const T* pa3;
+  int h00, h01, h02, h03, w00, w01, w02, w03;
+  auto init_row = [&](int i, const T*& pa, int& h0, int& w0) __attribute__((always_inline)) {
+    const Pixel px = decode(m0 + lrow + 64 * i);
+    if (DGRAD) {
+      h0 = par ? (px.hd + p.pad - r0) >> 1 : px.hd + p.pad;
+      w0 = par ? (px.wd + p.pad - s0) >> 1 : px.wd + p.pad;
+    } else {
+      h0 = px.hd * p.stride - p.pad;
+      w0 = px.wd * p.stride - p.pad;
+    }
+    pa = asrc + ((long long)px.img * p.Hs * p.Ws + (long long)h0 * p.Ws + w0) * p.Ca + chunk_a * VE;
+    if (!px.ok) h0 = -(1 << 20);
+  };
+  init_row(0, pa0, h00, w00);
+  init_row(1, pa1, h01, w01);
+  init_row(2, pa2, h02, w02);
+  init_row(3, pa3, h03, w03);
+  const long long wrow = (long long)p.R * p.S * p.Ca;
+  const T* pb0 = wsrc + (long long)(n0 + lrow) * wrow + chunk_b * VE;
+  const long long wrow64 = 64 * wrow;
+  const int dma_row0 = wave * 8 * 128;  // + i * 64 * 128: wave-uniform LDS offset of this wave's 8 rows
+
+  // DMA state of the NEXT k-step (wave-uniform): tap walk, element offsets, destination stage
+  int l_cs = 0, l_tr = 0, l_ts = 0;
+  int n_hoff = 0, n_woff = 0, n_aoff = 0, n_boff = 0;
+  unsigned n_dA = 0;
+  bool n_live = true;  // false on the last k-step: its (branch-free) DMAs fetch the zero page into the idle stage
+  auto next_step = [&](int stage) __attribute__((always_inline)) {
+    n_hoff = dh * l_tr;
+    n_woff = dh * l_ts;
+    n_aoff = (n_hoff * p.Ws + n_woff) * p.Ca + l_cs * KE;
+    n_boff = ((r0 + rstep * l_tr) * p.S + (s0 + rstep * l_ts)) * p.Ca + l_cs * KE;
+    n_dA = smem_addr + stage * STAGE + dma_row0;
+    if (++l_cs == csteps) {  // tap-major k order (taps innermost measured the same: the re-reads are not the limiter)
+      l_cs = 0;
+      if (++l_ts == nts) {
+        l_ts = 0;
+        ++l_tr;
+      }
+    }
+  };
+  // part q of the 8 DMA instructions of a k-step: 0-3 = A rows lrow + 64 q, 4-7 = weight rows lrow + 64 (q - 4)
+  auto dma_part = [&](int q) __attribute__((always_inline)) {
+    auto dma_a = [&](const T* pa, int h0, int w0, int i) __attribute__((always_inline)) {
+      const bool ok = n_live && (unsigned)(h0 + n_hoff) < (unsigned)p.Hs && (unsigned)(w0 + n_woff) < (unsigned)p.Ws;
+      const char* src = ok ? reinterpret_cast<const char*>(pa + n_aoff) : zsrc;
+      dma16(src, n_dA + i * 64 * 128);
+    };
+#ifndef SH_ABL256
+#define SH_ABL256 0
+#endif
+    // SH_ABL256 (scripts/igemm256_ablate.sh; garbage results): 1 = A from the zero page, 2 = no A DMAs, 3 = no B DMAs, 4 = none
+#if SH_ABL256 == 1
+    if (q < 4) { dma16(zsrc, n_dA + q * 64 * 128); return; }
+#elif SH_ABL256 == 2
+    if (q < 4) return;
+#elif SH_ABL256 == 3
+    if (q >= 4) return;
+#elif SH_ABL256 == 4
+    return;
+#endif
+    if (q == 0) dma_a(pa0, h00, w00, 0);
+    else if (q == 1) dma_a(pa1, h01, w01, 1);
+    else if (q == 2) dma_a(pa2, h02, w02, 2);
+    else if (q == 3) dma_a(pa3, h03, w03, 3);
+    else dma16(n_live ? reinterpret_cast<const char*>(pb0 + (q - 4) * wrow64 + n_boff) : zsrc, n_dA + A_BYTES + (q - 4) * 64 * 128);
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fkey = (li >> 1) & 7;
+  const int fo0 = (g ^ fkey) * 16;
+  const int fa_base = (wm * 128 + li) * 128;
+  const int rowb0 = wn * 64 + chan_of(0, li);
+  const int fbo = A_BYTES + rowb0 * 128 + ((g ^ key_b(rowb0)) * 16);
+
+  // ---- main loop: ONE barrier per k-step.  Before it every wave has (a) waited for its own DMAs of step kt and (b)
+  // finished reading the other stage (step kt - 1); after it the DMAs of step kt + 1 go out into that other stage, one
+  // after every 8 MFMAs, and have the whole step to land.  The fragments of MFMA group grp + 1 are read before the
+  // MFMAs of group grp are issued.  (Measured alternatives, both slower: two barriers per step with all DMAs up front;
+  // two wave groups ping-ponging load / compute segments across 8 barriers per step -- s_barrier costs ~250 cycles.)
+  if (nk > 0) {
+    next_step(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma_part(q);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    n_live = kt + 1 < nk;  // last step: the (branch-free) DMAs fetch the zero page into the idle stage
+    next_step((kt + 1) & 1);
+    const char* st = smem + (kt & 1) * STAGE;
+    uint4 fb[2][NI], fa[2][2];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) fb[0][ni] = *reinterpret_cast<const uint4*>(st + fbo + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
+    fa[0][0] = *reinterpret_cast<const uint4*>(st + fa_base + fo0);
+    fa[0][1] = *reinterpret_cast<const uint4*>(st + fa_base + 16 * 128 + fo0);
+#pragma unroll
+    for (int grp = 0; grp < 8; ++grp) {
+      const int kk = grp >> 2, q = grp & 3;
+      if (grp < 7) {
+        const int nkk = (grp + 1) >> 2, nq = (grp + 1) & 3;
+        const int fo = nkk == 0 ? fo0 : (fo0 ^ 64);
+        if (grp == 3) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            fb[1][ni] = *reinterpret_cast<const uint4*>(st + (fbo ^ 64) + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
+        }
+        fa[(grp + 1) & 1][0] = *reinterpret_cast<const uint4*>(st + fa_base + (2 * nq) * 16 * 128 + fo);
+        fa[(grp + 1) & 1][1] = *reinterpret_cast<const uint4*>(st + fa_base + (2 * nq + 1) * 16 * 128 + fo);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[2 * q][ni] = Mma<T>::run(fb[kk][ni], fa[grp & 1][0], acc[2 * q][ni]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[2 * q + 1][ni] = Mma<T>::run(fb[kk][ni], fa[grp & 1][1], acc[2 * q + 1][ni]);
+      dma_part(grp);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS is reused by the epilogues
+
+  // ---- fused BatchNorm partial statistics (forward): lane holds pixel wm*128 + mi*16 + li, channels wn*64 + chan_of(ni, 4g + r)
+  if (!DGRAD && p.bn_partial != nullptr) {
+    float* red = reinterpret_cast<float*>(smem);  // [2 (wm)][2][BN]
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const float v = acc[mi][ni][r];
+          s1 += v;
+          s2 += v * v;
+        }
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
+        if (li == 0) {
+          const int c = wn * 64 + chan_of(ni, 4 * g + r);
+          red[(wm * 2 + 0) * BN + c] = s1;
+          red[(wm * 2 + 1) * BN + c] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const int which = tid / BN, c = tid - which * BN;  // 512 threads = 2 x BN
+      const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c];
+      p.bn_partial[((long long)m_tile * 2 + which) * p.Ng + n0 + c] = v;
+    }
+  }
+
+  // ---- epilogue (as igemm_kernel): 16-B vectors from registers, channels ch0 + j*32 .. +8 of pixel row mi ----
+  {
+    constexpr int NCH = 2;
+    T* __restrict__ out = reinterpret_cast<T*>(p.out);
+    const int ch0 = n0 + wn * 64 + g * VE;
+    auto pixel_of = [&](int mi) __attribute__((always_inline)) -> long long {
+      const unsigned mrow = m0 + wm * 128 + mi * 16 + li;
+      long long pix = (long long)mrow;
+      bool ok = pix < p.Mg;
+      if (par) {
+        const Pixel px = decode(mrow);
+        ok = px.ok;
+        pix = ((long long)px.img * p.Hd + px.hd) * p.Wd + px.wd;
+      }
+      return ok ? pix : -1;
+    };
+    auto chunk_out = [&](int mi, int j, long long pix) __attribute__((always_inline)) -> uint4 {
+      uint4 v;
+      const f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
+      v.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
+      v.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
+      v.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
+      v.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
+      const int ch = ch0 + j * 32;
+      T* dst = out + pix * p.Ng + ch;
+      if (p.accumulate == 2) {
+        const uint4 o = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res_grad) + pix * p.Ng + ch);
+        const unsigned bits = p.res_mask[pix * (p.Ng / VE) + ch / VE];
+        const unsigned m0w = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
+        const unsigned m1w = ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
+        const unsigned m2w = ((bits & 16u) ? 0x0000ffffu : 0u) | ((bits & 32u) ? 0xffff0000u : 0u);
+        const unsigned m3w = ((bits & 64u) ? 0x0000ffffu : 0u) | ((bits & 128u) ? 0xffff0000u : 0u);
+        v.x = add_bf16x2(v.x, o.x & m0w);
+        v.y = add_bf16x2(v.y, o.y & m1w);
+        v.z = add_bf16x2(v.z, o.z & m2w);
+        v.w = add_bf16x2(v.w, o.w & m3w);
+      } else if (p.accumulate) {
+        const uint4 o = *reinterpret_cast<const uint4*>(dst);
+        v.x = add_bf16x2(v.x, o.x);
+        v.y = add_bf16x2(v.y, o.y);
+        v.z = add_bf16x2(v.z, o.z);
+        v.w = add_bf16x2(v.w, o.w);
+      }
+#if SH_ABL256 != 5
+      *reinterpret_cast<uint4*>(dst) = v;
+#else
+      if (v.x == 0x12345678u) *reinterpret_cast<uint4*>(dst) = v;  // ablation: no output stores
+#endif
+      return v;
+    };
+    if (!DGRAD || p.fy == nullptr) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const long long pix = pixel_of(mi);
+        if (pix < 0) continue;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) chunk_out(mi, j, pix);
+      }
+    } else {
+      // fused BatchNorm-backward partial sums of the previous unit (see igemm_kernel)
+      float* red = reinterpret_cast<float*>(smem);  // [2 (wm)][2][BN]
+      const T* __restrict__ fy = reinterpret_cast<const T*>(p.fy);
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int ch = ch0 + j * 32;
+        float sc[VE], sh[VE], s1[VE], s2[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          sc[e] = p.fmode == 2 ? p.fscale[ch + e] : 0.f;
+          sh[e] = p.fmode == 2 ? p.fshift[ch + e] : 0.f;
+          s1[e] = s2[e] = 0.f;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const long long pix = pixel_of(mi);
+          if (pix < 0) continue;
+          float yy[VE];
+          Vec16<T>::load(fy + pix * p.Ng + ch, yy);
+          unsigned bits = 0xffu;
+          if (p.fmode == 3) bits = p.fmask[pix * (p.Ng / VE) + ch / VE];
+          const uint4 v = chunk_out(mi, j, pix);
+          const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int e = 2 * i + h;
+              const float gq = h == 0 ? __uint_as_float(w4[i] << 16) : __uint_as_float(w4[i] & 0xffff0000u);
+              bool on = true;
+              if (p.fmode == 2) on = yy[e] * sc[e] + sh[e] > 0.f;
+              else if (p.fmode == 3) on = (bits >> e) & 1u;
+              const float gv = on ? gq : 0.f;
+              s1[e] += gv;
+              s2[e] += gv * yy[e];
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const float t1 = row16_sum(s1[e]), t2 = row16_sum(s2[e]);
+          if (li == 0) {
+            const int c = wn * 64 + g * VE + j * 32 + e;
+            red[(wm * 2 + 0) * BN + c] = t1;
+            red[(wm * 2 + 1) * BN + c] = t2;
+          }
+        }
+      }
+      __syncthreads();
+      {
+        const int which = tid / BN, c = tid - which * BN;
+        const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c];
+        p.fpartial[(((long long)m_tile * p.classes + cls) * 2 + which) * p.Ng + n0 + c] = v;
+      }
+    }
+  }
+}
+
+// the 256 x 256 kernel takes the bf16 layers with >= 256 destination channels in multiples of 256 and a reduction long
+// enough (>= 8 k-steps of 64) to amortise its one-block-per-CU prologue / epilogue
+static int g_use_256 = 1;
+static bool use_256(int dtype, int Ng, int Ca, int taps, long long Mg) {
+  if (!g_use_256 || dtype != SH_BF16 || Ng % 256 != 0 || Ca % 64 != 0) return false;
+  return g_use_256 == 2 || ((long long)taps * Ca >= 512 && Mg >= 256 * 64);  // 2 = forced (tests)
+}
+
+// data gradient: the stride-2 parity classes (uneven work per class, three empty ones for a 1x1/2) run better as many
+// small tiles, so they stay on the 128 x 128 kernel unless forced
+static bool use_256_dgrad(const sh_conv_desc* d, long long Mg) {
+  if (d->stride == 2 && g_use_256 != 2) return false;
+  return use_256(d->dtype, d->cin, d->cout, d->r * d->s, Mg);
+}
+
 template <typename T, bool DGRAD>
 static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   const int nblk = a.classes * a.m_tiles * a.n_tiles;
@@ -535,6 +942,15 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     igemm_kernel<T, DGRAD, 64><<<nblk, 256, 0, s>>>(a);
   }
   return check_launch(DGRAD ? "conv2d_dgrad" : "conv2d_fwd");
+}
+
+template <bool DGRAD>
+static int launch_igemm256(IgemmArgs a, hipStream_t s) {
+  a.m_tiles = ceil_div(a.Mg, 256);
+  a.n_tiles = a.Ng / 256;
+  const int nblk = a.classes * a.m_tiles * a.n_tiles;
+  igemm256_kernel<DGRAD><<<nblk, 512, 0, s>>>(a);
+  return check_launch(DGRAD ? "conv2d_dgrad (256x256)" : "conv2d_fwd (256x256)");
 }
 
 static int check_desc(const sh_conv_desc* d, const char* who) {
@@ -568,10 +984,18 @@ int simhand_conv1x1_set_rows(int k, int mf) {
   return 0;
 }
 
+// tuning hook: route eligible layers to the 256 x 256 LDS-DMA kernel (0 = never, 1 = default heuristic, 2 = whenever legal)
+int simhand_igemm256_enable(int on) {
+  g_use_256 = on < 0 ? 0 : (on > 2 ? 2 : on);
+  return 0;
+}
+
 int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d) {
   if (!d) return 0;
-  const int rows = use_1x1(d, d->cin, d->cout) ? gemm1x1_rows_per_block(d->cin) : 128;
-  return ceil_div((long long)d->n * d->ho * d->wo, rows);
+  const long long m = (long long)d->n * d->ho * d->wo;
+  const int rows = use_1x1(d, d->cin, d->cout) ? gemm1x1_rows_per_block(d->cin)
+                                              : (use_256(d->dtype, d->cout, d->cin, d->r * d->s, m) ? 256 : 128);
+  return ceil_div(m, rows);
 }
 
 int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void* y, float* bn_partial, sh_stream_t stream) {
@@ -604,6 +1028,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
     launch_gemm1x1(g, d->cin, false, (hipStream_t)stream);
     return check_launch("conv2d_fwd (1x1)");
   }
+  if (use_256(d->dtype, a.Ng, a.Ca, d->r * d->s, a.Mg)) return launch_igemm256<false>(a, (hipStream_t)stream);
   return d->dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 
@@ -655,8 +1080,9 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
 // tiles (= rows of the fused BatchNorm-backward partial buffer) of the data-gradient launch
 static int dgrad_stat_blocks(const sh_conv_desc* d) {
   if (use_1x1(d, d->cout, d->cin)) return ceil_div((long long)d->n * d->h * d->w, gemm1x1_rows_per_block(d->cout));
-  if (d->stride == 2) return 4 * ceil_div((long long)d->n * ((d->h + 1) / 2) * ((d->w + 1) / 2), 128);
-  return ceil_div((long long)d->n * d->h * d->w, 128);
+  const long long mg = d->stride == 2 ? (long long)d->n * ((d->h + 1) / 2) * ((d->w + 1) / 2) : (long long)d->n * d->h * d->w;
+  const int rows = use_256_dgrad(d, mg) ? 256 : 128;
+  return (d->stride == 2 ? 4 : 1) * ceil_div(mg, rows);
 }
 
 static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
@@ -713,6 +1139,7 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
     launch_gemm1x1(g, d->cout, true, (hipStream_t)stream);
     return check_launch("conv2d_dgrad (1x1)");
   }
+  if (use_256_dgrad(d, a.Mg)) return launch_igemm256<true>(a, (hipStream_t)stream);
   return d->dtype == SH_F32 ? launch_igemm<float, true>(a, (hipStream_t)stream) : launch_igemm<bf16_t, true>(a, (hipStream_t)stream);
 }
 

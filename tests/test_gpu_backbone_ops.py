@@ -340,3 +340,133 @@ def test_lars_adam_multi_tensor_matches_per_tensor_and_oracle():
         for i, (a, b, c) in enumerate(zip(pm, ps_, pc)):
             _check(a.detach().cpu(), b.detach().cpu(), 1e-6, f"multi vs single, tensor {i} step {t}")
             _check(a.detach().cpu(), c.detach(), 1e-5, f"multi vs oracle, tensor {i} step {t}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 256 x 256 LDS-DMA tile kernel (bf16 layers with >= 256 destination channels) and the fused BN-backward sums
+# ---------------------------------------------------------------------------------------------------------------------
+BIG_TILE_SHAPES = [
+    # n, h, w, cin, cout, k, stride, pad  (bf16; forced onto the 256x256 kernel whatever the size heuristics say)
+    (3, 14, 14, 256, 256, 3, 1, 1),
+    (5, 7, 7, 512, 512, 3, 1, 1),      # M = 245: a single ragged tile
+    (2, 14, 14, 512, 256, 1, 1, 0),    # fwd -> 256 channels, dgrad -> 512
+    (2, 16, 16, 256, 512, 3, 2, 1),    # stride 2: dgrad runs the four parity classes
+    (2, 15, 15, 256, 256, 3, 2, 1),    # odd spatial size, ragged classes
+    (2, 16, 16, 512, 1024, 1, 2, 0),   # 1x1 / 2 shortcut: three empty parity classes
+    (40, 3, 3, 1024, 256, 1, 1, 0),
+]
+
+
+@pytest.fixture
+def force_big_tile():
+    from simhand_amd import ops
+
+    lib = ops._lib_dev()
+    lib.simhand_igemm256_enable(2)
+    yield
+    lib.simhand_igemm256_enable(1)
+
+
+@pytest.mark.parametrize("shape", BIG_TILE_SHAPES)
+def test_big_tile_conv_fwd_dgrad(shape, force_big_tile):
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    n, h, w, cin, cout, k, stride, pad = shape
+    g = torch.Generator().manual_seed(hash(shape) % 10000)
+    x = _rnd(torch.randn(n, cin, h, w, generator=g), dtype)
+    wt = _rnd(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k), dtype)
+    x.requires_grad_(True)
+    y = F.conv2d(x, wt, stride=stride, padding=pad)
+    dy = _rnd(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    d = ops.conv_desc(n, h, w, cin, cout, k, k, stride, pad, dtype)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    wd = ops.pack_krsc(wt.detach().to(DEV), dtype)
+    wtd = ops.pack_crsk(wt.detach().to(DEV), dtype)
+    yd, part = ops.conv2d_fwd(d, xd, wd, want_stats=True)
+    m = n * d.ho * d.wo
+    assert part.shape[0] == (m + 255) // 256  # the 256-row kernel took it
+    _check(yd.float().cpu().permute(0, 3, 1, 2), y.detach(), _tol(dtype), "fwd")
+    yf = y.detach().permute(0, 2, 3, 1).reshape(m, cout)
+    _check(part[:, 0].sum(0).cpu() / m, yf.mean(0), 1e-2, "stat mean")
+    _check(part[:, 1].sum(0).cpu() / m, (yf * yf).mean(0), 1e-2, "stat sumsq")
+    # bit-for-bit the 128x128 kernel's result: same k order, same fp32 MFMA accumulation
+    lib = ops._lib_dev()
+    lib.simhand_igemm256_enable(0)
+    y_ref, _ = ops.conv2d_fwd(d, xd, wd, want_stats=True)
+    lib.simhand_igemm256_enable(2)
+    assert torch.equal(yd, y_ref)
+
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    dxd = ops.conv2d_dgrad(d, dyd, wtd)
+    _check(dxd.float().cpu().permute(0, 3, 1, 2), x.grad, _tol(dtype), "dgrad")
+    base = _rnd(torch.randn(n, h, w, cin, generator=g), dtype)
+    acc = base.to(DEV).to(dtype).contiguous()
+    ops.conv2d_dgrad(d, dyd, wtd, dx=acc, accumulate=True)
+    _check(acc.float().cpu(), base + x.grad.permute(0, 2, 3, 1), 2 * _tol(dtype), "dgrad accumulate")
+
+
+def _bn_sums_reference(dx, y, mode, st_scale, st_shift, mask_bits):
+    """sum g, sum g*y per channel with g = dx * relu'(.) -- dx / y as the stored (rounded) tensors."""
+    dxf, yf = dx.float(), y.float()
+    if mode == 2:
+        on = (yf * st_scale + st_shift) > 0
+    elif mode == 3:
+        on = mask_bits
+    else:
+        on = torch.ones_like(yf, dtype=torch.bool)
+    gq = torch.where(on, dxf, torch.zeros_like(dxf))
+    c = dx.shape[-1]
+    return gq.reshape(-1, c).double().sum(0), (gq * yf).reshape(-1, c).double().sum(0)
+
+
+@pytest.mark.parametrize("route", ["tile", "big_tile", "short_k_1x1"])
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dgrad_fused_bn_backward_sums(route, mode, dtype):
+    """conv2d_dgrad_fused: dx is unchanged and the raw partial sums equal a direct reduction of the stored dx."""
+    from simhand_amd import ops
+
+    if dtype == torch.float32 and route != "tile":
+        pytest.skip("the fp32 parity mode only has the 128x128 tile kernel")
+    lib = ops._lib_dev()
+    # (n, h, cin, cout, k, stride): dgrad has cout as its reduction and cin destination channels
+    shape = {"tile": (3, 12, 128, 64, 3, 1), "big_tile": (3, 13, 256, 512, 3, 2), "short_k_1x1": (3, 13, 512, 128, 1, 1)}[route]
+    n, h, cin, cout, k, stride = shape
+    g = torch.Generator().manual_seed(11 + mode)
+    pad = k // 2
+    d = ops.conv_desc(n, h, h, cin, cout, k, k, stride, pad, dtype)
+    wt = _rnd(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k), dtype)
+    dy = _rnd(torch.randn(n, d.ho, d.wo, cout, generator=g), dtype).to(DEV).to(dtype)
+    y_prev = _rnd(torch.randn(n, h, h, cin, generator=g), dtype).to(DEV).to(dtype)
+    res_grad = _rnd(torch.randn(n, h, h, cin, generator=g), dtype).to(DEV).to(dtype)
+    st = ops.BNState(cin, DEV)
+    st.scale.copy_(torch.randn(cin, generator=g).to(DEV))
+    st.shift.copy_(torch.randn(cin, generator=g).to(DEV) * 0.3)
+    act = _rnd(torch.randn(n * h * h, cin, generator=g), dtype).to(DEV).to(dtype)
+    one = ops.BNState(cin, DEV)
+    one.scale.fill_(1.0)
+    one.shift.fill_(0.0)
+    _, mask = ops.bn_apply(act, one, n * h * h, cin, True, None, want_mask=True)
+    wtd = ops.pack_crsk(wt.to(DEV), dtype)
+    lib.simhand_igemm256_enable(2 if route == "big_tile" else 0)
+    lib.simhand_conv2d_dgrad_fuse_1x1(1)
+    try:
+        for kind in ("store", "masked_residual"):
+            if kind == "store":
+                want_dx = ops.conv2d_dgrad(d, dy, wtd)
+                dx, part = ops.conv2d_dgrad_fused(d, dy, wtd, y_prev, st if mode == 2 else None, mask if mode == 3 else None)
+            else:
+                want_dx = ops.conv2d_dgrad_masked_residual(d, dy, wtd, res_grad, mask)
+                dx, part = ops.conv2d_dgrad_fused(d, dy, wtd, y_prev, st if mode == 2 else None, mask if mode == 3 else None,
+                                                  res_grad=res_grad, res_mask=mask)
+            assert torch.equal(dx, want_dx), kind
+            s1, s2 = _bn_sums_reference(dx, y_prev, mode, st.scale, st.shift, (act.float() > 0).view(n, h, h, cin))
+            got1, got2 = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+            tol = 1e-5 if dtype == torch.float32 else 1e-4  # fp32 partial sums of identical addends, other order
+            assert (got1 - s1).abs().max().item() <= tol * s1.abs().max().item() + 1e-4, (kind, "sum g")
+            assert (got2 - s2).abs().max().item() <= tol * s2.abs().max().item() + 1e-4, (kind, "sum g*y")
+    finally:
+        lib.simhand_igemm256_enable(1)
+        lib.simhand_conv2d_dgrad_fuse_1x1(0)
