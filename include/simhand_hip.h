@@ -265,6 +265,18 @@ int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const f
                            const float* scale, const float* shift, int relu, int64_t m, int c, int dtype, float* partial,
                            sh_stream_t stream);
 int simhand_bn_bwd_finalize(const float* partial, int nblk, int c, float* dgamma, float* dbeta, sh_stream_t stream);
+/* Stem block fused: out, idx = MaxPool(3, 2, 1)(ReLU(y*scale + shift)) without storing the activation in between, and
+ * its backward: the BatchNorm-backward passes gather the pooled gradient dz through idx (partial: simhand_bn_stat_blocks
+ * (n*h*w, c) blocks of [2][c] sums of g and g*xhat -> simhand_bn_bwd_finalize; apply: dy).  y is [n][h][w][c].
+ * Replaces (reference): bn1 -> relu -> maxpool of the torchvision ResNet stem (src/models/resnet_model.py:13-26). */
+int simhand_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int n, int h, int w,
+                                int c, int dtype, sh_stream_t stream);
+int simhand_maxpool_bn_bwd_partial(const void* dz, const uint8_t* idx, const void* y, const float* mean, const float* invstd,
+                                   const float* scale, const float* shift, int n, int h, int w, int c, int dtype, float* partial,
+                                   sh_stream_t stream);
+int simhand_maxpool_bn_bwd_apply(const void* dz, const uint8_t* idx, const void* y, const float* mean, const float* invstd,
+                                 const float* gamma, const float* dgamma, const float* dbeta, const float* scale, const float* shift,
+                                 void* dy, int n, int h, int w, int c, int dtype, sh_stream_t stream);
 /* same for the RAW partial sums of simhand_conv2d_dgrad_fused (sum g, sum g*y):
  * dbeta = sum g, dgamma = invstd * (sum g*y - mean * sum g), folded in fp64 */
 int simhand_bn_bwd_finalize_raw(const float* partial, int nblk, int c, const float* mean, const float* invstd, float* dgamma,

@@ -392,6 +392,172 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+
+// ---- stem block: BatchNorm + ReLU + MaxPool(3, 2, 1) fused, forward and backward ------------------------------------------
+// Replaces (reference): bn1 -> relu -> maxpool of torchvision's ResNet stem (src/models/resnet_model.py:13-26) and
+// their autograd backward.  The 112x112x64 activation between ReLU and the pool (3.3 GB at 2048 images, bf16) is never
+// written: forward reads the raw conv output y through the pool windows (L2 absorbs the 2.25x window overlap);
+// backward gathers the pooled gradient through the stored winner index inside the BatchNorm-backward passes instead
+// of materialising the un-pooled gradient.  Values are rounded exactly where the unfused kernels store them.
+template <typename T> __device__ __forceinline__ float round_as(float v);
+template <> __device__ __forceinline__ float round_as<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_as<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, T* __restrict__ out,
+                                                                  uint8_t* __restrict__ idx, int n, int h, int w, int c, int ho, int wo) {
+  constexpr int VE = Vec16<T>::N;
+  const int cvecs = c / VE;
+  const int64_t total = (int64_t)n * ho * wo * cvecs;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cvecs);
+    int64_t t = i / cvecs;
+    const int ow = (int)(t % wo);
+    t /= wo;
+    const int oh = (int)(t % ho);
+    const int img = (int)(t / ho);
+    float sc[VE], sh[VE], best[VE];
+    int bi[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      sc[e] = scale[cv * VE + e];
+      sh[e] = shift[cv * VE + e];
+      best[e] = -INFINITY;
+      bi[e] = 0;
+    }
+    // scan order kh then kw, strict '>' (first maximum wins) like ATen's max_pool2d
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh * 2 - 1 + kh;
+      if ((unsigned)ih >= (unsigned)h) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow * 2 - 1 + kw;
+        if ((unsigned)iw >= (unsigned)w) continue;
+        float v[VE];
+        Vec16<T>::load(y + (((int64_t)img * h + ih) * w + iw) * c + cv * VE, v);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          float a = v[e] * sc[e] + sh[e];
+          a = round_as<T>(a > 0.f ? a : 0.f);  // the activation as bn_apply would have stored it
+          if (a > best[e] || a != a) {
+            best[e] = a;
+            bi[e] = kh * 3 + kw;
+          }
+        }
+      }
+    }
+    Vec16<T>::template store<true>(out + i * VE, best);
+    uint8_t* ip = idx + i * VE;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) ip[e] = (uint8_t)bi[e];
+  }
+}
+
+// gradient w.r.t. the (never stored) post-ReLU activation at input pixel (img, ih, iw): sum of dz over the <= 4 windows
+// whose winner is this pixel, rounded as maxpool_bwd would have stored it
+template <typename T, int VE>
+__device__ __forceinline__ void pool_gather(const T* __restrict__ dz, const uint8_t* __restrict__ idx, int img, int ih, int iw,
+                                            int cv, int cvecs, int ho, int wo, float (&g)[VE]) {
+#pragma unroll
+  for (int e = 0; e < VE; ++e) g[e] = 0.f;
+  for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {
+    const int kh = ih + 1 - 2 * oh;
+    if (oh >= ho) continue;
+    for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
+      const int kw = iw + 1 - 2 * ow;
+      if (ow >= wo) continue;
+      const int64_t o = ((((int64_t)img * ho + oh) * wo + ow) * cvecs + cv) * VE;
+      float d[VE];
+      Vec16<T>::load(dz + o, d);
+      const uint8_t* ip = idx + o;
+      const int me = kh * 3 + kw;
+      uint8_t wi[VE];
+      if (VE == 8) {
+        const uint2 q = *reinterpret_cast<const uint2*>(ip);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) wi[e] = (uint8_t)(((e < 4 ? q.x : q.y) >> (8 * (e & 3))) & 0xffu);
+      } else {
+        const unsigned q = *reinterpret_cast<const unsigned*>(ip);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) wi[e] = (uint8_t)((q >> (8 * e)) & 0xffu);
+      }
+#pragma unroll
+      for (int e = 0; e < VE; ++e) g[e] += wi[e] == me ? d[e] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VE; ++e) g[e] = round_as<T>(g[e]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bn_bwd_partial_kernel(const T* __restrict__ dz, const uint8_t* __restrict__ idx,
+                                                                  const T* __restrict__ y, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, int n, int h, int w, int c,
+                                                                  int ho, int wo, int rows_per_blk, float* __restrict__ partial) {
+  constexpr int VE = Vec16<T>::N;
+  const int cvecs = c / VE;
+  const int64_t m = (int64_t)n * h * w;
+  column_reduce<T>(m, c, rows_per_blk, partial, [&](int64_t r, int cv, float(&s1)[VE], float(&s2)[VE]) {
+    const int iw = (int)(r % w);
+    const int64_t t = r / w;
+    const int ih = (int)(t % h), img = (int)(t / h);
+    float g[VE], yy[VE];
+    pool_gather<T, VE>(dz, idx, img, ih, iw, cv, cvecs, ho, wo, g);
+    Vec16<T>::template load<true>(y + r * c + cv * VE, yy);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int ch = cv * VE + e;
+      const float gv = yy[e] * scale[ch] + shift[ch] > 0.f ? g[e] : 0.f;
+      s1[e] += gv;
+      s2[e] += gv * ((yy[e] - mean[ch]) * invstd[ch]);
+    }
+  });
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const T* __restrict__ dz, const uint8_t* __restrict__ idx,
+                                                                const T* __restrict__ y, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                T* __restrict__ dy, int n, int h, int w, int c, int ho, int wo,
+                                                                float inv_m) {
+  constexpr int VE = Vec16<T>::N;
+  const int cvecs = c / VE;
+  const int64_t m = (int64_t)n * h * w;
+  const RowWalk rw = row_walk<VE>(m, c);
+  if (rw.rl >= rw.rowlanes) return;
+  for (int cv = rw.cv; cv < cvecs; cv += rw.span) {
+    float mu[VE], is[VE], A[VE], k2[VE], k3[VE], sc[VE], sh[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int ch = cv * VE + e;
+      mu[e] = mean[ch];
+      is[e] = invstd[ch];
+      A[e] = (gamma ? gamma[ch] : 1.0f) * is[e];
+      k2[e] = dbeta[ch] * inv_m;
+      k3[e] = A[e] * dgamma[ch] * inv_m;
+      sc[e] = scale[ch];
+      sh[e] = shift[ch];
+    }
+    for (int64_t r = rw.r0 + rw.rl; r < rw.r1; r += rw.rowlanes) {
+      const int iw = (int)(r % w);
+      const int64_t t = r / w;
+      const int ih = (int)(t % h), img = (int)(t / h);
+      float g[VE], yy[VE], o[VE];
+      pool_gather<T, VE>(dz, idx, img, ih, iw, cv, cvecs, ho, wo, g);
+      Vec16<T>::template load<true>(y + r * c + cv * VE, yy);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const float gv = yy[e] * sc[e] + sh[e] > 0.f ? g[e] : 0.f;
+        o[e] = A[e] * (gv - k2[e]) - (yy[e] - mu[e]) * is[e] * k3[e];
+      }
+      Vec16<T>::template store<true>(dy + r * c + cv * VE, o);
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t m, int c, int rows_per_blk,
                                                      float* __restrict__ partial) {
@@ -553,6 +719,63 @@ int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const flo
   else { if (g_bn_nt) SH_BN_BA(bf16_t, true); else SH_BN_BA(bf16_t, false); }
 #undef SH_BN_BA
   return check_launch("bn_bwd_apply");
+}
+
+int simhand_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int n, int h, int w,
+                                int c, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(y && scale && shift && out && idx, "bn_relu_maxpool_fwd: NULL pointer");
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  SH_REQUIRE(c % ve == 0, "bn_relu_maxpool_fwd: c=%d not a multiple of %d", c, ve);
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)n * ho * wo * (c / ve);
+  hipStream_t s = (hipStream_t)stream;
+  const double es = dtype == SH_F32 ? 4 : 2;
+  ProfScope ps(SH_PROF_BN, s, 0, es * ((double)n * h * w * c + (double)n * ho * wo * c) + (double)n * ho * wo * c);
+  if (dtype == SH_F32)
+    bn_relu_maxpool_fwd_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)y, scale, shift, (float*)out, idx, n, h, w, c, ho, wo);
+  else
+    bn_relu_maxpool_fwd_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)y, scale, shift, (bf16_t*)out, idx, n, h, w, c, ho, wo);
+  return check_launch("bn_relu_maxpool_fwd");
+}
+
+int simhand_maxpool_bn_bwd_partial(const void* dz, const uint8_t* idx, const void* y, const float* mean, const float* invstd,
+                                   const float* scale, const float* shift, int n, int h, int w, int c, int dtype, float* partial,
+                                   sh_stream_t stream) {
+  SH_REQUIRE(dz && idx && y && mean && invstd && scale && shift && partial, "maxpool_bn_bwd_partial: NULL pointer");
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  SH_REQUIRE(c % ve == 0, "maxpool_bn_bwd_partial: c=%d not a multiple of %d", c, ve);
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const int64_t m = (int64_t)n * h * w;
+  int rpb, nblk;
+  col_plan(m, &rpb, &nblk);
+  hipStream_t s = (hipStream_t)stream;
+  const double es = dtype == SH_F32 ? 4 : 2;
+  ProfScope ps(SH_PROF_BN, s, 0, es * ((double)m * c + (double)n * ho * wo * c) + (double)n * ho * wo * c);
+  if (dtype == SH_F32)
+    pool_bn_bwd_partial_kernel<float><<<nblk, 256, 0, s>>>((const float*)dz, idx, (const float*)y, mean, invstd, scale, shift, n, h, w, c, ho, wo, rpb, partial);
+  else
+    pool_bn_bwd_partial_kernel<bf16_t><<<nblk, 256, 0, s>>>((const bf16_t*)dz, idx, (const bf16_t*)y, mean, invstd, scale, shift, n, h, w, c, ho, wo, rpb, partial);
+  return check_launch("maxpool_bn_bwd_partial");
+}
+
+int simhand_maxpool_bn_bwd_apply(const void* dz, const uint8_t* idx, const void* y, const float* mean, const float* invstd,
+                                 const float* gamma, const float* dgamma, const float* dbeta, const float* scale, const float* shift,
+                                 void* dy, int n, int h, int w, int c, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(dz && idx && y && mean && invstd && dgamma && dbeta && scale && shift && dy, "maxpool_bn_bwd_apply: NULL pointer");
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  SH_REQUIRE(c % ve == 0, "maxpool_bn_bwd_apply: c=%d not a multiple of %d", c, ve);
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const int64_t m = (int64_t)n * h * w;
+  hipStream_t s = (hipStream_t)stream;
+  const double es = dtype == SH_F32 ? 4 : 2;
+  ProfScope ps(SH_PROF_BN, s, 0, es * (2.0 * (double)m * c + (double)n * ho * wo * c) + (double)n * ho * wo * c);
+  const float inv_m = (float)(1.0 / (double)m);
+  const int grid = row_grid(m, c / ve);
+  if (dtype == SH_F32)
+    pool_bn_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)dz, idx, (const float*)y, mean, invstd, gamma, dgamma, dbeta, scale, shift, (float*)dy, n, h, w, c, ho, wo, inv_m);
+  else
+    pool_bn_bwd_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dz, idx, (const bf16_t*)y, mean, invstd, gamma, dgamma, dbeta, scale, shift, (bf16_t*)dy, n, h, w, c, ho, wo, inv_m);
+  return check_launch("maxpool_bn_bwd_apply");
 }
 
 int simhand_colsum(const void* x, int64_t m, int c, int dtype, float* partial, float* out, sh_stream_t stream) {

@@ -194,16 +194,15 @@ class ResNetEngine:
         d = ops.conv_desc(n, h, w, 3, 64, 7, 7, 2, 3, self.dtype)  # bookkeeping only (n, h, w, ho, wo, cout)
         m = n * ho * wo
         st = self._bn(bn1, part, m, 64, training)
-        a = ops.bn_apply(y, st, m, 64, True, None)
-        x, idx = ops.maxpool_fwd(a)
+        # BN + ReLU + MaxPool in one pass: the 112x112x64 activation in between is never stored
+        x, idx = ops.bn_relu_maxpool_fwd(y, st)
         if want_ctx:
             u = _Unit()
-            u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv1, bn1, d, xp, y, a, st, True, True
+            u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv1, bn1, d, xp, y, None, st, True, True
             u.has_res = False
             u.mask = None
             ctx["stem"] = u
             ctx["pool_idx"] = idx
-            ctx["pool_in_shape"] = tuple(a.shape)
         for li in (4, 5, 6, 7):
             for blk in f[li]:
                 saved: Optional[list] = [] if want_ctx else None
@@ -286,8 +285,12 @@ class ResNetEngine:
                 below = blocks[bi - 1][0][-1] if bi > 0 else None
                 dz, dz_part = self._unit_bwd(first, dt_, grads, True, res_grad=dz, res_mask=last.mask, raw_partial=part, prev=below)
             saved.clear()
-        da = ops.maxpool_bwd(dz, ctx["pool_idx"], ctx["pool_in_shape"])
-        self._unit_bwd(ctx["stem"], da, grads, need_dx=False)
+        # stem: the pooled gradient is gathered through the winner index inside the BatchNorm-backward passes
+        u = ctx["stem"]
+        dy, dg, db = ops.maxpool_bn_backward(dz, ctx["pool_idx"], u.y, u.st, u.bn.weight.detach())
+        grads[u.bn.weight] = dg
+        grads[u.bn.bias] = db
+        grads[u.conv.weight] = ops.stem_conv_wgrad(u.x, dy, u.desc.h, u.desc.w)
         return grads
 
 

@@ -402,6 +402,37 @@ def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_d
     return dy, dres, dg, db
 
 
+def bn_relu_maxpool_fwd(y: torch.Tensor, st: BNState):
+    """Stem: MaxPool(3,2,1)(ReLU(BN(y))) in one pass; y is [n][h][w][c].  Returns (pooled, winner index)."""
+    lib = _lib_dev()
+    n, h, w, c = y.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty(n, ho, wo, c, dtype=y.dtype, device=y.device)
+    idx = torch.empty(n, ho, wo, c, dtype=torch.uint8, device=y.device)
+    check(lib.simhand_bn_relu_maxpool_fwd(_ptr(y), _ptr(st.scale), _ptr(st.shift), _ptr(out), _ptr(idx), n, h, w, c, dt(y.dtype),
+                                          _stream()), "bn_relu_maxpool_fwd")
+    return out, idx
+
+
+def maxpool_bn_backward(dz: torch.Tensor, idx: torch.Tensor, y: torch.Tensor, st: BNState, gamma):
+    """Backward of bn_relu_maxpool_fwd: (dy, dgamma, dbeta); dz is the gradient of the pooled output."""
+    lib = _lib_dev()
+    n, h, w, c = y.shape
+    m = n * h * w
+    dev = y.device
+    nblk = lib.simhand_bn_stat_blocks(m, c)
+    part = torch.empty(nblk, 2, c, dtype=torch.float32, device=dev)
+    check(lib.simhand_maxpool_bn_bwd_partial(_ptr(dz), _ptr(idx), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
+                                             n, h, w, c, dt(y.dtype), _ptr(part), _stream()), "maxpool_bn_bwd_partial")
+    dg = torch.empty(c, dtype=torch.float32, device=dev)
+    db = torch.empty(c, dtype=torch.float32, device=dev)
+    check(lib.simhand_bn_bwd_finalize(_ptr(part), nblk, c, _ptr(dg), _ptr(db), _stream()), "bn_bwd_finalize")
+    dy = torch.empty_like(y)
+    check(lib.simhand_maxpool_bn_bwd_apply(_ptr(dz), _ptr(idx), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(dg), _ptr(db),
+                                           _ptr(st.scale), _ptr(st.shift), _ptr(dy), n, h, w, c, dt(y.dtype), _stream()), "maxpool_bn_bwd_apply")
+    return dy, dg, db
+
+
 # ------------------------------------------------------------------------ pools
 def maxpool_fwd(x: torch.Tensor):
     lib = _lib_dev()

@@ -23,11 +23,21 @@ def record_hip_relu_masks(store: list):
             store.append((a > 0).cpu())
         return res
 
+    orig_stem = ops.bn_relu_maxpool_fwd
+
+    def bn_relu_maxpool_fwd(y, st):
+        # the fused stem kernel never stores the activation: take its ReLU mask from the unfused kernel (same fp32 expression)
+        n, h, w, c = y.shape
+        store.append((orig(y.view(n * h * w, c), st, n * h * w, c, True, None) > 0).view(n, h, w, c).cpu())
+        return orig_stem(y, st)
+
     ops.bn_apply = bn_apply
+    ops.bn_relu_maxpool_fwd = bn_relu_maxpool_fwd
     try:
         yield store
     finally:
         ops.bn_apply = orig
+        ops.bn_relu_maxpool_fwd = orig_stem
 
 
 @contextlib.contextmanager

@@ -470,3 +470,30 @@ def test_dgrad_fused_bn_backward_sums(route, mode, dtype):
     finally:
         lib.simhand_igemm256_enable(1)
         lib.simhand_conv2d_dgrad_fuse_1x1(0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,h,w", [(3, 16, 16), (2, 15, 23), (1, 7, 9)])
+def test_stem_bn_relu_maxpool_fused_equals_unfused(dtype, n, h, w):
+    """bn_relu_maxpool_fwd / maxpool_bn_backward == bn_apply -> maxpool_fwd and maxpool_bwd -> bn_backward, bit for bit
+    (the fused kernels round exactly where the unfused ones store)."""
+    from simhand_amd import ops
+
+    c = 64
+    g = torch.Generator().manual_seed(n * 100 + h)
+    y = _rnd(torch.randn(n, h, w, c, generator=g), dtype).to(DEV).to(dtype)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(c, generator=g) * 0.2).to(DEV)
+    m = n * h * w
+    st = ops.bn_finalize(ops.bn_partial_stats(y.view(m, c), m, c), m, c, gamma, beta, None, None, None)
+    a = ops.bn_apply(y.view(m, c), st, m, c, True, None).view(n, h, w, c)
+    want_x, want_idx = ops.maxpool_fwd(a)
+    got_x, got_idx = ops.bn_relu_maxpool_fwd(y, st)
+    assert torch.equal(got_x, want_x) and torch.equal(got_idx, want_idx)
+
+    dz = _rnd(torch.randn(want_x.shape, generator=g), dtype).to(DEV).to(dtype)
+    da = ops.maxpool_bwd(dz, want_idx, tuple(a.shape))
+    want_dy, _, want_dg, want_db = ops.bn_backward(da.view(m, c), a.view(m, c), y.view(m, c), st, gamma, m, c, True, False, mask_from_y=True)
+    dy, dg, db = ops.maxpool_bn_backward(dz, got_idx, y, st, gamma)
+    assert torch.equal(dy.view(m, c), want_dy)
+    assert torch.equal(dg, want_dg) and torch.equal(db, want_db)
