@@ -219,6 +219,9 @@ int simhand_igemm256_enable(int on);
 /* tuning hook: non-temporal (streaming) loads / stores in the BatchNorm passes (1 = on [default]) */
 int simhand_bn_set_nt(int on);
 
+/* tuning hook: the all-taps 3x3 / stride-1 weight-gradient kernel (bf16; 1 = default, 0 = tap-by-tap kernel) */
+int simhand_wgrad3x3_enable(int on);
+
 /* test hook: bf16 wgrad LDS transpose path (1 = ds_read_b64_tr_b16 [default], 0 = scalar LDS reads) */
 int simhand_wgrad_set_tr(int on);
 

@@ -93,6 +93,7 @@ SIGNATURES = {
     "simhand_stem_conv_wgrad": (_I, [_P, _P, _P, _P, _S, _I, _I, _I, _I, _P]),
     "simhand_conv2d_wgrad_oihw": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _S, _P]),
     "simhand_wgrad_set_tr": (_I, [_I]),
+    "simhand_wgrad3x3_enable": (_I, [_I]),
     "simhand_bn_set_nt": (_I, [_I]),
     "simhand_igemm256_enable": (_I, [_I]),
     "simhand_nchw_f32_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -338,6 +338,190 @@ static void launch_reduce(const float* part, long long count, int splitk, float*
     wgrad_reduce_kernel<16><<<ceil_div(groups, 16), 256, 0, s>>>(part, count, splitk, dw, cin, rs, c_real);
 }
 
+
+// ======================================================================================================================
+// 3x3 / stride 1 / pad 1 weight gradient, all nine taps in one block (bf16).
+// The tap-by-tap kernel above re-stages the dy tile and a shifted x tile for every tap (16 KB of operands per 64 MFMAs of
+// a 128x128 tile; 8 KB per 16 for the 64-channel layers).  Here the reduction runs over the ZERO-PADDED pixel grid
+// ((H+2) x (W+2) per image, images back to back): in that index space tap (r, s) is the constant row shift
+// (r-1)(W+2) + (s-1), so one block keeps a sliding window of x rows in an LDS ring, reads the nine tap operands from it
+// at nine row offsets, and reuses each dy fragment nine times: 8 KB staged per 144 MFMAs, no halo masks (pad positions
+// hold zeros in both operands; the price is the (H+2)(W+2)/(HW) longer reduction).
+//   block = 64 cout x 64 cin x 9 taps, 4 waves side by side along cin (64 x 16 x 9 taps = 144 accumulator registers:
+//   one x fragment address feeds four MFMAs -- the loop is VALU-issue-bound);
+//   k-step = 32 padded pixels: one 16-B chunk of dy and one of x per thread, global -> VGPR -> LDS;
+//   rows are 128 B + 32 B pad (the 8 rows a 32-lane group of ds_read_b64_tr_b16 touches fall on distinct bank slots);
+//   x ring = 256 rows: window [32j - 64, 32j + 96) for step j, chunk j + 3 is staged during step j;
+//   one barrier per k-step.  Split-K over padded-pixel ranges; partials in the layout of wgrad_kernel.
+struct Wgrad3Args {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* part;            // [splitk][Cout][9*Cin]
+  int Cout, Cin, H, W;
+  int nt;                 // cin tiles
+  long long q_total;      // N * (H+2) * (W+2)
+  int per_split;          // padded pixels per split (multiple of 32)
+  FastDiv div_pp, div_wp; // (H+2)*(W+2), W+2
+};
+
+__device__ uint4 g_wg_zero_page[8];  // 128 B of zeros: source of the LDS-DMA lanes that fall on pad positions
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args p) {
+  constexpr int RING = 256;      // x ring rows (8 chunks of 32)
+  constexpr int KP = 32;
+  constexpr int D = 3;           // DMA distance in k-steps: 2 x D x 1 KB in flight per wave
+  constexpr int AHEAD = 2 + D;   // chunk issued at step j (x needs 2 chunks of look-ahead; dy rides along: one decode)
+  constexpr int NDY = AHEAD + 1; // dy buffers
+  __shared__ __attribute__((aligned(16))) char smem[RING * 128 + NDY * KP * 128];
+  char* ring = smem;
+  char* sdy = smem + RING * 128;
+
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int wn = wave;  // waves side by side along cin: each 64 cout x 16 cin x 9 taps (a B fragment feeds 4 MFMAs)
+  int logical = xcd_remap_w(blockIdx.x, gridDim.x);
+  const int nt_i = logical % p.nt; logical /= p.nt;
+  const int mt = p.Cout >> 6;
+  const int mt_i = logical % mt;
+  const int split = logical / mt;
+  const int k0 = mt_i * 64, c0 = nt_i * 64;
+  const long long q0 = (long long)split * p.per_split;
+  long long q1 = q0 + p.per_split;
+  if (q1 > p.q_total) q1 = p.q_total;
+  const int nk = q0 < q1 ? (int)((q1 - q0 + KP - 1) / KP) : 0;
+  const int WP = p.W + 2;
+
+  // Operands go global -> LDS by LDS-DMA (inline asm: see igemm256_kernel), D k-steps ahead of their use.  A DMA
+  // instruction of wave w fills rows 8w .. 8w+7 of a 32-row chunk: lane l = row 8w + (l >> 3), 16-B slot l & 7.  Rows are
+  // 128 B, unpadded; the four 32-B channel groups of row R are rotated by R >> 1 (applied on the source side of the DMA
+  // and in the fragment addresses) so the 8 consecutive rows a 32-lane group of ds_read_b64_tr_b16 touches fall on 8
+  // distinct bank slots (SQ_LDS_BANK_CONFLICT = 0).  The loop is VALU-issue-bound, not latency-bound: everything that
+  // does not depend on the step (rotations, tap offsets, channel offsets) is hoisted, and dy / x share one index decode.
+  const int srow = tid >> 3, slot = tid & 7;
+  auto dma16 = [](const void* src, unsigned lds_addr) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src));
+  };
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const char* zsrc = reinterpret_cast<const char*>(g_wg_zero_page) + slot * 16;
+  // channel offset (elements) of the 16-B slot this lane fills in a row with rotation key (R >> 1) & 3: a chunk's rows
+  // R = 32 * chunk + srow (+ 64) all have the key of srow
+  const int ch_slot = ((((slot >> 1) - (srow >> 1)) & 3) * 16) + (slot & 1) * 8;
+  const char* xb = reinterpret_cast<const char*>(p.x + c0 + ch_slot);
+  const char* dyb = reinterpret_cast<const char*>(p.dy + k0 + ch_slot);
+  const unsigned xstride = (unsigned)p.Cin * 2u, dystride = (unsigned)p.Cout * 2u;
+  // chunk c (>= -2): x rows -> ring slot (c + 2) % 8; dy rows (c >= 0, inside this block's range) -> buffer c % NDY
+  auto dma_chunk = [&](int c, bool with_dy) __attribute__((always_inline)) {
+    const long long q = q0 + (long long)c * KP + srow;
+    const bool in = q >= 0 && q < p.q_total;
+    const unsigned qu = in ? (unsigned)q : 0u;  // q_total < 2^31 (checked on the host)
+    const unsigned img = fdiv(qu, p.div_pp);
+    const unsigned rem = qu - img * p.div_pp.d;
+    const unsigned hp = fdiv(rem, p.div_wp);
+    const unsigned wp = rem - hp * p.div_wp.d;
+    const bool ok = in && hp - 1u < (unsigned)p.H && wp - 1u < (unsigned)p.W;
+    const unsigned pix = (img * (unsigned)p.H + (hp - 1u)) * (unsigned)p.W + (wp - 1u);  // < 2^31 real pixels
+    dma16(ok ? xb + (unsigned long long)pix * xstride : zsrc, smem_addr + ((((c + 2) * KP) & (RING - 1)) + wave * 8) * 128);
+    if (with_dy)
+      dma16(ok && q < q1 ? dyb + (unsigned long long)pix * dystride : zsrc, smem_addr + RING * 128 + ((c % NDY) * KP + wave * 8) * 128);
+  };
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) acc[t][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // prologue, in the order the loop's counted vmcnt waits assume (two DMAs per step from chunk 0 on)
+  dma_chunk(-2, false);
+  dma_chunk(-1, false);
+#pragma unroll
+  for (int c = 0; c < AHEAD; ++c) dma_chunk(c, true);
+
+  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  typedef __attribute__((ext_vector_type(8))) __bf16 frag_t;
+  auto tr2 = [](const char* a_lo, const char* a_hi) __attribute__((always_inline)) -> uint4 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a_lo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a_hi));
+    uint4 f;
+    f.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+    f.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+    f.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+    f.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+    return f;
+  };
+  // lane's rows inside a 32-row k-step: 4g + (li >> 2) and + 16; its 8 bytes inside the 32-B channel group: (li & 3) * 8
+  const int frow = 4 * g + (li >> 2);
+  const int fcol = (li & 3) * 8;
+  // dy fragments: rows frow / frow + 16 of the buffer (same rotation key: 16 >> 1 = 0 mod 4), channel groups mi = 0..3
+  const int key_a = (frow >> 1) & 3;
+  int offa[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) offa[mi] = frow * 128 + (((mi + key_a) & 3) * 32) + fcol;
+  // x fragment of tap t: ring row (32 (j + 2) + frow + off_t) & 255; its key does not depend on j (32 j = 0 mod 8)
+  int trow[9], tcol[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int off = (t / 3 - 1) * WP + (t % 3 - 1);
+    trow[t] = 64 + frow + off;  // >= 0: off >= -(W + 3) >= -61
+    tcol[t] = (((wn + (trow[t] >> 1)) & 3) * 32) + fcol;
+  }
+  for (int j = 0; j < nk; ++j) {
+    // everything but the DMAs of the last D - 1 steps has landed (2 per step and wave); after the barrier every wave's
+    // part of dy chunk j / x chunk j + 2 is visible and every wave is done with step j - 1's operands
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (D - 1)) : "memory");
+    dma_chunk(j + AHEAD, true);  // ring slot (j + AHEAD + 2) % 8: outside the window (slots j .. j + 4) and the chunks in
+                                 // flight; dy buffer (j + AHEAD) % NDY = the one step j - 1 read
+    const char* tA = sdy + (j % NDY) * (KP * 128);
+    uint4 fa[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) fa[mi] = tr2(tA + offa[mi], tA + offa[mi] + 16 * 128);
+    const int jb = (j * KP) & (RING - 1);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int r_lo = (jb + trow[t]) & (RING - 1), r_hi = (r_lo + 16) & (RING - 1);
+      const uint4 fb = tr2(ring + r_lo * 128 + tcol[t], ring + r_hi * 128 + tcol[t]);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        acc[t][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag_t, fa[mi]), __builtin_bit_cast(frag_t, fb), acc[t][mi], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragment reads are done before the next barrier
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // C[m = cout][n = cin] per tap: lane holds cin = c0 + wn*16 + li, couts k0 + mi*16 + 4g + r
+  const long long row_len = 9ll * p.Cin;
+  float* dst = p.part + (long long)split * p.Cout * row_len;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = k0 + mi * 16 + 4 * g + r;
+        const int c = c0 + wn * 16 + li;
+        dst[(long long)k * row_len + (long long)t * p.Cin + c] = acc[t][mi][r];
+      }
+}
+
+static int g_use_wgrad3 = 1;
+static bool use_wgrad3(const sh_conv_desc* d) {
+  return g_use_wgrad3 && d->dtype == SH_BF16 && d->r == 3 && d->s == 3 && d->stride == 1 && d->pad == 1 && d->w + 3 <= 64 &&
+         (long long)d->n * (d->h + 2) * (d->w + 2) < (1ll << 31);
+}
+static void plan3(const sh_conv_desc* d, int* splitk, int* per) {
+  const long long q_total = (long long)d->n * (d->h + 2) * (d->w + 2);
+  const long long tiles = (long long)(d->cout / 64) * (d->cin / 64);
+  const long long ksteps = (q_total + 31) / 32;
+  long long sk = (768 + tiles - 1) / tiles;       // ~3 blocks per CU in flight
+  const long long max_sk = (ksteps + 31) / 32;    // at least 32 k-steps per block (the 5-chunk prologue is per block)
+  if (sk > max_sk) sk = max_sk;
+  if (sk < 1) sk = 1;
+  long long pr = (ksteps + sk - 1) / sk;
+  sk = (ksteps + pr - 1) / pr;
+  *splitk = (int)sk;
+  *per = (int)(pr * 32);
+}
+
 static int g_use_tr = 1;
 
 static void plan(const sh_conv_desc* d, int* bm, int* bn, int* splitk, int* pps) {
@@ -363,6 +547,12 @@ using namespace sh;
 
 extern "C" {
 
+// tuning hook: all-taps 3x3 weight-gradient kernel for the bf16 stride-1 layers (1 = default)
+int simhand_wgrad3x3_enable(int on) {
+  g_use_wgrad3 = on ? 1 : 0;
+  return 0;
+}
+
 // test hook: choose the bf16 LDS transpose path (1 = ds_read_b64_tr_b16, 0 = scalar reads)
 int simhand_wgrad_set_tr(int on) {
   g_use_tr = on ? 1 : 0;
@@ -372,7 +562,8 @@ int simhand_wgrad_set_tr(int on) {
 size_t simhand_conv2d_wgrad_workspace_bytes(const sh_conv_desc* d) {
   if (!d) return 0;
   int bm, bn, sk, pps;
-  plan(d, &bm, &bn, &sk, &pps);
+  if (use_wgrad3(d)) plan3(d, &sk, &pps);
+  else plan(d, &bm, &bn, &sk, &pps);
   return (size_t)sk * d->cout * d->cin * d->r * d->s * sizeof(float);
 }
 
@@ -388,6 +579,26 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
   const long long mo = (long long)d->n * d->ho * d->wo;
   SH_REQUIRE(mo < (1ll << 31), "conv2d_wgrad: %lld output pixels exceed the 2^31 index range", mo);
   SH_REQUIRE(workspace_bytes >= simhand_conv2d_wgrad_workspace_bytes(d), "conv2d_wgrad: workspace too small");
+  if (stem_wp == 0 && use_wgrad3(d)) {
+    Wgrad3Args b;
+    int sk, per;
+    plan3(d, &sk, &per);
+    b.x = (const bf16_t*)x; b.dy = (const bf16_t*)dy; b.part = (float*)workspace;
+    b.Cout = d->cout; b.Cin = d->cin; b.H = d->h; b.W = d->w;
+    b.nt = d->cin / 64;
+    b.q_total = (long long)d->n * (d->h + 2) * (d->w + 2);
+    b.per_split = per;
+    b.div_pp = make_fastdiv((unsigned)((d->h + 2) * (d->w + 2)));
+    b.div_wp = make_fastdiv((unsigned)(d->w + 2));
+    hipStream_t s3 = (hipStream_t)stream;
+    const double flops3 = 2.0 * (double)mo * d->cout * d->cin * 9;
+    const double bytes3 = 2.0 * ((double)d->n * d->h * d->w * d->cin + (double)mo * d->cout) + 4.0 * d->cout * d->cin * 9;
+    ProfScope ps3(SH_PROF_CONV_WGRAD, s3, flops3, bytes3);
+    wgrad3x3_kernel<<<sk * (d->cout / 64) * (d->cin / 64), 256, 0, s3>>>(b);
+    if (check_launch("conv2d_wgrad (3x3)")) return 1;
+    launch_reduce(b.part, (long long)d->cout * d->cin * 9, sk, dw, d->cin, 9, c_real, s3);
+    return check_launch("conv2d_wgrad (3x3) reduce");
+  }
   WgradArgs a;
   int bm, bn;
   plan(d, &bm, &bn, &a.splitk, &a.pix_per_split);

@@ -497,3 +497,29 @@ def test_stem_bn_relu_maxpool_fused_equals_unfused(dtype, n, h, w):
     dy, dg, db = ops.maxpool_bn_backward(dz, got_idx, y, st, gamma)
     assert torch.equal(dy.view(m, c), want_dy)
     assert torch.equal(dg, want_dg) and torch.equal(db, want_db)
+
+
+@pytest.mark.parametrize("shape", [(2, 56, 56, 64, 64), (3, 28, 28, 128, 128), (5, 14, 14, 256, 128), (7, 7, 7, 128, 256), (1, 5, 9, 64, 64),
+                                   (40, 14, 14, 64, 128)])
+def test_wgrad_3x3_all_taps_kernel(shape):
+    """bf16 3x3/1 weight gradient over the zero-padded pixel grid (all nine taps per block) vs ATen and vs the tap-by-tap kernel."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = _rnd(torch.randn(n, cin, h, w, generator=g), dtype)
+    dy = _rnd(torch.randn(n, cout, h, w, generator=g), dtype)
+    want = torch.nn.grad.conv2d_weight(x, (cout, cin, 3, 3), dy, stride=1, padding=1)
+    d = ops.conv_desc(n, h, w, cin, cout, 3, 3, 1, 1, dtype)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    lib = ops._lib_dev()
+    got = ops.conv2d_wgrad_oihw(d, xd, dyd, (cout, cin, 3, 3)).cpu()
+    lib.simhand_wgrad3x3_enable(0)
+    try:
+        old = ops.conv2d_wgrad_oihw(d, xd, dyd, (cout, cin, 3, 3)).cpu()
+    finally:
+        lib.simhand_wgrad3x3_enable(1)
+    _check(got, want, 2e-3, "wgrad 3x3 all taps")
+    _check(got, old, 1e-4, "vs tap-by-tap kernel")  # same products, fp32 sums in another order
