@@ -110,7 +110,10 @@ __device__ __forceinline__ uint4 frag_bf16_scalar(const char* tile, int stride, 
   return r;
 }
 
-template <typename T, int BM, int BN, bool STEM = false>
+// PLAIN = 1x1 / stride 1 / pad 0 (x rows are the output pixels themselves): the loader walks two pointers instead of
+// decoding a pixel and multiplying out 64-bit addresses every k-step -- the generic loop spends ~180 VALU instructions
+// per 16 MFMAs on addressing and is VALU-issue-bound.
+template <typename T, int BM, int BN, bool STEM = false, bool PLAIN = false>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   constexpr int KP = WgCfg<T>::KP;
   constexpr int SA = BM * (int)sizeof(T) + WgCfg<T>::PAD;  // dy tile row stride (bytes)
@@ -145,7 +148,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   const unsigned hw = (unsigned)(p.Ho * p.Wo);
 
   uint4 ra[NA], rb[NBL];
+  // PLAIN: per-thread row pointers of k-step 0 (chunk i = tile row (tid + 256 i) / CPR, 16-B chunk (tid + 256 i) % CPR)
+  const char* pdy[NA];
+  const char* px[NBL];
+  int rowa[NA], rowb[NBL];
+  if constexpr (PLAIN) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int id = tid + 256 * i;
+      rowa[i] = id / CPR_A;
+      pdy[i] = reinterpret_cast<const char*>(dys + (pix_begin + rowa[i]) * p.Cout + k0 + (id - rowa[i] * CPR_A) * VE);
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int id = tid + 256 * i;
+      rowb[i] = id / CPR_B;
+      px[i] = reinterpret_cast<const char*>(xs + (pix_begin + rowb[i]) * p.Cin + c0 + (id - rowb[i] * CPR_B) * VE);
+    }
+  }
+  const unsigned step_dy = (unsigned)KP * (unsigned)p.Cout * (unsigned)sizeof(T);
+  const unsigned step_x = (unsigned)KP * (unsigned)p.Cin * (unsigned)sizeof(T);
+  const int rows_total = (int)(pix_end - pix_begin);  // <= pix_per_split
   auto load_step = [&](int ks) __attribute__((always_inline)) {
+    if constexpr (PLAIN) {
+      const int left = rows_total - ks * KP;  // rows of this k-step inside the block's pixel range
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        ra[i] = rowa[i] < left ? *reinterpret_cast<const uint4*>(pdy[i]) : make_uint4(0, 0, 0, 0);
+        pdy[i] += step_dy;
+      }
+#pragma unroll
+      for (int i = 0; i < NBL; ++i) {
+        rb[i] = rowb[i] < left ? *reinterpret_cast<const uint4*>(px[i]) : make_uint4(0, 0, 0, 0);
+        px[i] += step_x;
+      }
+      return;
+    }
     const long long base = pix_begin + (long long)ks * KP;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -217,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
     const char* tB = sB + buf * (KP * SB);
     if constexpr (sizeof(T) == 2) {
       uint4 fa[MI], fb[NI];
-      if (p.use_tr) {
+      if (PLAIN || p.use_tr) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) fa[mi] = frag_bf16_tr(tA, SA, wm * (BM / 2) + mi * 16, lane);
 #pragma unroll
@@ -630,6 +668,13 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
     else if (bm == 128) SH_WG(float, 128, 64);
     else if (bn == 128) SH_WG(float, 64, 128);
     else SH_WG(float, 64, 64);
+  } else if (d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && a.use_tr) {
+#define SH_WGP(BM, BN) wgrad_kernel<bf16_t, BM, BN, false, true><<<nblk, 256, 0, s>>>(a)
+    if (bm == 128 && bn == 128) SH_WGP(128, 128);
+    else if (bm == 128) SH_WGP(128, 64);
+    else if (bn == 128) SH_WGP(64, 128);
+    else SH_WGP(64, 64);
+#undef SH_WGP
   } else {
     if (bm == 128 && bn == 128) SH_WG(bf16_t, 128, 128);
     else if (bm == 128) SH_WG(bf16_t, 128, 64);
