@@ -184,37 +184,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
       }
       return;
     }
-    const long long base = pix_begin + (long long)ks * KP;
+    // 32-bit pixel arithmetic (Mo < 2^31 is checked on the host); one 64-bit multiply-add per address
+    const unsigned base = (unsigned)pix_begin + (unsigned)ks * KP, endu = (unsigned)pix_end;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int id = tid + 256 * i;
       const int row = id / CPR_A, ch = id - row * CPR_A;
-      const long long m = base + row;
+      const unsigned m = base + row;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (m < pix_end) v = *reinterpret_cast<const uint4*>(dys + m * p.Cout + k0 + ch * VE);
+      if (m < endu) v = *reinterpret_cast<const uint4*>(dys + (unsigned long long)m * (unsigned)p.Cout + (k0 + ch * VE));
       ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
       const int id = tid + 256 * i;
       const int row = id / CPR_B, ch = id - row * CPR_B;
-      const long long m = base + row;
+      const unsigned mu = base + row;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (m < pix_end) {
-        const unsigned mu = (unsigned)m;
+      if (mu < endu) {
         const unsigned img = fdiv(mu, p.div_hw);
         const unsigned rem = mu - img * hw;
         const unsigned ho = fdiv(rem, p.div_w);
         const unsigned wo = rem - ho * (unsigned)p.Wo;
         if constexpr (STEM) {
           const int vc = c0 + ch * VE;  // virtual channel: filter row vc / 32, element vc % 32 of its 8 x 4 run
-          v = *reinterpret_cast<const uint4*>(xs + (((long long)img * p.stem_hp + 2 * ho + (vc >> 5)) * p.stem_wp + 2 * wo) * 4 +
-                                              (vc & 31));
+          const unsigned prow = (img * (unsigned)p.stem_hp + 2 * ho + (unsigned)(vc >> 5)) * (unsigned)p.stem_wp + 2 * wo;  // < 2^31 padded pixels
+          v = *reinterpret_cast<const uint4*>(xs + (unsigned long long)prow * 4u + (vc & 31));
         } else {
           const int hs = (int)ho * p.stride - p.pad + fr;
           const int ws = (int)wo * p.stride - p.pad + fs;
-          if ((unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W)
-            v = *reinterpret_cast<const uint4*>(xs + (((long long)img * p.H + hs) * p.W + ws) * p.Cin + c0 + ch * VE);
+          if ((unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W) {
+            const unsigned pix = (img * (unsigned)p.H + (unsigned)hs) * (unsigned)p.W + (unsigned)ws;  // < 2^31 input pixels
+            v = *reinterpret_cast<const uint4*>(xs + (unsigned long long)pix * (unsigned)p.Cin + (c0 + ch * VE));
+          }
         }
       }
       rb[i] = v;
@@ -616,6 +618,8 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
              "conv2d_wgrad: ho/wo inconsistent");
   const long long mo = (long long)d->n * d->ho * d->wo;
   SH_REQUIRE(mo < (1ll << 31), "conv2d_wgrad: %lld output pixels exceed the 2^31 index range", mo);
+  SH_REQUIRE((long long)d->n * d->h * d->w < (1ll << 31), "conv2d_wgrad: input pixels exceed the 2^31 index range");
+  SH_REQUIRE(stem_wp == 0 || (long long)d->n * stem_hp * stem_wp < (1ll << 31), "conv2d_wgrad: padded stem pixels exceed the 2^31 index range");
   SH_REQUIRE(workspace_bytes >= simhand_conv2d_wgrad_workspace_bytes(d), "conv2d_wgrad: workspace too small");
   if (stem_wp == 0 && use_wgrad3(d)) {
     Wgrad3Args b;
