@@ -282,8 +282,9 @@ int simhand_maxpool_bn_bwd_apply(const void* dz, const uint8_t* idx, const void*
                                  void* dy, int n, int h, int w, int c, int dtype, sh_stream_t stream);
 /* same for the RAW partial sums of simhand_conv2d_dgrad_fused (sum g, sum g*y):
  * dbeta = sum g, dgamma = invstd * (sum g*y - mean * sum g), folded in fp64 */
+size_t simhand_bn_bwd_finalize_raw_workspace_bytes(int nblk, int c);
 int simhand_bn_bwd_finalize_raw(const float* partial, int nblk, int c, const float* mean, const float* invstd, float* dgamma,
-                                float* dbeta, sh_stream_t stream);
+                                float* dbeta, void* workspace, size_t workspace_bytes, sh_stream_t stream);
 int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const float* mean, const float* invstd,
                          const float* gamma, const float* dgamma, const float* dbeta, const float* scale, const float* shift,
                          int relu, void* dy, void* dres, int64_t m, int c, int dtype, sh_stream_t stream);

@@ -295,24 +295,32 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
 // dbeta = sum g, dgamma = sum g*xhat over <= ~2048 partial blocks: 16 channels x 64 row lanes per block, four
 // independent accumulator pairs per thread so the (L2-resident) partial loads overlap instead of forming one
 // dependent chain; fixed summation order (deterministic)
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int c,
+// TIn = float (level-1 partials) or double (level-2 slices).  gridDim.y > 1: slice blockIdx.y of the partial rows is folded
+// to lvl2[blockIdx.y][2][c] (doubles) for a second launch -- the fused dgrad epilogues emit one partial row per 128-row
+// tile (50 176 rows at 2048 x 56 x 56), far too many for c / 16 blocks.
+template <typename TIn>
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const TIn* __restrict__ partial, int nblk, int c,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                const float* __restrict__ mean = nullptr,
-                                                               const float* __restrict__ invstd = nullptr) {
+                                                               const float* __restrict__ invstd = nullptr,
+                                                               double* __restrict__ lvl2 = nullptr) {
   __shared__ double red[64][2][16];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cl;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b_begin = blockIdx.y * per;
+  const int b_end = b_begin + per < nblk ? b_begin + per : nblk;
   double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
   if (ch < c) {
-    int b = rl;
-    for (; b + 3 * 64 < nblk; b += 4 * 64) {
+    int b = b_begin + rl;
+    for (; b + 3 * 64 < b_end; b += 4 * 64) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         a1[j] += (double)partial[((int64_t)(b + j * 64) * 2 + 0) * c + ch];
         a2[j] += (double)partial[((int64_t)(b + j * 64) * 2 + 1) * c + ch];
       }
     }
-    for (; b < nblk; b += 64) {
+    for (; b < b_end; b += 64) {
       a1[0] += (double)partial[((int64_t)b * 2 + 0) * c + ch];
       a2[0] += (double)partial[((int64_t)b * 2 + 1) * c + ch];
     }
@@ -321,24 +329,20 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   red[rl][0][cl] = s1;
   red[rl][1][cl] = s2;
   __syncthreads();
-  if (mean != nullptr) {  // raw sums (sum g, sum g*y) from the fused dgrad epilogue: sum g*xhat = invstd*(sum g*y - mean*sum g)
-    if (rl == 0 && ch < c) {
-      double t1 = 0.0, t2 = 0.0;
-      for (int j = 0; j < 64; ++j) {
-        t1 += red[j][0][cl];
-        t2 += red[j][1][cl];
-      }
-      dbeta[ch] = (float)t1;
-      dgamma[ch] = (float)((double)invstd[ch] * (t2 - (double)mean[ch] * t1));
-    }
+  if (rl != 0 || ch >= c) return;
+  double t1 = 0.0, t2 = 0.0;
+  for (int j = 0; j < 64; ++j) {  // fixed order: deterministic
+    t1 += red[j][0][cl];
+    t2 += red[j][1][cl];
+  }
+  if (lvl2 != nullptr) {
+    lvl2[((int64_t)blockIdx.y * 2 + 0) * c + ch] = t1;
+    lvl2[((int64_t)blockIdx.y * 2 + 1) * c + ch] = t2;
     return;
   }
-  if (rl < 2 && ch < c) {  // row lane 0 folds the sums, row lane 1 the xhat-weighted sums
-    double t = 0.0;
-    for (int j = 0; j < 64; ++j) t += red[j][rl][cl];
-    if (rl == 0) dbeta[ch] = (float)t;
-    else dgamma[ch] = (float)t;
-  }
+  dbeta[ch] = (float)t1;
+  // raw sums (sum g, sum g*y) from the fused dgrad epilogue: sum g*xhat = invstd * (sum g*y - mean * sum g)
+  dgamma[ch] = mean != nullptr ? (float)((double)invstd[ch] * (t2 - (double)mean[ch] * t1)) : (float)t2;
 }
 
 template <typename T, bool NT>
@@ -406,17 +410,19 @@ template <> __device__ __forceinline__ float round_as<bf16_t>(float v) { return 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, T* __restrict__ out,
-                                                                  uint8_t* __restrict__ idx, int n, int h, int w, int c, int ho, int wo) {
+                                                                  uint8_t* __restrict__ idx, int n, int h, int w, int c, int ho, int wo,
+                                                                  FastDiv div_cv, FastDiv div_wo, FastDiv div_ho) {
   constexpr int VE = Vec16<T>::N;
   const int cvecs = c / VE;
-  const int64_t total = (int64_t)n * ho * wo * cvecs;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % cvecs);
-    int64_t t = i / cvecs;
-    const int ow = (int)(t % wo);
-    t /= wo;
-    const int oh = (int)(t % ho);
-    const int img = (int)(t / ho);
+  const unsigned total = (unsigned)n * ho * wo * cvecs;  // < 2^31 (checked on the host)
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned t = fdiv(i, div_cv);
+    const int cv = (int)(i - t * (unsigned)cvecs);
+    unsigned q = fdiv(t, div_wo);
+    const int ow = (int)(t - q * (unsigned)wo);
+    const unsigned im = fdiv(q, div_ho);
+    const int oh = (int)(q - im * (unsigned)ho);
+    const int img = (int)im;
     float sc[VE], sh[VE], best[VE];
     int bi[VE];
 #pragma unroll
@@ -446,8 +452,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
         }
       }
     }
-    Vec16<T>::template store<true>(out + i * VE, best);
-    uint8_t* ip = idx + i * VE;
+    Vec16<T>::template store<true>(out + (size_t)i * VE, best);
+    uint8_t* ip = idx + (size_t)i * VE;
 #pragma unroll
     for (int e = 0; e < VE; ++e) ip[e] = (uint8_t)bi[e];
   }
@@ -494,14 +500,16 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_partial_kernel(const T* __res
                                                                   const T* __restrict__ y, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, int n, int h, int w, int c,
-                                                                  int ho, int wo, int rows_per_blk, float* __restrict__ partial) {
+                                                                  int ho, int wo, int rows_per_blk, float* __restrict__ partial,
+                                                                  FastDiv div_w, FastDiv div_h) {
   constexpr int VE = Vec16<T>::N;
   const int cvecs = c / VE;
   const int64_t m = (int64_t)n * h * w;
   column_reduce<T>(m, c, rows_per_blk, partial, [&](int64_t r, int cv, float(&s1)[VE], float(&s2)[VE]) {
-    const int iw = (int)(r % w);
-    const int64_t t = r / w;
-    const int ih = (int)(t % h), img = (int)(t / h);
+    const unsigned t = fdiv((unsigned)r, div_w);  // m < 2^31 (checked on the host)
+    const int iw = (int)((unsigned)r - t * (unsigned)w);
+    const unsigned im = fdiv(t, div_h);
+    const int ih = (int)(t - im * (unsigned)h), img = (int)im;
     float g[VE], yy[VE];
     pool_gather<T, VE>(dz, idx, img, ih, iw, cv, cvecs, ho, wo, g);
     Vec16<T>::template load<true>(y + r * c + cv * VE, yy);
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const T* __restr
                                                                 const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 T* __restrict__ dy, int n, int h, int w, int c, int ho, int wo,
-                                                                float inv_m) {
+                                                                float inv_m, FastDiv div_w, FastDiv div_h) {
   constexpr int VE = Vec16<T>::N;
   const int cvecs = c / VE;
   const int64_t m = (int64_t)n * h * w;
@@ -542,9 +550,10 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const T* __restr
       sh[e] = shift[ch];
     }
     for (int64_t r = rw.r0 + rw.rl; r < rw.r1; r += rw.rowlanes) {
-      const int iw = (int)(r % w);
-      const int64_t t = r / w;
-      const int ih = (int)(t % h), img = (int)(t / h);
+      const unsigned t = fdiv((unsigned)r, div_w);
+      const int iw = (int)((unsigned)r - t * (unsigned)w);
+      const unsigned im = fdiv(t, div_h);
+      const int ih = (int)(t - im * (unsigned)h), img = (int)im;
       float g[VE], yy[VE], o[VE];
       pool_gather<T, VE>(dz, idx, img, ih, iw, cv, cvecs, ho, wo, g);
       Vec16<T>::template load<true>(y + r * c + cv * VE, yy);
@@ -688,16 +697,32 @@ int simhand_bn_bwd_finalize(const float* partial, int nblk, int c, float* dgamma
   SH_REQUIRE(partial && dgamma && dbeta, "bn_bwd_finalize: NULL pointer");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 0, (double)nblk * 2 * c * 4);
-  bn_bwd_finalize_kernel<<<ceil_div(c, 16), 1024, 0, s>>>(partial, nblk, c, dgamma, dbeta);
+  bn_bwd_finalize_kernel<float><<<ceil_div(c, 16), 1024, 0, s>>>(partial, nblk, c, dgamma, dbeta);
   return check_launch("bn_bwd_finalize");
 }
 
+static int raw_slices(int nblk) { return nblk >= 4096 ? 64 : 1; }
+
+size_t simhand_bn_bwd_finalize_raw_workspace_bytes(int nblk, int c) {
+  const int sl = raw_slices(nblk);
+  return sl > 1 ? (size_t)sl * 2 * c * sizeof(double) : 16;
+}
+
 int simhand_bn_bwd_finalize_raw(const float* partial, int nblk, int c, const float* mean, const float* invstd, float* dgamma,
-                                float* dbeta, sh_stream_t stream) {
+                                float* dbeta, void* workspace, size_t workspace_bytes, sh_stream_t stream) {
   SH_REQUIRE(partial && mean && invstd && dgamma && dbeta, "bn_bwd_finalize_raw: NULL pointer");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 0, (double)nblk * 2 * c * 4);
-  bn_bwd_finalize_kernel<<<ceil_div(c, 16), 1024, 0, s>>>(partial, nblk, c, dgamma, dbeta, mean, invstd);
+  const int sl = raw_slices(nblk);
+  if (sl > 1) {
+    SH_REQUIRE(workspace && workspace_bytes >= simhand_bn_bwd_finalize_raw_workspace_bytes(nblk, c), "bn_bwd_finalize_raw: workspace too small");
+    double* lvl2 = (double*)workspace;
+    bn_bwd_finalize_kernel<float><<<dim3(ceil_div(c, 16), sl), 1024, 0, s>>>(partial, nblk, c, nullptr, nullptr, nullptr, nullptr, lvl2);
+    if (check_launch("bn_bwd_finalize_raw fold")) return 1;
+    bn_bwd_finalize_kernel<double><<<ceil_div(c, 16), 1024, 0, s>>>(lvl2, sl, c, dgamma, dbeta, mean, invstd);
+  } else {
+    bn_bwd_finalize_kernel<float><<<ceil_div(c, 16), 1024, 0, s>>>(partial, nblk, c, dgamma, dbeta, mean, invstd);
+  }
   return check_launch("bn_bwd_finalize_raw");
 }
 
@@ -731,10 +756,12 @@ int simhand_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* 
   hipStream_t s = (hipStream_t)stream;
   const double es = dtype == SH_F32 ? 4 : 2;
   ProfScope ps(SH_PROF_BN, s, 0, es * ((double)n * h * w * c + (double)n * ho * wo * c) + (double)n * ho * wo * c);
+  SH_REQUIRE(total < (1ll << 31), "bn_relu_maxpool_fwd: %lld output vectors exceed the 2^31 index range", (long long)total);
+  const FastDiv d1 = make_fastdiv((unsigned)(c / ve)), d2 = make_fastdiv((unsigned)wo), d3 = make_fastdiv((unsigned)ho);
   if (dtype == SH_F32)
-    bn_relu_maxpool_fwd_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)y, scale, shift, (float*)out, idx, n, h, w, c, ho, wo);
+    bn_relu_maxpool_fwd_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)y, scale, shift, (float*)out, idx, n, h, w, c, ho, wo, d1, d2, d3);
   else
-    bn_relu_maxpool_fwd_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)y, scale, shift, (bf16_t*)out, idx, n, h, w, c, ho, wo);
+    bn_relu_maxpool_fwd_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)y, scale, shift, (bf16_t*)out, idx, n, h, w, c, ho, wo, d1, d2, d3);
   return check_launch("bn_relu_maxpool_fwd");
 }
 
@@ -746,15 +773,17 @@ int simhand_maxpool_bn_bwd_partial(const void* dz, const uint8_t* idx, const voi
   SH_REQUIRE(c % ve == 0, "maxpool_bn_bwd_partial: c=%d not a multiple of %d", c, ve);
   const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
   const int64_t m = (int64_t)n * h * w;
+  SH_REQUIRE(m < (1ll << 31), "maxpool_bn_bwd_partial: %lld pixels exceed the 2^31 index range", (long long)m);
+  const FastDiv dw_ = make_fastdiv((unsigned)w), dh_ = make_fastdiv((unsigned)h);
   int rpb, nblk;
   col_plan(m, &rpb, &nblk);
   hipStream_t s = (hipStream_t)stream;
   const double es = dtype == SH_F32 ? 4 : 2;
   ProfScope ps(SH_PROF_BN, s, 0, es * ((double)m * c + (double)n * ho * wo * c) + (double)n * ho * wo * c);
   if (dtype == SH_F32)
-    pool_bn_bwd_partial_kernel<float><<<nblk, 256, 0, s>>>((const float*)dz, idx, (const float*)y, mean, invstd, scale, shift, n, h, w, c, ho, wo, rpb, partial);
+    pool_bn_bwd_partial_kernel<float><<<nblk, 256, 0, s>>>((const float*)dz, idx, (const float*)y, mean, invstd, scale, shift, n, h, w, c, ho, wo, rpb, partial, dw_, dh_);
   else
-    pool_bn_bwd_partial_kernel<bf16_t><<<nblk, 256, 0, s>>>((const bf16_t*)dz, idx, (const bf16_t*)y, mean, invstd, scale, shift, n, h, w, c, ho, wo, rpb, partial);
+    pool_bn_bwd_partial_kernel<bf16_t><<<nblk, 256, 0, s>>>((const bf16_t*)dz, idx, (const bf16_t*)y, mean, invstd, scale, shift, n, h, w, c, ho, wo, rpb, partial, dw_, dh_);
   return check_launch("maxpool_bn_bwd_partial");
 }
 
@@ -769,12 +798,14 @@ int simhand_maxpool_bn_bwd_apply(const void* dz, const uint8_t* idx, const void*
   hipStream_t s = (hipStream_t)stream;
   const double es = dtype == SH_F32 ? 4 : 2;
   ProfScope ps(SH_PROF_BN, s, 0, es * (2.0 * (double)m * c + (double)n * ho * wo * c) + (double)n * ho * wo * c);
+  SH_REQUIRE(m < (1ll << 31), "maxpool_bn_bwd_apply: %lld pixels exceed the 2^31 index range", (long long)m);
+  const FastDiv dw_ = make_fastdiv((unsigned)w), dh_ = make_fastdiv((unsigned)h);
   const float inv_m = (float)(1.0 / (double)m);
   const int grid = row_grid(m, c / ve);
   if (dtype == SH_F32)
-    pool_bn_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)dz, idx, (const float*)y, mean, invstd, gamma, dgamma, dbeta, scale, shift, (float*)dy, n, h, w, c, ho, wo, inv_m);
+    pool_bn_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)dz, idx, (const float*)y, mean, invstd, gamma, dgamma, dbeta, scale, shift, (float*)dy, n, h, w, c, ho, wo, inv_m, dw_, dh_);
   else
-    pool_bn_bwd_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dz, idx, (const bf16_t*)y, mean, invstd, gamma, dgamma, dbeta, scale, shift, (bf16_t*)dy, n, h, w, c, ho, wo, inv_m);
+    pool_bn_bwd_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dz, idx, (const bf16_t*)y, mean, invstd, gamma, dgamma, dbeta, scale, shift, (bf16_t*)dy, n, h, w, c, ho, wo, inv_m, dw_, dh_);
   return check_launch("maxpool_bn_bwd_apply");
 }
 
@@ -789,7 +820,7 @@ int simhand_colsum(const void* x, int64_t m, int c, int dtype, float* partial, f
   else colsum_kernel<bf16_t><<<nblk, 256, 0, s>>>((const bf16_t*)x, m, c, rpb, partial);
   if (check_launch("colsum")) return 1;
   // reuse the bwd finalize reducer: "dbeta" slot = sum of s1, "dgamma" slot (s2 = 0) goes to scratch inside partial
-  bn_bwd_finalize_kernel<<<ceil_div(c, 16), 1024, 0, s>>>(partial, nblk, c, partial + (int64_t)nblk * 2 * c, out);
+  bn_bwd_finalize_kernel<float><<<ceil_div(c, 16), 1024, 0, s>>>(partial, nblk, c, partial + (int64_t)nblk * 2 * c, out);
   return check_launch("colsum finalize");
 }
 

@@ -125,4 +125,25 @@ __device__ __forceinline__ float wave_min(float v) {
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// 32-bit division by an invariant divisor (host-precomputed magic number), valid for n < 2^31
+struct FastDiv {
+  unsigned d, mul, shr;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d ? d : 1;
+  if (f.d == 1) {
+    f.mul = 0;
+    f.shr = 0;
+    return f;
+  }
+  unsigned lg = 31 - __builtin_clz(f.d);
+  if (f.d & (f.d - 1)) lg += 1;
+  const unsigned pw = 31 + lg;
+  f.mul = (unsigned)(((1ull << pw) + f.d - 1) / f.d);
+  f.shr = pw - 32;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr); }
+
 }  // namespace sh

@@ -29,27 +29,6 @@
 
 namespace sh {
 
-// 32-bit division by an invariant divisor (host-precomputed), n < 2^31
-struct FastDiv {
-  unsigned d, mul, shr;
-};
-static FastDiv make_fastdiv(unsigned d) {
-  FastDiv f;
-  f.d = d ? d : 1;
-  if (f.d == 1) {
-    f.mul = 0;
-    f.shr = 0;
-    return f;
-  }
-  unsigned lg = 31 - __builtin_clz(f.d);
-  if (f.d & (f.d - 1)) lg += 1;
-  const unsigned pw = 31 + lg;
-  f.mul = (unsigned)(((1ull << pw) + f.d - 1) / f.d);
-  f.shr = pw - 32;
-  return f;
-}
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr); }
-
 struct IgemmArgs {
   const void* a;      // source activations (x or dy), NHWC
   const void* w;      // [Ng][taps][Ca]

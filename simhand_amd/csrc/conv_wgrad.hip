@@ -22,28 +22,6 @@
 
 namespace sh {
 
-struct FastDiv {
-  unsigned d, mul, shr;
-};
-static FastDiv make_fastdiv(unsigned d) {
-  FastDiv f;
-  f.d = d;
-  if (d == 1) {
-    f.mul = 0;
-    f.shr = 0;
-    return f;
-  }
-  unsigned lg = 31 - __builtin_clz(d);
-  if (d & (d - 1)) lg += 1;
-  const unsigned p = 31 + lg;
-  f.mul = (unsigned)(((1ull << p) + d - 1) / d);
-  f.shr = p - 32;
-  return f;
-}
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {  // n < 2^31
-  return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr);
-}
-
 struct WgradArgs {
   const void* x;
   const void* dy;

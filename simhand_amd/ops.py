@@ -387,8 +387,10 @@ def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_d
     db = torch.empty(c, dtype=torch.float32, device=dev)
     if raw_partial is not None:
         # sums of g and g*y came out of the epilogue of the dgrad that produced `da` (conv2d_dgrad_fused)
+        nb = lib.simhand_bn_bwd_finalize_raw_workspace_bytes(raw_partial.shape[0], c)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
         check(lib.simhand_bn_bwd_finalize_raw(_ptr(raw_partial), raw_partial.shape[0], c, _ptr(st.mean), _ptr(st.invstd), _ptr(dg),
-                                              _ptr(db), _stream()), "bn_bwd_finalize_raw")
+                                              _ptr(db), _ptr(ws), nb, _stream()), "bn_bwd_finalize_raw")
     else:
         nblk = lib.simhand_bn_stat_blocks(m, c)
         part = torch.empty(nblk, 2, c, dtype=torch.float32, device=dev)
