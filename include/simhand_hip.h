@@ -183,7 +183,9 @@ int simhand_conv2d_dgrad_masked_residual(const sh_conv_desc* d, const void* dy, 
  * The dx this call stores is that unit's incoming gradient da (its raw conv output y has dx's layout), so instead
  * of a separate simhand_bn_bwd_partial pass (reads da and y) the epilogue reads y once and emits per tile
  *   partial[blk][0][c] = sum g,  partial[blk][1][c] = sum g * y,   g = da * relu'(.)
- * relu_mode 0: no ReLU; 2: mask recomputed as y*scale + shift > 0; 3: 1-bit mask written by simhand_bn_apply.
+ * relu_mode 0: no ReLU; 2: mask recomputed as y*scale + shift > 0; 3: 1-bit mask written by simhand_bn_apply;
+ * 4: the STORED dx is the masked gradient g = dx * bit(mask) (y unused; partial[blk][1] = 0) -- the form the folded
+ *    BatchNorm backward of a 1x1 conv + BN unit consumes (simhand host: ResNetEngine._unit3_bwd_folded).
  * blk runs over simhand_conv2d_dgrad_stat_blocks(d) tiles; finish with simhand_bn_bwd_finalize_raw.
  * accumulate: 0 store, 1 dx += result, 2 dx = result + res_grad * bit(res_mask) (as the two entry points above).
  * Replaces (reference): autograd's native_batch_norm_backward reduction after each Conv2d input-gradient in
@@ -203,10 +205,26 @@ int simhand_conv2d_dgrad_fuse_pays(const sh_conv_desc* d);
 int simhand_conv2d_dgrad_fuse_1x1(int on);
 int simhand_conv2d_dgrad_fused(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
                                const uint8_t* res_mask, const sh_bn_bwd_fuse* fuse, sh_stream_t stream);
+/* General form: accumulate modes as above, optional fusion, optional fp32 per-channel bias (length cin) added to the
+ * result before accumulation / rounding. */
+typedef struct sh_dgrad_opts {
+  int32_t accumulate;
+  const void* res_grad;
+  const uint8_t* res_mask;
+  const float* bias;
+  const sh_bn_bwd_fuse* fuse;
+} sh_dgrad_opts;
+int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, const sh_dgrad_opts* opts, sh_stream_t stream);
 
 /* dw (fp32, KRSC) = sum over output pixels of dy (x) patches(x); deterministic two-stage split-K */
 size_t simhand_conv2d_wgrad_workspace_bytes(const sh_conv_desc* d);
 int simhand_conv2d_wgrad(const sh_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, sh_stream_t stream);
+/* bf16 1x1 / stride-1 only: the same gradient (KRSC fp32) plus, as a by-product of the dy tiles the kernel stages anyway,
+ * the per-channel sums of dy: dy_colsum[split][0][cout] for split < simhand_conv2d_wgrad_splits(d) ([split][1][.] = 0, so the
+ * buffer has the layout simhand_bn_bwd_finalize_raw folds).  Used by the folded BatchNorm backward of conv3 + bn3. */
+int simhand_conv2d_wgrad_splits(const sh_conv_desc* d);
+int simhand_conv2d_wgrad_colsum(const sh_conv_desc* d, const void* x, const void* dy, float* dw, float* dy_colsum, void* workspace,
+                                size_t workspace_bytes, sh_stream_t stream);
 /* Same, but the split-K reduction writes the gradient directly in the reference's nn.Conv2d.weight.grad layout
  * OIHW fp32 [cout][c_real][r][s]; c_real <= cin drops zero-padded input channels (the im2col'd stem: cin = 192
  * columns, c_real = 147 = 3*7*7 -> exactly weight.grad.view(64, 147)). */

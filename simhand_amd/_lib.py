@@ -46,6 +46,12 @@ class BnBwdFuse(C.Structure):
                 ("relu_mode", C.c_int32), ("partial", C.c_void_p)]
 
 
+class DgradOpts(C.Structure):
+    """sh_dgrad_opts (include/simhand_hip.h)."""
+    _fields_ = [("accumulate", C.c_int32), ("res_grad", C.c_void_p), ("res_mask", C.c_void_p), ("bias", C.c_void_p),
+                ("fuse", C.POINTER(BnBwdFuse))]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [
         ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("cin", C.c_int),
@@ -91,6 +97,8 @@ SIGNATURES = {
     "simhand_stem_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "simhand_stem_conv_wgrad_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "simhand_stem_conv_wgrad": (_I, [_P, _P, _P, _P, _S, _I, _I, _I, _I, _P]),
+    "simhand_conv2d_wgrad_splits": (_I, [C.POINTER(ConvDesc)]),
+    "simhand_conv2d_wgrad_colsum": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _S, _P]),
     "simhand_conv2d_wgrad_oihw": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _S, _P]),
     "simhand_wgrad_set_tr": (_I, [_I]),
     "simhand_wgrad3x3_enable": (_I, [_I]),
@@ -116,6 +124,7 @@ SIGNATURES = {
     "simhand_bn_bwd_finalize_raw_workspace_bytes": (_S, [_I, _I]),
     "simhand_bn_bwd_finalize_raw": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_conv2d_dgrad_stat_blocks": (_I, [C.POINTER(ConvDesc)]),
+    "simhand_conv2d_dgrad_ex": (_I, [C.POINTER(ConvDesc), _P, _P, _P, C.POINTER(DgradOpts), _P]),
     "simhand_conv2d_dgrad_fuse_pays": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_dgrad_fuse_1x1": (_I, [_I]),
     "simhand_conv2d_dgrad_fused": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _P, C.POINTER(BnBwdFuse), _P]),

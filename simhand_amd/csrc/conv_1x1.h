@@ -20,7 +20,8 @@ struct Gemm1x1Args {
   const float* fshift;
   const unsigned char* fmask;
   int fmode;
-  float* fpartial;    // [ceil(M / rows_per_block)][2][N]
+  float* fpartial;    // [ceil(M / rows_per_block)][2][N]; null = off
+  const float* bias;  // dgrad: per output channel, added to the fp32 result (null = none)
 };
 
 bool gemm1x1_supported(int k, int n);

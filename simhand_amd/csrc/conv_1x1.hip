@@ -176,8 +176,14 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
             }
         }
         // ---- 64 channels out: two 16-B vectors per lane and pixel (channels n0 + j*32 + g*8 .. +8)
-        auto store_chunk = [&](int mi, int j, long long row) __attribute__((always_inline)) -> uint4 {
-          const f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
+        auto store_chunk = [&](int mi, int j, long long row, unsigned keep = 0xffu) __attribute__((always_inline)) -> uint4 {
+          f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
+          if (DGRAD && p.bias != nullptr) {
+            const int chb = n0 + j * 32 + g * 8;
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + chb), b1 = *reinterpret_cast<const float4*>(p.bias + chb + 4);
+            lo[0] += b0.x; lo[1] += b0.y; lo[2] += b0.z; lo[3] += b0.w;
+            hi[0] += b1.x; hi[1] += b1.y; hi[2] += b1.z; hi[3] += b1.w;
+          }
           uint4 v;
           v.x = pack_bf16x2(lo[0], lo[1]);
           v.y = pack_bf16x2(lo[2], lo[3]);
@@ -203,6 +209,12 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
             v.z = add_bf16x2_g1(v.z, o.z);
             v.w = add_bf16x2_g1(v.w, o.w);
           }
+          if (DGRAD && p.fmode == 4) {  // the stored gradient is the masked one
+            v.x &= ((keep & 1u) ? 0x0000ffffu : 0u) | ((keep & 2u) ? 0xffff0000u : 0u);
+            v.y &= ((keep & 4u) ? 0x0000ffffu : 0u) | ((keep & 8u) ? 0xffff0000u : 0u);
+            v.z &= ((keep & 16u) ? 0x0000ffffu : 0u) | ((keep & 32u) ? 0xffff0000u : 0u);
+            v.w &= ((keep & 64u) ? 0x0000ffffu : 0u) | ((keep & 128u) ? 0xffff0000u : 0u);
+          }
           *reinterpret_cast<uint4*>(dst) = v;
           return v;
         };
@@ -224,10 +236,12 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
               const long long row = mbase + mi * 16 + li;
               if (row < p.M) {
                 float yy[8];
-                Vec16<bf16_t>::load(p.fy + row * p.N + ch, yy);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) yy[e] = 0.f;
+                if (p.fmode != 4) Vec16<bf16_t>::load(p.fy + row * p.N + ch, yy);
                 unsigned bits = 0xffu;
-                if (p.fmode == 3) bits = p.fmask[row * (p.N >> 3) + (ch >> 3)];
-                const uint4 v = store_chunk(mi, j, row);
+                if (p.fmode >= 3) bits = p.fmask[row * (p.N >> 3) + (ch >> 3)];
+                const uint4 v = store_chunk(mi, j, row, bits);
                 const unsigned w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
                     const float gq = h == 0 ? __uint_as_float(w4[i] << 16) : __uint_as_float(w4[i] & 0xffff0000u);
                     bool on = true;
                     if (p.fmode == 2) on = yy[e] * sc[e] + sh[e] > 0.f;
-                    else if (p.fmode == 3) on = (bits >> e) & 1u;
+                    else if (p.fmode == 3) on = (bits >> e) & 1u;  // mode 4: the value is already masked
                     const float gv = on ? gq : 0.f;
                     s1[e] += gv;
                     s2[e] += gv * yy[e];
@@ -261,7 +275,11 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
             const long long row = mbase + mi * 16 + li;
             if (row < p.M) {
 #pragma unroll
-              for (int j = 0; j < 2; ++j) store_chunk(mi, j, row);
+              for (int j = 0; j < 2; ++j) {
+                unsigned keep = 0xffu;
+                if (DGRAD && p.fmode == 4) keep = p.fmask[row * (p.N >> 3) + ((n0 + j * 32 + g * 8) >> 3)];  // masked store, no sums
+                store_chunk(mi, j, row, keep);
+              }
             }
           }
         }
@@ -302,7 +320,7 @@ int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
   const int nblk = ceil_div(a.M, 64 * mf);
 #define SH_G1(KV, MFV)                                                                          \
   do {                                                                                          \
-    if (dgrad && a.fy != nullptr) gemm1x1_kernel<KV, MFV, true, true><<<nblk, 256, 0, s>>>(a);  \
+    if (dgrad && a.fpartial != nullptr) gemm1x1_kernel<KV, MFV, true, true><<<nblk, 256, 0, s>>>(a);  \
     else if (dgrad) gemm1x1_kernel<KV, MFV, true><<<nblk, 256, 0, s>>>(a);                      \
     else gemm1x1_kernel<KV, MFV, false><<<nblk, 256, 0, s>>>(a);                                \
   } while (0)

@@ -53,9 +53,10 @@ struct IgemmArgs {
   const void* fy;              // that unit's raw conv output, laid out like out; null = no fusion
   const float* fscale;         // fmode 2: ReLU mask recomputed from fy * fscale + fshift > 0
   const float* fshift;
-  const unsigned char* fmask;  // fmode 3: ReLU bit mask [pixel][Ng / VE]
-  int fmode;
-  float* fpartial;             // [m_tiles * classes][2][Ng]: sum g, sum g * y
+  const unsigned char* fmask;  // fmode 3 / 4: ReLU bit mask [pixel][Ng / VE]
+  int fmode;                   // 4: the STORED gradient is masked (out = result * bit), sums of it only (fy unused)
+  float* fpartial;             // [m_tiles * classes][2][Ng]: sum g, sum g * y; null = no fusion
+  const float* bias;           // dgrad: per destination channel, added to the fp32 result before any accumulate / rounding
 };
 
 template <typename T> struct Mma;
@@ -413,21 +414,31 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
       return ok ? pix : -1;
     };
     // value of chunk j of row mi after the accumulate mode, as stored
-    auto chunk_out = [&](int mi, int j, long long pix) __attribute__((always_inline)) -> uint4 {
+    auto chunk_out = [&](int mi, int j, long long pix, unsigned keep = 0xffu) __attribute__((always_inline)) -> uint4 {
       uint4 v;
+      const int ch = ch0 + j * 4 * VE;
       if (sizeof(T) == 4) {
-        v.x = __float_as_uint(acc[mi][j % NI][0]);
-        v.y = __float_as_uint(acc[mi][j % NI][1]);
-        v.z = __float_as_uint(acc[mi][j % NI][2]);
-        v.w = __float_as_uint(acc[mi][j % NI][3]);
+        f32x4 a0 = acc[mi][j % NI];
+        if (DGRAD && p.bias != nullptr) {
+          const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ch);
+          a0[0] += b0.x; a0[1] += b0.y; a0[2] += b0.z; a0[3] += b0.w;
+        }
+        v.x = __float_as_uint(a0[0]);
+        v.y = __float_as_uint(a0[1]);
+        v.z = __float_as_uint(a0[2]);
+        v.w = __float_as_uint(a0[3]);
       } else {
-        const f32x4 lo = acc[mi][(2 * j) % NI], hi = acc[mi][(2 * j + 1) % NI];
+        f32x4 lo = acc[mi][(2 * j) % NI], hi = acc[mi][(2 * j + 1) % NI];
+        if (DGRAD && p.bias != nullptr) {
+          const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ch), b1 = *reinterpret_cast<const float4*>(p.bias + ch + 4);
+          lo[0] += b0.x; lo[1] += b0.y; lo[2] += b0.z; lo[3] += b0.w;
+          hi[0] += b1.x; hi[1] += b1.y; hi[2] += b1.z; hi[3] += b1.w;
+        }
         v.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
         v.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
         v.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
         v.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
       }
-      const int ch = ch0 + j * 4 * VE;
       T* dst = out + pix * p.Ng + ch;
       if (p.accumulate == 2) {
         // identity-branch gradient g = res_grad * relu_mask, merged here instead of being materialised
@@ -462,16 +473,30 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
           v.w = add_bf16x2(v.w, o.w);
         }
       }
+      if (DGRAD && p.fmode == 4) {  // the stored gradient is the masked one
+        if (sizeof(T) == 4) {
+          v.x = (keep & 1u) ? v.x : 0u; v.y = (keep & 2u) ? v.y : 0u; v.z = (keep & 4u) ? v.z : 0u; v.w = (keep & 8u) ? v.w : 0u;
+        } else {
+          v.x &= ((keep & 1u) ? 0x0000ffffu : 0u) | ((keep & 2u) ? 0xffff0000u : 0u);
+          v.y &= ((keep & 4u) ? 0x0000ffffu : 0u) | ((keep & 8u) ? 0xffff0000u : 0u);
+          v.z &= ((keep & 16u) ? 0x0000ffffu : 0u) | ((keep & 32u) ? 0xffff0000u : 0u);
+          v.w &= ((keep & 64u) ? 0x0000ffffu : 0u) | ((keep & 128u) ? 0xffff0000u : 0u);
+        }
+      }
       *reinterpret_cast<uint4*>(dst) = v;
       return v;
     };
-    if (!DGRAD || p.fy == nullptr) {
+    if (!DGRAD || p.fpartial == nullptr) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         const long long pix = pixel_of(mi);
         if (pix < 0) continue;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) chunk_out(mi, j, pix);
+        for (int j = 0; j < NCH; ++j) {
+          unsigned keep = 0xffu;
+          if (DGRAD && p.fmode == 4) keep = p.fmask[pix * (p.Ng / VE) + (ch0 + j * 4 * VE) / VE];  // masked store, no sums
+          chunk_out(mi, j, pix, keep);
+        }
       }
     } else {
       // Fused BatchNorm-backward partial sums of the PREVIOUS unit: the stored gradient (rounded as stored) is that
@@ -497,10 +522,12 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
           const long long pix = pixs[mi];
           if (pix < 0) continue;
           float yy[VE], gg[VE];
-          Vec16<T>::load(fy + pix * p.Ng + ch, yy);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) yy[e] = 0.f;
+          if (p.fmode != 4) Vec16<T>::load(fy + pix * p.Ng + ch, yy);
           unsigned bits = 0xffu;
-          if (p.fmode == 3) bits = p.fmask[pix * (p.Ng / VE) + ch / VE];
-          const uint4 v = chunk_out(mi, j, pix);
+          if (p.fmode >= 3) bits = p.fmask[pix * (p.Ng / VE) + ch / VE];
+          const uint4 v = chunk_out(mi, j, pix, bits);
           if (sizeof(T) == 4) {
             gg[0] = __uint_as_float(v.x); gg[1] = __uint_as_float(v.y); gg[2] = __uint_as_float(v.z); gg[3] = __uint_as_float(v.w);
           } else {
@@ -515,7 +542,7 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
           for (int e = 0; e < VE; ++e) {
             bool on = true;
             if (p.fmode == 2) on = yy[e] * sc[e] + sh[e] > 0.f;
-            else if (p.fmode == 3) on = (bits >> e) & 1u;
+            else if (p.fmode == 3) on = (bits >> e) & 1u;  // mode 4: the value is already masked
             const float gv = on ? gg[e] : 0.f;
             s1[e] += gv;
             s2[e] += gv * yy[e];
@@ -796,9 +823,15 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
       }
       return ok ? pix : -1;
     };
-    auto chunk_out = [&](int mi, int j, long long pix) __attribute__((always_inline)) -> uint4 {
+    auto chunk_out = [&](int mi, int j, long long pix, unsigned keep = 0xffu) __attribute__((always_inline)) -> uint4 {
       uint4 v;
-      const f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
+      f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
+      if (DGRAD && p.bias != nullptr) {
+        const int chb = ch0 + j * 32;
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + chb), b1 = *reinterpret_cast<const float4*>(p.bias + chb + 4);
+        lo[0] += b0.x; lo[1] += b0.y; lo[2] += b0.z; lo[3] += b0.w;
+        hi[0] += b1.x; hi[1] += b1.y; hi[2] += b1.z; hi[3] += b1.w;
+      }
       v.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
       v.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
       v.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
@@ -823,6 +856,12 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         v.z = add_bf16x2(v.z, o.z);
         v.w = add_bf16x2(v.w, o.w);
       }
+      if (DGRAD && p.fmode == 4) {  // the stored gradient is the masked one
+        v.x &= ((keep & 1u) ? 0x0000ffffu : 0u) | ((keep & 2u) ? 0xffff0000u : 0u);
+        v.y &= ((keep & 4u) ? 0x0000ffffu : 0u) | ((keep & 8u) ? 0xffff0000u : 0u);
+        v.z &= ((keep & 16u) ? 0x0000ffffu : 0u) | ((keep & 32u) ? 0xffff0000u : 0u);
+        v.w &= ((keep & 64u) ? 0x0000ffffu : 0u) | ((keep & 128u) ? 0xffff0000u : 0u);
+      }
 #if SH_ABL256 != 5
       *reinterpret_cast<uint4*>(dst) = v;
 #else
@@ -830,13 +869,17 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
 #endif
       return v;
     };
-    if (!DGRAD || p.fy == nullptr) {
+    if (!DGRAD || p.fpartial == nullptr) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const long long pix = pixel_of(mi);
         if (pix < 0) continue;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) chunk_out(mi, j, pix);
+        for (int j = 0; j < NCH; ++j) {
+          unsigned keep = 0xffu;
+          if (DGRAD && p.fmode == 4) keep = p.fmask[pix * (p.Ng / VE) + (ch0 + j * 32) / VE];  // masked store, no sums
+          chunk_out(mi, j, pix, keep);
+        }
       }
     } else {
       // fused BatchNorm-backward partial sums of the previous unit (see igemm_kernel)
@@ -857,10 +900,12 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
           const long long pix = pixel_of(mi);
           if (pix < 0) continue;
           float yy[VE];
-          Vec16<T>::load(fy + pix * p.Ng + ch, yy);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) yy[e] = 0.f;
+          if (p.fmode != 4) Vec16<T>::load(fy + pix * p.Ng + ch, yy);
           unsigned bits = 0xffu;
-          if (p.fmode == 3) bits = p.fmask[pix * (p.Ng / VE) + ch / VE];
-          const uint4 v = chunk_out(mi, j, pix);
+          if (p.fmode >= 3) bits = p.fmask[pix * (p.Ng / VE) + ch / VE];
+          const uint4 v = chunk_out(mi, j, pix, bits);
           const unsigned w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -870,7 +915,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
               const float gq = h == 0 ? __uint_as_float(w4[i] << 16) : __uint_as_float(w4[i] & 0xffff0000u);
               bool on = true;
               if (p.fmode == 2) on = yy[e] * sc[e] + sh[e] > 0.f;
-              else if (p.fmode == 3) on = (bits >> e) & 1u;
+              else if (p.fmode == 3) on = (bits >> e) & 1u;  // mode 4: the value is already masked
               const float gv = on ? gq : 0.f;
               s1[e] += gv;
               s2[e] += gv * yy[e];
@@ -989,7 +1034,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
   a.accumulate = 0; a.res_grad = nullptr; a.res_mask = nullptr;
   a.classes = 1; a.Hq = a.Wq = 0;
   a.stem_hp = a.stem_wp = 0;
-  a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr;
+  a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr; a.bias = nullptr;
   SH_REQUIRE(a.Mg < (1ll << 31) - 256, "conv2d_fwd: %lld output pixels exceed the 2^31 index range", a.Mg);
   a.div_hw = make_fastdiv((unsigned)(a.Hd * a.Wd));
   a.div_w = make_fastdiv((unsigned)a.Wd);
@@ -1003,7 +1048,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
     Gemm1x1Args g;
     g.a = (const bf16_t*)x; g.w = (const bf16_t*)w; g.out = (bf16_t*)y; g.bn_partial = bn_partial;
     g.M = a.Mg; g.N = d->cout; g.accumulate = 0; g.res_grad = nullptr; g.res_mask = nullptr;
-    g.fy = nullptr; g.fscale = g.fshift = nullptr; g.fmask = nullptr; g.fmode = 0; g.fpartial = nullptr;
+    g.fy = nullptr; g.fscale = g.fshift = nullptr; g.fmask = nullptr; g.fmode = 0; g.fpartial = nullptr; g.bias = nullptr;
     launch_gemm1x1(g, d->cin, false, (hipStream_t)stream);
     return check_launch("conv2d_fwd (1x1)");
   }
@@ -1042,7 +1087,7 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
   a.accumulate = 0; a.res_grad = nullptr; a.res_mask = nullptr;
   a.classes = 1; a.Hq = a.Wq = 0;
   a.stem_hp = hp; a.stem_wp = wp;
-  a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr;
+  a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr; a.bias = nullptr;
   SH_REQUIRE(a.Mg < (1ll << 31) - 256, "stem_conv_fwd: %lld output pixels exceed the 2^31 index range", a.Mg);
   SH_REQUIRE((long long)n * hp * wp * 4 < (1ll << 40), "stem_conv_fwd: input too large");
   a.div_hw = make_fastdiv((unsigned)(ho * wo));
@@ -1065,7 +1110,8 @@ static int dgrad_stat_blocks(const sh_conv_desc* d) {
 }
 
 static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
-                      const unsigned char* res_mask, sh_stream_t stream, const sh_bn_bwd_fuse* fuse = nullptr) {
+                      const unsigned char* res_mask, sh_stream_t stream, const sh_bn_bwd_fuse* fuse = nullptr,
+                      const float* bias = nullptr) {
   if (check_desc(d, "conv2d_dgrad")) return 1;
   SH_REQUIRE(dy && wt && dx, "conv2d_dgrad: NULL pointer");
   const int ke = d->dtype == SH_F32 ? 32 : 64;
@@ -1078,17 +1124,19 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   a.Hd = d->h; a.Wd = d->w; a.Hs = d->ho; a.Ws = d->wo;
   a.accumulate = accumulate; a.res_grad = res_grad; a.res_mask = res_mask;
   a.stem_hp = a.stem_wp = 0;
-  a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr;
+  a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr; a.bias = nullptr;
   if (fuse != nullptr) {
-    SH_REQUIRE(fuse->y && fuse->partial, "conv2d_dgrad_fused: NULL y / partial");
-    SH_REQUIRE(fuse->relu_mode == 0 || fuse->relu_mode == 2 || fuse->relu_mode == 3, "conv2d_dgrad_fused: relu_mode %d", fuse->relu_mode);
+    SH_REQUIRE(fuse->partial || fuse->relu_mode == 4, "conv2d_dgrad_fused: NULL partial (only relu_mode 4 may omit the sums)");
+    SH_REQUIRE(fuse->relu_mode == 0 || (fuse->relu_mode >= 2 && fuse->relu_mode <= 4), "conv2d_dgrad_fused: relu_mode %d", fuse->relu_mode);
+    SH_REQUIRE(fuse->relu_mode == 4 || fuse->y, "conv2d_dgrad_fused: NULL y");
     SH_REQUIRE(fuse->relu_mode != 2 || (fuse->scale && fuse->shift), "conv2d_dgrad_fused: relu_mode 2 needs scale / shift");
-    SH_REQUIRE(fuse->relu_mode != 3 || fuse->mask, "conv2d_dgrad_fused: relu_mode 3 needs the bit mask");
+    SH_REQUIRE(fuse->relu_mode < 3 || fuse->mask, "conv2d_dgrad_fused: relu_mode 3 / 4 needs the bit mask");
     // a stride-2 1x1 shortcut that accumulates skips the parity classes no tap reaches: their pixels would be missing
     SH_REQUIRE(!(accumulate == 1 && d->stride == 2 && d->r == 1), "conv2d_dgrad_fused: not available for an accumulating stride-2 1x1");
     a.fy = fuse->y; a.fscale = fuse->scale; a.fshift = fuse->shift; a.fmask = fuse->mask; a.fmode = fuse->relu_mode;
     a.fpartial = fuse->partial;
   }
+  a.bias = bias;
   if (d->stride == 2) {
     a.classes = 4;
     a.Hq = (d->h + 1) / 2;
@@ -1115,6 +1163,7 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
     g.a = (const bf16_t*)dy; g.w = (const bf16_t*)wt; g.out = (bf16_t*)dx; g.bn_partial = nullptr;
     g.M = a.Mg; g.N = d->cin; g.accumulate = accumulate; g.res_grad = (const bf16_t*)res_grad; g.res_mask = res_mask;
     g.fy = (const bf16_t*)a.fy; g.fscale = a.fscale; g.fshift = a.fshift; g.fmask = a.fmask; g.fmode = a.fmode; g.fpartial = a.fpartial;
+    g.bias = a.bias;
     launch_gemm1x1(g, d->cout, true, (hipStream_t)stream);
     return check_launch("conv2d_dgrad (1x1)");
   }
@@ -1156,6 +1205,13 @@ int simhand_conv2d_dgrad_fused(const sh_conv_desc* d, const void* dy, const void
   SH_REQUIRE(accumulate >= 0 && accumulate <= 2, "conv2d_dgrad_fused: accumulate mode %d", accumulate);
   SH_REQUIRE(accumulate != 2 || (res_grad && res_mask), "conv2d_dgrad_fused: accumulate 2 needs res_grad / res_mask");
   return dgrad_impl(d, dy, wt, dx, accumulate, res_grad, res_mask, stream, fuse);
+}
+
+int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, const sh_dgrad_opts* o, sh_stream_t stream) {
+  SH_REQUIRE(o != nullptr, "conv2d_dgrad_ex: opts is NULL");
+  SH_REQUIRE(o->accumulate >= 0 && o->accumulate <= 2, "conv2d_dgrad_ex: accumulate mode %d", o->accumulate);
+  SH_REQUIRE(o->accumulate != 2 || (o->res_grad && o->res_mask), "conv2d_dgrad_ex: accumulate 2 needs res_grad / res_mask");
+  return dgrad_impl(d, dy, wt, dx, o->accumulate, o->res_grad, o->res_mask, stream, o->fuse, o->bias);
 }
 
 }  // extern "C"

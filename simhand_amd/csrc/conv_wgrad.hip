@@ -35,6 +35,8 @@ struct WgradArgs {
   int mt, nt;           // cout tiles, cin tiles
   FastDiv div_hw, div_w;
   int use_tr;           // bf16: 1 = ds_read_b64_tr_b16, 0 = scalar fallback (self-test)
+  float* dy_colsum;     // PLAIN kernel only: [splitk][2][Cout] -- row 0 = per-channel sums of dy over the split's pixels
+                        // (emitted by the cin-tile-0 blocks from the tiles they stage anyway), row 1 = 0; null = off
   int stem_hp, stem_wp; // > 0: x is the zero-padded NHWC4 stem input [N][hp][wp][4]; Cin = 256 virtual channels
                         // = 8 filter rows x (8 taps x 4 channels), row r of output pixel (ho, wo) at (2ho + r, 2wo)
 };
@@ -144,6 +146,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
       px[i] = reinterpret_cast<const char*>(xs + (pix_begin + rowb[i]) * p.Cin + c0 + (id - rowb[i] * CPR_B) * VE);
     }
   }
+  // PLAIN + dy_colsum: every chunk of this thread is the same 8 channels k0 + (tid % CPR_A) * 8 .. (CPR_A divides 256)
+  const bool want_colsum = PLAIN && sizeof(T) == 2 && p.dy_colsum != nullptr && nt_i == 0;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const unsigned step_dy = (unsigned)KP * (unsigned)p.Cout * (unsigned)sizeof(T);
   const unsigned step_x = (unsigned)KP * (unsigned)p.Cin * (unsigned)sizeof(T);
   const int rows_total = (int)(pix_end - pix_begin);  // <= pix_per_split
@@ -154,6 +159,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
       for (int i = 0; i < NA; ++i) {
         ra[i] = rowa[i] < left ? *reinterpret_cast<const uint4*>(pdy[i]) : make_uint4(0, 0, 0, 0);
         pdy[i] += step_dy;
+      }
+      if (want_colsum) {  // block-uniform
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const unsigned w4[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            csum[2 * q] += __uint_as_float(w4[q] << 16);
+            csum[2 * q + 1] += __uint_as_float(w4[q] & 0xffff0000u);
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < NBL; ++i) {
@@ -272,6 +288,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
     }
     if (ks + 1 < nk) store_step(buf ^ 1);
     __syncthreads();
+  }
+
+  if (want_colsum) {
+    // threads tid, tid + CPR_A, ... hold the same channel chunk: fold them through LDS in a fixed order
+    float* red = reinterpret_cast<float*>(smem);  // [256 / CPR_A][CPR_A * 8]; the tiles are dead (loop ended with a barrier)
+    const int chc = tid % CPR_A, rr = tid / CPR_A;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rr * (CPR_A * 8) + chc * 8 + e] = csum[e];
+    __syncthreads();
+    if (tid < CPR_A * 8) {
+      float t = 0.f;
+      for (int r2 = 0; r2 < 256 / CPR_A; ++r2) t += red[r2 * (CPR_A * 8) + tid];
+      p.dy_colsum[((long long)split * 2 + 0) * p.Cout + k0 + tid] = t;
+      p.dy_colsum[((long long)split * 2 + 1) * p.Cout + k0 + tid] = 0.f;
+    }
   }
 
   // C[m = cout][n = cin]: lane holds cin = c0 + wn*BN/2 + ni*16 + li, couts k0 + wm*BM/2 + mi*16 + 4g + r
@@ -586,7 +617,7 @@ size_t simhand_conv2d_wgrad_workspace_bytes(const sh_conv_desc* d) {
 }
 
 static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, float* dw, int c_real, void* workspace,
-                      size_t workspace_bytes, sh_stream_t stream, int stem_hp = 0, int stem_wp = 0) {
+                      size_t workspace_bytes, sh_stream_t stream, int stem_hp = 0, int stem_wp = 0, float* dy_colsum = nullptr) {
   SH_REQUIRE(d != nullptr, "conv2d_wgrad: desc is NULL");
   SH_REQUIRE(x && dy && dw && workspace, "conv2d_wgrad: NULL pointer");
   SH_REQUIRE(d->dtype == SH_F32 || d->dtype == SH_BF16, "conv2d_wgrad: bad dtype %d", d->dtype);
@@ -631,6 +662,9 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
   a.div_w = make_fastdiv((unsigned)d->wo);
   a.use_tr = g_use_tr;
   a.stem_hp = stem_hp; a.stem_wp = stem_wp;
+  a.dy_colsum = dy_colsum;
+  const bool plain = d->dtype == SH_BF16 && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && a.use_tr && stem_wp == 0;
+  SH_REQUIRE(dy_colsum == nullptr || plain, "conv2d_wgrad_colsum: only for bf16 1x1 / stride-1 convolutions");
   hipStream_t s = (hipStream_t)stream;
   const int nblk = a.splitk * d->r * d->s * a.mt * a.nt;
   const double es = d->dtype == SH_F32 ? 4 : 2;
@@ -673,6 +707,20 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
 int simhand_conv2d_wgrad(const sh_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
                          sh_stream_t stream) {
   return wgrad_impl(d, x, dy, dw, 0, workspace, workspace_bytes, stream);
+}
+
+int simhand_conv2d_wgrad_splits(const sh_conv_desc* d) {
+  if (!d) return 0;
+  int bm, bn, sk, pps;
+  if (use_wgrad3(d)) plan3(d, &sk, &pps);
+  else plan(d, &bm, &bn, &sk, &pps);
+  return sk;
+}
+
+int simhand_conv2d_wgrad_colsum(const sh_conv_desc* d, const void* x, const void* dy, float* dw, float* dy_colsum, void* workspace,
+                                size_t workspace_bytes, sh_stream_t stream) {
+  SH_REQUIRE(dy_colsum != nullptr, "conv2d_wgrad_colsum: NULL dy_colsum");
+  return wgrad_impl(d, x, dy, dw, 0, workspace, workspace_bytes, stream, 0, 0, dy_colsum);
 }
 
 int simhand_conv2d_wgrad_oihw(const sh_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int c_real, void* workspace,

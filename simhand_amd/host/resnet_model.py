@@ -133,6 +133,8 @@ class ResNetEngine:
         self._packs: Dict[int, _Packed] = {}
         # BN-backward partial sums of a unit fused into the epilogue of the dgrad that produces its incoming gradient
         self.fuse_bn_bwd = True
+        # bottleneck conv3 + bn3: BatchNorm backward folded into the 1x1 conv's own gradients (_unit3_bwd_folded)
+        self.fold_bn3 = True
 
     # -- weights -------------------------------------------------------------
     def _pack(self, conv: nn.Conv2d, need_t: bool, stem: bool = False) -> _Packed:
@@ -226,8 +228,71 @@ class ResNetEngine:
         return out, ctx
 
     # -- backward --------------------------------------------------------------
+    @staticmethod
+    def _foldable(u: Optional[_Unit]) -> bool:
+        """1x1 / stride-1 conv followed by BN + residual + ReLU (the last unit of a Bottleneck)."""
+        return (u is not None and u.has_res and u.mask is not None and u.conv.kernel_size == (1, 1) and u.conv.stride == (1, 1)
+                and u.conv.in_channels % 64 == 0)
+
+    def _small_gemm(self, a: Tensor, bt: Tensor) -> Tensor:
+        """a [m][k] @ bt[n][k]^T in fp32 through the exact-f32 MFMA tile kernel (parameter-sized operands)."""
+        m, k = a.shape
+        n = bt.shape[0]
+        d = ops.conv_desc(m, 1, 1, k, n, 1, 1, 1, 0, torch.float32)
+        y, _ = ops.conv2d_fwd(d, a.contiguous().view(m, 1, 1, k), bt.contiguous(), want_stats=False)
+        return y.view(m, n)
+
+    def _unit3_bwd_folded(self, u: _Unit, g, g_part, grads: dict, prev: _Unit):
+        """Backward of y = conv1x1(a2; W), out = relu(bn(y) + identity) WITHOUT the two BatchNorm-backward passes.
+        `g` is the incoming gradient already gated by the output ReLU mask (stored that way by the dgrad that produced
+        it); its channel sums come out of the G = g^T a2 kernel.  Because y = a2 W^T pixel by pixel, everything BN backward needs is
+        parameter-sized:  G = g^T a2 (the un-normalised weight gradient), s = sum g, S2 = a2^T a2, t2 = sum a2;
+            sum g*y = rowdot(G, W);   dgamma = invstd (sum g*y - mean s);   dbeta = s
+            dy = A g - B y + C  with  A = gamma invstd,  B = invstd A dgamma / M,  C = -A dbeta / M + mean B
+            dW  = diag(A) G - diag(B) W S2 + C t2^T
+            da2 = g (diag(A) W) - a2 (W^T diag(B) W) + C W
+        so y and dy (4x wider than a2) are neither read nor written: 12.5 instead of 30 passes over a2-sized data.
+        Replaces (reference): autograd's native_batch_norm_backward + Conv2d backward for conv3 / bn3 of torchvision's
+        Bottleneck (src/models/resnet_model.py:13-58).  Returns (da2, raw partial sums for `prev` or None)."""
+        d = u.desc
+        cw, cc = d.cin, d.cout
+        m = d.n * d.ho * d.wo
+        a2, st = u.x, u.st
+        f32 = torch.float32
+        w2 = u.conv.weight.detach().to(f32).view(cc, cw)
+        gamma = u.bn.weight.detach().to(f32)
+        if self.dtype == torch.bfloat16:
+            gmat, s = ops.conv2d_wgrad_colsum(d, a2, g)                     # [cc][cw] fp32, [cc]: sum g rides along
+        else:
+            gmat = ops.conv2d_wgrad(d, a2, g)
+            s = ops.colsum(g.view(m, cc), m, cc)
+        dww = ops.conv_desc(d.n, d.h, d.w, cw, cw, 1, 1, 1, 0, self.dtype)
+        s2 = ops.conv2d_wgrad(dww, a2, a2)                                  # [cw][cw] fp32 (symmetric)
+        t2 = ops.colsum(a2.view(m, cw), m, cw)
+        # parameter-sized algebra (O(cc * cw) elementwise in torch, the three small GEMMs through the f32 MFMA kernel)
+        sgy = (gmat * w2).sum(1)
+        dbeta = s
+        dgamma = st.invstd * (sgy - st.mean * s)
+        ca = gamma * st.invstd
+        cb = st.invstd * (ca * dgamma / m)
+        ccst = -ca * dbeta / m + st.mean * cb
+        bw = cb[:, None] * w2
+        ws2 = self._small_gemm(w2, s2)                                      # W S2   (S2 symmetric)
+        m2 = self._small_gemm(w2.t().contiguous(), bw.t().contiguous())     # W^T diag(B) W
+        bias = self._small_gemm(ccst[None, :].contiguous(), w2.t().contiguous())[0].contiguous() if cc % 32 == 0 else ccst @ w2
+        grads[u.bn.weight] = dgamma
+        grads[u.bn.bias] = dbeta
+        grads[u.conv.weight] = (ca[:, None] * gmat - cb[:, None] * ws2 + ccst[:, None] * t2[None, :]).view(cc, cw, 1, 1)
+        wa = ops.pack_crsk((ca[:, None] * w2).view(cc, cw, 1, 1).contiguous(), self.dtype)
+        wm = ops.pack_crsk((-m2).view(cw, cw, 1, 1).contiguous(), self.dtype)
+        da2, _ = ops.conv2d_dgrad_ex(d, g, wa, bias=bias)
+        if self.fuse_bn_bwd and ops.conv2d_dgrad_fuse_pays(dww):
+            return ops.conv2d_dgrad_ex(dww, a2, wm, dx=da2, accumulate=True, fuse_mode=2 if prev.relu else 0, prev_y=prev.y, prev_st=prev.st)
+        da2, _ = ops.conv2d_dgrad_ex(dww, a2, wm, dx=da2, accumulate=True)
+        return da2, None
+
     def _unit_bwd(self, u: _Unit, da, grads: dict, need_dx: bool, dx_into=None, relu_mask=None, res_grad=None, res_mask=None,
-                  raw_partial=None, prev: Optional[_Unit] = None):
+                  raw_partial=None, prev: Optional[_Unit] = None, prev_masked_store: bool = False):
         """BN bwd -> wgrad (+ dgrad).  relu_mask: bit mask that gates `da` (residual units: their own output mask;
         downsample branch: the block output's mask).  res_grad/res_mask: merge the identity-branch gradient
         res_grad * bit(res_mask) into dx inside the dgrad epilogue.  raw_partial: this unit's BN-backward sums
@@ -249,6 +314,11 @@ class ResNetEngine:
         if not need_dx:
             return None, None
         pk = self._pack(u.conv, need_t=True)
+        if prev is not None and prev_masked_store:
+            # store dx gated by prev's output ReLU mask + its channel sums: the form _unit3_bwd_folded consumes
+            dxm, _ = ops.conv2d_dgrad_ex(d, dy, pk.crsk, dx=dx_into, accumulate=dx_into is not None, res_grad=res_grad, res_mask=res_mask,
+                                         fuse_mode=4, prev_mask=prev.mask, want_sums=False)
+            return dxm, None
         if prev is not None and self.fuse_bn_bwd and ops.conv2d_dgrad_fuse_pays(d):
             # prev's incoming gradient = this dx; residual units gate it with their output mask, the others with
             # the mask recomputed from their own y
@@ -264,13 +334,17 @@ class ResNetEngine:
         grads: Dict[nn.Parameter, Tensor] = {}
         g = d_enc.contiguous() if d_enc.dtype == self.dtype else ops.cast(d_enc.contiguous(), self.dtype)
         dz = ops.avgpool_bwd(g, ctx["last_shape"])
-        dz_part = None  # BN-backward sums of the current block's last unit, when the next block's dgrad produced them
+        dz_part = None  # per-tile sums for the current block's last unit, when the next block's dgrad produced them
+        dz_masked = False  # dz was stored already gated by this block's output ReLU mask (dz_part = its channel sums)
         blocks = ctx["blocks"]
         for bi in range(len(blocks) - 1, -1, -1):
             saved, ds = blocks[bi]
             last = saved[-1]
             # out = relu(bn(conv(t)) + idn): the gradient of both branches is dz gated by the output's ReLU mask
-            dt_, part = self._unit_bwd(last, dz, grads, True, relu_mask=last.mask, raw_partial=dz_part, prev=saved[-2])
+            if dz_masked:
+                dt_, part = self._unit3_bwd_folded(last, dz, dz_part, grads, prev=saved[-2])
+            else:
+                dt_, part = self._unit_bwd(last, dz, grads, True, relu_mask=last.mask, raw_partial=dz_part, prev=saved[-2])
             for ui in range(len(saved) - 2, 0, -1):
                 dt_, part = self._unit_bwd(saved[ui], dt_, grads, True, raw_partial=part, prev=saved[ui - 1])
             first = saved[0]
@@ -279,11 +353,14 @@ class ResNetEngine:
                 # dgrad kernel then only visits the one parity class its taps can reach (1/4 of dx)
                 dx, _ = self._unit_bwd(first, dt_, grads, True, raw_partial=part)
                 dz, _ = self._unit_bwd(ds, dz, grads, True, relu_mask=last.mask, dx_into=dx)
-                dz_part = None
+                dz_part, dz_masked = None, False
             else:
-                # identity block: dz of the block below = conv1's dgrad + masked dz; that block's last unit is `prev`
+                # identity block: dz of the block below = conv1's dgrad + masked dz; that block's last unit is `below`
                 below = blocks[bi - 1][0][-1] if bi > 0 else None
-                dz, dz_part = self._unit_bwd(first, dt_, grads, True, res_grad=dz, res_mask=last.mask, raw_partial=part, prev=below)
+                fold = self.fold_bn3 and self._foldable(below)
+                dz, dz_part = self._unit_bwd(first, dt_, grads, True, res_grad=dz, res_mask=last.mask, raw_partial=part, prev=below,
+                                             prev_masked_store=fold)
+                dz_masked = fold
             saved.clear()
         # stem: the pooled gradient is gathered through the winner index inside the BatchNorm-backward passes
         u = ctx["stem"]

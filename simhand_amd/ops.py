@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BnBwdFuse, ConvDesc, NtxentParams, check
+from ._lib import BnBwdFuse, ConvDesc, DgradOpts, NtxentParams, check
 
 _DT = {torch.float32: _lib.SH_F32, torch.bfloat16: _lib.SH_BF16}
 
@@ -191,6 +191,38 @@ def conv2d_dgrad_fused(d: ConvDesc, dy, wt, prev_y, prev_st: Optional["BNState"]
     return dx, part
 
 
+def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accumulate: bool = False, res_grad=None, res_mask=None,
+                    bias=None, fuse_mode: Optional[int] = None, prev_y=None, prev_st: Optional["BNState"] = None, prev_mask=None,
+                    want_sums: bool = True):
+    """General data gradient (simhand_conv2d_dgrad_ex): optional accumulate / masked-residual merge, fp32 per-channel
+    bias, and epilogue fusion.  fuse_mode: None = none; 0 / 2 / 3 = BN-backward sums of the previous unit (no ReLU /
+    mask from prev_y*scale+shift / bit mask); 4 = store the gradient masked by prev_mask and emit its channel sums.
+    Returns (dx, partial or None)."""
+    lib = _lib_dev()
+    if dx is None:
+        dx = torch.empty(d.n, d.h, d.w, d.cin, dtype=dy.dtype, device=dy.device)
+    o = DgradOpts()
+    o.accumulate = 2 if res_grad is not None else int(accumulate)
+    o.res_grad = _ptr(res_grad)
+    o.res_mask = _ptr(res_mask)
+    o.bias = _ptr(bias)
+    part = None
+    if fuse_mode is not None:
+        if want_sums or fuse_mode != 4:  # mode 4 may store the masked gradient without emitting its sums
+            nblk = lib.simhand_conv2d_dgrad_stat_blocks(C.byref(d))
+            part = torch.empty(nblk, 2, d.cin, dtype=torch.float32, device=dy.device)
+        f = BnBwdFuse()
+        f.y = _ptr(prev_y)
+        f.mask = _ptr(prev_mask)
+        f.relu_mode = fuse_mode
+        f.scale = _ptr(prev_st.scale) if fuse_mode == 2 else None
+        f.shift = _ptr(prev_st.shift) if fuse_mode == 2 else None
+        f.partial = _ptr(part)
+        o.fuse = C.pointer(f)
+    check(lib.simhand_conv2d_dgrad_ex(C.byref(d), _ptr(dy), _ptr(wt), _ptr(dx), C.byref(o), _stream()), "conv2d_dgrad_ex")
+    return dx, part
+
+
 def conv2d_dgrad_fuse_pays(d: ConvDesc) -> bool:
     return bool(_lib_dev().simhand_conv2d_dgrad_fuse_pays(C.byref(d)))
 
@@ -203,6 +235,18 @@ def conv2d_wgrad(d: ConvDesc, x, dy) -> torch.Tensor:
     dw = torch.empty(d.cout, d.r * d.s * d.cin, dtype=torch.float32, device=x.device)
     check(lib.simhand_conv2d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nb, _stream()), "conv2d_wgrad")
     return dw
+
+
+def conv2d_wgrad_colsum(d: ConvDesc, x, dy):
+    """1x1 / stride-1 bf16: (fp32 KRSC gradient [cout][cin], per-channel sums of dy [cout] fp32) -- the sums ride along
+    with the dy tiles the kernel stages anyway."""
+    lib = _lib_dev()
+    nb = lib.simhand_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    dw = torch.empty(d.cout, d.r * d.s * d.cin, dtype=torch.float32, device=x.device)
+    part = torch.empty(lib.simhand_conv2d_wgrad_splits(C.byref(d)), 2, d.cout, dtype=torch.float32, device=x.device)
+    check(lib.simhand_conv2d_wgrad_colsum(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(part), _ptr(ws), nb, _stream()), "conv2d_wgrad_colsum")
+    return dw, bn_channel_sums(part, d.cout)
 
 
 def conv2d_wgrad_oihw(d: ConvDesc, x, dy, shape) -> torch.Tensor:
@@ -468,6 +512,21 @@ def avgpool_bwd(dy: torch.Tensor, in_shape) -> torch.Tensor:
     dx = torch.empty(n, h, w, c, dtype=dy.dtype, device=dy.device)
     check(lib.simhand_avgpool_bwd(_ptr(dy), _ptr(dx), n, h * w, c, dt(dy.dtype), _stream()), "avgpool_bwd")
     return dx
+
+
+def bn_channel_sums(raw_partial: torch.Tensor, c: int) -> torch.Tensor:
+    """Column 0 of the tile partials of a fused dgrad epilogue (sum over tiles, fp64 fold): [c] fp32."""
+    lib = _lib_dev()
+    dev = raw_partial.device
+    out = torch.empty(2, c, dtype=torch.float32, device=dev)
+    one = torch.ones(c, dtype=torch.float32, device=dev)
+    zero = torch.zeros(c, dtype=torch.float32, device=dev)
+    nb = lib.simhand_bn_bwd_finalize_raw_workspace_bytes(raw_partial.shape[0], c)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    # finalize_raw with mean = 0, invstd = 1: "dbeta" = sum of column 0, "dgamma" = sum of column 1
+    check(lib.simhand_bn_bwd_finalize_raw(_ptr(raw_partial), raw_partial.shape[0], c, _ptr(zero), _ptr(one), _ptr(out[1]), _ptr(out[0]),
+                                          _ptr(ws), nb, _stream()), "bn_bwd_finalize_raw")
+    return out[0]
 
 
 def colsum(x: torch.Tensor, m: int, c: int) -> torch.Tensor:
