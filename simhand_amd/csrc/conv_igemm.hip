@@ -1132,7 +1132,8 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
     SH_REQUIRE(fuse->relu_mode != 2 || (fuse->scale && fuse->shift), "conv2d_dgrad_fused: relu_mode 2 needs scale / shift");
     SH_REQUIRE(fuse->relu_mode < 3 || fuse->mask, "conv2d_dgrad_fused: relu_mode 3 / 4 needs the bit mask");
     // a stride-2 1x1 shortcut that accumulates skips the parity classes no tap reaches: their pixels would be missing
-    SH_REQUIRE(!(accumulate == 1 && d->stride == 2 && d->r == 1), "conv2d_dgrad_fused: not available for an accumulating stride-2 1x1");
+    SH_REQUIRE(fuse->partial == nullptr || !(accumulate == 1 && d->stride == 2 && d->r == 1),
+               "conv2d_dgrad_fused: sums are not available for an accumulating stride-2 1x1 (it skips the classes no tap reaches)");
     a.fy = fuse->y; a.fscale = fuse->scale; a.fshift = fuse->shift; a.fmask = fuse->mask; a.fmode = fuse->relu_mode;
     a.fpartial = fuse->partial;
   }

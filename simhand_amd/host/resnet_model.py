@@ -278,7 +278,9 @@ class ResNetEngine:
         ccst = -ca * dbeta / m + st.mean * cb
         bw = cb[:, None] * w2
         ws2 = self._small_gemm(w2, s2)                                      # W S2   (S2 symmetric)
-        m2 = self._small_gemm(w2.t().contiguous(), bw.t().contiguous())     # W^T diag(B) W
+        # W^T diag(B) W = "weight gradient" of a cc-pixel 1x1 conv (x = B W, dy = W): split-K over the cc rows fills the chip
+        dm2 = ops.conv_desc(cc, 1, 1, cw, cw, 1, 1, 1, 0, f32)
+        m2 = ops.conv2d_wgrad(dm2, bw.contiguous().view(cc, 1, 1, cw), w2.contiguous().view(cc, 1, 1, cw))
         bias = self._small_gemm(ccst[None, :].contiguous(), w2.t().contiguous())[0].contiguous() if cc % 32 == 0 else ccst @ w2
         grads[u.bn.weight] = dgamma
         grads[u.bn.bias] = dbeta
@@ -350,10 +352,14 @@ class ResNetEngine:
             first = saved[0]
             if ds is not None:
                 # main branch first (plain store), then the shortcut accumulates: for a stride-2 1x1 shortcut the
-                # dgrad kernel then only visits the one parity class its taps can reach (1/4 of dx)
-                dx, _ = self._unit_bwd(first, dt_, grads, True, raw_partial=part)
-                dz, _ = self._unit_bwd(ds, dz, grads, True, relu_mask=last.mask, dx_into=dx)
-                dz_part, dz_masked = None, False
+                # dgrad kernel then only visits the one parity class its taps can reach (1/4 of dx).  When the block
+                # below folds its bn3 backward both kernels store through its output mask (mask(mask(a) + b) = mask(a + b)).
+                below = blocks[bi - 1][0][-1] if bi > 0 else None
+                fold = self.fold_bn3 and self._foldable(below)
+                dx, _ = self._unit_bwd(first, dt_, grads, True, raw_partial=part, prev=below if fold else None, prev_masked_store=fold)
+                dz, _ = self._unit_bwd(ds, dz, grads, True, relu_mask=last.mask, dx_into=dx, prev=below if fold else None,
+                                       prev_masked_store=fold)
+                dz_part, dz_masked = None, fold
             else:
                 # identity block: dz of the block below = conv1's dgrad + masked dz; that block's last unit is `below`
                 below = blocks[bi - 1][0][-1] if bi > 0 else None
