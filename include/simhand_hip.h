@@ -311,6 +311,9 @@ int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const flo
  * and AdaptiveAvgPool2d(1) */
 int simhand_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int n, int h, int w, int c, int dtype, sh_stream_t stream);
 int simhand_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int n, int h, int w, int c, int dtype, sh_stream_t stream);
+/* y[n][ceil(h/2)][ceil(w/2)][c] = x[n][2i][2j][c]: the pixels a stride-2 1x1 convolution reads (dense operand for the folded
+ * BatchNorm backward of the strided shortcut) */
+int simhand_subsample2(const void* x, void* y, int n, int h, int w, int c, int dtype, sh_stream_t stream);
 int simhand_avgpool_fwd(const void* x, void* y, int n, int hw, int c, int dtype, sh_stream_t stream);
 int simhand_avgpool_bwd(const void* dy, void* dx, int n, int hw, int c, int dtype, sh_stream_t stream);
 

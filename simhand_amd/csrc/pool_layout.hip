@@ -98,6 +98,24 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// ---- every second pixel of every second row (the input a stride-2 1x1 convolution actually reads) -------------------
+template <typename T>
+__global__ __launch_bounds__(256) void subsample2_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c, int ho,
+                                                         int wo) {
+  constexpr int VE = Vec16<T>::N;
+  const int cvecs = c / VE;
+  const int64_t total = (int64_t)n * ho * wo * cvecs;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cvecs);
+    int64_t t = i / cvecs;
+    const int ow = (int)(t % wo);
+    t /= wo;
+    const int oh = (int)(t % ho);
+    const int img = (int)(t / ho);
+    *reinterpret_cast<uint4*>(y + i * VE) = *reinterpret_cast<const uint4*>(x + (((int64_t)img * h + 2 * oh) * w + 2 * ow) * c + cv * VE);
+  }
+}
+
 // ---- global average pool ---------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int hw, int c) {
@@ -373,6 +391,19 @@ int simhand_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int n
   SH_DISPATCH(dtype, (maxpool_bwd_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)dy, idx, (float*)dx, n, h, w, c, ho, wo)),
               (maxpool_bwd_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)dy, idx, (bf16_t*)dx, n, h, w, c, ho, wo)));
   return check_launch("maxpool_bwd");
+}
+
+int simhand_subsample2(const void* x, void* y, int n, int h, int w, int c, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(x && y, "subsample2: NULL pointer");
+  if (vec_ok(c, dtype, "subsample2")) return 1;
+  const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  const int64_t total = (int64_t)n * ho * wo * (c / ve);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_MISC, s, 0, 2.0 * (double)n * ho * wo * c * (dtype == SH_F32 ? 4 : 2));
+  SH_DISPATCH(dtype, (subsample2_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)x, (float*)y, n, h, w, c, ho, wo)),
+              (subsample2_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, n, h, w, c, ho, wo)));
+  return check_launch("subsample2");
 }
 
 int simhand_avgpool_fwd(const void* x, void* y, int n, int hw, int c, int dtype, sh_stream_t stream) {

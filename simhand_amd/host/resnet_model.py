@@ -242,34 +242,37 @@ class ResNetEngine:
         y, _ = ops.conv2d_fwd(d, a.contiguous().view(m, 1, 1, k), bt.contiguous(), want_stats=False)
         return y.view(m, n)
 
-    def _unit3_bwd_folded(self, u: _Unit, g, g_part, grads: dict, prev: _Unit):
-        """Backward of y = conv1x1(a2; W), out = relu(bn(y) + identity) WITHOUT the two BatchNorm-backward passes.
-        `g` is the incoming gradient already gated by the output ReLU mask (stored that way by the dgrad that produced
-        it); its channel sums come out of the G = g^T a2 kernel.  Because y = a2 W^T pixel by pixel, everything BN backward needs is
-        parameter-sized:  G = g^T a2 (the un-normalised weight gradient), s = sum g, S2 = a2^T a2, t2 = sum a2;
+    def _fold_1x1_bn(self, u: _Unit, g, a_in, grads: dict, s=None):
+        """Core of the folded BatchNorm backward of y = conv1x1(a_in; W), z = bn(y): a_in [n][ho][wo][cw] dense (already
+        subsampled for a strided shortcut), g [n][ho][wo][cc] the gradient w.r.t. z.  Because y = a_in W^T pixel by
+        pixel, everything BN backward needs is parameter-sized:  G = g^T a_in (the un-normalised weight gradient),
+        s = sum g, S2 = a_in^T a_in, t2 = sum a_in;
             sum g*y = rowdot(G, W);   dgamma = invstd (sum g*y - mean s);   dbeta = s
             dy = A g - B y + C  with  A = gamma invstd,  B = invstd A dgamma / M,  C = -A dbeta / M + mean B
             dW  = diag(A) G - diag(B) W S2 + C t2^T
-            da2 = g (diag(A) W) - a2 (W^T diag(B) W) + C W
-        so y and dy (4x wider than a2) are neither read nor written: 12.5 instead of 30 passes over a2-sized data.
-        Replaces (reference): autograd's native_batch_norm_backward + Conv2d backward for conv3 / bn3 of torchvision's
-        Bottleneck (src/models/resnet_model.py:13-58).  Returns (da2, raw partial sums for `prev` or None)."""
-        d = u.desc
-        cw, cc = d.cin, d.cout
-        m = d.n * d.ho * d.wo
-        a2, st = u.x, u.st
+            d a_in = g (diag(A) W) - a_in (W^T diag(B) W) + C W
+        so y and dy (cc wide) are neither read nor written.  Sets the three parameter gradients; returns the packed
+        dgrad weights of the two terms, the bias C W, and s.
+        Replaces (reference): autograd's native_batch_norm_backward + Conv2d backward of the 1x1 conv + BN pairs of
+        torchvision's Bottleneck (conv3 / bn3, downsample) -- src/models/resnet_model.py:13-58."""
+        n, ho, wo, cw = a_in.shape
+        cc = g.shape[-1]
+        m = n * ho * wo
+        st = u.st
         f32 = torch.float32
+        d1 = ops.conv_desc(n, ho, wo, cw, cc, 1, 1, 1, 0, self.dtype)
         w2 = u.conv.weight.detach().to(f32).view(cc, cw)
         gamma = u.bn.weight.detach().to(f32)
-        if self.dtype == torch.bfloat16:
-            gmat, s = ops.conv2d_wgrad_colsum(d, a2, g)                     # [cc][cw] fp32, [cc]: sum g rides along
+        if s is None and self.dtype == torch.bfloat16:
+            gmat, s = ops.conv2d_wgrad_colsum(d1, a_in, g)                  # [cc][cw] fp32, [cc]: sum g rides along
         else:
-            gmat = ops.conv2d_wgrad(d, a2, g)
-            s = ops.colsum(g.view(m, cc), m, cc)
-        dww = ops.conv_desc(d.n, d.h, d.w, cw, cw, 1, 1, 1, 0, self.dtype)
-        s2 = ops.conv2d_wgrad(dww, a2, a2)                                  # [cw][cw] fp32 (symmetric)
-        t2 = ops.colsum(a2.view(m, cw), m, cw)
-        # parameter-sized algebra (O(cc * cw) elementwise in torch, the three small GEMMs through the f32 MFMA kernel)
+            gmat = ops.conv2d_wgrad(d1, a_in, g)
+            if s is None:
+                s = ops.colsum(g.view(m, cc), m, cc)
+        dww = ops.conv_desc(n, ho, wo, cw, cw, 1, 1, 1, 0, self.dtype)
+        s2 = ops.conv2d_wgrad(dww, a_in, a_in)                              # [cw][cw] fp32 (symmetric)
+        t2 = ops.colsum(a_in.view(m, cw), m, cw)
+        # parameter-sized algebra: O(cc * cw) elementwise in torch, the small GEMMs through the exact-f32 MFMA kernels
         sgy = (gmat * w2).sum(1)
         dbeta = s
         dgamma = st.invstd * (sgy - st.mean * s)
@@ -281,17 +284,42 @@ class ResNetEngine:
         # W^T diag(B) W = "weight gradient" of a cc-pixel 1x1 conv (x = B W, dy = W): split-K over the cc rows fills the chip
         dm2 = ops.conv_desc(cc, 1, 1, cw, cw, 1, 1, 1, 0, f32)
         m2 = ops.conv2d_wgrad(dm2, bw.contiguous().view(cc, 1, 1, cw), w2.contiguous().view(cc, 1, 1, cw))
-        bias = self._small_gemm(ccst[None, :].contiguous(), w2.t().contiguous())[0].contiguous() if cc % 32 == 0 else ccst @ w2
+        bias = self._small_gemm(ccst[None, :].contiguous(), w2.t().contiguous())[0].contiguous()
         grads[u.bn.weight] = dgamma
         grads[u.bn.bias] = dbeta
         grads[u.conv.weight] = (ca[:, None] * gmat - cb[:, None] * ws2 + ccst[:, None] * t2[None, :]).view(cc, cw, 1, 1)
         wa = ops.pack_crsk((ca[:, None] * w2).view(cc, cw, 1, 1).contiguous(), self.dtype)
         wm = ops.pack_crsk((-m2).view(cw, cw, 1, 1).contiguous(), self.dtype)
+        return wa, wm, bias, s
+
+    def _unit3_bwd_folded(self, u: _Unit, g, grads: dict, prev: _Unit):
+        """conv3 + bn3 of a Bottleneck (out = relu(bn(conv1x1(a2)) + identity)) without the two BatchNorm-backward
+        passes: `g` is the incoming gradient already gated by the output ReLU mask (stored that way by the dgrad that
+        produced it).  12.5 instead of 30 passes over a2-sized data.  Returns (da2, raw partial sums for `prev` or None, s)."""
+        d = u.desc
+        a2 = u.x
+        wa, wm, bias, s = self._fold_1x1_bn(u, g, a2, grads)
+        dww = ops.conv_desc(d.n, d.h, d.w, d.cin, d.cin, 1, 1, 1, 0, self.dtype)
         da2, _ = ops.conv2d_dgrad_ex(d, g, wa, bias=bias)
         if self.fuse_bn_bwd and ops.conv2d_dgrad_fuse_pays(dww):
-            return ops.conv2d_dgrad_ex(dww, a2, wm, dx=da2, accumulate=True, fuse_mode=2 if prev.relu else 0, prev_y=prev.y, prev_st=prev.st)
+            da2, part = ops.conv2d_dgrad_ex(dww, a2, wm, dx=da2, accumulate=True, fuse_mode=2 if prev.relu else 0, prev_y=prev.y,
+                                            prev_st=prev.st)
+            return da2, part, s
         da2, _ = ops.conv2d_dgrad_ex(dww, a2, wm, dx=da2, accumulate=True)
-        return da2, None
+        return da2, None, s
+
+    def _ds_bwd_folded(self, u: _Unit, g, s, grads: dict, dx, below: Optional[_Unit], masked_store: bool):
+        """Shortcut conv1x1(/stride) + BN of a stage's first block, folded like conv3 + bn3: its incoming gradient is the
+        same masked g (and the same s) as the block's bn3.  Both terms of the input gradient accumulate into `dx` (the
+        main branch's input gradient); for a stride-2 shortcut they only touch the even pixels -- so does the bias."""
+        d = u.desc
+        x_in = u.x if d.stride == 1 else ops.subsample2(u.x)
+        wa, wm, bias, _ = self._fold_1x1_bn(u, g, x_in, grads, s=s)
+        dterm = ops.conv_desc(d.n, d.h, d.w, d.cin, d.cin, 1, 1, d.stride, 0, self.dtype)
+        kw = dict(fuse_mode=4, prev_mask=below.mask, want_sums=False) if masked_store else {}
+        ops.conv2d_dgrad_ex(d, g, wa, dx=dx, accumulate=True, bias=bias, **kw)
+        ops.conv2d_dgrad_ex(dterm, x_in, wm, dx=dx, accumulate=True, **kw)
+        return dx
 
     def _unit_bwd(self, u: _Unit, da, grads: dict, need_dx: bool, dx_into=None, relu_mask=None, res_grad=None, res_mask=None,
                   raw_partial=None, prev: Optional[_Unit] = None, prev_masked_store: bool = False):
@@ -343,8 +371,9 @@ class ResNetEngine:
             saved, ds = blocks[bi]
             last = saved[-1]
             # out = relu(bn(conv(t)) + idn): the gradient of both branches is dz gated by the output's ReLU mask
+            s_g = None
             if dz_masked:
-                dt_, part = self._unit3_bwd_folded(last, dz, dz_part, grads, prev=saved[-2])
+                dt_, part, s_g = self._unit3_bwd_folded(last, dz, grads, prev=saved[-2])
             else:
                 dt_, part = self._unit_bwd(last, dz, grads, True, relu_mask=last.mask, raw_partial=dz_part, prev=saved[-2])
             for ui in range(len(saved) - 2, 0, -1):
@@ -353,12 +382,15 @@ class ResNetEngine:
             if ds is not None:
                 # main branch first (plain store), then the shortcut accumulates: for a stride-2 1x1 shortcut the
                 # dgrad kernel then only visits the one parity class its taps can reach (1/4 of dx).  When the block
-                # below folds its bn3 backward both kernels store through its output mask (mask(mask(a) + b) = mask(a + b)).
+                # below folds its bn3 backward every kernel stores through its output mask (mask(mask(a) + b) = mask(a + b)).
                 below = blocks[bi - 1][0][-1] if bi > 0 else None
                 fold = self.fold_bn3 and self._foldable(below)
                 dx, _ = self._unit_bwd(first, dt_, grads, True, raw_partial=part, prev=below if fold else None, prev_masked_store=fold)
-                dz, _ = self._unit_bwd(ds, dz, grads, True, relu_mask=last.mask, dx_into=dx, prev=below if fold else None,
-                                       prev_masked_store=fold)
+                if dz_masked and self.fold_bn3 and ds.conv.in_channels % 64 == 0:
+                    dz = self._ds_bwd_folded(ds, dz, s_g, grads, dx, below, fold)
+                else:
+                    dz, _ = self._unit_bwd(ds, dz, grads, True, relu_mask=last.mask, dx_into=dx, prev=below if fold else None,
+                                           prev_masked_store=fold)
                 dz_part, dz_masked = None, fold
             else:
                 # identity block: dz of the block below = conv1's dgrad + masked dz; that block's last unit is `below`

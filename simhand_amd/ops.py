@@ -498,6 +498,15 @@ def maxpool_bwd(dy: torch.Tensor, idx: torch.Tensor, in_shape) -> torch.Tensor:
     return dx
 
 
+def subsample2(x: torch.Tensor) -> torch.Tensor:
+    """x[:, ::2, ::2, :] as a dense tensor (the pixels a stride-2 1x1 convolution reads)."""
+    lib = _lib_dev()
+    n, h, w, c = x.shape
+    y = torch.empty(n, (h + 1) // 2, (w + 1) // 2, c, dtype=x.dtype, device=x.device)
+    check(lib.simhand_subsample2(_ptr(x), _ptr(y), n, h, w, c, dt(x.dtype), _stream()), "subsample2")
+    return y
+
+
 def avgpool_fwd(x: torch.Tensor) -> torch.Tensor:
     lib = _lib_dev()
     n, h, w, c = x.shape
