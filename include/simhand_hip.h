@@ -179,6 +179,15 @@ int simhand_conv2d_dgrad(const sh_conv_desc* d, const void* dy, const void* wt, 
  * res_mask = the block output's ReLU bit mask from simhand_bn_apply; both laid out like dx). */
 int simhand_conv2d_dgrad_masked_residual(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, const void* res_grad,
                                          const uint8_t* res_mask, sh_stream_t stream);
+/* bf16 forward with the whole BatchNorm + residual + ReLU tail in the epilogue:
+ *   out = act(conv(x) * scale[c] + shift[c] (+ residual)),  relu_mask (optional) = its 1-bit ReLU mask [pixel][cout/8]
+ * for statistics that are known BEFORE the convolution runs: eval mode, or train mode for a 1x1 convolution whose
+ * batch statistics follow from the Gram matrix of its input (mean_c = W_c . sum(x) / M, E[y^2]_c = W_c^T (x^T x) W_c / M).
+ * The raw convolution output is never stored.  Replaces (reference): conv3 -> bn3 -> (+identity) -> relu and the
+ * downsample conv -> bn of torchvision's Bottleneck (src/models/resnet_model.py:13-58). */
+int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
+                             const void* residual, int relu, void* out, uint8_t* relu_mask, sh_stream_t stream);
+
 /* Data gradient with the BatchNorm-backward partial sums of the PREVIOUS conv+BN unit fused into the epilogue.
  * The dx this call stores is that unit's incoming gradient da (its raw conv output y has dx's layout), so instead
  * of a separate simhand_bn_bwd_partial pass (reads da and y) the epilogue reads y once and emits per tile
@@ -286,6 +295,8 @@ int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const f
                            const float* scale, const float* shift, int relu, int64_t m, int c, int dtype, float* partial,
                            sh_stream_t stream);
 int simhand_bn_bwd_finalize(const float* partial, int nblk, int c, float* dgamma, float* dbeta, sh_stream_t stream);
+/* out = x gated by the ReLU bit mask simhand_bn_apply / simhand_conv2d_fwd_bnact wrote ([m][c/VE] bytes) */
+int simhand_apply_relu_bitmask(const void* x, const uint8_t* mask, void* out, int64_t m, int c, int dtype, sh_stream_t stream);
 /* Stem block fused: out, idx = MaxPool(3, 2, 1)(ReLU(y*scale + shift)) without storing the activation in between, and
  * its backward: the BatchNorm-backward passes gather the pooled gradient dz through idx (partial: simhand_bn_stat_blocks
  * (n*h*w, c) blocks of [2][c] sums of g and g*xhat -> simhand_bn_bwd_finalize; apply: dy).  y is [n][h][w][c].

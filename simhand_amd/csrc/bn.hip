@@ -567,6 +567,21 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const T* __restr
   }
 }
 
+// out = x gated by a ReLU bit mask [row][c / VE] (bit e of byte (row, cv) = channel cv*VE + e)
+template <typename T>
+__global__ __launch_bounds__(256) void apply_bitmask_kernel(const T* __restrict__ x, const uint8_t* __restrict__ mask, T* __restrict__ out,
+                                                            int64_t nvec) {
+  constexpr int VE = Vec16<T>::N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    float v[VE];
+    Vec16<T>::load(x + i * VE, v);
+    const unsigned bits = mask[i];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] = (bits >> e) & 1u ? v[e] : 0.f;
+    Vec16<T>::store(out + i * VE, v);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t m, int c, int rows_per_blk,
                                                      float* __restrict__ partial) {
@@ -807,6 +822,18 @@ int simhand_maxpool_bn_bwd_apply(const void* dz, const uint8_t* idx, const void*
   else
     pool_bn_bwd_apply_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dz, idx, (const bf16_t*)y, mean, invstd, gamma, dgamma, dbeta, scale, shift, (bf16_t*)dy, n, h, w, c, ho, wo, inv_m, dw_, dh_);
   return check_launch("maxpool_bn_bwd_apply");
+}
+
+int simhand_apply_relu_bitmask(const void* x, const uint8_t* mask, void* out, int64_t m, int c, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(x && mask && out, "apply_relu_bitmask: NULL pointer");
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  SH_REQUIRE(c % ve == 0, "apply_relu_bitmask: c=%d not a multiple of %d", c, ve);
+  const int64_t nvec = m * (c / ve);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_BN, s, 0, 2.0 * (double)m * c * (dtype == SH_F32 ? 4 : 2));
+  if (dtype == SH_F32) apply_bitmask_kernel<float><<<stream_grid(nvec), 256, 0, s>>>((const float*)x, mask, (float*)out, nvec);
+  else apply_bitmask_kernel<bf16_t><<<stream_grid(nvec), 256, 0, s>>>((const bf16_t*)x, mask, (bf16_t*)out, nvec);
+  return check_launch("apply_relu_bitmask");
 }
 
 int simhand_colsum(const void* x, int64_t m, int c, int dtype, float* partial, float* out, sh_stream_t stream) {

@@ -22,6 +22,12 @@ struct Gemm1x1Args {
   int fmode;
   float* fpartial;    // [ceil(M / rows_per_block)][2][N]; null = off
   const float* bias;  // dgrad: per output channel, added to the fp32 result (null = none)
+  // forward: out = act(acc * ep_scale[c] + ep_shift[c] (+ ep_res)), ReLU bit mask out (see IgemmArgs); ep_scale null = off
+  const float* ep_scale;
+  const float* ep_shift;
+  const bf16_t* ep_res;
+  unsigned char* ep_mask;
+  int ep_relu;
 };
 
 bool gemm1x1_supported(int k, int n);

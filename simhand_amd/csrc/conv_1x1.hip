@@ -184,13 +184,37 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
             lo[0] += b0.x; lo[1] += b0.y; lo[2] += b0.z; lo[3] += b0.w;
             hi[0] += b1.x; hi[1] += b1.y; hi[2] += b1.z; hi[3] += b1.w;
           }
+          const int ch = n0 + j * 32 + g * 8;
+          bf16_t* dst = p.out + row * p.N + ch;
+          if (!DGRAD && p.ep_scale != nullptr) {
+            // BatchNorm (statistics known up front) + residual + ReLU on the fp32 accumulators; ReLU bit mask out
+            const float4 s0 = *reinterpret_cast<const float4*>(p.ep_scale + ch), s1 = *reinterpret_cast<const float4*>(p.ep_scale + ch + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(p.ep_shift + ch), h1 = *reinterpret_cast<const float4*>(p.ep_shift + ch + 4);
+            float o[8] = {lo[0] * s0.x + h0.x, lo[1] * s0.y + h0.y, lo[2] * s0.z + h0.z, lo[3] * s0.w + h0.w,
+                          hi[0] * s1.x + h1.x, hi[1] * s1.y + h1.y, hi[2] * s1.z + h1.z, hi[3] * s1.w + h1.w};
+            if (p.ep_res != nullptr) {
+              float q[8];
+              Vec16<bf16_t>::load(p.ep_res + row * p.N + ch, q);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] += q[e];
+            }
+            if (p.ep_relu) {
+              unsigned bits = 0;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                bits |= (o[e] > 0.f ? 1u : 0u) << e;
+                o[e] = o[e] > 0.f ? o[e] : 0.f;
+              }
+              if (p.ep_mask != nullptr) p.ep_mask[row * (p.N >> 3) + (ch >> 3)] = (unsigned char)bits;
+            }
+            Vec16<bf16_t>::store(dst, o);
+            return make_uint4(0, 0, 0, 0);
+          }
           uint4 v;
           v.x = pack_bf16x2(lo[0], lo[1]);
           v.y = pack_bf16x2(lo[2], lo[3]);
           v.z = pack_bf16x2(hi[0], hi[1]);
           v.w = pack_bf16x2(hi[2], hi[3]);
-          const int ch = n0 + j * 32 + g * 8;
-          bf16_t* dst = p.out + row * p.N + ch;
           if (DGRAD && p.accumulate == 2) {
             const uint4 o = *reinterpret_cast<const uint4*>(p.res_grad + row * p.N + ch);
             const unsigned bits = p.res_mask[row * (p.N >> 3) + (ch >> 3)];

@@ -57,6 +57,14 @@ struct IgemmArgs {
   int fmode;                   // 4: the STORED gradient is masked (out = result * bit), sums of it only (fy unused)
   float* fpartial;             // [m_tiles * classes][2][Ng]: sum g, sum g * y; null = no fusion
   const float* bias;           // dgrad: per destination channel, added to the fp32 result before any accumulate / rounding
+  // forward only (bf16): epilogue out = act(acc * ep_scale[c] + ep_shift[c] (+ ep_res)) -- BatchNorm with statistics known
+  // BEFORE the convolution runs (eval mode, or train mode with the 1x1 Gram-matrix statistics), residual add, ReLU and its
+  // 1-bit mask [pixel][Ng / 8]; the raw convolution output is never stored.  ep_scale null = off
+  const float* ep_scale;
+  const float* ep_shift;
+  const void* ep_res;
+  unsigned char* ep_mask;
+  int ep_relu;
 };
 
 template <typename T> struct Mma;
@@ -486,7 +494,49 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
       *reinterpret_cast<uint4*>(dst) = v;
       return v;
     };
-    if (!DGRAD || p.fpartial == nullptr) {
+    if (!DGRAD && sizeof(T) == 2 && p.ep_scale != nullptr) {
+      // BatchNorm (statistics known up front) + residual + ReLU applied to the fp32 accumulators; ReLU bit mask out
+      const bf16_t* __restrict__ res = reinterpret_cast<const bf16_t*>(p.ep_res);
+      bf16_t* __restrict__ outb = reinterpret_cast<bf16_t*>(p.out);
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int ch = ch0 + j * 32;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sc[e] = p.ep_scale[ch + e];
+          sh[e] = p.ep_shift[ch + e];
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const long long pix = pixel_of(mi);
+          if (pix < 0) continue;
+          const f32x4 lo = acc[mi][(2 * j) % NI], hi = acc[mi][(2 * j + 1) % NI];
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = lo[e] * sc[e] + sh[e];
+            o[4 + e] = hi[e] * sc[4 + e] + sh[4 + e];
+          }
+          if (res != nullptr) {
+            float q[8];
+            Vec16<bf16_t>::load(res + pix * p.Ng + ch, q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += q[e];
+          }
+          if (p.ep_relu) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              bits |= (o[e] > 0.f ? 1u : 0u) << e;
+              o[e] = o[e] > 0.f ? o[e] : 0.f;
+            }
+            if (p.ep_mask != nullptr) p.ep_mask[pix * (p.Ng / 8) + ch / 8] = (unsigned char)bits;
+          }
+          Vec16<bf16_t>::store(outb + pix * p.Ng + ch, o);
+        }
+      }
+    } else if (!DGRAD || p.fpartial == nullptr) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         const long long pix = pixel_of(mi);
@@ -869,7 +919,49 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
 #endif
       return v;
     };
-    if (!DGRAD || p.fpartial == nullptr) {
+    if (!DGRAD && sizeof(T) == 2 && p.ep_scale != nullptr) {
+      // BatchNorm (statistics known up front) + residual + ReLU applied to the fp32 accumulators; ReLU bit mask out
+      const bf16_t* __restrict__ res = reinterpret_cast<const bf16_t*>(p.ep_res);
+      bf16_t* __restrict__ outb = reinterpret_cast<bf16_t*>(p.out);
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int ch = ch0 + j * 32;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sc[e] = p.ep_scale[ch + e];
+          sh[e] = p.ep_shift[ch + e];
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const long long pix = pixel_of(mi);
+          if (pix < 0) continue;
+          const f32x4 lo = acc[mi][(2 * j) % NI], hi = acc[mi][(2 * j + 1) % NI];
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = lo[e] * sc[e] + sh[e];
+            o[4 + e] = hi[e] * sc[4 + e] + sh[4 + e];
+          }
+          if (res != nullptr) {
+            float q[8];
+            Vec16<bf16_t>::load(res + pix * p.Ng + ch, q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += q[e];
+          }
+          if (p.ep_relu) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              bits |= (o[e] > 0.f ? 1u : 0u) << e;
+              o[e] = o[e] > 0.f ? o[e] : 0.f;
+            }
+            if (p.ep_mask != nullptr) p.ep_mask[pix * (p.Ng / 8) + ch / 8] = (unsigned char)bits;
+          }
+          Vec16<bf16_t>::store(outb + pix * p.Ng + ch, o);
+        }
+      }
+    } else if (!DGRAD || p.fpartial == nullptr) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const long long pix = pixel_of(mi);
@@ -1035,6 +1127,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
   a.classes = 1; a.Hq = a.Wq = 0;
   a.stem_hp = a.stem_wp = 0;
   a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr; a.bias = nullptr;
+  a.ep_scale = a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_mask = nullptr; a.ep_relu = 0;
   SH_REQUIRE(a.Mg < (1ll << 31) - 256, "conv2d_fwd: %lld output pixels exceed the 2^31 index range", a.Mg);
   a.div_hw = make_fastdiv((unsigned)(a.Hd * a.Wd));
   a.div_w = make_fastdiv((unsigned)a.Wd);
@@ -1049,11 +1142,50 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
     g.a = (const bf16_t*)x; g.w = (const bf16_t*)w; g.out = (bf16_t*)y; g.bn_partial = bn_partial;
     g.M = a.Mg; g.N = d->cout; g.accumulate = 0; g.res_grad = nullptr; g.res_mask = nullptr;
     g.fy = nullptr; g.fscale = g.fshift = nullptr; g.fmask = nullptr; g.fmode = 0; g.fpartial = nullptr; g.bias = nullptr;
+    g.ep_scale = g.ep_shift = nullptr; g.ep_res = nullptr; g.ep_mask = nullptr; g.ep_relu = 0;
     launch_gemm1x1(g, d->cin, false, (hipStream_t)stream);
     return check_launch("conv2d_fwd (1x1)");
   }
   if (use_256(d->dtype, a.Ng, a.Ca, d->r * d->s, a.Mg)) return launch_igemm256<false>(a, (hipStream_t)stream);
   return d->dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
+}
+
+int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
+                             const void* residual, int relu, void* out, uint8_t* relu_mask, sh_stream_t stream) {
+  if (check_desc(d, "conv2d_fwd_bnact")) return 1;
+  SH_REQUIRE(x && w && out && scale && shift, "conv2d_fwd_bnact: NULL pointer");
+  SH_REQUIRE(d->dtype == SH_BF16, "conv2d_fwd_bnact: bf16 only");
+  SH_REQUIRE(!relu_mask || relu, "conv2d_fwd_bnact: a ReLU mask is only produced with relu != 0");
+  IgemmArgs a;
+  a.a = x; a.w = w; a.out = out; a.bn_partial = nullptr;
+  a.Mg = (long long)d->n * d->ho * d->wo;
+  a.Ng = d->cout; a.Ca = d->cin;
+  a.R = d->r; a.S = d->s; a.stride = d->stride; a.pad = d->pad;
+  a.Hd = d->ho; a.Wd = d->wo; a.Hs = d->h; a.Ws = d->w;
+  a.accumulate = 0; a.res_grad = nullptr; a.res_mask = nullptr;
+  a.classes = 1; a.Hq = a.Wq = 0;
+  a.stem_hp = a.stem_wp = 0;
+  a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr; a.bias = nullptr;
+  a.ep_scale = scale; a.ep_shift = shift; a.ep_res = residual; a.ep_mask = relu_mask; a.ep_relu = relu;
+  SH_REQUIRE(a.Mg < (1ll << 31) - 256, "conv2d_fwd_bnact: %lld output pixels exceed the 2^31 index range", a.Mg);
+  a.div_hw = make_fastdiv((unsigned)(a.Hd * a.Wd));
+  a.div_w = make_fastdiv((unsigned)a.Wd);
+  a.m_tiles = ceil_div(a.Mg, 128);
+  a.n_tiles = a.Ng % 128 == 0 ? a.Ng / 128 : a.Ng / 64;
+  const double flops = 2.0 * (double)a.Mg * d->cout * d->cin * d->r * d->s;
+  const double bytes = 2.0 * ((double)d->n * d->h * d->w * d->cin + (double)a.Mg * d->cout * (residual ? 2 : 1) + (double)d->cout * d->cin * d->r * d->s);
+  ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, flops, bytes);
+  if (use_1x1(d, d->cin, d->cout)) {
+    Gemm1x1Args g;
+    g.a = (const bf16_t*)x; g.w = (const bf16_t*)w; g.out = (bf16_t*)out; g.bn_partial = nullptr;
+    g.M = a.Mg; g.N = d->cout; g.accumulate = 0; g.res_grad = nullptr; g.res_mask = nullptr;
+    g.fy = nullptr; g.fscale = g.fshift = nullptr; g.fmask = nullptr; g.fmode = 0; g.fpartial = nullptr; g.bias = nullptr;
+    g.ep_scale = scale; g.ep_shift = shift; g.ep_res = (const bf16_t*)residual; g.ep_mask = relu_mask; g.ep_relu = relu;
+    launch_gemm1x1(g, d->cin, false, (hipStream_t)stream);
+    return check_launch("conv2d_fwd_bnact (1x1)");
+  }
+  if (use_256(d->dtype, a.Ng, a.Ca, d->r * d->s, a.Mg)) return launch_igemm256<false>(a, (hipStream_t)stream);
+  return launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 
 // ---- direct 7x7 / stride 2 / pad 3 / 3 -> 64 stem --------------------------------------------------------------------
@@ -1088,6 +1220,7 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
   a.classes = 1; a.Hq = a.Wq = 0;
   a.stem_hp = hp; a.stem_wp = wp;
   a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr; a.bias = nullptr;
+  a.ep_scale = a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_mask = nullptr; a.ep_relu = 0;
   SH_REQUIRE(a.Mg < (1ll << 31) - 256, "stem_conv_fwd: %lld output pixels exceed the 2^31 index range", a.Mg);
   SH_REQUIRE((long long)n * hp * wp * 4 < (1ll << 40), "stem_conv_fwd: input too large");
   a.div_hw = make_fastdiv((unsigned)(ho * wo));
@@ -1125,6 +1258,7 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   a.accumulate = accumulate; a.res_grad = res_grad; a.res_mask = res_mask;
   a.stem_hp = a.stem_wp = 0;
   a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr; a.bias = nullptr;
+  a.ep_scale = a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_mask = nullptr; a.ep_relu = 0;
   if (fuse != nullptr) {
     SH_REQUIRE(fuse->partial || fuse->relu_mode == 4, "conv2d_dgrad_fused: NULL partial (only relu_mode 4 may omit the sums)");
     SH_REQUIRE(fuse->relu_mode == 0 || (fuse->relu_mode >= 2 && fuse->relu_mode <= 4), "conv2d_dgrad_fused: relu_mode %d", fuse->relu_mode);

@@ -123,7 +123,7 @@ class _Packed:
 
 class _Unit:
     """Saved tensors of one conv+BN unit for the backward pass."""
-    __slots__ = ("conv", "bn", "desc", "x", "y", "a", "st", "relu", "stem", "has_res", "mask")
+    __slots__ = ("conv", "bn", "desc", "x", "y", "a", "st", "relu", "stem", "has_res", "mask", "x_in", "s2", "t2", "ws2")
 
 
 class ResNetEngine:
@@ -135,6 +135,8 @@ class ResNetEngine:
         self.fuse_bn_bwd = True
         # bottleneck conv3 + bn3: BatchNorm backward folded into the 1x1 conv's own gradients (_unit3_bwd_folded)
         self.fold_bn3 = True
+        # the folds need every block's incoming gradient in masked form, which only the all-1x1 tails of Bottleneck nets give
+        self._bottleneck = all(isinstance(b, Bottleneck) for li in (4, 5, 6, 7) for b in features[li])
 
     # -- weights -------------------------------------------------------------
     def _pack(self, conv: nn.Conv2d, need_t: bool, stem: bool = False) -> _Packed:
@@ -161,7 +163,51 @@ class ResNetEngine:
                                    bn.num_batches_tracked, None, bn.eps, bn.momentum)
         return ops.bn_eval_state(c, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
 
+    def _fold_fwd_ok(self, conv, relu, residual) -> bool:
+        """1x1 convolutions with a narrow input whose BatchNorm statistics follow from the input's Gram matrix: a
+        Bottleneck's conv3 (+ identity + ReLU) and its shortcut conv (no ReLU)."""
+        return (self.fold_bn3 and self._bottleneck and self.dtype == torch.bfloat16 and conv.kernel_size == (1, 1) and conv.padding == (0, 0)
+                and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and conv.out_channels >= 2 * conv.in_channels
+                and (residual is not None or not relu))
+
+    def _conv_bn_folded(self, conv, bn, x, relu, residual, training, save: Optional[list]):
+        """y = conv1x1(x), out = act(bn(y) (+ residual)) in ONE pass over the wide tensor: train-mode batch statistics of y
+        come from the Gram matrix of the (narrow) input -- mean_c = W_c . sum(x) / M, E[y^2]_c = W_c^T (x^T x) W_c / M --
+        so they are known before the convolution runs and BN + residual + ReLU live in its epilogue; y itself is never
+        stored (the folded backward does not need it either)."""
+        n, h, w, cin = x.shape
+        s = conv.stride[0]
+        cout = conv.out_channels
+        d = ops.conv_desc(n, h, w, cin, cout, 1, 1, s, 0, self.dtype)
+        pk = self._pack(conv, need_t=False)
+        x_in = x if s == 1 else ops.subsample2(x)
+        m = n * d.ho * d.wo
+        s2 = t2 = ws2 = None
+        if training:
+            dww = ops.conv_desc(n, d.ho, d.wo, cin, cin, 1, 1, 1, 0, self.dtype)
+            s2, t2 = ops.conv2d_wgrad_colsum(dww, x_in, x_in)                # x^T x (fp32) and sum x ride on one kernel
+            w_r = conv.weight.detach().to(self.dtype).to(torch.float32).view(cout, cin)  # the weights the MFMAs see
+            ws2 = self._small_gemm(w_r, s2)                                   # [cout][cin] = W S2
+            part = torch.stack((w_r @ t2, (ws2 * w_r).sum(1))).view(1, 2, cout).contiguous()  # (sum y, sum y^2) per channel
+            st = ops.bn_finalize(part, m, cout, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                 bn.num_batches_tracked, None, bn.eps, bn.momentum)
+        else:
+            st = ops.bn_eval_state(cout, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+        want_mask = save is not None and relu and residual is not None
+        res = ops.conv2d_fwd_bnact(d, x, pk.krsc, st, relu, residual, want_mask=want_mask)
+        a, mask = res if want_mask else (res, None)
+        if save is not None:
+            u = _Unit()
+            u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv, bn, d, x, None, a, st, relu, False
+            u.has_res = residual is not None
+            u.mask = mask
+            u.x_in, u.s2, u.t2, u.ws2 = x_in, s2, t2, ws2
+            save.append(u)
+        return a
+
     def _conv_bn(self, conv, bn, x, relu, residual, training, save: Optional[list], need_dgrad=True):
+        if self._fold_fwd_ok(conv, relu, residual):
+            return self._conv_bn_folded(conv, bn, x, relu, residual, training, save)
         n, h, w, cin = x.shape
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         d = ops.conv_desc(n, h, w, cin, conv.out_channels, k, k, s, p, self.dtype)
@@ -179,6 +225,7 @@ class ResNetEngine:
             u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv, bn, d, x, y, a, st, relu, False
             u.has_res = residual is not None
             u.mask = mask
+            u.x_in = u.s2 = u.t2 = u.ws2 = None
             save.append(u)
         return a
 
@@ -203,6 +250,7 @@ class ResNetEngine:
             u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv1, bn1, d, xp, y, None, st, True, True
             u.has_res = False
             u.mask = None
+            u.x_in = u.s2 = u.t2 = u.ws2 = None
             ctx["stem"] = u
             ctx["pool_idx"] = idx
         for li in (4, 5, 6, 7):
@@ -261,7 +309,7 @@ class ResNetEngine:
         st = u.st
         f32 = torch.float32
         d1 = ops.conv_desc(n, ho, wo, cw, cc, 1, 1, 1, 0, self.dtype)
-        w2 = u.conv.weight.detach().to(f32).view(cc, cw)
+        w2 = u.conv.weight.detach().to(self.dtype).to(f32).view(cc, cw)     # the weights the forward MFMAs saw
         gamma = u.bn.weight.detach().to(f32)
         if s is None and self.dtype == torch.bfloat16:
             gmat, s = ops.conv2d_wgrad_colsum(d1, a_in, g)                  # [cc][cw] fp32, [cc]: sum g rides along
@@ -269,9 +317,12 @@ class ResNetEngine:
             gmat = ops.conv2d_wgrad(d1, a_in, g)
             if s is None:
                 s = ops.colsum(g.view(m, cc), m, cc)
-        dww = ops.conv_desc(n, ho, wo, cw, cw, 1, 1, 1, 0, self.dtype)
-        s2 = ops.conv2d_wgrad(dww, a_in, a_in)                              # [cw][cw] fp32 (symmetric)
-        t2 = ops.colsum(a_in.view(m, cw), m, cw)
+        if u.s2 is not None:                                                # Gram products saved by the folded forward
+            s2, t2 = u.s2, u.t2
+        else:
+            dww = ops.conv_desc(n, ho, wo, cw, cw, 1, 1, 1, 0, self.dtype)
+            s2 = ops.conv2d_wgrad(dww, a_in, a_in)                          # [cw][cw] fp32 (symmetric)
+            t2 = ops.colsum(a_in.view(m, cw), m, cw)
         # parameter-sized algebra: O(cc * cw) elementwise in torch, the small GEMMs through the exact-f32 MFMA kernels
         sgy = (gmat * w2).sum(1)
         dbeta = s
@@ -280,7 +331,7 @@ class ResNetEngine:
         cb = st.invstd * (ca * dgamma / m)
         ccst = -ca * dbeta / m + st.mean * cb
         bw = cb[:, None] * w2
-        ws2 = self._small_gemm(w2, s2)                                      # W S2   (S2 symmetric)
+        ws2 = u.ws2 if u.ws2 is not None else self._small_gemm(w2, s2)      # W S2   (S2 symmetric)
         # W^T diag(B) W = "weight gradient" of a cc-pixel 1x1 conv (x = B W, dy = W): split-K over the cc rows fills the chip
         dm2 = ops.conv_desc(cc, 1, 1, cw, cw, 1, 1, 1, 0, f32)
         m2 = ops.conv2d_wgrad(dm2, bw.contiguous().view(cc, 1, 1, cw), w2.contiguous().view(cc, 1, 1, cw))
@@ -313,7 +364,7 @@ class ResNetEngine:
         same masked g (and the same s) as the block's bn3.  Both terms of the input gradient accumulate into `dx` (the
         main branch's input gradient); for a stride-2 shortcut they only touch the even pixels -- so does the bias."""
         d = u.desc
-        x_in = u.x if d.stride == 1 else ops.subsample2(u.x)
+        x_in = u.x_in if u.x_in is not None else (u.x if d.stride == 1 else ops.subsample2(u.x))
         wa, wm, bias, _ = self._fold_1x1_bn(u, g, x_in, grads, s=s)
         dterm = ops.conv_desc(d.n, d.h, d.w, d.cin, d.cin, 1, 1, d.stride, 0, self.dtype)
         kw = dict(fuse_mode=4, prev_mask=below.mask, want_sums=False) if masked_store else {}
@@ -332,6 +383,8 @@ class ResNetEngine:
         d = u.desc
         m = d.n * d.ho * d.wo
         c = d.cout
+        if u.y is None:
+            raise RuntimeError("this unit ran the folded forward (its raw conv output was never stored): its backward must be folded too")
         dy, _, dg, db = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, False,
                                         mask_from_y=u.relu and not u.has_res, relu_mask=relu_mask, raw_partial=raw_partial)
         grads[u.bn.weight] = dg
@@ -364,9 +417,14 @@ class ResNetEngine:
         grads: Dict[nn.Parameter, Tensor] = {}
         g = d_enc.contiguous() if d_enc.dtype == self.dtype else ops.cast(d_enc.contiguous(), self.dtype)
         dz = ops.avgpool_bwd(g, ctx["last_shape"])
-        dz_part = None  # per-tile sums for the current block's last unit, when the next block's dgrad produced them
-        dz_masked = False  # dz was stored already gated by this block's output ReLU mask (dz_part = its channel sums)
         blocks = ctx["blocks"]
+        top = blocks[-1][0][-1] if blocks else None
+        top_fold = self.fold_bn3 and self._foldable(top)
+        if top_fold:  # the last block's bn3 folds as well: gate its incoming gradient by the output ReLU mask
+            n_, h_, w_, c_ = dz.shape
+            dz = ops.apply_relu_bitmask(dz, top.mask)
+        dz_part = None  # per-tile sums for the current block's last unit, when the next block's dgrad produced them
+        dz_masked = top_fold  # dz is stored already gated by this block's output ReLU mask
         for bi in range(len(blocks) - 1, -1, -1):
             saved, ds = blocks[bi]
             last = saved[-1]

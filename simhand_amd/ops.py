@@ -150,6 +150,17 @@ def conv2d_fwd(d: ConvDesc, x, w, want_stats: bool = True):
     return y, part
 
 
+def conv2d_fwd_bnact(d: ConvDesc, x, w, st: "BNState", relu: bool, residual=None, want_mask: bool = False):
+    """out = act(conv(x) * st.scale + st.shift (+ residual)) with the BN / residual / ReLU tail in the conv epilogue
+    (bf16; the raw conv output is never stored).  Returns out or (out, ReLU bit mask)."""
+    lib = _lib_dev()
+    out = torch.empty(d.n, d.ho, d.wo, d.cout, dtype=x.dtype, device=x.device)
+    mask = torch.empty(d.n * d.ho * d.wo, d.cout // 8, dtype=torch.uint8, device=x.device) if want_mask else None
+    check(lib.simhand_conv2d_fwd_bnact(C.byref(d), _ptr(x), _ptr(w), _ptr(st.scale), _ptr(st.shift), _ptr(residual), int(relu), _ptr(out),
+                                       _ptr(mask), _stream()), "conv2d_fwd_bnact")
+    return (out, mask) if want_mask else out
+
+
 def conv2d_dgrad(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accumulate: bool = False):
     lib = _lib_dev()
     if dx is None:
@@ -521,6 +532,16 @@ def avgpool_bwd(dy: torch.Tensor, in_shape) -> torch.Tensor:
     dx = torch.empty(n, h, w, c, dtype=dy.dtype, device=dy.device)
     check(lib.simhand_avgpool_bwd(_ptr(dy), _ptr(dx), n, h * w, c, dt(dy.dtype), _stream()), "avgpool_bwd")
     return dx
+
+
+def apply_relu_bitmask(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """x gated by a ReLU bit mask ([rows][c / VE] bytes from bn_apply / conv2d_fwd_bnact)."""
+    lib = _lib_dev()
+    c = x.shape[-1]
+    m = x.numel() // c
+    out = torch.empty_like(x)
+    check(lib.simhand_apply_relu_bitmask(_ptr(x), _ptr(mask), _ptr(out), m, c, dt(x.dtype), _stream()), "apply_relu_bitmask")
+    return out
 
 
 def bn_channel_sums(raw_partial: torch.Tensor, c: int) -> torch.Tensor:

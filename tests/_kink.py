@@ -31,13 +31,23 @@ def record_hip_relu_masks(store: list):
         store.append((orig(y.view(n * h * w, c), st, n * h * w, c, True, None) > 0).view(n, h, w, c).cpu())
         return orig_stem(y, st)
 
+    orig_fused = ops.conv2d_fwd_bnact
+
+    def conv2d_fwd_bnact(d, x, w, st, relu, residual=None, want_mask=False):
+        res = orig_fused(d, x, w, st, relu, residual, want_mask)
+        if relu:
+            store.append(((res[0] if want_mask else res) > 0).cpu())
+        return res
+
     ops.bn_apply = bn_apply
     ops.bn_relu_maxpool_fwd = bn_relu_maxpool_fwd
+    ops.conv2d_fwd_bnact = conv2d_fwd_bnact
     try:
         yield store
     finally:
         ops.bn_apply = orig
         ops.bn_relu_maxpool_fwd = orig_stem
+        ops.conv2d_fwd_bnact = orig_fused
 
 
 @contextlib.contextmanager

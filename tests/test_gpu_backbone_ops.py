@@ -523,3 +523,51 @@ def test_wgrad_3x3_all_taps_kernel(shape):
         lib.simhand_wgrad3x3_enable(1)
     _check(got, want, 2e-3, "wgrad 3x3 all taps")
     _check(got, old, 1e-4, "vs tap-by-tap kernel")  # same products, fp32 sums in another order
+
+
+@pytest.mark.parametrize("shape", [(3, 14, 14, 64, 256, 1), (2, 13, 13, 256, 1024, 1), (2, 16, 16, 256, 512, 2), (5, 7, 7, 512, 2048, 1)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_conv_fwd_bnact_epilogue_and_gram_statistics(shape, with_res):
+    """bf16 1x1 conv with BN + residual + ReLU in the epilogue == conv -> bn_apply (to one bf16 ulp: the fused form
+    normalises the fp32 accumulators, not the rounded conv output), and the batch statistics derived from the input's
+    Gram matrix (mean_c = W_c . sum x / M, E[y^2]_c = W_c^T (x^T x) W_c / M) match those of the conv output."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    n, h, w, cin, cout, stride = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = _rnd(torch.randn(n, h, w, cin, generator=g).relu(), dtype).to(DEV).to(dtype)
+    wt = _rnd(torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin), dtype).to(DEV)
+    d = ops.conv_desc(n, h, w, cin, cout, 1, 1, stride, 0, dtype)
+    wk = ops.pack_krsc(wt, dtype)
+    y, part = ops.conv2d_fwd(d, x, wk, want_stats=True)
+    m = n * d.ho * d.wo
+    gamma = (torch.rand(cout, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(cout, generator=g) * 0.3).to(DEV)
+    st = ops.bn_finalize(part, m, cout, gamma, beta, None, None, None)
+    res = _rnd(torch.randn(n, d.ho, d.wo, cout, generator=g), dtype).to(DEV).to(dtype) if with_res else None
+    relu = with_res
+    if relu:
+        want, want_mask = ops.bn_apply(y.view(m, cout), st, m, cout, True, res.view(m, cout), want_mask=True)
+        got, got_mask = ops.conv2d_fwd_bnact(d, x, wk, st, True, res, want_mask=True)
+        flips = (got_mask ^ want_mask).to(torch.int32)
+        nflip = sum(((flips >> b) & 1).sum().item() for b in range(8))
+        assert nflip <= 1e-2 * m * cout  # only values within a bf16 ulp of zero may land on the other side
+    else:
+        want = ops.bn_apply(y.view(m, cout), st, m, cout, False, None)
+        got = ops.conv2d_fwd_bnact(d, x, wk, st, False, None)
+    err = (got.float().view(m, cout) - want.float()).abs().max().item()
+    assert err <= 2e-2 * want.float().abs().max().item() + 1e-3, err
+
+    # Gram-matrix statistics
+    x_in = x if stride == 1 else ops.subsample2(x)
+    dww = ops.conv_desc(n, d.ho, d.wo, cin, cin, 1, 1, 1, 0, dtype)
+    s2, t2 = ops.conv2d_wgrad_colsum(dww, x_in, x_in)
+    w_r = wt.view(cout, cin).float()
+    sum_y = w_r @ t2
+    sum_y2 = ((w_r @ s2) * w_r).sum(1)
+    ref1, ref2 = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    assert (sum_y.double() - ref1).abs().max().item() <= 1e-3 * ref1.abs().max().item() + 1e-3
+    assert (sum_y2.double() - ref2).abs().max().item() <= 1e-3 * ref2.abs().max().item()
+    xs = x_in.float().view(m, cin)
+    assert torch.allclose(t2, xs.sum(0), rtol=1e-4, atol=1e-2) and torch.allclose(s2, xs.t() @ xs, rtol=1e-3, atol=1e-2)

@@ -330,6 +330,7 @@ def test_folded_bn3_backward_equals_two_pass_backward(dtype):
     x = torch.randn(6, 3, 64, 64, device=DEV)
     w_out = torch.randn(6, net.out_features, device=DEV)
     res = {}
+    net.engine._fold_fwd_ok = lambda *a, **k: False  # same (unfolded) forward in both runs: this test isolates the backward
     for fold in (False, True):
         net.engine.fold_bn3 = fold
         for p_ in net.parameters():
@@ -345,3 +346,28 @@ def test_folded_bn3_backward_equals_two_pass_backward(dtype):
     # fp32: re-association only; bf16: dy3 is never rounded to bf16 on the folded path (it is the more accurate one)
     med, mx = (1e-5, 2e-3) if dtype == torch.float32 else (2e-2, 1.5e-1)
     assert rel[len(rel) // 2] <= med and rel[-1] <= mx, (rel[len(rel) // 2], rel[-1])
+
+
+def test_folded_forward_tracks_the_two_pass_forward():
+    """bf16 Bottleneck net: conv3 / shortcut with Gram-matrix statistics and BN + residual + ReLU in the conv epilogue
+    (the raw conv output is never stored) vs conv -> stats -> bn_apply.  The folded form normalises fp32 accumulators
+    instead of bf16-rounded conv outputs, so per unit the two agree to bf16 round-off (tests/test_gpu_backbone_ops.py
+    checks that bound); through 16 randomly initialised blocks bf16 noise is amplified by the BatchNorms, so the
+    network-level check is against the fp32 engine: the folded forward must be as close to it as the two-pass one."""
+    from simhand_amd.host.resnet_model import ResNetModel
+    from types import SimpleNamespace
+
+    torch.manual_seed(5)
+    cfg = SimpleNamespace(model=SimpleNamespace(backend_model="resnet50", pretrained=False))
+    net = ResNetModel(cfg, mode="pretraining", compute_dtype=torch.float32).to(DEV).train()
+    x = torch.randn(16, 3, 128, 128, device=DEV)
+    cos = lambda a, b: (torch.dot(a, b) / (a.norm() * b.norm())).item()
+    with torch.no_grad():
+        ref = net(x).float().flatten()
+        net.set_compute_dtype(torch.bfloat16)
+        folded = net(x).float().flatten()
+        net.engine._fold_fwd_ok = lambda *a, **k: False
+        two_pass = net(x).float().flatten()
+    c_f, c_t = cos(folded, ref), cos(two_pass, ref)
+    assert c_t > 0.97 and c_f >= c_t - 5e-3, (c_f, c_t)
+    assert cos(folded, two_pass) > 0.98
