@@ -1156,6 +1156,7 @@ int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w
   SH_REQUIRE(x && w && out && scale && shift, "conv2d_fwd_bnact: NULL pointer");
   SH_REQUIRE(d->dtype == SH_BF16, "conv2d_fwd_bnact: bf16 only");
   SH_REQUIRE(!relu_mask || relu, "conv2d_fwd_bnact: a ReLU mask is only produced with relu != 0");
+  SH_REQUIRE(d->cout <= 2048, "conv2d_fwd_bnact: cout=%d > 2048 (epilogue coefficient cache)", d->cout);
   IgemmArgs a;
   a.a = x; a.w = w; a.out = out; a.bn_partial = nullptr;
   a.Mg = (long long)d->n * d->ho * d->wo;
