@@ -295,6 +295,24 @@ int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const f
                            const float* scale, const float* shift, int relu, int64_t m, int c, int dtype, float* partial,
                            sh_stream_t stream);
 int simhand_bn_bwd_finalize(const float* partial, int nblk, int c, float* dgamma, float* dbeta, sh_stream_t stream);
+/* Folded BatchNorm of a 1x1 convolution y = a W^T: the parameter-sized algebra.  w = fp32 master weight
+ * [cc][cw] (rounded to bf16 first when round_bf16), s2 = a^T a [cw][cw], t2 = sum a [cw] (simhand_conv2d_wgrad_colsum with
+ * x = dy = a), m = pixels.
+ * fwd: batch statistics of y without y: mean / invstd / scale / shift (+ running statistics), ws2 = W s2 [cc][cw] (kept for
+ *      the backward).
+ * bwd: gmat = g^T a [cc][cw] (simhand_conv2d_wgrad_colsum), s = sum g [cc]  ->  dgamma, dbeta, dw [cc][cw] (= OIHW),
+ *      wa = diag(A) W as the CRSK operand [cw][cc] of the first data-gradient term, wm = -(W^T diag(B) W) [cw][cw] the
+ *      operand of the second (accumulating) one, bias = C W [cw];  bw [cc][cw], ccoef [cc]: scratch.
+ * Replaces (reference): native_batch_norm(_backward) around conv3 / downsample of torchvision's Bottleneck. */
+size_t simhand_bn_fold_workspace_bytes(int cc, int cw); /* split-K scratch of the two small GEMMs (either call) */
+int simhand_bn_fold_fwd(const float* w, int round_bf16, const float* s2, const float* t2, int cc, int cw, int64_t m, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift, float* ws2,
+                        void* workspace, size_t workspace_bytes, sh_stream_t stream);
+int simhand_bn_fold_bwd(const float* w, int round_bf16, const float* gmat, const float* s, const float* ws2, const float* t2,
+                        const float* mean, const float* invstd, const float* gamma, int cc, int cw, int64_t m, float* dgamma,
+                        float* dbeta, float* dw, void* wa, float* bw, float* ccoef, void* wm, float* bias, int dtype,
+                        void* workspace, size_t workspace_bytes, sh_stream_t stream);
 /* out = x gated by the ReLU bit mask simhand_bn_apply / simhand_conv2d_fwd_bnact wrote ([m][c/VE] bytes) */
 int simhand_apply_relu_bitmask(const void* x, const uint8_t* mask, void* out, int64_t m, int c, int dtype, sh_stream_t stream);
 /* Stem block fused: out, idx = MaxPool(3, 2, 1)(ReLU(y*scale + shift)) without storing the activation in between, and

@@ -582,6 +582,206 @@ __global__ __launch_bounds__(256) void apply_bitmask_kernel(const T* __restrict_
   }
 }
 
+
+// ---- folded BatchNorm of a 1x1 convolution: the parameter-sized algebra -----------------------------------
+// y = a W^T pixel by pixel, so with S2 = a^T a [cw][cw], t2 = sum a [cw] (both from the 1x1 weight-gradient kernel):
+//   sum y_c = W_c . t2,   sum y_c^2 = W_c^T S2 W_c.
+// One block per output channel c.  W is the fp32 master weight, rounded to bf16 first when the MFMAs see bf16.
+__device__ __forceinline__ float fold_w(const float* w, int idx, int round_bf16) {
+  const float v = w[idx];
+  return round_bf16 ? bf16_to_f32(f32_to_bf16(v)) : v;
+}
+__device__ __forceinline__ double block_sum256(double v, double* red) {  // 256 threads, fixed order
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int h = 128; h >= 1; h >>= 1) {
+    if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+
+// C[m][n] (+ epilogue) = sum_k A(m, k) B(k, n) for parameter-sized fp32 operands with arbitrary strides; 64 x 64 tile,
+// 16-deep slabs, 4 x 4 outputs per thread.  MODE 0: store fp32 (ldc); MODE 1: store -C in T (the CRSK operand of the
+// second folded dgrad term).  A may be rounded to bf16 on load (the weights the MFMAs saw).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void fold_sgemm_kernel(const float* __restrict__ a, int sam, int sak, int round_a,
+                                                         const float* __restrict__ b, int sbk, int sbn, int m, int n, int k,
+                                                         float* __restrict__ cf, T* __restrict__ ct, int ldc, int kper) {
+  __shared__ float sa[16][68], sb[16][68];
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // outputs rows ty*4.., cols tx*4..
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  // loader: 1024 elements per operand slab, 4 per thread; lanes run along the operand's unit-stride axis
+  const bool a_k_fast = sak == 1, b_n_fast = sbn == 1;
+  // split-K: slice blockIdx.z reduces k in [z * kper, (z + 1) * kper) and stores its fp32 partial at cf + z * m * ldc
+  // (fold_sum_kernel adds the slices in a fixed order); gridDim.z == 1: final result with the MODE epilogue
+  const int kbeg = blockIdx.z * kper;
+  k = kbeg + kper < k ? kbeg + kper : k;
+  const bool partial = gridDim.z > 1;
+  if (partial) cf += (int64_t)blockIdx.z * m * ldc;
+  for (int k0 = kbeg; k0 < k; k0 += 16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int id = threadIdx.x + 256 * e;
+      const int am = a_k_fast ? id >> 4 : id & 63, ak = a_k_fast ? id & 15 : id >> 6;
+      float av = 0.f;
+      if (m0 + am < m && k0 + ak < k) {
+        av = a[(int64_t)(m0 + am) * sam + (int64_t)(k0 + ak) * sak];
+        if (round_a) av = bf16_to_f32(f32_to_bf16(av));
+      }
+      sa[ak][am] = av;
+      const int bn_ = b_n_fast ? id & 63 : id >> 4, bk = b_n_fast ? id >> 6 : id & 15;
+      sb[bk][bn_] = (n0 + bn_ < n && k0 + bk < k) ? b[(int64_t)(k0 + bk) * sbk + (int64_t)(n0 + bn_) * sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float4 av = *reinterpret_cast<const float4*>(&sa[kk][ty * 4]);
+      const float4 bv = *reinterpret_cast<const float4*>(&sb[kk][tx * 4]);
+      const float ar[4] = {av.x, av.y, av.z, av.w}, br[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += ar[i] * br[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = m0 + ty * 4 + i;
+    if (r >= m) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cidx = n0 + tx * 4 + j;
+      if (cidx >= n) continue;
+      if (MODE == 0 || partial) cf[(int64_t)r * ldc + cidx] = acc[i][j];
+      else Elem<T>::store(ct + (int64_t)r * ldc + cidx, -acc[i][j]);
+    }
+  }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void fold_sum_kernel(const float* __restrict__ part, int ks, int64_t count, float* __restrict__ cf,
+                                                       T* __restrict__ ct) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float t = 0.f;
+  for (int z = 0; z < ks; ++z) t += part[(int64_t)z * count + i];
+  if (MODE == 0) cf[i] = t;
+  else Elem<T>::store(ct + i, -t);
+}
+
+// split factor: ~512 blocks in flight, slices of at least 64 k, multiples of 16
+static inline void fold_split(int tiles, int k, int* ks, int* kper) {
+  int s_ = (512 + tiles - 1) / tiles;
+  const int maxs = k / 64 > 0 ? k / 64 : 1;
+  if (s_ > maxs) s_ = maxs;
+  if (s_ < 1) s_ = 1;
+  int per = ((k + s_ - 1) / s_ + 15) / 16 * 16;
+  *ks = (k + per - 1) / per;
+  *kper = per;
+}
+
+__global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restrict__ w, int round_bf16, const float* __restrict__ s2,
+                                                          const float* __restrict__ t2, int cc, int cw, int64_t m,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          float momentum, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                          float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                          float* __restrict__ scale_o, float* __restrict__ shift_o,
+                                                          const float* __restrict__ ws2) {
+  __shared__ double red[256];
+  const int c = blockIdx.x;
+  double sy = 0.0, sy2 = 0.0;
+  for (int j = threadIdx.x; j < cw; j += 256) {  // ws2 = W S2 comes from fold_sgemm_kernel
+    const float wv = fold_w(w, c * cw + j, round_bf16);
+    sy += (double)wv * (double)t2[j];
+    sy2 += (double)ws2[(int64_t)c * cw + j] * (double)wv;
+  }
+  sy = block_sum256(sy, red);
+  sy2 = block_sum256(sy2, red);
+  if (threadIdx.x == 0) {
+    if (c == 0 && nbt) nbt[0] += 1;
+    const double mean = sy / (double)m;
+    double var = sy2 / (double)m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = (gamma ? gamma[c] : 1.0f) * invstd;
+    mean_o[c] = (float)mean;
+    invstd_o[c] = invstd;
+    scale_o[c] = sc;
+    shift_o[c] = (beta ? beta[c] : 0.0f) - (float)mean * sc;
+    if (running_mean) {
+      const double unbiased = m > 1 ? var * (double)m / (double)(m - 1) : var;
+      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+// backward coefficients and everything that is per output channel:
+//   sum g*y = G_c . W_c;  dgamma = invstd (sum g*y - mean s);  dbeta = s;  A = gamma invstd;  B = invstd A dgamma / M;
+//   C = -A dbeta / M + mean B;   dW_c = A G_c - B (W S2)_c + C t2;   wa[j][c] = A W_c[j] (CRSK operand of the first dgrad
+//   term);  bw_c = B W_c (operand of W^T diag(B) W);  ccoef[c] = C
+template <typename T>
+__global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float* __restrict__ w, int round_bf16, const float* __restrict__ gmat,
+                                                          const float* __restrict__ s, const float* __restrict__ ws2,
+                                                          const float* __restrict__ t2, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ gamma, int cc,
+                                                          int cw, int64_t m, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ dw, T* __restrict__ wa, float* __restrict__ bw,
+                                                          float* __restrict__ ccoef) {
+  __shared__ double red[256];
+  const int c = blockIdx.x;
+  double sgy = 0.0;
+  for (int j = threadIdx.x; j < cw; j += 256) sgy += (double)gmat[(int64_t)c * cw + j] * (double)fold_w(w, c * cw + j, round_bf16);
+  sgy = block_sum256(sgy, red);
+  const float is = invstd[c], mu = mean[c], sc_ = s[c];
+  const float dg = is * (float)(sgy - (double)mu * (double)sc_);
+  const float ca = (gamma ? gamma[c] : 1.0f) * is;
+  const float inv_m = (float)(1.0 / (double)m);
+  const float cb = is * (ca * dg * inv_m);
+  const float cconst = -ca * sc_ * inv_m + mu * cb;
+  if (threadIdx.x == 0) {
+    dgamma[c] = dg;
+    dbeta[c] = sc_;
+    ccoef[c] = cconst;
+  }
+  for (int j = threadIdx.x; j < cw; j += 256) {
+    const int64_t o = (int64_t)c * cw + j;
+    const float wv = fold_w(w, (int)o, round_bf16);
+    dw[o] = ca * gmat[o] - cb * ws2[o] + cconst * t2[j];
+    Elem<T>::store(wa + (int64_t)j * cc + c, ca * wv);
+    bw[o] = cb * wv;
+  }
+}
+
+// bias[j] = sum_c C_c W[c][j]: 32 columns per block (lanes along j: coalesced rows of W), 32 row lanes over c, fixed-order fold
+__global__ __launch_bounds__(1024) void bn_fold_bias_kernel(const float* __restrict__ w, int round_bf16, const float* __restrict__ ccoef,
+                                                            int cc, int cw, float* __restrict__ bias) {
+  __shared__ float red[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + tx;
+  float acc = 0.f;
+  if (j < cw)
+    for (int c = ty; c < cc; c += 32) acc += ccoef[c] * fold_w(w, c * cw + j, round_bf16);
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && j < cw) {
+    float t = 0.f;
+    for (int r = 0; r < 32; ++r) t += red[r][tx];
+    bias[j] = t;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t m, int c, int rows_per_blk,
                                                      float* __restrict__ partial) {
@@ -834,6 +1034,79 @@ int simhand_apply_relu_bitmask(const void* x, const uint8_t* mask, void* out, in
   if (dtype == SH_F32) apply_bitmask_kernel<float><<<stream_grid(nvec), 256, 0, s>>>((const float*)x, mask, (float*)out, nvec);
   else apply_bitmask_kernel<bf16_t><<<stream_grid(nvec), 256, 0, s>>>((const bf16_t*)x, mask, (bf16_t*)out, nvec);
   return check_launch("apply_relu_bitmask");
+}
+
+size_t simhand_bn_fold_workspace_bytes(int cc, int cw) {
+  int ks1, kp1, ks2, kp2;
+  fold_split(ceil_div(cw, 64) * ceil_div(cc, 64), cw, &ks1, &kp1);
+  fold_split(ceil_div(cw, 64) * ceil_div(cw, 64), cc, &ks2, &kp2);
+  const size_t a = (size_t)ks1 * cc * cw, b = (size_t)ks2 * cw * cw;
+  return (a > b ? a : b) * sizeof(float);
+}
+
+int simhand_bn_fold_fwd(const float* w, int round_bf16, const float* s2, const float* t2, int cc, int cw, int64_t m, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift, float* ws2,
+                        void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+  SH_REQUIRE(w && s2 && t2 && mean && invstd && scale && shift && ws2, "bn_fold_fwd: NULL pointer");
+  SH_REQUIRE(cc >= 1 && cw >= 1 && m >= 1, "bn_fold_fwd: bad shape");
+  SH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_fold_fwd: running stats must be given together");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_BN, s, 2.0 * cc * (double)cw * cw, 4.0 * ((double)cc * cw * 2 + (double)cw * cw));
+  // ws2[c][j] = sum_i W[c][i] S2[i][j]
+  {
+    int ks, kper;
+    const int tiles = ceil_div(cw, 64) * ceil_div(cc, 64);
+    fold_split(tiles, cw, &ks, &kper);
+    SH_REQUIRE(ks == 1 || (workspace && workspace_bytes >= (size_t)ks * cc * cw * sizeof(float)), "bn_fold_fwd: workspace too small");
+    float* dst = ks > 1 ? (float*)workspace : ws2;
+    fold_sgemm_kernel<float, 0><<<dim3(ceil_div(cw, 64), ceil_div(cc, 64), ks), 256, 0, s>>>(w, cw, 1, round_bf16, s2, cw, 1, cc, cw, cw, dst,
+                                                                                             nullptr, cw, kper);
+    if (check_launch("bn_fold_fwd gemm")) return 1;
+    if (ks > 1) {
+      const int64_t count = (int64_t)cc * cw;
+      fold_sum_kernel<float, 0><<<ceil_div(count, 256), 256, 0, s>>>(dst, ks, count, ws2, nullptr);
+      if (check_launch("bn_fold_fwd sum")) return 1;
+    }
+  }
+  bn_fold_fwd_kernel<<<cc, 256, 0, s>>>(w, round_bf16, s2, t2, cc, cw, m, gamma, beta, eps, momentum, running_mean, running_var,
+                                        num_batches_tracked, mean, invstd, scale, shift, ws2);
+  return check_launch("bn_fold_fwd");
+}
+
+int simhand_bn_fold_bwd(const float* w, int round_bf16, const float* gmat, const float* s_, const float* ws2, const float* t2,
+                        const float* mean, const float* invstd, const float* gamma, int cc, int cw, int64_t m, float* dgamma,
+                        float* dbeta, float* dw, void* wa, float* bw, float* ccoef, void* wm, float* bias, int dtype,
+                        void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+  SH_REQUIRE(w && gmat && s_ && ws2 && t2 && mean && invstd && dgamma && dbeta && dw && wa && bw && ccoef && wm && bias,
+             "bn_fold_bwd: NULL pointer");
+  SH_REQUIRE(cc % 32 == 0 && cw % 32 == 0 && m >= 1, "bn_fold_bwd: cc=%d / cw=%d must be multiples of 32", cc, cw);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_BN, s, 2.0 * cc * (double)cw * cw, 4.0 * (double)cc * cw * 5);
+  if (dtype == SH_F32)
+    bn_fold_bwd_kernel<float><<<cc, 256, 0, s>>>(w, round_bf16, gmat, s_, ws2, t2, mean, invstd, gamma, cc, cw, m, dgamma, dbeta, dw, (float*)wa, bw, ccoef);
+  else
+    bn_fold_bwd_kernel<bf16_t><<<cc, 256, 0, s>>>(w, round_bf16, gmat, s_, ws2, t2, mean, invstd, gamma, cc, cw, m, dgamma, dbeta, dw, (bf16_t*)wa, bw, ccoef);
+  if (check_launch("bn_fold_bwd")) return 1;
+  // wm[i][j] = -sum_c W[c][i] bw[c][j]  (A(m = i, k = c) = w[c * cw + i])
+  int ks, kper;
+  fold_split(ceil_div(cw, 64) * ceil_div(cw, 64), cc, &ks, &kper);
+  SH_REQUIRE(ks == 1 || (workspace && workspace_bytes >= (size_t)ks * cw * cw * sizeof(float)), "bn_fold_bwd: workspace too small");
+  const dim3 grid(ceil_div(cw, 64), ceil_div(cw, 64), ks);
+  float* part = (float*)workspace;
+  if (dtype == SH_F32)
+    fold_sgemm_kernel<float, 1><<<grid, 256, 0, s>>>(w, 1, cw, round_bf16, bw, cw, 1, cw, cw, cc, part, (float*)wm, cw, kper);
+  else
+    fold_sgemm_kernel<bf16_t, 1><<<grid, 256, 0, s>>>(w, 1, cw, round_bf16, bw, cw, 1, cw, cw, cc, part, (bf16_t*)wm, cw, kper);
+  if (check_launch("bn_fold_bwd gemm")) return 1;
+  if (ks > 1) {
+    const int64_t count = (int64_t)cw * cw;
+    if (dtype == SH_F32) fold_sum_kernel<float, 1><<<ceil_div(count, 256), 256, 0, s>>>(part, ks, count, nullptr, (float*)wm);
+    else fold_sum_kernel<bf16_t, 1><<<ceil_div(count, 256), 256, 0, s>>>(part, ks, count, nullptr, (bf16_t*)wm);
+    if (check_launch("bn_fold_bwd sum")) return 1;
+  }
+  bn_fold_bias_kernel<<<ceil_div(cw, 32), 1024, 0, s>>>(w, round_bf16, ccoef, cc, cw, bias);
+  return check_launch("bn_fold_bias");
 }
 
 int simhand_colsum(const void* x, int64_t m, int c, int dtype, float* partial, float* out, sh_stream_t stream) {

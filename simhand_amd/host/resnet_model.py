@@ -186,11 +186,9 @@ class ResNetEngine:
         if training:
             dww = ops.conv_desc(n, d.ho, d.wo, cin, cin, 1, 1, 1, 0, self.dtype)
             s2, t2 = ops.conv2d_wgrad_colsum(dww, x_in, x_in)                # x^T x (fp32) and sum x ride on one kernel
-            w_r = conv.weight.detach().to(self.dtype).to(torch.float32).view(cout, cin)  # the weights the MFMAs see
-            ws2 = self._small_gemm(w_r, s2)                                   # [cout][cin] = W S2
-            part = torch.stack((w_r @ t2, (ws2 * w_r).sum(1))).view(1, 2, cout).contiguous()  # (sum y, sum y^2) per channel
-            st = ops.bn_finalize(part, m, cout, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                 bn.num_batches_tracked, None, bn.eps, bn.momentum)
+            # sum y = W . sum x, sum y^2 = rowdot(W S2, W) with the weights the MFMAs see -> statistics, running stats, W S2
+            st, ws2 = ops.bn_fold_fwd(conv.weight.detach().view(cout, cin), True, s2, t2, m, bn.weight.detach(), bn.bias.detach(),
+                                      bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum)
         else:
             st = ops.bn_eval_state(cout, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
         want_mask = save is not None and relu and residual is not None
@@ -309,8 +307,8 @@ class ResNetEngine:
         st = u.st
         f32 = torch.float32
         d1 = ops.conv_desc(n, ho, wo, cw, cc, 1, 1, 1, 0, self.dtype)
-        w2 = u.conv.weight.detach().to(self.dtype).to(f32).view(cc, cw)     # the weights the forward MFMAs saw
-        gamma = u.bn.weight.detach().to(f32)
+        wmaster = u.conv.weight.detach().view(cc, cw)
+        rnd = self.dtype == torch.bfloat16                                  # the algebra uses the weights the MFMAs saw
         if s is None and self.dtype == torch.bfloat16:
             gmat, s = ops.conv2d_wgrad_colsum(d1, a_in, g)                  # [cc][cw] fp32, [cc]: sum g rides along
         else:
@@ -318,29 +316,18 @@ class ResNetEngine:
             if s is None:
                 s = ops.colsum(g.view(m, cc), m, cc)
         if u.s2 is not None:                                                # Gram products saved by the folded forward
-            s2, t2 = u.s2, u.t2
+            s2, t2, ws2 = u.s2, u.t2, u.ws2
         else:
             dww = ops.conv_desc(n, ho, wo, cw, cw, 1, 1, 1, 0, self.dtype)
             s2 = ops.conv2d_wgrad(dww, a_in, a_in)                          # [cw][cw] fp32 (symmetric)
             t2 = ops.colsum(a_in.view(m, cw), m, cw)
-        # parameter-sized algebra: O(cc * cw) elementwise in torch, the small GEMMs through the exact-f32 MFMA kernels
-        sgy = (gmat * w2).sum(1)
-        dbeta = s
-        dgamma = st.invstd * (sgy - st.mean * s)
-        ca = gamma * st.invstd
-        cb = st.invstd * (ca * dgamma / m)
-        ccst = -ca * dbeta / m + st.mean * cb
-        bw = cb[:, None] * w2
-        ws2 = u.ws2 if u.ws2 is not None else self._small_gemm(w2, s2)      # W S2   (S2 symmetric)
-        # W^T diag(B) W = "weight gradient" of a cc-pixel 1x1 conv (x = B W, dy = W): split-K over the cc rows fills the chip
-        dm2 = ops.conv_desc(cc, 1, 1, cw, cw, 1, 1, 1, 0, f32)
-        m2 = ops.conv2d_wgrad(dm2, bw.contiguous().view(cc, 1, 1, cw), w2.contiguous().view(cc, 1, 1, cw))
-        bias = self._small_gemm(ccst[None, :].contiguous(), w2.t().contiguous())[0].contiguous()
+            w2 = wmaster.to(self.dtype).to(f32) if rnd else wmaster.to(f32)
+            ws2 = self._small_gemm(w2, s2)                                  # W S2   (S2 symmetric)
+        # the parameter-sized algebra: two launches (per-channel coefficients / dW / operands, then W^T diag(B) W and C W)
+        dgamma, dbeta, dw, wa, wm, bias = ops.bn_fold_bwd(wmaster, rnd, gmat, s, ws2, t2, st, u.bn.weight.detach(), m, self.dtype)
         grads[u.bn.weight] = dgamma
         grads[u.bn.bias] = dbeta
-        grads[u.conv.weight] = (ca[:, None] * gmat - cb[:, None] * ws2 + ccst[:, None] * t2[None, :]).view(cc, cw, 1, 1)
-        wa = ops.pack_crsk((ca[:, None] * w2).view(cc, cw, 1, 1).contiguous(), self.dtype)
-        wm = ops.pack_crsk((-m2).view(cw, cw, 1, 1).contiguous(), self.dtype)
+        grads[u.conv.weight] = dw.view(cc, cw, 1, 1)
         return wa, wm, bias, s
 
     def _unit3_bwd_folded(self, u: _Unit, g, grads: dict, prev: _Unit):

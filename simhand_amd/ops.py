@@ -534,6 +534,45 @@ def avgpool_bwd(dy: torch.Tensor, in_shape) -> torch.Tensor:
     return dx
 
 
+def bn_fold_fwd(w: torch.Tensor, round_bf16: bool, s2, t2, m: int, gamma, beta, running_mean, running_var, nbt, eps: float = 1e-5,
+                momentum: float = 0.1):
+    """Batch statistics of y = a W^T from the Gram matrix of a (see simhand_bn_fold_fwd).  w: fp32 [cc][cw].
+    Returns (BNState, ws2 = W s2)."""
+    lib = _lib_dev()
+    cc, cw = w.shape
+    st = BNState(cc, w.device)
+    ws2 = torch.empty(cc, cw, dtype=torch.float32, device=w.device)
+    nb = lib.simhand_bn_fold_workspace_bytes(cc, cw)
+    wsp = torch.empty(nb, dtype=torch.uint8, device=w.device)
+    check(lib.simhand_bn_fold_fwd(_ptr(w), int(round_bf16), _ptr(s2), _ptr(t2), cc, cw, m, _ptr(gamma), _ptr(beta), eps, momentum,
+                                  _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale),
+                                  _ptr(st.shift), _ptr(ws2), _ptr(wsp), nb, _stream()), "bn_fold_fwd")
+    return st, ws2
+
+
+def bn_fold_bwd(w: torch.Tensor, round_bf16: bool, gmat, s, ws2, t2, st: BNState, gamma, m: int, dtype: torch.dtype):
+    """Parameter-sized part of the folded BatchNorm backward (see simhand_bn_fold_bwd).
+    Returns (dgamma, dbeta, dw [cc][cw], wa CRSK [cw][cc], wm CRSK [cw][cw], bias [cw])."""
+    lib = _lib_dev()
+    cc, cw = w.shape
+    dev = w.device
+    f32 = torch.float32
+    dg = torch.empty(cc, dtype=f32, device=dev)
+    db = torch.empty(cc, dtype=f32, device=dev)
+    dw = torch.empty(cc, cw, dtype=f32, device=dev)
+    wa = torch.empty(cw, cc, dtype=dtype, device=dev)
+    wm = torch.empty(cw, cw, dtype=dtype, device=dev)
+    bw = torch.empty(cc, cw, dtype=f32, device=dev)
+    cco = torch.empty(cc, dtype=f32, device=dev)
+    bias = torch.empty(cw, dtype=f32, device=dev)
+    nb = lib.simhand_bn_fold_workspace_bytes(cc, cw)
+    wsp = torch.empty(nb, dtype=torch.uint8, device=dev)
+    check(lib.simhand_bn_fold_bwd(_ptr(w), int(round_bf16), _ptr(gmat), _ptr(s), _ptr(ws2), _ptr(t2), _ptr(st.mean), _ptr(st.invstd),
+                                  _ptr(gamma), cc, cw, m, _ptr(dg), _ptr(db), _ptr(dw), _ptr(wa), _ptr(bw), _ptr(cco), _ptr(wm), _ptr(bias),
+                                  dt(dtype), _ptr(wsp), nb, _stream()), "bn_fold_bwd")
+    return dg, db, dw, wa, wm, bias
+
+
 def apply_relu_bitmask(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """x gated by a ReLU bit mask ([rows][c / VE] bytes from bn_apply / conv2d_fwd_bnact)."""
     lib = _lib_dev()
