@@ -343,6 +343,9 @@ int simhand_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int n
 /* y[n][ceil(h/2)][ceil(w/2)][c] = x[n][2i][2j][c]: the pixels a stride-2 1x1 convolution reads (dense operand for the folded
  * BatchNorm backward of the strided shortcut) */
 int simhand_subsample2(const void* x, void* y, int n, int h, int w, int c, int dtype, sh_stream_t stream);
+/* its transpose with accumulation: dx[n][2i][2j][:] = gate(dx[n][2i][2j][:] + src[n][i][j][:]), dx is [n][h][w][c];
+ * gate = optional ReLU bit mask over dx's pixels ([n*h*w][c/VE]) */
+int simhand_scatter2_add(const void* src, void* dx, const uint8_t* mask, int n, int h, int w, int c, int dtype, sh_stream_t stream);
 int simhand_avgpool_fwd(const void* x, void* y, int n, int hw, int c, int dtype, sh_stream_t stream);
 int simhand_avgpool_bwd(const void* dy, void* dx, int n, int hw, int c, int dtype, sh_stream_t stream);
 

@@ -138,6 +138,7 @@ SIGNATURES = {
     "simhand_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "simhand_avgpool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "simhand_subsample2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "simhand_scatter2_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "simhand_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "simhand_colsum": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "simhand_sumsq_partial": (_I, [_P, _L, _P, _I, _P]),

@@ -116,6 +116,36 @@ __global__ __launch_bounds__(256) void subsample2_kernel(const T* __restrict__ x
   }
 }
 
+// dx[n][2i][2j][:] = gate(dx[n][2i][2j][:] + src[n][i][j][:]): the transpose of subsample2 with accumulation; gate = the
+// consumer block's ReLU bit mask [pixel of dx][c / VE] (optional).  Used by the folded shortcut backward: its input
+// gradient is computed densely at the output resolution and lands on the even pixels of the block-input gradient.
+template <typename T>
+__global__ __launch_bounds__(256) void scatter2_add_kernel(const T* __restrict__ src, T* __restrict__ dx, const uint8_t* __restrict__ mask,
+                                                           int n, int h, int w, int c, int ho, int wo) {
+  constexpr int VE = Vec16<T>::N;
+  const int cvecs = c / VE;
+  const int64_t total = (int64_t)n * ho * wo * cvecs;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cvecs);
+    int64_t t = i / cvecs;
+    const int ow = (int)(t % wo);
+    t /= wo;
+    const int oh = (int)(t % ho);
+    const int img = (int)(t / ho);
+    const int64_t pix = ((int64_t)img * h + 2 * oh) * w + 2 * ow;
+    float a[VE], b[VE];
+    Vec16<T>::load(src + i * VE, a);
+    Vec16<T>::load(dx + pix * c + cv * VE, b);
+    const unsigned bits = mask ? mask[pix * cvecs + cv] : 0xffu;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const float v = Elem<T>::kDtype == SH_BF16 ? bf16_to_f32(f32_to_bf16(a[e] + b[e])) : a[e] + b[e];
+      b[e] = (bits >> e) & 1u ? v : 0.f;
+    }
+    Vec16<T>::store(dx + pix * c + cv * VE, b);
+  }
+}
+
 // ---- global average pool ---------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int hw, int c) {
@@ -404,6 +434,19 @@ int simhand_subsample2(const void* x, void* y, int n, int h, int w, int c, int d
   SH_DISPATCH(dtype, (subsample2_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)x, (float*)y, n, h, w, c, ho, wo)),
               (subsample2_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, n, h, w, c, ho, wo)));
   return check_launch("subsample2");
+}
+
+int simhand_scatter2_add(const void* src, void* dx, const uint8_t* mask, int n, int h, int w, int c, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(src && dx, "scatter2_add: NULL pointer");
+  if (vec_ok(c, dtype, "scatter2_add")) return 1;
+  const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+  const int ve = dtype == SH_F32 ? 4 : 8;
+  const int64_t total = (int64_t)n * ho * wo * (c / ve);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_MISC, s, 0, 3.0 * (double)n * ho * wo * c * (dtype == SH_F32 ? 4 : 2));
+  SH_DISPATCH(dtype, (scatter2_add_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)src, (float*)dx, mask, n, h, w, c, ho, wo)),
+              (scatter2_add_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)src, (bf16_t*)dx, mask, n, h, w, c, ho, wo)));
+  return check_launch("scatter2_add");
 }
 
 int simhand_avgpool_fwd(const void* x, void* y, int n, int hw, int c, int dtype, sh_stream_t stream) {

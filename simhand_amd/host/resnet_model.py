@@ -353,10 +353,19 @@ class ResNetEngine:
         d = u.desc
         x_in = u.x_in if u.x_in is not None else (u.x if d.stride == 1 else ops.subsample2(u.x))
         wa, wm, bias, _ = self._fold_1x1_bn(u, g, x_in, grads, s=s)
-        dterm = ops.conv_desc(d.n, d.h, d.w, d.cin, d.cin, 1, 1, d.stride, 0, self.dtype)
         kw = dict(fuse_mode=4, prev_mask=below.mask, want_sums=False) if masked_store else {}
-        ops.conv2d_dgrad_ex(d, g, wa, dx=dx, accumulate=True, bias=bias, **kw)
-        ops.conv2d_dgrad_ex(dterm, x_in, wm, dx=dx, accumulate=True, **kw)
+        if d.stride == 1:
+            dterm = ops.conv_desc(d.n, d.h, d.w, d.cin, d.cin, 1, 1, 1, 0, self.dtype)
+            ops.conv2d_dgrad_ex(d, g, wa, dx=dx, accumulate=True, bias=bias, **kw)
+            ops.conv2d_dgrad_ex(dterm, x_in, wm, dx=dx, accumulate=True, **kw)
+            return dx
+        # stride 2: both terms densely at the output resolution (the stride-1 kernels run near their bounds, the
+        # parity-class dgrad does not), then one scatter-add onto the even pixels of dx, through the consumer's mask
+        dd = ops.conv_desc(d.n, d.ho, d.wo, d.cin, d.cout, 1, 1, 1, 0, self.dtype)
+        dterm = ops.conv_desc(d.n, d.ho, d.wo, d.cin, d.cin, 1, 1, 1, 0, self.dtype)
+        dsub, _ = ops.conv2d_dgrad_ex(dd, g, wa, bias=bias)
+        ops.conv2d_dgrad_ex(dterm, x_in, wm, dx=dsub, accumulate=True)
+        ops.scatter2_add(dsub, dx, below.mask if masked_store else None)
         return dx
 
     def _unit_bwd(self, u: _Unit, da, grads: dict, need_dx: bool, dx_into=None, relu_mask=None, res_grad=None, res_mask=None,

@@ -518,6 +518,14 @@ def subsample2(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def scatter2_add(src: torch.Tensor, dx: torch.Tensor, mask=None) -> torch.Tensor:
+    """dx[:, ::2, ::2, :] = gate(dx[:, ::2, ::2, :] + src) in place (gate: optional ReLU bit mask over dx's pixels)."""
+    lib = _lib_dev()
+    n, h, w, c = dx.shape
+    check(lib.simhand_scatter2_add(_ptr(src), _ptr(dx), _ptr(mask), n, h, w, c, dt(dx.dtype), _stream()), "scatter2_add")
+    return dx
+
+
 def avgpool_fwd(x: torch.Tensor) -> torch.Tensor:
     lib = _lib_dev()
     n, h, w, c = x.shape
