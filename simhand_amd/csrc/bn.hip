@@ -583,6 +583,142 @@ __global__ __launch_bounds__(256) void apply_bitmask_kernel(const T* __restrict_
 }
 
 
+
+// 2x2-block form of the stem backward (even h, w; c / VE a power of two <= 256): a thread owns the input pixels
+// (2a..2a+1, 2b..2b+1) of one channel vector.  They are covered by exactly the four windows (a..a+1, b..b+1), so dz and the
+// winner index are loaded 4 times per 4 pixels instead of 9 (pool_gather).  APPLY = false: BatchNorm-backward partial
+// sums (one [2][c] row per block, same meaning as pool_bn_bwd_partial_kernel); APPLY = true: dy.
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void pool_bn_bwd_blk_kernel(const T* __restrict__ dz, const uint8_t* __restrict__ idx,
+                                                              const T* __restrict__ y, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              T* __restrict__ dy, float* __restrict__ partial, int n, int h, int w,
+                                                              int c, int ho, int wo, float inv_m, FastDiv div_wb, FastDiv div_hb,
+                                                              int blocks_per_cta) {
+  constexpr int VE = Vec16<T>::N;
+  __shared__ float red[2][256][VE];
+  const int cvecs = c / VE;
+  const int cv = threadIdx.x & (cvecs - 1);
+  const int lanes = 256 / cvecs;             // 2x2 blocks handled concurrently by a CTA
+  const int bl = threadIdx.x / cvecs;
+  const int hb = h / 2, wb = w / 2;
+  const unsigned nblocks = (unsigned)n * hb * wb;  // < 2^31 (checked on the host)
+  float mu[VE], is[VE], A[VE], k2[VE], k3[VE], sc[VE], sh[VE], s1[VE], s2[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    const int ch = cv * VE + e;
+    mu[e] = mean[ch];
+    is[e] = invstd[ch];
+    sc[e] = scale[ch];
+    sh[e] = shift[ch];
+    s1[e] = s2[e] = 0.f;
+    if (APPLY) {
+      A[e] = (gamma ? gamma[ch] : 1.0f) * is[e];
+      k2[e] = dbeta[ch] * inv_m;
+      k3[e] = A[e] * dgamma[ch] * inv_m;
+    }
+  }
+  const unsigned b_begin = blockIdx.x * (unsigned)blocks_per_cta;
+  unsigned b_end = b_begin + blocks_per_cta;
+  if (b_end > nblocks) b_end = nblocks;
+  for (unsigned q = b_begin + bl; q < b_end; q += lanes) {
+    const unsigned t = fdiv(q, div_wb);
+    const int b = (int)(q - t * (unsigned)wb);
+    const unsigned img = fdiv(t, div_hb);
+    const int a = (int)(t - img * (unsigned)hb);
+    // the four windows (a + i, b + j): gradient and winner taps
+    float d[2][2][VE];
+    uint8_t wi[2][2][VE];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bool ok = a + i < ho && b + j < wo;
+        const int64_t o = ((((int64_t)img * ho + (a + i)) * wo + (b + j)) * cvecs + cv) * VE;
+        if (ok) {
+          Vec16<T>::load(dz + o, d[i][j]);
+          if (VE == 8) {
+            const uint2 u = *reinterpret_cast<const uint2*>(idx + o);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) wi[i][j][e] = (uint8_t)(((e < 4 ? u.x : u.y) >> (8 * (e & 3))) & 0xffu);
+          } else {
+            const unsigned u = *reinterpret_cast<const unsigned*>(idx + o);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) wi[i][j][e] = (uint8_t)((u >> (8 * e)) & 0xffu);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            d[i][j][e] = 0.f;
+            wi[i][j][e] = 255;
+          }
+        }
+      }
+    // all four y rows are requested before any of the gather arithmetic (12 loads in flight per thread)
+    float yq[2][2][VE];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+      for (int pj = 0; pj < 2; ++pj)
+        Vec16<T>::template load<true>(y + (((int64_t)img * h + 2 * a + pi) * w + 2 * b + pj) * c + cv * VE, yq[pi][pj]);
+    // input pixel (2a + pi, 2b + pj): window (a + i, b + j) reaches it with tap kh = 2 pi + 1 - 2 i, kw = 2 pj + 1 - 2 j
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+      for (int pj = 0; pj < 2; ++pj) {
+        float gq[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) gq[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i <= pi; ++i)
+#pragma unroll
+          for (int j = 0; j <= pj; ++j) {
+            const int me = (pi + 1 - 2 * i) * 3 + (pj + 1 - 2 * j);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) gq[e] += wi[i][j][e] == me ? d[i][j][e] : 0.f;
+          }
+        const int64_t pix = ((int64_t)img * h + 2 * a + pi) * w + 2 * b + pj;
+        const float(&yy)[VE] = yq[pi][pj];
+        float o[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const float gv = yy[e] * sc[e] + sh[e] > 0.f ? round_as<T>(gq[e]) : 0.f;
+          const float xh = (yy[e] - mu[e]) * is[e];
+          if (APPLY) {
+            o[e] = A[e] * (gv - k2[e]) - xh * k3[e];
+          } else {
+            s1[e] += gv;
+            s2[e] += gv * xh;
+          }
+        }
+        if (APPLY) Vec16<T>::template store<true>(dy + pix * c + cv * VE, o);
+      }
+  }
+  if (!APPLY) {
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      red[0][threadIdx.x][e] = s1[e];
+      red[1][threadIdx.x][e] = s2[e];
+    }
+    __syncthreads();
+    if (bl == 0) {
+      for (int r = 1; r < lanes; ++r)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          s1[e] += red[0][r * cvecs + cv][e];
+          s2[e] += red[1][r * cvecs + cv][e];
+        }
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        partial[((int64_t)blockIdx.x * 2 + 0) * c + cv * VE + e] = s1[e];
+        partial[((int64_t)blockIdx.x * 2 + 1) * c + cv * VE + e] = s2[e];
+      }
+    }
+  }
+}
+
 // ---- folded BatchNorm of a 1x1 convolution: the parameter-sized algebra -----------------------------------
 // y = a W^T pixel by pixel, so with S2 = a^T a [cw][cw], t2 = sum a [cw] (both from the 1x1 weight-gradient kernel):
 //   sum y_c = W_c . t2,   sum y_c^2 = W_c^T S2 W_c.
@@ -995,6 +1131,20 @@ int simhand_maxpool_bn_bwd_partial(const void* dz, const uint8_t* idx, const voi
   hipStream_t s = (hipStream_t)stream;
   const double es = dtype == SH_F32 ? 4 : 2;
   ProfScope ps(SH_PROF_BN, s, 0, es * ((double)m * c + (double)n * ho * wo * c) + (double)n * ho * wo * c);
+  const int cvecs_ = c / ve;
+  if (h % 2 == 0 && w % 2 == 0 && cvecs_ <= 256 && (cvecs_ & (cvecs_ - 1)) == 0) {
+    const int64_t nb2 = (int64_t)n * (h / 2) * (w / 2);
+    const int bpc = (int)((nb2 + nblk - 1) / nblk);
+    const FastDiv dwb = make_fastdiv((unsigned)(w / 2)), dhb = make_fastdiv((unsigned)(h / 2));
+    // every one of the nblk partial rows is written (rows past the last 2x2 block get zeros)
+    if (dtype == SH_F32)
+      pool_bn_bwd_blk_kernel<float, false><<<nblk, 256, 0, s>>>((const float*)dz, idx, (const float*)y, mean, invstd, nullptr, nullptr, nullptr,
+                                                                scale, shift, nullptr, partial, n, h, w, c, ho, wo, 0.f, dwb, dhb, bpc);
+    else
+      pool_bn_bwd_blk_kernel<bf16_t, false><<<nblk, 256, 0, s>>>((const bf16_t*)dz, idx, (const bf16_t*)y, mean, invstd, nullptr, nullptr,
+                                                                 nullptr, scale, shift, nullptr, partial, n, h, w, c, ho, wo, 0.f, dwb, dhb, bpc);
+    return check_launch("maxpool_bn_bwd_partial (2x2)");
+  }
   if (dtype == SH_F32)
     pool_bn_bwd_partial_kernel<float><<<nblk, 256, 0, s>>>((const float*)dz, idx, (const float*)y, mean, invstd, scale, shift, n, h, w, c, ho, wo, rpb, partial, dw_, dh_);
   else
@@ -1017,6 +1167,22 @@ int simhand_maxpool_bn_bwd_apply(const void* dz, const uint8_t* idx, const void*
   const FastDiv dw_ = make_fastdiv((unsigned)w), dh_ = make_fastdiv((unsigned)h);
   const float inv_m = (float)(1.0 / (double)m);
   const int grid = row_grid(m, c / ve);
+  const int cvecs_ = c / ve;
+  if (h % 2 == 0 && w % 2 == 0 && cvecs_ <= 256 && (cvecs_ & (cvecs_ - 1)) == 0) {
+    const int64_t nb2 = (int64_t)n * (h / 2) * (w / 2);
+    const int lanes = 256 / cvecs_;
+    int64_t g2 = (nb2 + (int64_t)lanes * 4 - 1) / ((int64_t)lanes * 4);  // ~4 blocks of 2x2 per thread
+    if (g2 > 16384) g2 = 16384;
+    const int bpc = (int)((nb2 + g2 - 1) / g2);
+    const FastDiv dwb = make_fastdiv((unsigned)(w / 2)), dhb = make_fastdiv((unsigned)(h / 2));
+    if (dtype == SH_F32)
+      pool_bn_bwd_blk_kernel<float, true><<<(int)g2, 256, 0, s>>>((const float*)dz, idx, (const float*)y, mean, invstd, gamma, dgamma, dbeta,
+                                                                 scale, shift, (float*)dy, nullptr, n, h, w, c, ho, wo, inv_m, dwb, dhb, bpc);
+    else
+      pool_bn_bwd_blk_kernel<bf16_t, true><<<(int)g2, 256, 0, s>>>((const bf16_t*)dz, idx, (const bf16_t*)y, mean, invstd, gamma, dgamma, dbeta,
+                                                                  scale, shift, (bf16_t*)dy, nullptr, n, h, w, c, ho, wo, inv_m, dwb, dhb, bpc);
+    return check_launch("maxpool_bn_bwd_apply (2x2)");
+  }
   if (dtype == SH_F32)
     pool_bn_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)dz, idx, (const float*)y, mean, invstd, gamma, dgamma, dbeta, scale, shift, (float*)dy, n, h, w, c, ho, wo, inv_m, dw_, dh_);
   else

@@ -473,7 +473,7 @@ def test_dgrad_fused_bn_backward_sums(route, mode, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("n,h,w", [(3, 16, 16), (2, 15, 23), (1, 7, 9)])
+@pytest.mark.parametrize("n,h,w", [(3, 16, 16), (2, 15, 23), (1, 7, 9), (2, 12, 20)])
 def test_stem_bn_relu_maxpool_fused_equals_unfused(dtype, n, h, w):
     """bn_relu_maxpool_fwd / maxpool_bn_backward == bn_apply -> maxpool_fwd and maxpool_bwd -> bn_backward, bit for bit
     (the fused kernels round exactly where the unfused ones store)."""
@@ -495,8 +495,12 @@ def test_stem_bn_relu_maxpool_fused_equals_unfused(dtype, n, h, w):
     da = ops.maxpool_bwd(dz, want_idx, tuple(a.shape))
     want_dy, _, want_dg, want_db = ops.bn_backward(da.view(m, c), a.view(m, c), y.view(m, c), st, gamma, m, c, True, False, mask_from_y=True)
     dy, dg, db = ops.maxpool_bn_backward(dz, got_idx, y, st, gamma)
-    assert torch.equal(dy.view(m, c), want_dy)
-    assert torch.equal(dg, want_dg) and torch.equal(db, want_db)
+    if h % 2 or w % 2:  # pixel-by-pixel gather kernels: the unfused arithmetic, bit for bit
+        assert torch.equal(dy.view(m, c), want_dy)
+        assert torch.equal(dg, want_dg) and torch.equal(db, want_db)
+    else:  # 2x2-block kernels: same addends, another summation order for the channel sums
+        assert torch.allclose(dg, want_dg, rtol=1e-4, atol=1e-4) and torch.allclose(db, want_db, rtol=1e-4, atol=1e-4)
+        _check(dy.view(m, c).float(), want_dy.float(), 1e-5 if dtype == torch.float32 else 1e-2, "fused stem dy")
 
 
 @pytest.mark.parametrize("shape", [(2, 56, 56, 64, 64), (3, 28, 28, 128, 128), (5, 14, 14, 256, 128), (7, 7, 7, 128, 256), (1, 5, 9, 64, 64),
