@@ -93,9 +93,11 @@ __device__ __forceinline__ uint4 frag_bf16_scalar(const char* tile, int stride, 
 // PLAIN = 1x1 / stride 1 / pad 0 (x rows are the output pixels themselves): the loader walks two pointers instead of
 // decoding a pixel and multiplying out 64-bit addresses every k-step -- the generic loop spends ~180 VALU instructions
 // per 16 MFMAs on addressing and is VALU-issue-bound.
-template <typename T, int BM, int BN, bool STEM = false, bool PLAIN = false>
+// KPM: k-step = KPM x the base 32 (bf16) / 16 (fp32) pixels.  PLAIN uses 2: one barrier (~250 cycles) per 32 MFMAs of a
+// wave instead of per 16.
+template <typename T, int BM, int BN, bool STEM = false, bool PLAIN = false, int KPM = 1>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
-  constexpr int KP = WgCfg<T>::KP;
+  constexpr int KP = WgCfg<T>::KP * KPM;
   constexpr int SA = BM * (int)sizeof(T) + WgCfg<T>::PAD;  // dy tile row stride (bytes)
   constexpr int SB = BN * (int)sizeof(T) + WgCfg<T>::PAD;  // x tile row stride
   constexpr int VE = 16 / (int)sizeof(T);
@@ -250,25 +252,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
     const char* tA = sA + buf * (KP * SA);
     const char* tB = sB + buf * (KP * SB);
     if constexpr (sizeof(T) == 2) {
-      uint4 fa[MI], fb[NI];
-      if (PLAIN || p.use_tr) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) fa[mi] = frag_bf16_tr(tA, SA, wm * (BM / 2) + mi * 16, lane);
+      for (int sub = 0; sub < KPM; ++sub) {  // 32-pixel sub-tiles of the k-step
+        const char* uA = tA + sub * 32 * SA;
+        const char* uB = tB + sub * 32 * SB;
+        uint4 fa[MI], fb[NI];
+        if (PLAIN || p.use_tr) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) fb[ni] = frag_bf16_tr(tB, SB, wn * (BN / 2) + ni * 16, lane);
-      } else {
+          for (int mi = 0; mi < MI; ++mi) fa[mi] = frag_bf16_tr(uA, SA, wm * (BM / 2) + mi * 16, lane);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) fa[mi] = frag_bf16_scalar(tA, SA, wm * (BM / 2) + mi * 16, lane);
+          for (int ni = 0; ni < NI; ++ni) fb[ni] = frag_bf16_tr(uB, SB, wn * (BN / 2) + ni * 16, lane);
+        } else {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) fb[ni] = frag_bf16_scalar(tB, SB, wn * (BN / 2) + ni * 16, lane);
+          for (int mi = 0; mi < MI; ++mi) fa[mi] = frag_bf16_scalar(uA, SA, wm * (BM / 2) + mi * 16, lane);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) fb[ni] = frag_bf16_scalar(uB, SB, wn * (BN / 2) + ni * 16, lane);
+        }
+        typedef __attribute__((ext_vector_type(8))) __bf16 frag_t;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag_t, fa[mi]),
+                                                                  __builtin_bit_cast(frag_t, fb[ni]), acc[mi][ni], 0, 0, 0);
       }
-      typedef __attribute__((ext_vector_type(8))) __bf16 frag_t;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag_t, fa[mi]),
-                                                                __builtin_bit_cast(frag_t, fb[ni]), acc[mi][ni], 0, 0, 0);
     } else {
 #pragma unroll
       for (int j = 0; j < KP / 4; ++j) {
@@ -572,9 +579,12 @@ static void plan3(const sh_conv_desc* d, int* splitk, int* per) {
 }
 
 static int g_use_tr = 1;
-
+static int g_plain_kpm = 2;  // k-step multiplier of the 1x1 pointer-walking kernel (2 = 64 pixels per barrier)
+static bool is_plain(const sh_conv_desc* d) {
+  return d->dtype == SH_BF16 && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0;
+}
 static void plan(const sh_conv_desc* d, int* bm, int* bn, int* splitk, int* pps) {
-  const int kp = d->dtype == SH_F32 ? 16 : 32;
+  const int kp = d->dtype == SH_F32 ? 16 : (is_plain(d) && g_use_tr ? 32 * g_plain_kpm : 32);
   *bm = d->cout % 128 == 0 ? 128 : 64;
   *bn = d->cin % 128 == 0 ? 128 : 64;
   const long long mo = (long long)d->n * d->ho * d->wo;
@@ -685,7 +695,11 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
     else if (bn == 128) SH_WG(float, 64, 128);
     else SH_WG(float, 64, 64);
   } else if (d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && a.use_tr) {
-#define SH_WGP(BM, BN) wgrad_kernel<bf16_t, BM, BN, false, true><<<nblk, 256, 0, s>>>(a)
+#define SH_WGP(BM, BN)                                                                     \
+  do {                                                                                     \
+    if (g_plain_kpm == 2) wgrad_kernel<bf16_t, BM, BN, false, true, 2><<<nblk, 256, 0, s>>>(a); \
+    else wgrad_kernel<bf16_t, BM, BN, false, true><<<nblk, 256, 0, s>>>(a);                  \
+  } while (0)
     if (bm == 128 && bn == 128) SH_WGP(128, 128);
     else if (bm == 128) SH_WGP(128, 64);
     else if (bn == 128) SH_WGP(64, 128);
