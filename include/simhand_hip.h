@@ -156,6 +156,10 @@ typedef struct sh_conv_desc {
  * partial (sum, sum of squares) of the fp32 accumulators per output channel:
  * bn_partial [nblk_m][2][cout] fp32 with nblk_m = simhand_conv2d_fwd_stat_blocks(). */
 int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d);
+/* 64 -> 64 channel 3x3 / stride 1 / pad 1 bf16 layers (forward and store-only data gradient) run on the padded pixel
+ * grid with the whole filter resident in registers (conv3x3_c64.hip); 0 routes them through the generic tile kernels
+ * (tuning / test hook). */
+int simhand_conv3x3_c64_enable(int on);
 /* tuning / test hook of the short-K (cin or cout in {64,128,256}) bf16 stride-1 1x1 kernel: rows per block = 64*mf */
 int simhand_conv1x1_set_rows(int k, int mf);
 int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void* y, float* bn_partial, sh_stream_t stream);
@@ -195,7 +199,8 @@ int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w
  * relu_mode 0: no ReLU; 2: mask recomputed as y*scale + shift > 0; 3: 1-bit mask written by simhand_bn_apply;
  * 4: the STORED dx is the masked gradient g = dx * bit(mask) (y unused; partial[blk][1] = 0) -- the form the folded
  *    BatchNorm backward of a 1x1 conv + BN unit consumes (simhand host: ResNetEngine._unit3_bwd_folded).
- * blk runs over simhand_conv2d_dgrad_stat_blocks(d) tiles; finish with simhand_bn_bwd_finalize_raw.
+ * blk runs over simhand_conv2d_dgrad_stat_blocks(d, accumulate, relu_mode) rows (the launch the same three arguments
+ * select); finish with simhand_bn_bwd_finalize_raw.
  * accumulate: 0 store, 1 dx += result, 2 dx = result + res_grad * bit(res_mask) (as the two entry points above).
  * Replaces (reference): autograd's native_batch_norm_backward reduction after each Conv2d input-gradient in
  * torchvision's Bottleneck / BasicBlock (src/models/resnet_model.py:13-58). */
@@ -207,7 +212,7 @@ typedef struct sh_bn_bwd_fuse {
   int32_t relu_mode;
   float* partial;
 } sh_bn_bwd_fuse;
-int simhand_conv2d_dgrad_stat_blocks(const sh_conv_desc* d);
+int simhand_conv2d_dgrad_stat_blocks(const sh_conv_desc* d, int accumulate, int relu_mode);
 /* 1 if the fused form is the faster choice for this layer (callers keep the standalone pass otherwise);
  * simhand_conv2d_dgrad_fuse_1x1(1) forces it for the short-K 1x1 layers too (tuning hook) */
 int simhand_conv2d_dgrad_fuse_pays(const sh_conv_desc* d);

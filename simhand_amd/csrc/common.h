@@ -37,13 +37,14 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;  // 8 bf16 in 4 VGPRs
 typedef unsigned short bf16_t;                              // raw bf16 bits
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-// round-to-nearest-even, NaN preserved (same rounding as torch's .to(bfloat16))
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// round-to-nearest-even, NaN stays NaN (same rounding as torch's .to(bfloat16)): gfx950's v_cvt_pk_bf16_f32
+typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  const hw_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hw_bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -102,7 +103,7 @@ template <> struct Vec16<bf16_t> {
   template <bool NT = false> __device__ static __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
     unsigned w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16(o[2 * i]) | ((unsigned)f32_to_bf16(o[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
     st16<NT>(p, make_uint4(w[0], w[1], w[2], w[3]));
   }
 };

@@ -34,7 +34,6 @@ __device__ __forceinline__ float row16_sum_g1(float v) {
   return v;
 }
 
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
 
 __device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
   const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);

@@ -26,6 +26,7 @@
 // Block ids are remapped so all n-tiles of an m-tile run on one XCD (shared L2 for A rows).
 #include "common.h"
 #include "conv_1x1.h"
+#include "conv3x3_c64.h"
 
 namespace sh {
 
@@ -101,7 +102,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 __device__ __forceinline__ unsigned add_bf16x2(unsigned a, unsigned b) {
   const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
   const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  return pack_bf16x2(lo, hi);
 }
 
 // sum over the 16 lanes of a DPP row (lanes sharing lane>>4), result in every lane: four row_ror
@@ -442,10 +443,10 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
           lo[0] += b0.x; lo[1] += b0.y; lo[2] += b0.z; lo[3] += b0.w;
           hi[0] += b1.x; hi[1] += b1.y; hi[2] += b1.z; hi[3] += b1.w;
         }
-        v.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
-        v.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
-        v.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
-        v.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
+        v.x = pack_bf16x2(lo[0], lo[1]);
+        v.y = pack_bf16x2(lo[2], lo[3]);
+        v.z = pack_bf16x2(hi[0], hi[1]);
+        v.w = pack_bf16x2(hi[2], hi[3]);
       }
       T* dst = out + pix * p.Ng + ch;
       if (p.accumulate == 2) {
@@ -882,10 +883,10 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         lo[0] += b0.x; lo[1] += b0.y; lo[2] += b0.z; lo[3] += b0.w;
         hi[0] += b1.x; hi[1] += b1.y; hi[2] += b1.z; hi[3] += b1.w;
       }
-      v.x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
-      v.y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
-      v.z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
-      v.w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
+      v.x = pack_bf16x2(lo[0], lo[1]);
+      v.y = pack_bf16x2(lo[2], lo[3]);
+      v.z = pack_bf16x2(hi[0], hi[1]);
+      v.w = pack_bf16x2(hi[2], hi[3]);
       const int ch = ch0 + j * 32;
       T* dst = out + pix * p.Ng + ch;
       if (p.accumulate == 2) {
@@ -1106,8 +1107,40 @@ int simhand_igemm256_enable(int on) {
   return 0;
 }
 
+// 64 -> 64 channel 3x3 / stride 1 on the padded pixel grid with register-resident weights (conv3x3_c64.hip)
+static long long c64_q_total(const sh_conv_desc* d) { return (long long)d->n * (d->h + 2) * (d->w + 2); }
+static bool use_c64(const sh_conv_desc* d) {
+  return c64_supported(d->dtype, d->cin, d->cout, d->r, d->s, d->stride, d->pad, d->w, c64_q_total(d));
+}
+// the data-gradient form stores only (no accumulate / residual merge / bias) and fuses relu_mode 0 / 2 sums
+static bool use_c64_dgrad(const sh_conv_desc* d, int accumulate, int relu_mode, bool has_bias) {
+  return use_c64(d) && accumulate == 0 && !has_bias && (relu_mode < 0 || relu_mode == 0 || relu_mode == 2);
+}
+static int launch_c64_conv(const sh_conv_desc* d, const void* x, const void* w, void* out, float* partial, bool dgrad,
+                           const sh_bn_bwd_fuse* fuse, hipStream_t s) {
+  C64Args c;
+  c.x = (const bf16_t*)x; c.w = (const bf16_t*)w; c.out = (bf16_t*)out; c.partial = partial;
+  c.fy = fuse ? (const bf16_t*)fuse->y : nullptr;
+  c.fscale = fuse ? fuse->scale : nullptr;
+  c.fshift = fuse ? fuse->shift : nullptr;
+  c.relu = fuse && fuse->relu_mode == 2 ? 1 : 0;
+  c.N = d->n; c.H = d->h; c.W = d->w; c.dgrad = dgrad ? 1 : 0;
+  c.q_total = c64_q_total(d);
+  c.steps_per_block = 0;
+  c.div_pp = make_fastdiv((unsigned)((d->h + 2) * (d->w + 2)));
+  c.div_wp = make_fastdiv((unsigned)(d->w + 2));
+  launch_c64(c, s);
+  return check_launch(dgrad ? "conv2d_dgrad (3x3 c64)" : "conv2d_fwd (3x3 c64)");
+}
+
+int simhand_conv3x3_c64_enable(int on) {
+  c64_enable(on);
+  return 0;
+}
+
 int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d) {
   if (!d) return 0;
+  if (use_c64(d)) return c64_blocks(c64_q_total(d));
   const long long m = (long long)d->n * d->ho * d->wo;
   const int rows = use_1x1(d, d->cin, d->cout) ? gemm1x1_rows_per_block(d->cin)
                                               : (use_256(d->dtype, d->cout, d->cin, d->r * d->s, m) ? 256 : 128);
@@ -1146,6 +1179,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
     launch_gemm1x1(g, d->cin, false, (hipStream_t)stream);
     return check_launch("conv2d_fwd (1x1)");
   }
+  if (use_c64(d)) return launch_c64_conv(d, x, w, y, bn_partial, false, nullptr, (hipStream_t)stream);
   if (use_256(d->dtype, a.Ng, a.Ca, d->r * d->s, a.Mg)) return launch_igemm256<false>(a, (hipStream_t)stream);
   return d->dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
@@ -1236,7 +1270,8 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
 }
 
 // tiles (= rows of the fused BatchNorm-backward partial buffer) of the data-gradient launch
-static int dgrad_stat_blocks(const sh_conv_desc* d) {
+static int dgrad_stat_blocks(const sh_conv_desc* d, int accumulate, int relu_mode) {
+  if (use_c64_dgrad(d, accumulate, relu_mode, false)) return c64_blocks(c64_q_total(d));
   if (use_1x1(d, d->cout, d->cin)) return ceil_div((long long)d->n * d->h * d->w, gemm1x1_rows_per_block(d->cout));
   const long long mg = d->stride == 2 ? (long long)d->n * ((d->h + 1) / 2) * ((d->w + 1) / 2) : (long long)d->n * d->h * d->w;
   const int rows = use_256_dgrad(d, mg) ? 256 : 128;
@@ -1303,6 +1338,8 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
     launch_gemm1x1(g, d->cout, true, (hipStream_t)stream);
     return check_launch("conv2d_dgrad (1x1)");
   }
+  if (use_c64_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr)
+    return launch_c64_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream);
   if (use_256_dgrad(d, a.Mg)) return launch_igemm256<true>(a, (hipStream_t)stream);
   return d->dtype == SH_F32 ? launch_igemm<float, true>(a, (hipStream_t)stream) : launch_igemm<bf16_t, true>(a, (hipStream_t)stream);
 }
@@ -1331,9 +1368,9 @@ int simhand_conv2d_dgrad_fuse_pays(const sh_conv_desc* d) {
   return (!use_1x1(d, d->cout, d->cin) || g_fuse_1x1) ? 1 : 0;
 }
 
-int simhand_conv2d_dgrad_stat_blocks(const sh_conv_desc* d) {
+int simhand_conv2d_dgrad_stat_blocks(const sh_conv_desc* d, int accumulate, int relu_mode) {
   if (!d) return 0;
-  return dgrad_stat_blocks(d);
+  return dgrad_stat_blocks(d, accumulate, relu_mode);
 }
 
 int simhand_conv2d_dgrad_fused(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,

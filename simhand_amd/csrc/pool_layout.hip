@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void stem_pad_kernel(const float* __restrict__
       *reinterpret_cast<float4*>(xp + i * 4) = make_float4(v0, v1, v2, 0.f);
     } else {
       uint2 o;
-      o.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+      o.x = pack_bf16x2(v0, v1);
       o.y = (unsigned)f32_to_bf16(v2);
       *reinterpret_cast<uint2*>(xp + i * 4) = o;
     }

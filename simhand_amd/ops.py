@@ -187,16 +187,17 @@ def conv2d_dgrad_fused(d: ConvDesc, dy, wt, prev_y, prev_st: Optional["BNState"]
     lib = _lib_dev()
     if dx is None:
         dx = torch.empty(d.n, d.h, d.w, d.cin, dtype=dy.dtype, device=dy.device)
-    nblk = lib.simhand_conv2d_dgrad_stat_blocks(C.byref(d))
+    mode = 2 if res_grad is not None else int(accumulate)
+    relu_mode = 3 if prev_mask is not None else (2 if prev_st is not None else 0)
+    nblk = lib.simhand_conv2d_dgrad_stat_blocks(C.byref(d), mode, relu_mode)
     part = torch.empty(nblk, 2, d.cin, dtype=torch.float32, device=dy.device)
     f = BnBwdFuse()
     f.y = _ptr(prev_y)
     f.mask = _ptr(prev_mask)
-    f.relu_mode = 3 if prev_mask is not None else (2 if prev_st is not None else 0)
+    f.relu_mode = relu_mode
     f.scale = _ptr(prev_st.scale) if f.relu_mode == 2 else None
     f.shift = _ptr(prev_st.shift) if f.relu_mode == 2 else None
     f.partial = _ptr(part)
-    mode = 2 if res_grad is not None else int(accumulate)
     check(lib.simhand_conv2d_dgrad_fused(C.byref(d), _ptr(dy), _ptr(wt), _ptr(dx), mode, _ptr(res_grad), _ptr(res_mask), C.byref(f),
                                          _stream()), "conv2d_dgrad_fused")
     return dx, part
@@ -220,7 +221,7 @@ def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accu
     part = None
     if fuse_mode is not None:
         if want_sums or fuse_mode != 4:  # mode 4 may store the masked gradient without emitting its sums
-            nblk = lib.simhand_conv2d_dgrad_stat_blocks(C.byref(d))
+            nblk = lib.simhand_conv2d_dgrad_stat_blocks(C.byref(d), o.accumulate, fuse_mode)
             part = torch.empty(nblk, 2, d.cin, dtype=torch.float32, device=dy.device)
         f = BnBwdFuse()
         f.y = _ptr(prev_y)

@@ -407,6 +407,69 @@ def test_big_tile_conv_fwd_dgrad(shape, force_big_tile):
     _check(acc.float().cpu(), base + x.grad.permute(0, 2, 3, 1), 2 * _tol(dtype), "dgrad accumulate")
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# 64 -> 64 channel 3x3 on the padded pixel grid, filter resident in registers (conv3x3_c64.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+C64_SHAPES = [(8, 28, 28), (4, 56, 56), (16, 5, 61), (9, 23, 17)]  # n, h, w (w + 3 <= 64; >= 4096 padded pixels)
+
+
+@pytest.mark.parametrize("shape", C64_SHAPES)
+def test_c64_conv3x3_fwd_dgrad(shape):
+    """Forward (+ BN partial statistics) and data gradient (plain, and with the previous unit's BN-backward sums) against
+    fp32 torch, and bit-for-bit against the generic tile kernel (same tap / channel order of the fp32 MFMA chain)."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    n, h, w = shape
+    lib = ops._lib_dev()
+    g = torch.Generator().manual_seed(n * 1000 + h)
+    x = _rnd(torch.randn(n, 64, h, w, generator=g), dtype)
+    wt = _rnd(torch.randn(64, 64, 3, 3, generator=g) / 24.0, dtype)
+    x.requires_grad_(True)
+    y = F.conv2d(x, wt, padding=1)
+    dy = _rnd(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    d = ops.conv_desc(n, h, w, 64, 64, 3, 3, 1, 1, dtype)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    wd = ops.pack_krsc(wt.detach().to(DEV), dtype)
+    wtd = ops.pack_crsk(wt.detach().to(DEV), dtype)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    m = n * h * w
+    yd, part = ops.conv2d_fwd(d, xd, wd, want_stats=True)
+    assert part.shape[0] < (m + 127) // 128  # the persistent kernel took it (one partial row per block)
+    _check(yd.float().cpu().permute(0, 3, 1, 2), y.detach(), _tol(dtype), "fwd")
+    yf = y.detach().permute(0, 2, 3, 1).reshape(m, 64)
+    _check(part[:, 0].sum(0).cpu() / m, yf.mean(0), 1e-2, "stat mean")
+    _check(part[:, 1].sum(0).cpu() / m, (yf * yf).mean(0), 1e-2, "stat sumsq")
+    dxd = ops.conv2d_dgrad(d, dyd, wtd)
+    _check(dxd.float().cpu().permute(0, 3, 1, 2), x.grad, _tol(dtype), "dgrad")
+
+    y_prev = _rnd(torch.randn(n, h, w, 64, generator=g), dtype).to(DEV).to(dtype)
+    st = ops.BNState(64, DEV)
+    st.scale.copy_(torch.randn(64, generator=g).to(DEV))
+    st.shift.copy_(torch.randn(64, generator=g).to(DEV) * 0.3)
+    fused = {}
+    for mode in (2, 0):
+        dx2, p2 = ops.conv2d_dgrad_fused(d, dyd, wtd, y_prev, st if mode == 2 else None, None)
+        assert torch.equal(dx2, dxd), mode
+        s1, s2 = _bn_sums_reference(dx2, y_prev, mode, st.scale, st.shift, None)
+        got1, got2 = p2[:, 0].double().sum(0), p2[:, 1].double().sum(0)
+        assert (got1 - s1).abs().max().item() <= 1e-4 * s1.abs().max().item() + 1e-4, (mode, "sum g")
+        assert (got2 - s2).abs().max().item() <= 1e-4 * s2.abs().max().item() + 1e-4, (mode, "sum g*y")
+        fused[mode] = p2
+
+    lib.simhand_conv3x3_c64_enable(0)
+    try:
+        y_ref, part_ref = ops.conv2d_fwd(d, xd, wd, want_stats=True)
+        dx_ref = ops.conv2d_dgrad(d, dyd, wtd)
+    finally:
+        lib.simhand_conv3x3_c64_enable(1)
+    assert part_ref.shape[0] == (m + 127) // 128
+    assert torch.equal(yd, y_ref)
+    assert torch.equal(dxd, dx_ref)
+    _check(part.sum(0).cpu(), part_ref.sum(0).cpu(), 1e-5, "partials vs tile kernel")
+
+
 def _bn_sums_reference(dx, y, mode, st_scale, st_shift, mask_bits):
     """sum g, sum g*y per channel with g = dx * relu'(.) -- dx / y as the stored (rounded) tensors."""
     dxf, yf = dx.float(), y.float()
