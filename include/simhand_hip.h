@@ -51,6 +51,9 @@ int simhand_device_check(void);
 enum sh_prof_class { SH_PROF_CONV_FWD = 0, SH_PROF_CONV_DGRAD = 1, SH_PROF_CONV_WGRAD = 2,
                      SH_PROF_BN = 3, SH_PROF_POOL = 4, SH_PROF_LOSS = 5, SH_PROF_MISC = 6, SH_PROF_NCLASS = 7 };
 int simhand_prof_enable(int on);
+/* bit c set = launches of class c record their event pair (default: all).  An event pair costs ~1-3 us of queue time per
+ * launch, so a timed region records only the class it needs. */
+int simhand_prof_set_classes(uint32_t mask);
 /* blocks until recorded events completed; out_ms/out_flops/out_bytes/out_count are host arrays of SH_PROF_NCLASS */
 int simhand_prof_collect(double* out_ms, double* out_flops, double* out_bytes, int64_t* out_count);
 int simhand_prof_reset(void);

@@ -34,11 +34,12 @@ struct ProfRec {
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
+static unsigned g_prof_mask = ~0u;  // classes that record events
 static std::vector<ProfRec> g_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
 
 ProfScope::ProfScope(int c, hipStream_t s, double flops, double bytes) : cls(c), stream(s), on(false), slot(-1) {
-  if (!g_prof_on) return;
+  if (!g_prof_on || !((g_prof_mask >> c) & 1u)) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r;
   if (!g_pool.empty()) {
@@ -94,6 +95,12 @@ int simhand_device_check(void) {
 int simhand_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(sh::g_prof_mu);
   sh::g_prof_on = on != 0;
+  return 0;
+}
+
+int simhand_prof_set_classes(uint32_t mask) {
+  std::lock_guard<std::mutex> lk(sh::g_prof_mu);
+  sh::g_prof_mask = mask;
   return 0;
 }
 

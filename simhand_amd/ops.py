@@ -592,13 +592,18 @@ def apply_relu_bitmask(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_UNIT_COEF: dict = {}
+
+
 def bn_channel_sums(raw_partial: torch.Tensor, c: int) -> torch.Tensor:
     """Column 0 of the tile partials of a fused dgrad epilogue (sum over tiles, fp64 fold): [c] fp32."""
     lib = _lib_dev()
     dev = raw_partial.device
     out = torch.empty(2, c, dtype=torch.float32, device=dev)
-    one = torch.ones(c, dtype=torch.float32, device=dev)
-    zero = torch.zeros(c, dtype=torch.float32, device=dev)
+    key = (c, dev)
+    if key not in _UNIT_COEF:  # constant (mean = 0, invstd = 1) vectors: built once per channel count, not per call
+        _UNIT_COEF[key] = (torch.zeros(c, dtype=torch.float32, device=dev), torch.ones(c, dtype=torch.float32, device=dev))
+    zero, one = _UNIT_COEF[key]
     nb = lib.simhand_bn_bwd_finalize_raw_workspace_bytes(raw_partial.shape[0], c)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     # finalize_raw with mean = 0, invstd = 1: "dbeta" = sum of column 0, "dgamma" = sum of column 1
@@ -673,6 +678,12 @@ def lars_adam_multi(plan: LarsAdamPlan, records: "np.ndarray", betas=(0.9, 0.999
 # --------------------------------------------------------------------- profiler
 def prof_enable(on: bool) -> None:
     _lib.load().simhand_prof_enable(int(on))
+
+
+def prof_set_classes(names=None) -> None:
+    """Restrict the event profiler to the named kernel classes (None = all)."""
+    mask = 0xFFFFFFFF if names is None else sum(1 << _lib.PROF_CLASSES.index(n) for n in names)
+    _lib.load().simhand_prof_set_classes(mask)
 
 
 def prof_reset() -> None:
