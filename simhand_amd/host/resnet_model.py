@@ -227,14 +227,17 @@ class ResNetEngine:
             save.append(u)
         return a
 
-    def forward(self, images: Tensor, training: bool, want_ctx: bool):
+    def forward(self, images, training: bool, want_ctx: bool):
+        """images: NCHW fp32 batch, or a tuple of such batches (the views) that is processed as their concatenation."""
         f = self.features
         conv1, bn1 = f[0], f[1]
-        n, _, h, w = images.shape
+        views = tuple(images) if isinstance(images, (tuple, list)) else (images,)
+        n = sum(v.shape[0] for v in views)
+        h, w = views[0].shape[-2:]
         ctx: Optional[dict] = {"units": [], "blocks": []} if want_ctx else None
         # stem: direct 7x7/2 conv from the zero-padded NHWC4 copy of the batch (0.9 GB at 2048 x 224^2 -- an im2col
         # matrix would be 9.9 GB); the same copy feeds the stem's weight gradient
-        xp = ops.stem_pad_input(images.contiguous(), self.dtype)
+        xp = ops.stem_pad_input(tuple(v.contiguous() for v in views), self.dtype)
         pk = self._pack(conv1, need_t=False, stem=True)
         y, part = ops.stem_conv_fwd(xp, pk.krsc, h, w, want_stats=training)
         ho, wo = y.shape[1], y.shape[2]
@@ -472,7 +475,7 @@ class _EncoderFn(torch.autograd.Function):
         need = grad_mode and any(p.requires_grad for p in params)
         if need and not training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the training step")
-        enc, ectx = engine.forward(images.contiguous(), training, need)
+        enc, ectx = engine.forward(images, training, need)
         ctx.engine, ctx.ectx, ctx.params = engine, ectx, params
         return enc
 
@@ -507,7 +510,9 @@ class ResNetModel(nn.Module):
     def set_compute_dtype(self, dtype: torch.dtype) -> None:
         self.engine = ResNetEngine(self.features, dtype)
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x) -> Tensor:
+        """x: image batch, or a tuple of batches (the two views) encoded as their concatenation -- the stem reads each
+        view in place, so the 1.2 GB torch.cat of the reference's training_step is not materialised."""
         if self.mode != "pretraining":
             raise NotImplementedError("only mode='pretraining' (the contrastive hot path) is built; "
                                       "the supervised 2.5D head is out of scope (SURVEY 2 #5)")

@@ -108,8 +108,9 @@ class SimCLR(BaseModel):
         return mu.projection_stats(projection, name)
 
     def _projections(self, batch: Dict[str, Tensor]) -> Tensor:
-        x = torch.cat((batch["transformed_image1"], batch["transformed_image2"]), dim=0)
-        b = x.shape[0] // 2
+        # reference: torch.cat of the two views (simclr_model.py:30-37); the encoder takes the pair and reads each view in place
+        x = (batch["transformed_image1"], batch["transformed_image2"])
+        b = x[0].shape[0]
         p = self._head(self.get_encodings(x))
         if not self.unwarps:
             return mu.normalize(p)

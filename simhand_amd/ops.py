@@ -325,14 +325,21 @@ def stem_geometry(h: int, w: int):
     return tuple(i.value for i in v)
 
 
-def stem_pad_input(x: torch.Tensor, dtype) -> torch.Tensor:
-    """NCHW fp32 [n,3,h,w] -> zero-padded NHWC4 [n,hp,wp,4] in the compute dtype."""
+def stem_pad_input(x, dtype) -> torch.Tensor:
+    """NCHW fp32 [n,3,h,w] -> zero-padded NHWC4 [n,hp,wp,4] in the compute dtype.  x may be a tuple of such tensors
+    (the two views of a contrastive batch): they are packed back to back, i.e. the result equals that of their
+    concatenation without the concatenated copy ever being made."""
     lib = _lib_dev()
-    n, c, h, w = x.shape
-    assert c == 3 and x.dtype == torch.float32 and x.is_contiguous()
+    views = tuple(x) if isinstance(x, (tuple, list)) else (x,)
+    _, c, h, w = views[0].shape
     hp, wp, _, _ = stem_geometry(h, w)
-    xp = torch.empty(n, hp, wp, 4, dtype=dtype, device=x.device)
-    check(lib.simhand_stem_pad_input(_ptr(x), _ptr(xp), n, h, w, dt(dtype), _stream()), "stem_pad_input")
+    n = sum(v.shape[0] for v in views)
+    xp = torch.empty(n, hp, wp, 4, dtype=dtype, device=views[0].device)
+    at = 0
+    for v in views:
+        assert v.shape[1:] == (3, h, w) and v.dtype == torch.float32 and v.is_contiguous()
+        check(lib.simhand_stem_pad_input(_ptr(v), _ptr(xp[at:]), v.shape[0], h, w, dt(dtype), _stream()), "stem_pad_input")
+        at += v.shape[0]
     return xp
 
 
