@@ -223,14 +223,22 @@ int simhand_conv2d_dgrad_fuse_1x1(int on);
 int simhand_conv2d_dgrad_fused(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
                                const uint8_t* res_mask, const sh_bn_bwd_fuse* fuse, sh_stream_t stream);
 /* General form: accumulate modes as above, optional fusion, optional fp32 per-channel bias (length cin) added to the
- * result before accumulation / rounding. */
+ * result before accumulation / rounding, and an optional SECOND reduction segment for 1x1 / stride-1 layers:
+ *   dx = dy * wt^T + x2 * wt2^T   (x2 [n][h][w][c2], wt2 [cin][c2], c2 a multiple of 64)
+ * accumulated in fp32 in one pass -- the two terms of the folded BatchNorm backward's input gradient
+ * (g (diag(A) W) - a (W^T diag(B) W)) without a second launch re-reading and re-writing dx.  Only where
+ * simhand_conv2d_dgrad_concat_ok(d, c2) says so (the tile-kernel routes); x2 = NULL: off. */
 typedef struct sh_dgrad_opts {
   int32_t accumulate;
   const void* res_grad;
   const uint8_t* res_mask;
   const float* bias;
   const sh_bn_bwd_fuse* fuse;
+  const void* x2;
+  const void* wt2;
+  int32_t c2;
 } sh_dgrad_opts;
+int simhand_conv2d_dgrad_concat_ok(const sh_conv_desc* d, int c2);
 int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, const sh_dgrad_opts* opts, sh_stream_t stream);
 
 /* dw (fp32, KRSC) = sum over output pixels of dy (x) patches(x); deterministic two-stage split-K */

@@ -49,7 +49,7 @@ class BnBwdFuse(C.Structure):
 class DgradOpts(C.Structure):
     """sh_dgrad_opts (include/simhand_hip.h)."""
     _fields_ = [("accumulate", C.c_int32), ("res_grad", C.c_void_p), ("res_mask", C.c_void_p), ("bias", C.c_void_p),
-                ("fuse", C.POINTER(BnBwdFuse))]
+                ("fuse", C.POINTER(BnBwdFuse)), ("x2", C.c_void_p), ("wt2", C.c_void_p), ("c2", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -130,6 +130,7 @@ SIGNATURES = {
     "simhand_bn_bwd_finalize_raw": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_conv2d_dgrad_stat_blocks": (_I, [C.POINTER(ConvDesc), _I, _I]),
     "simhand_conv3x3_c64_enable": (_I, [_I]),
+    "simhand_conv2d_dgrad_concat_ok": (_I, [C.POINTER(ConvDesc), _I]),
     "simhand_conv2d_fwd_bnact": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "simhand_conv2d_dgrad_ex": (_I, [C.POINTER(ConvDesc), _P, _P, _P, C.POINTER(DgradOpts), _P]),
     "simhand_conv2d_dgrad_fuse_pays": (_I, [C.POINTER(ConvDesc)]),

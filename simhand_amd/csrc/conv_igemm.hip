@@ -66,6 +66,13 @@ struct IgemmArgs {
   const void* ep_res;
   unsigned char* ep_mask;
   int ep_relu;
+  // dgrad, 1x1 / stride 1 only: a SECOND K segment -- out = a * w^T + a2 * w2^T in one accumulation (the two terms of the folded
+  // BatchNorm backward's input gradient).  Ca is then the total reduction length lda + Ca2; the k-steps past lda / KE read
+  // a2 [Mg][Ca2] and w2 [Ng][Ca2].  lda = channels per pixel / per tap of a and w (= Ca without a second segment).
+  const void* a2 = nullptr;
+  const void* w2 = nullptr;
+  int Ca2 = 0;
+  int lda = 0;
 };
 
 template <typename T> struct Mma;
@@ -219,16 +226,17 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
       h0 = px.hd * p.stride - p.pad;
       w0 = px.wd * p.stride - p.pad;
     }
-    pa = asrc + ((long long)px.img * p.Hs * p.Ws + (long long)h0 * p.Ws + w0) * p.Ca + chunk * VE;
+    pa = asrc + ((long long)px.img * p.Hs * p.Ws + (long long)h0 * p.Ws + w0) * p.lda + chunk * VE;
     if (!px.ok) h0 = -(1 << 20);  // fails every bounds test below
   };
   init_row(0, pa0, h00, w00);
   init_row(1, pa1, h01, w01);
   init_row(2, pa2, h02, w02);
   init_row(3, pa3, h03, w03);
-  const long long wrow = (long long)p.R * p.S * p.Ca;  // elements per weight row
+  const long long wrow = (long long)p.R * p.S * p.lda;  // elements per weight row
   const T* pb0 = wsrc + (long long)(n0 + lrow) * wrow + chunk * VE;  // rows n0 + lrow + 32 i (always < Ng)
-  const long long wrow32 = 32 * wrow;
+  long long wrow32 = 32 * wrow;
+  const int cs1 = p.lda / KE;  // k-steps of the first K segment (== csteps without a second one)
   // LDS store offsets of this thread's rows.  The B (weight) tile uses its own swizzle key because its rows are
   // read in a permuted order (see the fragment offsets below).
   // rows lrow + 32 i share one swizzle key (the keys only look at row bits 1..4): offsets differ by 32 * 128 bytes
@@ -251,9 +259,21 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
   // staging registers as named scalars: an array here ends up in scratch / promoted to LDS (hipcc 7.2)
   uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2 = make_uint4(0, 0, 0, 0), rb3 = make_uint4(0, 0, 0, 0);
   auto load_step = [&]() __attribute__((always_inline)) {
+    if (DGRAD && p.a2 != nullptr && l_cs == cs1) {
+      // second K segment (1x1 / stride 1: pixel index == m): re-base the row and weight pointers so that the same
+      // l_cs * KE offsets walk a2 / w2; dead rows keep their h0 = -2^20
+      const T* a2 = reinterpret_cast<const T*>(p.a2);
+      const long long back = (long long)chunk * VE - (long long)cs1 * KE;
+      pa0 = a2 + (long long)(m0 + lrow) * p.Ca2 + back;
+      pa1 = a2 + (long long)(m0 + lrow + 32) * p.Ca2 + back;
+      pa2 = a2 + (long long)(m0 + lrow + 64) * p.Ca2 + back;
+      pa3 = a2 + (long long)(m0 + lrow + 96) * p.Ca2 + back;
+      pb0 = reinterpret_cast<const T*>(p.w2) + (long long)(n0 + lrow) * p.Ca2 + back;
+      wrow32 = 32ll * p.Ca2;
+    }
     const int hoff = dh * l_tr, woff = dh * l_ts;
-    const int aoff = (hoff * p.Ws + woff) * p.Ca + l_cs * KE;                              // elements, |.| < 2^31
-    const int boff = ((r0 + rstep * l_tr) * p.S + (s0 + rstep * l_ts)) * p.Ca + l_cs * KE;
+    const int aoff = (hoff * p.Ws + woff) * p.lda + l_cs * KE;                              // elements, |.| < 2^31
+    const int boff = ((r0 + rstep * l_tr) * p.S + (s0 + rstep * l_ts)) * p.lda + l_cs * KE;
     auto load_a = [&](const T* pa, int h0, int w0) __attribute__((always_inline)) -> uint4 {
       const bool ok = (unsigned)(h0 + hoff) < (unsigned)p.Hs && (unsigned)(w0 + woff) < (unsigned)p.Ws;
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -714,16 +734,17 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
       h0 = px.hd * p.stride - p.pad;
       w0 = px.wd * p.stride - p.pad;
     }
-    pa = asrc + ((long long)px.img * p.Hs * p.Ws + (long long)h0 * p.Ws + w0) * p.Ca + chunk_a * VE;
+    pa = asrc + ((long long)px.img * p.Hs * p.Ws + (long long)h0 * p.Ws + w0) * p.lda + chunk_a * VE;
     if (!px.ok) h0 = -(1 << 20);
   };
   init_row(0, pa0, h00, w00);
   init_row(1, pa1, h01, w01);
   init_row(2, pa2, h02, w02);
   init_row(3, pa3, h03, w03);
-  const long long wrow = (long long)p.R * p.S * p.Ca;
+  const long long wrow = (long long)p.R * p.S * p.lda;
   const T* pb0 = wsrc + (long long)(n0 + lrow) * wrow + chunk_b * VE;
-  const long long wrow64 = 64 * wrow;
+  long long wrow64 = 64 * wrow;
+  const int cs1 = p.lda / KE;  // k-steps of the first K segment (== csteps without a second one)
   const int dma_row0 = wave * 8 * 128;  // + i * 64 * 128: wave-uniform LDS offset of this wave's 8 rows
 
   // DMA state of the NEXT k-step (wave-uniform): tap walk, element offsets, destination stage
@@ -732,10 +753,22 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   unsigned n_dA = 0;
   bool n_live = true;  // false on the last k-step: its (branch-free) DMAs fetch the zero page into the idle stage
   auto next_step = [&](int stage) __attribute__((always_inline)) {
+    if (DGRAD && p.a2 != nullptr && l_cs == cs1) {
+      // second K segment (1x1 / stride 1: pixel index == m): re-base the row and weight pointers so that the same
+      // l_cs * KE offsets walk a2 / w2; dead rows keep their h0 = -2^20
+      const T* a2 = reinterpret_cast<const T*>(p.a2);
+      const long long back = -(long long)cs1 * KE;
+      pa0 = a2 + (long long)(m0 + lrow) * p.Ca2 + chunk_a * VE + back;
+      pa1 = a2 + (long long)(m0 + lrow + 64) * p.Ca2 + chunk_a * VE + back;
+      pa2 = a2 + (long long)(m0 + lrow + 128) * p.Ca2 + chunk_a * VE + back;
+      pa3 = a2 + (long long)(m0 + lrow + 192) * p.Ca2 + chunk_a * VE + back;
+      pb0 = reinterpret_cast<const T*>(p.w2) + (long long)(n0 + lrow) * p.Ca2 + chunk_b * VE + back;
+      wrow64 = 64ll * p.Ca2;
+    }
     n_hoff = dh * l_tr;
     n_woff = dh * l_ts;
-    n_aoff = (n_hoff * p.Ws + n_woff) * p.Ca + l_cs * KE;
-    n_boff = ((r0 + rstep * l_tr) * p.S + (s0 + rstep * l_ts)) * p.Ca + l_cs * KE;
+    n_aoff = (n_hoff * p.Ws + n_woff) * p.lda + l_cs * KE;
+    n_boff = ((r0 + rstep * l_tr) * p.S + (s0 + rstep * l_ts)) * p.lda + l_cs * KE;
     n_dA = smem_addr + stage * STAGE + dma_row0;
     if (++l_cs == csteps) {  // tap-major k order (taps innermost measured the same: the re-reads are not the limiter)
       l_cs = 0;
@@ -1051,7 +1084,9 @@ static bool use_256_dgrad(const sh_conv_desc* d, long long Mg) {
 }
 
 template <typename T, bool DGRAD>
-static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
+static int launch_igemm(const IgemmArgs& a0, hipStream_t s) {
+  IgemmArgs a = a0;
+  if (a.lda == 0) a.lda = a.Ca;
   const int nblk = a.classes * a.m_tiles * a.n_tiles;
   if (a.Ng % 128 == 0) {
     igemm_kernel<T, DGRAD, 128><<<nblk, 256, 0, s>>>(a);
@@ -1063,6 +1098,7 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
 
 template <bool DGRAD>
 static int launch_igemm256(IgemmArgs a, hipStream_t s) {
+  if (a.lda == 0) a.lda = a.Ca;
   a.m_tiles = ceil_div(a.Mg, 256);
   a.n_tiles = a.Ng / 256;
   const int nblk = a.classes * a.m_tiles * a.n_tiles;
@@ -1278,11 +1314,19 @@ static int dgrad_stat_blocks(const sh_conv_desc* d, int accumulate, int relu_mod
   return (d->stride == 2 ? 4 : 1) * ceil_div(mg, rows);
 }
 
+// second reduction segment (sh_dgrad_opts.x2): the tile kernels of the 1x1 / stride-1 bf16 layers
+static bool concat_ok(const sh_conv_desc* d, int c2) {
+  return d->dtype == SH_BF16 && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && c2 > 0 && c2 % 64 == 0 &&
+         !use_1x1(d, d->cout, d->cin);
+}
+
 static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
                       const unsigned char* res_mask, sh_stream_t stream, const sh_bn_bwd_fuse* fuse = nullptr,
-                      const float* bias = nullptr) {
+                      const float* bias = nullptr, const void* x2 = nullptr, const void* wt2 = nullptr, int c2 = 0) {
   if (check_desc(d, "conv2d_dgrad")) return 1;
   SH_REQUIRE(dy && wt && dx, "conv2d_dgrad: NULL pointer");
+  SH_REQUIRE(x2 == nullptr || (wt2 != nullptr && concat_ok(d, c2)),
+             "conv2d_dgrad_ex: a second reduction segment needs wt2 and a layer simhand_conv2d_dgrad_concat_ok accepts");
   const int ke = d->dtype == SH_F32 ? 32 : 64;
   SH_REQUIRE(d->cout % ke == 0, "conv2d_dgrad: cout=%d must be a multiple of %d", d->cout, ke);
   SH_REQUIRE(d->cin % 64 == 0, "conv2d_dgrad: cin=%d must be a multiple of 64", d->cin);
@@ -1308,6 +1352,11 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
     a.fpartial = fuse->partial;
   }
   a.bias = bias;
+  if (x2 != nullptr) {
+    a.a2 = x2; a.w2 = wt2; a.Ca2 = c2;
+    a.lda = d->cout;
+    a.Ca = d->cout + c2;
+  }
   if (d->stride == 2) {
     a.classes = 4;
     a.Hq = (d->h + 1) / 2;
@@ -1384,7 +1433,12 @@ int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* w
   SH_REQUIRE(o != nullptr, "conv2d_dgrad_ex: opts is NULL");
   SH_REQUIRE(o->accumulate >= 0 && o->accumulate <= 2, "conv2d_dgrad_ex: accumulate mode %d", o->accumulate);
   SH_REQUIRE(o->accumulate != 2 || (o->res_grad && o->res_mask), "conv2d_dgrad_ex: accumulate 2 needs res_grad / res_mask");
-  return dgrad_impl(d, dy, wt, dx, o->accumulate, o->res_grad, o->res_mask, stream, o->fuse, o->bias);
+  return dgrad_impl(d, dy, wt, dx, o->accumulate, o->res_grad, o->res_mask, stream, o->fuse, o->bias, o->x2, o->wt2, o->c2);
+}
+
+int simhand_conv2d_dgrad_concat_ok(const sh_conv_desc* d, int c2) {
+  if (!d) return 0;
+  return concat_ok(d, c2) ? 1 : 0;
 }
 
 }  // extern "C"

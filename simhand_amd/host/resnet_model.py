@@ -135,6 +135,8 @@ class ResNetEngine:
         self.fuse_bn_bwd = True
         # bottleneck conv3 + bn3: BatchNorm backward folded into the 1x1 conv's own gradients (_unit3_bwd_folded)
         self.fold_bn3 = True
+        # both terms of the folded input gradient in one launch where the tile kernels take a second K segment
+        self.concat_fold = True
         # the folds need every block's incoming gradient in masked form, which only the all-1x1 tails of Bottleneck nets give
         self._bottleneck = all(isinstance(b, Bottleneck) for li in (4, 5, 6, 7) for b in features[li])
 
@@ -341,6 +343,14 @@ class ResNetEngine:
         a2 = u.x
         wa, wm, bias, s = self._fold_1x1_bn(u, g, a2, grads)
         dww = ops.conv_desc(d.n, d.h, d.w, d.cin, d.cin, 1, 1, 1, 0, self.dtype)
+        if self.concat_fold and ops.conv2d_dgrad_concat_ok(d, d.cin):
+            # both terms in one accumulation (K = cout + cin): da2 is written once, and the tile kernel carries prev's sums
+            if self.fuse_bn_bwd:
+                da2, part = ops.conv2d_dgrad_ex(d, g, wa, bias=bias, x2=a2, wt2=wm, fuse_mode=2 if prev.relu else 0, prev_y=prev.y,
+                                                prev_st=prev.st)
+                return da2, part, s
+            da2, _ = ops.conv2d_dgrad_ex(d, g, wa, bias=bias, x2=a2, wt2=wm)
+            return da2, None, s
         da2, _ = ops.conv2d_dgrad_ex(d, g, wa, bias=bias)
         if self.fuse_bn_bwd and ops.conv2d_dgrad_fuse_pays(dww):
             da2, part = ops.conv2d_dgrad_ex(dww, a2, wm, dx=da2, accumulate=True, fuse_mode=2 if prev.relu else 0, prev_y=prev.y,
@@ -359,6 +369,9 @@ class ResNetEngine:
         kw = dict(fuse_mode=4, prev_mask=below.mask, want_sums=False) if masked_store else {}
         if d.stride == 1:
             dterm = ops.conv_desc(d.n, d.h, d.w, d.cin, d.cin, 1, 1, 1, 0, self.dtype)
+            if self.concat_fold and ops.conv2d_dgrad_concat_ok(d, d.cin):
+                ops.conv2d_dgrad_ex(d, g, wa, dx=dx, accumulate=True, bias=bias, x2=x_in, wt2=wm, **kw)
+                return dx
             ops.conv2d_dgrad_ex(d, g, wa, dx=dx, accumulate=True, bias=bias, **kw)
             ops.conv2d_dgrad_ex(dterm, x_in, wm, dx=dx, accumulate=True, **kw)
             return dx
@@ -366,8 +379,11 @@ class ResNetEngine:
         # parity-class dgrad does not), then one scatter-add onto the even pixels of dx, through the consumer's mask
         dd = ops.conv_desc(d.n, d.ho, d.wo, d.cin, d.cout, 1, 1, 1, 0, self.dtype)
         dterm = ops.conv_desc(d.n, d.ho, d.wo, d.cin, d.cin, 1, 1, 1, 0, self.dtype)
-        dsub, _ = ops.conv2d_dgrad_ex(dd, g, wa, bias=bias)
-        ops.conv2d_dgrad_ex(dterm, x_in, wm, dx=dsub, accumulate=True)
+        if self.concat_fold and ops.conv2d_dgrad_concat_ok(dd, dd.cin):
+            dsub, _ = ops.conv2d_dgrad_ex(dd, g, wa, bias=bias, x2=x_in, wt2=wm)
+        else:
+            dsub, _ = ops.conv2d_dgrad_ex(dd, g, wa, bias=bias)
+            ops.conv2d_dgrad_ex(dterm, x_in, wm, dx=dsub, accumulate=True)
         ops.scatter2_add(dsub, dx, below.mask if masked_store else None)
         return dx
 

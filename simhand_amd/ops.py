@@ -205,10 +205,11 @@ def conv2d_dgrad_fused(d: ConvDesc, dy, wt, prev_y, prev_st: Optional["BNState"]
 
 def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accumulate: bool = False, res_grad=None, res_mask=None,
                     bias=None, fuse_mode: Optional[int] = None, prev_y=None, prev_st: Optional["BNState"] = None, prev_mask=None,
-                    want_sums: bool = True):
+                    want_sums: bool = True, x2=None, wt2=None):
     """General data gradient (simhand_conv2d_dgrad_ex): optional accumulate / masked-residual merge, fp32 per-channel
     bias, and epilogue fusion.  fuse_mode: None = none; 0 / 2 / 3 = BN-backward sums of the previous unit (no ReLU /
     mask from prev_y*scale+shift / bit mask); 4 = store the gradient masked by prev_mask and emit its channel sums.
+    x2 / wt2: second reduction segment, dx = dy wt^T + x2 wt2^T in one pass (only where conv2d_dgrad_concat_ok).
     Returns (dx, partial or None)."""
     lib = _lib_dev()
     if dx is None:
@@ -218,6 +219,8 @@ def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accu
     o.res_grad = _ptr(res_grad)
     o.res_mask = _ptr(res_mask)
     o.bias = _ptr(bias)
+    if x2 is not None:
+        o.x2, o.wt2, o.c2 = _ptr(x2), _ptr(wt2), x2.shape[-1]
     part = None
     if fuse_mode is not None:
         if want_sums or fuse_mode != 4:  # mode 4 may store the masked gradient without emitting its sums
@@ -233,6 +236,10 @@ def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accu
         o.fuse = C.pointer(f)
     check(lib.simhand_conv2d_dgrad_ex(C.byref(d), _ptr(dy), _ptr(wt), _ptr(dx), C.byref(o), _stream()), "conv2d_dgrad_ex")
     return dx, part
+
+
+def conv2d_dgrad_concat_ok(d: ConvDesc, c2: int) -> bool:
+    return bool(_lib_dev().simhand_conv2d_dgrad_concat_ok(C.byref(d), c2))
 
 
 def conv2d_dgrad_fuse_pays(d: ConvDesc) -> bool:

@@ -470,6 +470,53 @@ def test_c64_conv3x3_fwd_dgrad(shape):
     _check(part.sum(0).cpu(), part_ref.sum(0).cpu(), 1e-5, "partials vs tile kernel")
 
 
+@pytest.mark.parametrize("route", ["tile", "big_tile"])
+@pytest.mark.parametrize("mode", ["store", "accumulate", "fused_sums"])
+def test_dgrad_second_reduction_segment(route, mode):
+    """conv2d_dgrad_ex with x2 / wt2: dx = dy wt^T + x2 wt2^T (+ bias) in one fp32 accumulation, against fp32 torch on
+    the bf16-rounded operands; with fused sums the partials must match a direct reduction of the stored dx."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    lib = ops._lib_dev()
+    n, h, cout, cin = (3, 14, 512, 128) if route == "tile" else (3, 14, 1024, 256)
+    g = torch.Generator().manual_seed(5)
+    d = ops.conv_desc(n, h, h, cin, cout, 1, 1, 1, 0, dtype)
+    assert ops.conv2d_dgrad_concat_ok(d, cin)
+    dy = _rnd(torch.randn(n, h, h, cout, generator=g), dtype)
+    x2 = _rnd(torch.randn(n, h, h, cin, generator=g), dtype)
+    wt = _rnd(torch.randn(cin, cout, generator=g) / math.sqrt(cout), dtype)      # CRSK of a 1x1: [cin][cout]
+    wt2 = _rnd(torch.randn(cin, cin, generator=g) / math.sqrt(cin), dtype)
+    bias = torch.randn(cin, generator=g)
+    base = _rnd(torch.randn(n, h, h, cin, generator=g), dtype)
+    want = dy.reshape(-1, cout) @ wt.t() + x2.reshape(-1, cin) @ wt2.t() + bias
+    if mode == "accumulate":
+        want = want + base.reshape(-1, cin)
+    dev = lambda t: t.to(DEV).to(dtype).contiguous()
+    lib.simhand_igemm256_enable(2 if route == "big_tile" else 0)
+    try:
+        kw = {}
+        if mode == "accumulate":
+            kw = dict(dx=dev(base), accumulate=True)
+        y_prev = dev(_rnd(torch.randn(n, h, h, cin, generator=g), dtype))
+        st = ops.BNState(cin, DEV)
+        st.scale.copy_(torch.randn(cin, generator=g).to(DEV))
+        st.shift.copy_(torch.randn(cin, generator=g).to(DEV) * 0.3)
+        if mode == "fused_sums":
+            kw = dict(fuse_mode=2, prev_y=y_prev, prev_st=st)
+        dx, part = ops.conv2d_dgrad_ex(d, dev(dy), dev(wt), bias=bias.to(DEV), x2=dev(x2), wt2=dev(wt2), **kw)
+    finally:
+        lib.simhand_igemm256_enable(1)
+    _check(dx.float().cpu().reshape(-1, cin), want, 2 * _tol(dtype), mode)
+    if mode == "fused_sums":
+        s1, s2 = _bn_sums_reference(dx, y_prev, 2, st.scale, st.shift, None)
+        got1, got2 = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+        assert (got1 - s1).abs().max().item() <= 1e-4 * s1.abs().max().item() + 1e-4
+        assert (got2 - s2).abs().max().item() <= 1e-4 * s2.abs().max().item() + 1e-4
+    else:
+        assert part is None
+
+
 def _bn_sums_reference(dx, y, mode, st_scale, st_shift, mask_bits):
     """sum g, sum g*y per channel with g = dx * relu'(.) -- dx / y as the stored (rounded) tensors."""
     dxf, yf = dx.float(), y.float()
