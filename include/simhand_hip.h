@@ -202,8 +202,8 @@ int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w
  * relu_mode 0: no ReLU; 2: mask recomputed as y*scale + shift > 0; 3: 1-bit mask written by simhand_bn_apply;
  * 4: the STORED dx is the masked gradient g = dx * bit(mask) (y unused; partial[blk][1] = 0) -- the form the folded
  *    BatchNorm backward of a 1x1 conv + BN unit consumes (simhand host: ResNetEngine._unit3_bwd_folded).
- * blk runs over simhand_conv2d_dgrad_stat_blocks(d, accumulate, relu_mode) rows (the launch the same three arguments
- * select); finish with simhand_bn_bwd_finalize_raw.
+ * blk runs over simhand_conv2d_dgrad_stat_blocks(d, accumulate, relu_mode, c2) rows (the launch the same arguments
+ * select; c2 = channels of sh_dgrad_opts.x2, 0 without); finish with simhand_bn_bwd_finalize_raw.
  * accumulate: 0 store, 1 dx += result, 2 dx = result + res_grad * bit(res_mask) (as the two entry points above).
  * Replaces (reference): autograd's native_batch_norm_backward reduction after each Conv2d input-gradient in
  * torchvision's Bottleneck / BasicBlock (src/models/resnet_model.py:13-58). */
@@ -215,7 +215,7 @@ typedef struct sh_bn_bwd_fuse {
   int32_t relu_mode;
   float* partial;
 } sh_bn_bwd_fuse;
-int simhand_conv2d_dgrad_stat_blocks(const sh_conv_desc* d, int accumulate, int relu_mode);
+int simhand_conv2d_dgrad_stat_blocks(const sh_conv_desc* d, int accumulate, int relu_mode, int c2);
 /* 1 if the fused form is the faster choice for this layer (callers keep the standalone pass otherwise);
  * simhand_conv2d_dgrad_fuse_1x1(1) forces it for the short-K 1x1 layers too (tuning hook) */
 int simhand_conv2d_dgrad_fuse_pays(const sh_conv_desc* d);
@@ -227,7 +227,7 @@ int simhand_conv2d_dgrad_fused(const sh_conv_desc* d, const void* dy, const void
  *   dx = dy * wt^T + x2 * wt2^T   (x2 [n][h][w][c2], wt2 [cin][c2], c2 a multiple of 64)
  * accumulated in fp32 in one pass -- the two terms of the folded BatchNorm backward's input gradient
  * (g (diag(A) W) - a (W^T diag(B) W)) without a second launch re-reading and re-writing dx.  Only where
- * simhand_conv2d_dgrad_concat_ok(d, c2) says so (the tile-kernel routes); x2 = NULL: off. */
+ * simhand_conv2d_dgrad_concat_ok(d, c2) says so (bf16 1x1 / stride 1, c2 a multiple of 64); x2 = NULL: off. */
 typedef struct sh_dgrad_opts {
   int32_t accumulate;
   const void* res_grad;

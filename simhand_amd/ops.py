@@ -189,7 +189,7 @@ def conv2d_dgrad_fused(d: ConvDesc, dy, wt, prev_y, prev_st: Optional["BNState"]
         dx = torch.empty(d.n, d.h, d.w, d.cin, dtype=dy.dtype, device=dy.device)
     mode = 2 if res_grad is not None else int(accumulate)
     relu_mode = 3 if prev_mask is not None else (2 if prev_st is not None else 0)
-    nblk = lib.simhand_conv2d_dgrad_stat_blocks(C.byref(d), mode, relu_mode)
+    nblk = lib.simhand_conv2d_dgrad_stat_blocks(C.byref(d), mode, relu_mode, 0)
     part = torch.empty(nblk, 2, d.cin, dtype=torch.float32, device=dy.device)
     f = BnBwdFuse()
     f.y = _ptr(prev_y)
@@ -224,7 +224,7 @@ def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accu
     part = None
     if fuse_mode is not None:
         if want_sums or fuse_mode != 4:  # mode 4 may store the masked gradient without emitting its sums
-            nblk = lib.simhand_conv2d_dgrad_stat_blocks(C.byref(d), o.accumulate, fuse_mode)
+            nblk = lib.simhand_conv2d_dgrad_stat_blocks(C.byref(d), o.accumulate, fuse_mode, int(o.c2))
             part = torch.empty(nblk, 2, d.cin, dtype=torch.float32, device=dy.device)
         f = BnBwdFuse()
         f.y = _ptr(prev_y)

@@ -470,7 +470,7 @@ def test_c64_conv3x3_fwd_dgrad(shape):
     _check(part.sum(0).cpu(), part_ref.sum(0).cpu(), 1e-5, "partials vs tile kernel")
 
 
-@pytest.mark.parametrize("route", ["tile", "big_tile"])
+@pytest.mark.parametrize("route", ["tile", "big_tile", "short_k"])
 @pytest.mark.parametrize("mode", ["store", "accumulate", "fused_sums"])
 def test_dgrad_second_reduction_segment(route, mode):
     """conv2d_dgrad_ex with x2 / wt2: dx = dy wt^T + x2 wt2^T (+ bias) in one fp32 accumulation, against fp32 torch on
@@ -479,7 +479,8 @@ def test_dgrad_second_reduction_segment(route, mode):
 
     dtype = torch.bfloat16
     lib = ops._lib_dev()
-    n, h, cout, cin = (3, 14, 512, 128) if route == "tile" else (3, 14, 1024, 256)
+    # short_k: a layer whose single-segment form takes the activation-stationary 1x1 kernel (K = 256 -> 64 channels)
+    n, h, cout, cin = {"tile": (3, 14, 512, 128), "big_tile": (3, 14, 1024, 256), "short_k": (3, 14, 256, 64)}[route]
     g = torch.Generator().manual_seed(5)
     d = ops.conv_desc(n, h, h, cin, cout, 1, 1, 1, 0, dtype)
     assert ops.conv2d_dgrad_concat_ok(d, cin)
