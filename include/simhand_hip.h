@@ -258,6 +258,9 @@ int simhand_conv2d_wgrad_oihw(const sh_conv_desc* d, const void* x, const void* 
 /* tuning hook: route the eligible bf16 layers (>= 256 destination channels, long reduction) to the 256x256 LDS-DMA
  * tile kernel (1 = default); the BN partial-sum block counts above follow the setting */
 int simhand_igemm256_enable(int on);
+/* 1 (default): a 256 x 256 launch whose last round of tiles would leave more than two thirds of the CUs idle hands those
+ * m-tiles to a second launch of the 128-row kernel (same results bit for bit); 0 = single launch (tuning / test hook) */
+int simhand_igemm256_split_tail(int on);
 
 /* tuning hook: non-temporal (streaming) loads / stores in the BatchNorm passes (1 = on [default]) */
 int simhand_bn_set_nt(int on);

@@ -73,6 +73,10 @@ struct IgemmArgs {
   const void* w2 = nullptr;
   int Ca2 = 0;
   int lda = 0;
+  // 128-row kernel only: this launch covers the m-tiles from m_tile_base on (the ragged last wave of a 256 x 256 launch,
+  // see split256) and writes its partial-sum rows from part_row_base on
+  int m_tile_base = 0;
+  int part_row_base = 0;
 };
 
 template <typename T> struct Mma;
@@ -160,7 +164,8 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
   const int n_tile = logical % p.n_tiles;
   logical /= p.n_tiles;
   const int cls = logical % p.classes;  // 0 unless classes == 4
-  const int m_tile = logical / p.classes;
+  const int m_tile = logical / p.classes + p.m_tile_base;
+  const int prow = m_tile - p.m_tile_base + p.part_row_base;  // row of the partial-sum buffers
   const int ph = cls >> 1, pw = cls & 1;
   const unsigned m0 = (unsigned)m_tile * 128u;  // Mg < 2^31 (checked on the host)
   const int n0 = n_tile * BN;
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
     if (tid < 2 * BN) {
       const int which = tid / BN, c = tid - which * BN;
       const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c];
-      p.bn_partial[((long long)m_tile * 2 + which) * p.Ng + n0 + c] = v;
+      p.bn_partial[((long long)prow * 2 + which) * p.Ng + n0 + c] = v;
     }
   }
 
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
       if (tid < 2 * BN) {
         const int which = tid / BN, c = tid - which * BN;
         const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c];
-        p.fpartial[(((long long)m_tile * p.classes + cls) * 2 + which) * p.Ng + n0 + c] = v;
+        p.fpartial[(((long long)prow * p.classes + cls) * 2 + which) * p.Ng + n0 + c] = v;
       }
     }
   }
@@ -1096,14 +1101,55 @@ static int launch_igemm(const IgemmArgs& a0, hipStream_t s) {
   return check_launch(DGRAD ? "conv2d_dgrad" : "conv2d_fwd");
 }
 
+// The 256 x 256 kernel runs one block per CU, so a launch of T tiles takes ceil(T / CUs) rounds: 1568 tiles (256 ch @ 14^2)
+// pay 7 rounds for 6.1 rounds of work.  When the last round would be less than a third full, its m-tiles go to a second
+// launch of the 128-row kernel instead (bit-identical results: same k order, same fp32 MFMA chain), which takes a
+// fraction of a round.  main_m = m-tiles of the 256-row launch, tail128 = 128-row m-tiles of the second one.
+static int g_split256 = 1;
+static void split256(long long Mg, int Ng, int classes, int* main_m, int* tail128) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  const int tiles_m = ceil_div(Mg, 256), n_tiles = Ng / 256;
+  *main_m = tiles_m;
+  *tail128 = 0;
+  const long long total = (long long)tiles_m * n_tiles;
+  const int rem = (int)(total % cus);
+  if (!g_split256 || classes != 1 || total <= cus || rem == 0 || 3 * rem > cus) return;
+  const int tail_m = ceil_div(rem, n_tiles);
+  *main_m = tiles_m - tail_m;
+  *tail128 = ceil_div(Mg - (long long)*main_m * 256, 128);
+}
+
 template <bool DGRAD>
 static int launch_igemm256(IgemmArgs a, hipStream_t s) {
   if (a.lda == 0) a.lda = a.Ca;
-  a.m_tiles = ceil_div(a.Mg, 256);
+  int main_m, tail128;
+  split256(a.Mg, a.Ng, a.classes, &main_m, &tail128);
+  a.m_tiles = main_m;
   a.n_tiles = a.Ng / 256;
   const int nblk = a.classes * a.m_tiles * a.n_tiles;
   igemm256_kernel<DGRAD><<<nblk, 512, 0, s>>>(a);
+  if (tail128 > 0) {
+    IgemmArgs t = a;
+    t.m_tiles = tail128;
+    t.n_tiles = a.Ng / 128;
+    t.m_tile_base = 2 * main_m;
+    t.part_row_base = main_m;
+    igemm_kernel<bf16_t, DGRAD, 128><<<t.m_tiles * t.n_tiles, 256, 0, s>>>(t);
+  }
   return check_launch(DGRAD ? "conv2d_dgrad (256x256)" : "conv2d_fwd (256x256)");
+}
+
+// rows of the partial-sum buffers a 256 x 256 launch writes
+static int stat_rows256(long long Mg, int Ng, int classes) {
+  int main_m, tail128;
+  split256(Mg, Ng, classes, &main_m, &tail128);
+  return classes * (main_m + tail128);
 }
 
 static int check_desc(const sh_conv_desc* d, const char* who) {
@@ -1138,6 +1184,11 @@ int simhand_conv1x1_set_rows(int k, int mf) {
 }
 
 // tuning hook: route eligible layers to the 256 x 256 LDS-DMA kernel (0 = never, 1 = default heuristic, 2 = whenever legal)
+int simhand_igemm256_split_tail(int on) {
+  g_split256 = on ? 1 : 0;
+  return 0;
+}
+
 int simhand_igemm256_enable(int on) {
   g_use_256 = on < 0 ? 0 : (on > 2 ? 2 : on);
   return 0;
@@ -1178,9 +1229,9 @@ int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d) {
   if (!d) return 0;
   if (use_c64(d)) return c64_blocks(c64_q_total(d));
   const long long m = (long long)d->n * d->ho * d->wo;
-  const int rows = use_1x1(d, d->cin, d->cout) ? gemm1x1_rows_per_block(d->cin)
-                                              : (use_256(d->dtype, d->cout, d->cin, d->r * d->s, m) ? 256 : 128);
-  return ceil_div(m, rows);
+  if (use_1x1(d, d->cin, d->cout)) return ceil_div(m, gemm1x1_rows_per_block(d->cin));
+  if (use_256(d->dtype, d->cout, d->cin, d->r * d->s, m)) return stat_rows256(m, d->cout, 1);
+  return ceil_div(m, 128);
 }
 
 int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void* y, float* bn_partial, sh_stream_t stream) {
@@ -1310,8 +1361,8 @@ static int dgrad_stat_blocks(const sh_conv_desc* d, int accumulate, int relu_mod
   if (use_c64_dgrad(d, accumulate, relu_mode, false)) return c64_blocks(c64_q_total(d));
   if (c2 == 0 && use_1x1(d, d->cout, d->cin)) return ceil_div((long long)d->n * d->h * d->w, gemm1x1_rows_per_block(d->cout));
   const long long mg = d->stride == 2 ? (long long)d->n * ((d->h + 1) / 2) * ((d->w + 1) / 2) : (long long)d->n * d->h * d->w;
-  const int rows = use_256_dgrad(d, mg) ? 256 : 128;
-  return (d->stride == 2 ? 4 : 1) * ceil_div(mg, rows);
+  if (use_256_dgrad(d, mg)) return stat_rows256(mg, d->cin, d->stride == 2 ? 4 : 1);
+  return (d->stride == 2 ? 4 : 1) * ceil_div(mg, 128);
 }
 
 // second reduction segment (sh_dgrad_opts.x2): 1x1 / stride-1 bf16 layers, always on the tile kernels (also where a single

@@ -518,6 +518,51 @@ def test_dgrad_second_reduction_segment(route, mode):
         assert part is None
 
 
+def test_big_tile_ragged_last_round_goes_to_the_128_row_kernel():
+    """264 m-tiles of 256 rows on 256 CUs: the 8 tiles of the second round run as a 128-row launch.  Outputs are bit-identical
+    to the single launch, the partial-sum buffers have one row per launched m-tile and the same totals."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    lib = ops._lib_dev()
+    n, h, cin, cout = 66, 32, 512, 256
+    m = n * h * h
+    assert m == 264 * 256
+    g = torch.Generator().manual_seed(3)
+    d = ops.conv_desc(n, h, h, cin, cout, 1, 1, 1, 0, dtype)
+    x = torch.randn(n, h, h, cin, generator=g).to(DEV).to(dtype)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)).to(DEV)
+    wk, wt = ops.pack_krsc(w, dtype), ops.pack_crsk(w, dtype)
+    dy = torch.randn(n, h, h, cout, generator=g).to(DEV).to(dtype)
+    dt_ = ops.conv_desc(n, h, h, cout, cin, 1, 1, 1, 0, dtype)   # its dgrad has 256 destination channels, K = 512
+    wt_t = ops.pack_crsk((torch.randn(cin, cout, 1, 1, generator=g) / math.sqrt(cout)).to(DEV), dtype)
+    xin = torch.randn(n, h, h, cin, generator=g).to(DEV).to(dtype)
+    y_prev = torch.randn(n, h, h, cout, generator=g).to(DEV).to(dtype)
+    st = ops.BNState(cout, DEV)
+    st.scale.copy_(torch.randn(cout, generator=g).to(DEV))
+    st.shift.copy_(torch.randn(cout, generator=g).to(DEV) * 0.3)
+
+    def run():
+        y, part = ops.conv2d_fwd(d, x, wk, want_stats=True)
+        dx, fpart = ops.conv2d_dgrad_fused(dt_, xin, wt_t, y_prev, st, None)
+        return y, part, dx, fpart
+
+    y1, p1, dx1, f1 = run()
+    lib.simhand_igemm256_split_tail(0)
+    try:
+        y0, p0, dx0, f0 = run()
+    finally:
+        lib.simhand_igemm256_split_tail(1)
+    assert p0.shape[0] == 264 and f0.shape[0] == 264
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert p1.shape[0] == 256 + 16 and f1.shape[0] == 256 + 16
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+    _check(p1.sum(0).cpu(), p0.sum(0).cpu(), 1e-5, "forward statistics")
+    _check(f1.sum(0).cpu(), f0.sum(0).cpu(), 1e-5, "fused BN-backward sums")
+    want = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.cpu().to(dtype).float())
+    _check(y1.float().cpu().permute(0, 3, 1, 2), want, _tol(dtype), "fwd vs torch")
+
+
 def _bn_sums_reference(dx, y, mode, st_scale, st_shift, mask_bits):
     """sum g, sum g*y per channel with g = dx * relu'(.) -- dx / y as the stored (rounded) tensors."""
     dxf, yf = dx.float(), y.float()
