@@ -8,13 +8,15 @@ root=$(pwd)
 out=$root/gpurun_out/refresh
 rm -rf "$out" && mkdir -p "$out"
 export TMPDIR=/tmp
-python bench.py > "$out/${tag}_bench_b1024.log" 2>&1
-tail -1 "$out/${tag}_bench_b1024.log" > "$out/${tag}_bench_b1024.json"
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/kt.log 2>&1
 python scripts/rocpd_stats.py /tmp/prof_kt/kt_results.db "$out/${tag}_bench_b1024_kernel_stats.md" > /dev/null
 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_f -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_w -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/w.log 2>&1
 python scripts/pmc_traffic.py /tmp/prof_f/f_results.db /tmp/prof_w/w_results.db "$out/${tag}_bench_b1024_hbm_traffic.md" "$out/hbm_traffic.json" > /dev/null
 tail -3 /tmp/f.log /tmp/w.log | cut -c1-200
+# the bench line last: its roofline.traffic reads the PMC-derived bytes per launch written just above
+cp "$out/hbm_traffic.json" "$root/profiles/hbm_traffic.json"
+python bench.py > "$out/${tag}_bench_b1024.log" 2>&1
+tail -1 "$out/${tag}_bench_b1024.log" > "$out/${tag}_bench_b1024.json"
 cat "$out/${tag}_bench_b1024.json"
 ls -la "$out"
