@@ -176,6 +176,9 @@ int simhand_stem_geometry(int h, int w, int* hp, int* wp, int* ho, int* wo);
 int simhand_stem_pad_input(const float* x_nchw, void* xp, int n, int h, int w, int dtype, sh_stream_t stream);
 int simhand_stem_pack_weights(const float* w_oihw, void* wp, int dtype, sh_stream_t stream);
 int simhand_stem_conv_fwd(const void* xp, const void* wp, void* y, float* bn_partial, int n, int h, int w, int dtype, sh_stream_t stream);
+/* bf16 route of simhand_stem_conv_fwd: 1 (default) = activation-stationary kernel, 0 = 128 x 64 tile kernel (same k order,
+ * bit-identical results; tuning / test hook) */
+int simhand_stem_conv_route(int activation_stationary);
 size_t simhand_stem_conv_wgrad_workspace_bytes(int n, int h, int w, int dtype);
 int simhand_stem_conv_wgrad(const void* xp, const void* dy, float* dw_oihw, void* workspace, size_t workspace_bytes, int n, int h, int w, int dtype, sh_stream_t stream);
 /* dx = conv_transpose(dy, w).  wt = weights permuted to [Cin][R][S][Cout] (simhand_oihw_f32_to_crsk).

@@ -28,11 +28,17 @@ struct Gemm1x1Args {
   const bf16_t* ep_res;
   unsigned char* ep_mask;
   int ep_relu;
+  // K = 256 forward only: the direct 7x7/2 stem.  a = zero-padded NHWC4 input [n][stem_hp][stem_wp][4]; row m = output pixel
+  // (img, ho, wo); its k-slice j (32 elements) is filter row j: 8 taps x 4 channels contiguous at padded (2 ho + j, 2 wo).
+  // stem_wp = 0: off
+  int stem_hp = 0, stem_wp = 0;
+  FastDiv div_hw = {1, 0, 0}, div_w = {1, 0, 0};  // ho * wo, wo
 };
 
 bool gemm1x1_supported(int k, int n);
 int gemm1x1_rows_per_block(int k);
 void gemm1x1_set_mf(int k, int mf);
 int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s);
+int launch_gemm1x1_stem(const Gemm1x1Args& a, hipStream_t s);  // 128 rows per block
 
 }  // namespace sh

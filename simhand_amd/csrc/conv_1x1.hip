@@ -110,8 +110,20 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
     const long long row = mbase + mi * 16 + li;
     const bool ok = row < p.M;
     const bf16_t* pr = p.a + (ok ? row : 0) * K + g * 8;
+    int jstride = 32;
+    if constexpr (K == 256 && !DGRAD && !FUSE && !EP) {
+      if (p.stem_wp > 0) {  // direct stem: k-slice j = filter row j of the padded NHWC4 input (see Gemm1x1Args)
+        const unsigned m = ok ? (unsigned)row : 0u;
+        const unsigned img = fdiv(m, p.div_hw);
+        const unsigned rem = m - img * p.div_hw.d;
+        const unsigned ho = fdiv(rem, p.div_w);
+        const unsigned wo = rem - ho * p.div_w.d;
+        pr = p.a + (((long long)img * p.stem_hp + 2 * ho) * p.stem_wp + 2 * wo) * 4 + g * 8;
+        jstride = p.stem_wp * 4;
+      }
+    }
 #pragma unroll
-    for (int j = 0; j < KF; ++j) afr[mi][j] = ok ? *reinterpret_cast<const uint4*>(pr + j * 32) : make_uint4(0, 0, 0, 0);
+    for (int j = 0; j < KF; ++j) afr[mi][j] = ok ? *reinterpret_cast<const uint4*>(pr + j * jstride) : make_uint4(0, 0, 0, 0);
   }
 
   // ---- EP: coefficients to LDS (visible after the first barrier below), residual rows of chunk 0 to registers -------
@@ -384,6 +396,11 @@ int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
     if (mf == 2) SH_G1(256, 2); else SH_G1(256, 1);
   }
 #undef SH_G1
+  return 0;
+}
+
+int launch_gemm1x1_stem(const Gemm1x1Args& a, hipStream_t s) {
+  gemm1x1_kernel<256, 2, false><<<ceil_div(a.M, 128), 256, 0, s>>>(a);
   return 0;
 }
 

@@ -1315,6 +1315,7 @@ int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w
 // operand, so the input is first repacked (simhand_stem_pad_input) to zero-padded NHWC4 [N][h+8][wp][4]; then filter
 // row r of an output pixel is ONE contiguous run of 8 taps x 4 channels (tap 7 and channel 3 carry zero weights) and
 // the stem is a K = 8 rows x 32 = 256 GEMM read straight from that buffer: no im2col matrix (9.9 GB at 2048 x 224^2).
+static int g_stem_1x1 = 1;
 int simhand_stem_geometry(int h, int w, int* hp, int* wp, int* ho, int* wo) {
   SH_REQUIRE(h >= 1 && w >= 1 && hp && wp && ho && wo, "stem_geometry: bad arguments");
   *ho = (h + 6 - 7) / 2 + 1;
@@ -1353,7 +1354,25 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
   const double es = dtype == SH_F32 ? 4 : 2;
   const double bytes = es * ((double)n * hp * wp * 4 + (double)a.Mg * 64 + 64.0 * 256);
   ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, flops, bytes);
+  if (dtype == SH_BF16 && g_stem_1x1) {
+    // bf16: the activation-stationary kernel (conv_1x1.hip) with the stem's row addressing -- the layer writes 3.7x what it
+    // reads and has only 4 k-steps per tile, the regime that kernel was built for (1.81 -> see DESIGN ms at 2048 x 224^2)
+    Gemm1x1Args g;
+    g.a = (const bf16_t*)xp; g.w = (const bf16_t*)wp_; g.out = (bf16_t*)y; g.bn_partial = bn_partial;
+    g.M = a.Mg; g.N = 64; g.accumulate = 0; g.res_grad = nullptr; g.res_mask = nullptr;
+    g.fy = nullptr; g.fscale = g.fshift = nullptr; g.fmask = nullptr; g.fmode = 0; g.fpartial = nullptr; g.bias = nullptr;
+    g.ep_scale = g.ep_shift = nullptr; g.ep_res = nullptr; g.ep_mask = nullptr; g.ep_relu = 0;
+    g.stem_hp = hp; g.stem_wp = wp;
+    g.div_hw = a.div_hw; g.div_w = a.div_w;
+    launch_gemm1x1_stem(g, (hipStream_t)stream);
+    return check_launch("stem_conv_fwd (activation-stationary)");
+  }
   return dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
+}
+
+int simhand_stem_conv_route(int activation_stationary) {
+  g_stem_1x1 = activation_stationary ? 1 : 0;
+  return 0;
 }
 
 // tiles (= rows of the fused BatchNorm-backward partial buffer) of the data-gradient launch
