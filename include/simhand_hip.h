@@ -340,9 +340,13 @@ int simhand_apply_relu_bitmask(const void* x, const uint8_t* mask, void* out, in
 /* Stem block fused: out, idx = MaxPool(3, 2, 1)(ReLU(y*scale + shift)) without storing the activation in between, and
  * its backward: the BatchNorm-backward passes gather the pooled gradient dz through idx (partial: simhand_bn_stat_blocks
  * (n*h*w, c) blocks of [2][c] sums of g and g*xhat -> simhand_bn_bwd_finalize; apply: dy).  y is [n][h][w][c].
+ * ywin (optional, laid out like out): the RAW conv output y of each window's winning tap.  Every pooled gradient reaches
+ * exactly one input pixel -- its winner -- so the BatchNorm-backward sums over the h x w grid equal
+ * simhand_bn_bwd_partial(dz, NULL, ywin, ..., relu_mode 2, m = n*ho*wo): 2 passes over pooled-size tensors instead of a
+ * gather pass over the 4x larger y (the only difference: gradients of windows sharing a winner are summed unrounded).
  * Replaces (reference): bn1 -> relu -> maxpool of the torchvision ResNet stem (src/models/resnet_model.py:13-26). */
-int simhand_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int n, int h, int w,
-                                int c, int dtype, sh_stream_t stream);
+int simhand_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, void* ywin, int n, int h,
+                                int w, int c, int dtype, sh_stream_t stream);
 int simhand_maxpool_bn_bwd_partial(const void* dz, const uint8_t* idx, const void* y, const float* mean, const float* invstd,
                                    const float* scale, const float* shift, int n, int h, int w, int c, int dtype, float* partial,
                                    sh_stream_t stream);

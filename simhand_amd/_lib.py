@@ -123,7 +123,7 @@ SIGNATURES = {
     "simhand_bn_fold_fwd": (_I, [_P, _I, _P, _P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_bn_fold_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _S, _P]),
     "simhand_apply_relu_bitmask": (_I, [_P, _P, _P, _L, _I, _I, _P]),
-    "simhand_bn_relu_maxpool_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "simhand_bn_relu_maxpool_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "simhand_maxpool_bn_bwd_partial": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "simhand_maxpool_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "simhand_bn_bwd_finalize_raw_workspace_bytes": (_S, [_I, _I]),

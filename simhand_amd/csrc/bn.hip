@@ -410,8 +410,8 @@ template <> __device__ __forceinline__ float round_as<bf16_t>(float v) { return 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, T* __restrict__ out,
-                                                                  uint8_t* __restrict__ idx, int n, int h, int w, int c, int ho, int wo,
-                                                                  FastDiv div_cv, FastDiv div_wo, FastDiv div_ho) {
+                                                                  uint8_t* __restrict__ idx, T* __restrict__ ywin, int n, int h, int w, int c,
+                                                                  int ho, int wo, FastDiv div_cv, FastDiv div_wo, FastDiv div_ho) {
   constexpr int VE = Vec16<T>::N;
   const int cvecs = c / VE;
   const unsigned total = (unsigned)n * ho * wo * cvecs;  // < 2^31 (checked on the host)
@@ -423,13 +423,14 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
     const unsigned im = fdiv(q, div_ho);
     const int oh = (int)(q - im * (unsigned)ho);
     const int img = (int)im;
-    float sc[VE], sh[VE], best[VE];
+    float sc[VE], sh[VE], best[VE], braw[VE];
     int bi[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
       sc[e] = scale[cv * VE + e];
       sh[e] = shift[cv * VE + e];
       best[e] = -INFINITY;
+      braw[e] = 0.f;
       bi[e] = 0;
     }
     // scan order kh then kw, strict '>' (first maximum wins) like ATen's max_pool2d
@@ -447,15 +448,23 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
           a = round_as<T>(a > 0.f ? a : 0.f);  // the activation as bn_apply would have stored it
           if (a > best[e] || a != a) {
             best[e] = a;
+            braw[e] = v[e];
             bi[e] = kh * 3 + kw;
           }
         }
       }
     }
     Vec16<T>::template store<true>(out + (size_t)i * VE, best);
-    uint8_t* ip = idx + (size_t)i * VE;
+    if (ywin != nullptr) Vec16<T>::template store<true>(ywin + (size_t)i * VE, braw);  // raw conv output of the winning tap
+    // winner taps: one 4- / 8-byte store
+    unsigned lo = 0, hi = 0;
 #pragma unroll
-    for (int e = 0; e < VE; ++e) ip[e] = (uint8_t)bi[e];
+    for (int e = 0; e < VE; ++e) {
+      if (e < 4) lo |= (unsigned)bi[e] << (8 * e);
+      else hi |= (unsigned)bi[e] << (8 * (e - 4));
+    }
+    if (VE == 8) *reinterpret_cast<uint2*>(idx + (size_t)i * VE) = make_uint2(lo, hi);
+    else *reinterpret_cast<unsigned*>(idx + (size_t)i * VE) = lo;
   }
 }
 
@@ -1097,8 +1106,8 @@ int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const flo
   return check_launch("bn_bwd_apply");
 }
 
-int simhand_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int n, int h, int w,
-                                int c, int dtype, sh_stream_t stream) {
+int simhand_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, void* ywin, int n, int h,
+                                int w, int c, int dtype, sh_stream_t stream) {
   SH_REQUIRE(y && scale && shift && out && idx, "bn_relu_maxpool_fwd: NULL pointer");
   const int ve = dtype == SH_F32 ? 4 : 8;
   SH_REQUIRE(c % ve == 0, "bn_relu_maxpool_fwd: c=%d not a multiple of %d", c, ve);
@@ -1110,9 +1119,9 @@ int simhand_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* 
   SH_REQUIRE(total < (1ll << 31), "bn_relu_maxpool_fwd: %lld output vectors exceed the 2^31 index range", (long long)total);
   const FastDiv d1 = make_fastdiv((unsigned)(c / ve)), d2 = make_fastdiv((unsigned)wo), d3 = make_fastdiv((unsigned)ho);
   if (dtype == SH_F32)
-    bn_relu_maxpool_fwd_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)y, scale, shift, (float*)out, idx, n, h, w, c, ho, wo, d1, d2, d3);
+    bn_relu_maxpool_fwd_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)y, scale, shift, (float*)out, idx, (float*)ywin, n, h, w, c, ho, wo, d1, d2, d3);
   else
-    bn_relu_maxpool_fwd_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)y, scale, shift, (bf16_t*)out, idx, n, h, w, c, ho, wo, d1, d2, d3);
+    bn_relu_maxpool_fwd_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)y, scale, shift, (bf16_t*)out, idx, (bf16_t*)ywin, n, h, w, c, ho, wo, d1, d2, d3);
   return check_launch("bn_relu_maxpool_fwd");
 }
 

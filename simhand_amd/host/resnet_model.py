@@ -247,7 +247,11 @@ class ResNetEngine:
         m = n * ho * wo
         st = self._bn(bn1, part, m, 64, training)
         # BN + ReLU + MaxPool in one pass: the 112x112x64 activation in between is never stored
-        x, idx = ops.bn_relu_maxpool_fwd(y, st)
+        ywin = None
+        if want_ctx:  # + the winning taps' raw conv outputs: the backward's statistics pass then runs over pooled-size tensors
+            x, idx, ywin = ops.bn_relu_maxpool_fwd(y, st, want_winner=True)
+        else:
+            x, idx = ops.bn_relu_maxpool_fwd(y, st)
         if want_ctx:
             u = _Unit()
             u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv1, bn1, d, xp, y, None, st, True, True
@@ -256,6 +260,7 @@ class ResNetEngine:
             u.x_in = u.s2 = u.t2 = u.ws2 = None
             ctx["stem"] = u
             ctx["pool_idx"] = idx
+            ctx["pool_ywin"] = ywin
         for li in (4, 5, 6, 7):
             for blk in f[li]:
                 saved: Optional[list] = [] if want_ctx else None
@@ -475,7 +480,7 @@ class ResNetEngine:
             saved.clear()
         # stem: the pooled gradient is gathered through the winner index inside the BatchNorm-backward passes
         u = ctx["stem"]
-        dy, dg, db = ops.maxpool_bn_backward(dz, ctx["pool_idx"], u.y, u.st, u.bn.weight.detach())
+        dy, dg, db = ops.maxpool_bn_backward(dz, ctx["pool_idx"], u.y, u.st, u.bn.weight.detach(), ywin=ctx.get("pool_ywin"))
         grads[u.bn.weight] = dg
         grads[u.bn.bias] = db
         grads[u.conv.weight] = ops.stem_conv_wgrad(u.x, dy, u.desc.h, u.desc.w)

@@ -474,28 +474,39 @@ def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_d
     return dy, dres, dg, db
 
 
-def bn_relu_maxpool_fwd(y: torch.Tensor, st: BNState):
-    """Stem: MaxPool(3,2,1)(ReLU(BN(y))) in one pass; y is [n][h][w][c].  Returns (pooled, winner index)."""
+def bn_relu_maxpool_fwd(y: torch.Tensor, st: BNState, want_winner: bool = False):
+    """Stem: MaxPool(3,2,1)(ReLU(BN(y))) in one pass; y is [n][h][w][c].  Returns (pooled, winner index) and, with
+    want_winner, the raw y of each window's winning tap (for maxpool_bn_backward's pooled-size statistics pass)."""
     lib = _lib_dev()
     n, h, w, c = y.shape
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     out = torch.empty(n, ho, wo, c, dtype=y.dtype, device=y.device)
     idx = torch.empty(n, ho, wo, c, dtype=torch.uint8, device=y.device)
-    check(lib.simhand_bn_relu_maxpool_fwd(_ptr(y), _ptr(st.scale), _ptr(st.shift), _ptr(out), _ptr(idx), n, h, w, c, dt(y.dtype),
-                                          _stream()), "bn_relu_maxpool_fwd")
-    return out, idx
+    ywin = torch.empty_like(out) if want_winner else None
+    check(lib.simhand_bn_relu_maxpool_fwd(_ptr(y), _ptr(st.scale), _ptr(st.shift), _ptr(out), _ptr(idx), _ptr(ywin), n, h, w, c,
+                                          dt(y.dtype), _stream()), "bn_relu_maxpool_fwd")
+    return (out, idx, ywin) if want_winner else (out, idx)
 
 
-def maxpool_bn_backward(dz: torch.Tensor, idx: torch.Tensor, y: torch.Tensor, st: BNState, gamma):
-    """Backward of bn_relu_maxpool_fwd: (dy, dgamma, dbeta); dz is the gradient of the pooled output."""
+def maxpool_bn_backward(dz: torch.Tensor, idx: torch.Tensor, y: torch.Tensor, st: BNState, gamma, ywin: Optional[torch.Tensor] = None):
+    """Backward of bn_relu_maxpool_fwd: (dy, dgamma, dbeta); dz is the gradient of the pooled output.  ywin (the raw y of
+    the winning taps, from bn_relu_maxpool_fwd(want_winner=True)): the BatchNorm-backward sums are taken over the pooled
+    tensors (each pooled gradient lands on exactly its winner) instead of a gather pass over the 4x larger y."""
     lib = _lib_dev()
     n, h, w, c = y.shape
     m = n * h * w
     dev = y.device
-    nblk = lib.simhand_bn_stat_blocks(m, c)
-    part = torch.empty(nblk, 2, c, dtype=torch.float32, device=dev)
-    check(lib.simhand_maxpool_bn_bwd_partial(_ptr(dz), _ptr(idx), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
-                                             n, h, w, c, dt(y.dtype), _ptr(part), _stream()), "maxpool_bn_bwd_partial")
+    if ywin is not None:
+        mo = dz.numel() // c
+        nblk = lib.simhand_bn_stat_blocks(mo, c)
+        part = torch.empty(nblk, 2, c, dtype=torch.float32, device=dev)
+        check(lib.simhand_bn_bwd_partial(_ptr(dz), None, _ptr(ywin), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift), 2, mo, c,
+                                         dt(y.dtype), _ptr(part), _stream()), "bn_bwd_partial (pooled)")
+    else:
+        nblk = lib.simhand_bn_stat_blocks(m, c)
+        part = torch.empty(nblk, 2, c, dtype=torch.float32, device=dev)
+        check(lib.simhand_maxpool_bn_bwd_partial(_ptr(dz), _ptr(idx), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
+                                                 n, h, w, c, dt(y.dtype), _ptr(part), _stream()), "maxpool_bn_bwd_partial")
     dg = torch.empty(c, dtype=torch.float32, device=dev)
     db = torch.empty(c, dtype=torch.float32, device=dev)
     check(lib.simhand_bn_bwd_finalize(_ptr(part), nblk, c, _ptr(dg), _ptr(db), _stream()), "bn_bwd_finalize")

@@ -25,11 +25,11 @@ def record_hip_relu_masks(store: list):
 
     orig_stem = ops.bn_relu_maxpool_fwd
 
-    def bn_relu_maxpool_fwd(y, st):
+    def bn_relu_maxpool_fwd(y, st, want_winner=False):
         # the fused stem kernel never stores the activation: take its ReLU mask from the unfused kernel (same fp32 expression)
         n, h, w, c = y.shape
         store.append((orig(y.view(n * h * w, c), st, n * h * w, c, True, None) > 0).view(n, h, w, c).cpu())
-        return orig_stem(y, st)
+        return orig_stem(y, st, want_winner)
 
     orig_fused = ops.conv2d_fwd_bnact
 

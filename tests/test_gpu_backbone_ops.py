@@ -666,6 +666,21 @@ def test_stem_bn_relu_maxpool_fused_equals_unfused(dtype, n, h, w):
     else:  # 2x2-block kernels: same addends, another summation order for the channel sums
         assert torch.allclose(dg, want_dg, rtol=1e-4, atol=1e-4) and torch.allclose(db, want_db, rtol=1e-4, atol=1e-4)
         _check(dy.view(m, c).float(), want_dy.float(), 1e-5 if dtype == torch.float32 else 1e-2, "fused stem dy")
+    # statistics over the pooled tensors (raw y of the winning taps): same sums, except that gradients of windows sharing a
+    # winner are added unrounded (bf16: the unfused path stores their sum in bf16 first)
+    x3, idx3, ywin = ops.bn_relu_maxpool_fwd(y, st, want_winner=True)
+    assert torch.equal(x3, want_x) and torch.equal(idx3, want_idx)
+    ho, wo = want_x.shape[1:3]
+    taps = want_idx.long()
+    ih = (torch.arange(ho, device=DEV).view(1, ho, 1, 1) * 2 - 1 + taps // 3)
+    iw = (torch.arange(wo, device=DEV).view(1, 1, wo, 1) * 2 - 1 + taps % 3)
+    flat = (ih * w + iw).view(n, ho * wo, c)
+    assert torch.equal(ywin.view(n, ho * wo, c), torch.gather(y.view(n, h * w, c), 1, flat))
+    dy2, dg2, db2 = ops.maxpool_bn_backward(dz, got_idx, y, st, gamma, ywin=ywin)
+    tol = 1e-5 if dtype == torch.float32 else 3e-3
+    _check(dg2, want_dg, tol, "dgamma from the pooled tensors")
+    _check(db2, want_db, tol, "dbeta from the pooled tensors")
+    _check(dy2.view(m, c).float(), want_dy.float(), 1e-5 if dtype == torch.float32 else 1e-2, "dy with pooled-tensor statistics")
 
 
 @pytest.mark.parametrize("shape", [(2, 56, 56, 64, 64), (3, 28, 28, 128, 128), (5, 14, 14, 256, 128), (7, 7, 7, 128, 256), (1, 5, 9, 64, 64),
