@@ -31,9 +31,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(" | ".join(out))
     sys.exit(0)
 
-names = {0: "baseline", 4: "no DMA", 5: "no output stores"}
+names = {0: "baseline", 2: "no A DMAs", 3: "no B DMAs", 4: "no DMA", 5: "no output stores", 6: "no sched_barrier"}
 print("layers: 3x3 256@14 | 1x1 1024->256@14 | 3x3 512@7 | 1x1 2048->512@7 | 1x1 512->2048@7")
-for n in (0, 4, 5):
+for n in [int(v) for v in os.environ.get("ABL_SET", "0 4 5").split()]:
     lib = os.path.join(HERE, "abl", f"libabl_{n}.so")
     r = subprocess.run([sys.executable, __file__, "child", lib], capture_output=True, text=True)
     print(f"{names[n]:18s}: {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]}")
