@@ -1484,6 +1484,9 @@ int simhand_conv2d_dgrad_fuse_1x1(int on) {
 }
 int simhand_conv2d_dgrad_fuse_pays(const sh_conv_desc* d) {
   if (!d) return 0;
+  // stride-2 3x3: each of the four parity-class launches pays the extra read of y against a quarter of the MFMA work; the
+  // standalone pass is faster (same-box A/B of the whole step: 126.4 -> 125.9 ms)
+  if (d->stride == 2 && d->r == 3 && !g_fuse_1x1) return 0;
   return (!use_1x1(d, d->cout, d->cin) || g_fuse_1x1) ? 1 : 0;
 }
 
