@@ -614,19 +614,25 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_blk_kernel(const T* __restric
   const int bl = threadIdx.x / cvecs;
   const int hb = h / 2, wb = w / 2;
   const unsigned nblocks = (unsigned)n * hb * wb;  // < 2^31 (checked on the host)
-  float mu[VE], is[VE], A[VE], k2[VE], k3[VE], sc[VE], sh[VE], s1[VE], s2[VE];
+  // APPLY: dy = A (g - dbeta/M) - xhat A dgamma/M  =  cA g + y cP + cQ  (three coefficient vectors instead of five);
+  // statistics pass: mean / invstd for xhat.  Winner taps stay packed (one byte per channel) until they are compared.
+  float mu[VE], is[VE], cA[VE], cP[VE], cQ[VE], sc[VE], sh[VE], s1[VE], s2[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) {
     const int ch = cv * VE + e;
-    mu[e] = mean[ch];
-    is[e] = invstd[ch];
     sc[e] = scale[ch];
     sh[e] = shift[ch];
     s1[e] = s2[e] = 0.f;
     if (APPLY) {
-      A[e] = (gamma ? gamma[ch] : 1.0f) * is[e];
-      k2[e] = dbeta[ch] * inv_m;
-      k3[e] = A[e] * dgamma[ch] * inv_m;
+      const float m_ = mean[ch], i_ = invstd[ch];
+      const float a_ = (gamma ? gamma[ch] : 1.0f) * i_;
+      const float k2 = dbeta[ch] * inv_m, k3 = a_ * dgamma[ch] * inv_m;
+      cA[e] = a_;
+      cP[e] = -i_ * k3;
+      cQ[e] = m_ * i_ * k3 - a_ * k2;
+    } else {
+      mu[e] = mean[ch];
+      is[e] = invstd[ch];
     }
   }
   const unsigned b_begin = blockIdx.x * (unsigned)blocks_per_cta;
@@ -637,32 +643,28 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_blk_kernel(const T* __restric
     const int b = (int)(q - t * (unsigned)wb);
     const unsigned img = fdiv(t, div_hb);
     const int a = (int)(t - img * (unsigned)hb);
-    // the four windows (a + i, b + j): gradient and winner taps
+    // the four windows (a + i, b + j): gradient and (packed) winner taps; 0xff = no such window
     float d[2][2][VE];
-    uint8_t wi[2][2][VE];
+    unsigned wlo[2][2], whi[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const bool ok = a + i < ho && b + j < wo;
         const int64_t o = ((((int64_t)img * ho + (a + i)) * wo + (b + j)) * cvecs + cv) * VE;
+        wlo[i][j] = whi[i][j] = 0xffffffffu;
         if (ok) {
           Vec16<T>::load(dz + o, d[i][j]);
           if (VE == 8) {
             const uint2 u = *reinterpret_cast<const uint2*>(idx + o);
-#pragma unroll
-            for (int e = 0; e < VE; ++e) wi[i][j][e] = (uint8_t)(((e < 4 ? u.x : u.y) >> (8 * (e & 3))) & 0xffu);
+            wlo[i][j] = u.x;
+            whi[i][j] = u.y;
           } else {
-            const unsigned u = *reinterpret_cast<const unsigned*>(idx + o);
-#pragma unroll
-            for (int e = 0; e < VE; ++e) wi[i][j][e] = (uint8_t)((u >> (8 * e)) & 0xffu);
+            wlo[i][j] = *reinterpret_cast<const unsigned*>(idx + o);
           }
         } else {
 #pragma unroll
-          for (int e = 0; e < VE; ++e) {
-            d[i][j][e] = 0.f;
-            wi[i][j][e] = 255;
-          }
+          for (int e = 0; e < VE; ++e) d[i][j][e] = 0.f;
         }
       }
     // all four y rows are requested before any of the gather arithmetic (12 loads in flight per thread)
@@ -684,9 +686,12 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_blk_kernel(const T* __restric
         for (int i = 0; i <= pi; ++i)
 #pragma unroll
           for (int j = 0; j <= pj; ++j) {
-            const int me = (pi + 1 - 2 * i) * 3 + (pj + 1 - 2 * j);
+            const unsigned me = (unsigned)((pi + 1 - 2 * i) * 3 + (pj + 1 - 2 * j));
 #pragma unroll
-            for (int e = 0; e < VE; ++e) gq[e] += wi[i][j][e] == me ? d[i][j][e] : 0.f;
+            for (int e = 0; e < VE; ++e) {
+              const unsigned tap = ((e < 4 ? wlo[i][j] : whi[i][j]) >> (8 * (e & 3))) & 0xffu;
+              gq[e] += tap == me ? d[i][j][e] : 0.f;
+            }
           }
         const int64_t pix = ((int64_t)img * h + 2 * a + pi) * w + 2 * b + pj;
         const float(&yy)[VE] = yq[pi][pj];
@@ -694,10 +699,10 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_blk_kernel(const T* __restric
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
           const float gv = yy[e] * sc[e] + sh[e] > 0.f ? round_as<T>(gq[e]) : 0.f;
-          const float xh = (yy[e] - mu[e]) * is[e];
           if (APPLY) {
-            o[e] = A[e] * (gv - k2[e]) - xh * k3[e];
+            o[e] = cA[e] * gv + (yy[e] * cP[e] + cQ[e]);
           } else {
+            const float xh = (yy[e] - mu[e]) * is[e];
             s1[e] += gv;
             s2[e] += gv * xh;
           }
