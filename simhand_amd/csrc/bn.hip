@@ -415,7 +415,10 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
   constexpr int VE = Vec16<T>::N;
   const int cvecs = c / VE;
   const unsigned total = (unsigned)n * ho * wo * cvecs;  // < 2^31 (checked on the host)
-  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+  // consecutive output rows share an input row: keep them on ONE XCD's L2 (blocks go to XCDs round-robin, so block b
+  // takes the b / 8-th slot of XCD b % 8's contiguous eighth of each grid-stride window)
+  const unsigned lb = (gridDim.x & 7u) == 0 ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  for (unsigned i = lb * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     unsigned t = fdiv(i, div_cv);
     const int cv = (int)(i - t * (unsigned)cvecs);
     unsigned q = fdiv(t, div_wo);
