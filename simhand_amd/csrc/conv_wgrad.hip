@@ -134,7 +134,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   const char* pdy[NA];
   const char* px[NBL];
   int rowa[NA], rowb[NBL];
-  if constexpr (PLAIN) {
+  // STEM walks its rows the same way: the padded-input address of output pixel (img, ho, wo) advances by 2 * KP pixels per
+  // k-step, plus a constant at every row / image wrap (swo / sho track the position; no division in the loop)
+  int swo[NBL], sho[NBL];
+  if constexpr (PLAIN || STEM) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int id = tid + 256 * i;
@@ -145,7 +148,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
     for (int i = 0; i < NBL; ++i) {
       const int id = tid + 256 * i;
       rowb[i] = id / CPR_B;
-      px[i] = reinterpret_cast<const char*>(xs + (pix_begin + rowb[i]) * p.Cin + c0 + (id - rowb[i] * CPR_B) * VE);
+      if constexpr (STEM) {
+        const long long m = pix_begin + rowb[i];
+        const unsigned mu = m < p.Mo ? (unsigned)m : 0u;
+        const unsigned img = fdiv(mu, p.div_hw);
+        const unsigned rem = mu - img * hw;
+        const unsigned ho = fdiv(rem, p.div_w);
+        const unsigned wo = rem - ho * (unsigned)p.Wo;
+        const int vc = c0 + (id - rowb[i] * CPR_B) * VE;  // virtual channel: filter row vc / 32, element vc % 32 of its 8 x 4 run
+        const unsigned prow = (img * (unsigned)p.stem_hp + 2 * ho + (unsigned)(vc >> 5)) * (unsigned)p.stem_wp + 2 * wo;  // < 2^31
+        px[i] = reinterpret_cast<const char*>(xs + (unsigned long long)prow * 4u + (vc & 31));
+        swo[i] = (int)wo;
+        sho[i] = (int)ho;
+      } else {
+        px[i] = reinterpret_cast<const char*>(xs + (pix_begin + rowb[i]) * p.Cin + c0 + (id - rowb[i] * CPR_B) * VE);
+      }
     }
   }
   // PLAIN + dy_colsum: every chunk of this thread is the same 8 channels k0 + (tid % CPR_A) * 8 .. (CPR_A divides 256)
@@ -154,8 +171,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   const unsigned step_dy = (unsigned)KP * (unsigned)p.Cout * (unsigned)sizeof(T);
   const unsigned step_x = (unsigned)KP * (unsigned)p.Cin * (unsigned)sizeof(T);
   const int rows_total = (int)(pix_end - pix_begin);  // <= pix_per_split
+  const long long stem_row_skip = ((long long)2 * p.stem_wp - 2 * p.Wo) * 4 * (long long)sizeof(T);             // bytes, at a row wrap
+  const long long stem_img_skip = ((long long)p.stem_hp - 2 * p.Ho) * p.stem_wp * 4 * (long long)sizeof(T);  // bytes, at an image wrap
   auto load_step = [&](int ks) __attribute__((always_inline)) {
-    if constexpr (PLAIN) {
+    if constexpr (PLAIN || STEM) {
       const int left = rows_total - ks * KP;  // rows of this k-step inside the block's pixel range
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
@@ -176,7 +195,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
       for (int i = 0; i < NBL; ++i) {
         rb[i] = rowb[i] < left ? *reinterpret_cast<const uint4*>(px[i]) : make_uint4(0, 0, 0, 0);
-        px[i] += step_x;
+        if constexpr (STEM) {
+          px[i] += 2 * KP * 4 * (int)sizeof(T);
+          swo[i] += KP;
+          while (swo[i] >= p.Wo) {  // at most once for Wo >= KP (the 224^2 stem: Wo = 112)
+            swo[i] -= p.Wo;
+            px[i] += stem_row_skip;
+            if (++sho[i] == p.Ho) {
+              sho[i] = 0;
+              px[i] += stem_img_skip;
+            }
+          }
+        } else {
+          px[i] += step_x;
+        }
       }
       return;
     }
@@ -688,6 +720,7 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
 #define SH_WG(T, BM, BN) wgrad_kernel<T, BM, BN><<<nblk, 256, 0, s>>>(a)
   if (stem_wp > 0) {  // cout 64 x 256 virtual channels -> the 64 x 128 tile with the NHWC4 address map
     if (d->dtype == SH_F32) wgrad_kernel<float, 64, 128, true><<<nblk, 256, 0, s>>>(a);
+    else if (g_plain_kpm == 2) wgrad_kernel<bf16_t, 64, 128, true, false, 2><<<nblk, 256, 0, s>>>(a);  // 64-pixel k-steps: 16 MFMAs per barrier
     else wgrad_kernel<bf16_t, 64, 128, true><<<nblk, 256, 0, s>>>(a);
   } else if (d->dtype == SH_F32) {
     if (bm == 128 && bn == 128) SH_WG(float, 128, 128);
