@@ -17,7 +17,8 @@ import threading
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsimhand_hip.so")
+# SIMHAND_LIB: another build of the same library (A/B timing of a kernel change on one GPU box)
+LIB_PATH = os.environ.get("SIMHAND_LIB") or os.path.join(_HERE, "libsimhand_hip.so")
 
 # enums of include/simhand_hip.h
 SH_F32, SH_BF16 = 0, 1
