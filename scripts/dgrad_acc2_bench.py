@@ -3,7 +3,10 @@ previous block's ReLU mask (accumulate 2 + relu_mode 4), per ResNet-50 stage.  u
 import sys, time, torch
 sys.path.insert(0, ".")
 from simhand_amd import ops
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+N = 2048
+for c in sys.argv[1:]:  # k:mf pairs -> rows per block of the activation-stationary kernel
+    k, mf = map(int, c.split(":"))
+    ops._lib_dev().simhand_conv1x1_set_rows(k, mf)
 dt = torch.bfloat16
 def timeit(fn, iters=10):
     fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
