@@ -273,6 +273,11 @@ int simhand_wgrad3x3_enable(int on);
 
 /* test hook: bf16 wgrad LDS transpose path (1 = ds_read_b64_tr_b16 [default], 0 = scalar LDS reads) */
 int simhand_wgrad_set_tr(int on);
+/* tuning hook: the bf16 1x1 / stride-1 weight gradient reduces 32 * kpm pixels per barrier (kpm 1 or 2, default 2) */
+int simhand_wgrad_plain_kpm(int kpm);
+/* tuning hook: blocks (tiles x split-K) a weight-gradient launch aims for: generic / 1x1 kernel, all-taps 3x3 kernel
+ * (< 64 restores the default) */
+int simhand_wgrad_target_blocks(int n, int n3x3);
 
 /* layout / dtype transforms.  k_pad = padded length of one flattened KRSC weight row
  * (>= r*s*c; rows are zero padded) -- r*s*c for ordinary convs, 192 for the im2col'd stem. */

@@ -103,6 +103,8 @@ SIGNATURES = {
     "simhand_conv2d_wgrad_colsum": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _S, _P]),
     "simhand_conv2d_wgrad_oihw": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _S, _P]),
     "simhand_wgrad_set_tr": (_I, [_I]),
+    "simhand_wgrad_plain_kpm": (_I, [_I]),
+    "simhand_wgrad_target_blocks": (_I, [_I, _I]),
     "simhand_wgrad3x3_enable": (_I, [_I]),
     "simhand_bn_set_nt": (_I, [_I]),
     "simhand_igemm256_enable": (_I, [_I]),

@@ -592,6 +592,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args p) {
 }
 
 static int g_use_wgrad3 = 1;
+static int g_wg3_blocks = 512;  // all-taps 3x3 kernel: two blocks per CU, one round (512 beats 768 by 4-10 %)
 static bool use_wgrad3(const sh_conv_desc* d) {
   return g_use_wgrad3 && d->dtype == SH_BF16 && d->r == 3 && d->s == 3 && d->stride == 1 && d->pad == 1 && d->w + 3 <= 64 &&
          (long long)d->n * (d->h + 2) * (d->w + 2) < (1ll << 31);
@@ -600,7 +601,7 @@ static void plan3(const sh_conv_desc* d, int* splitk, int* per) {
   const long long q_total = (long long)d->n * (d->h + 2) * (d->w + 2);
   const long long tiles = (long long)(d->cout / 64) * (d->cin / 64);
   const long long ksteps = (q_total + 31) / 32;
-  long long sk = (768 + tiles - 1) / tiles;       // ~3 blocks per CU in flight
+  long long sk = g_wg3_blocks / tiles;            // one full round of resident blocks (see plan)
   const long long max_sk = (ksteps + 31) / 32;    // at least 32 k-steps per block (the 5-chunk prologue is per block)
   if (sk > max_sk) sk = max_sk;
   if (sk < 1) sk = 1;
@@ -611,6 +612,9 @@ static void plan3(const sh_conv_desc* d, int* splitk, int* per) {
 }
 
 static int g_use_tr = 1;
+// blocks a launch aims for (tiles x splits): ONE round of the two blocks a CU holds.  Measured per shape (scripts/wgrad_kpm.py):
+// 512 beats 1024 by 1-7 % and 768 / 1536 (1.5 / 3 rounds: the last one half empty, more split-K partials) by 10-25 %
+static int g_wg_blocks = 512;
 static int g_plain_kpm = 2;  // k-step multiplier of the 1x1 pointer-walking kernel (2 = 64 pixels per barrier)
 static bool is_plain(const sh_conv_desc* d) {
   return d->dtype == SH_BF16 && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0;
@@ -622,7 +626,9 @@ static void plan(const sh_conv_desc* d, int* bm, int* bn, int* splitk, int* pps)
   const long long mo = (long long)d->n * d->ho * d->wo;
   const long long tiles = (long long)(d->cout / *bm) * (d->cin / *bn) * d->r * d->s;
   const long long ksteps = (mo + kp - 1) / kp;
-  long long sk = (1536 + tiles - 1) / tiles;   // aim for ~6 blocks per CU
+  // the pointer-walking 1x1 kernel (64-pixel k-steps, 70 KB of LDS) holds two blocks per CU, the generic one three
+  const int target = (is_plain(d) && g_use_tr && d->dtype == SH_BF16) ? g_wg_blocks : (g_wg_blocks * 3) / 2;
+  long long sk = target / tiles;               // never more blocks than one round
   const long long max_sk = (ksteps + 7) / 8;   // at least 8 k-steps per block
   if (sk > max_sk) sk = max_sk;
   if (sk < 1) sk = 1;
@@ -645,6 +651,18 @@ int simhand_wgrad3x3_enable(int on) {
 }
 
 // test hook: choose the bf16 LDS transpose path (1 = ds_read_b64_tr_b16, 0 = scalar reads)
+// tuning hook: pixels per k-step of the 1x1 pointer-walking kernel, 32 * kpm (kpm = 1 or 2; 2 = default)
+int simhand_wgrad_target_blocks(int n, int n3x3) {
+  g_wg_blocks = n >= 64 ? n : 512;
+  g_wg3_blocks = n3x3 >= 64 ? n3x3 : 512;
+  return 0;
+}
+
+int simhand_wgrad_plain_kpm(int kpm) {
+  g_plain_kpm = kpm == 1 ? 1 : 2;
+  return 0;
+}
+
 int simhand_wgrad_set_tr(int on) {
   g_use_tr = on ? 1 : 0;
   return 0;
