@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void fold_sum_kernel(const float* __restrict__
 
 // split factor: ~512 blocks in flight, slices of at least 64 k, multiples of 16
 static inline void fold_split(int tiles, int k, int* ks, int* kper) {
-  int s_ = (512 + tiles - 1) / tiles;
+  int s_ = (2048 + tiles - 1) / tiles;  // ~8 blocks of 256 threads per CU: the slab loads are latency-bound, occupancy hides them
   const int maxs = k / 64 > 0 ? k / 64 : 1;
   if (s_ > maxs) s_ = maxs;
   if (s_ < 1) s_ = 1;
