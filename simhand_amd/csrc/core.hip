@@ -52,7 +52,10 @@ ProfScope::ProfScope(int c, hipStream_t s, double flops, double bytes) : cls(c),
   r.cls = c;
   r.flops = flops;
   r.bytes = bytes;
-  hipEventRecord(r.a, s);
+  if (hipEventRecord(r.a, s) != hipSuccess) {  // profiling is best effort: drop the record, keep the launch
+    g_pool.push_back({r.a, r.b});
+    return;
+  }
   g_recs.push_back(r);
   slot = (int)g_recs.size() - 1;
   on = true;
@@ -61,7 +64,7 @@ ProfScope::ProfScope(int c, hipStream_t s, double flops, double bytes) : cls(c),
 ProfScope::~ProfScope() {
   if (!on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  hipEventRecord(g_recs[slot].b, stream);
+  (void)hipEventRecord(g_recs[slot].b, stream);  // a failed record surfaces as an error in prof_collect's synchronize
 }
 
 }  // namespace sh
@@ -79,7 +82,10 @@ int simhand_device_check(void) {
     return 1;
   }
   int dev = 0;
-  hipGetDevice(&dev);
+  if (hipGetDevice(&dev) != hipSuccess) {
+    sh::set_error("hipGetDevice failed");
+    return 1;
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
     sh::set_error("hipGetDeviceProperties failed");
@@ -107,7 +113,7 @@ int simhand_prof_set_classes(uint32_t mask) {
 int simhand_prof_reset(void) {
   std::lock_guard<std::mutex> lk(sh::g_prof_mu);
   for (auto& r : sh::g_recs) {
-    hipEventSynchronize(r.b);
+    (void)hipEventSynchronize(r.b);  // the pair goes back to the pool either way
     sh::g_pool.push_back({r.a, r.b});
   }
   sh::g_recs.clear();
@@ -128,7 +134,10 @@ int simhand_prof_collect(double* out_ms, double* out_flops, double* out_bytes, i
       return 1;
     }
     float ms = 0;
-    hipEventElapsedTime(&ms, r.a, r.b);
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) {
+      sh::set_error("hipEventElapsedTime failed in prof_collect");
+      return 1;
+    }
     out_ms[r.cls] += ms;
     out_flops[r.cls] += r.flops;
     out_bytes[r.cls] += r.bytes;
