@@ -111,7 +111,8 @@ def test_step_rn18_matches_reference_golden_and_oracle(golden_dir, cname):
     assert sorted(model.logged.keys()) == meta["logged"]
     assert sorted(model.plot_params.keys()) == meta["plot_params_keys"]
     for k, v in meta["metrics"].items():
-        assert abs(float(out[k]) - v) <= 1e-3 * abs(v) + 1e-5, (k, float(out[k]), v)
+        got = float(out[k].detach()) if torch.is_tensor(out[k]) else float(out[k])
+        assert abs(got - v) <= 1e-3 * abs(v) + 1e-5, (k, got, v)
     gw = dict(model.named_parameters())
     want = arrays[f"{cname}.dW_head3"]
     got = gw["projection_head.3.weight"].grad.cpu().numpy()
