@@ -290,7 +290,10 @@ void c64_enable(int on) { g_use_c64 = on ? 1 : 0; }
 int c64_blocks(long long q_total) {
   const long long steps = (q_total + 63) / 64;
   long long b = steps / 8;
-  if (b > 512) b = 512;
+#ifndef SH_C64_BLOCKS
+#define SH_C64_BLOCKS 512  // two resident blocks per CU: one round
+#endif
+  if (b > SH_C64_BLOCKS) b = SH_C64_BLOCKS;
   if (b < 1) b = 1;
   const long long per = (steps + b - 1) / b;
   return (int)((steps + per - 1) / per);
