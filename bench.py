@@ -180,7 +180,7 @@ def main():
     ops.prof_enable(False)
     prof = ops.prof_collect()
     ops.prof_set_classes(None)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
