@@ -971,6 +971,16 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
           sc[e] = p.ep_scale[ch + e];
           sh[e] = p.ep_shift[ch + e];
         }
+        // all residual rows of this 32-channel group are requested before the first one is used: one exposed global-load
+        // round trip per group instead of one per 16-pixel row (the block is alone on its CU, nothing else hides them)
+        uint4 rq[MI];
+        if (res != nullptr) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const long long pix = pixel_of(mi);
+            rq[mi] = pix >= 0 ? *reinterpret_cast<const uint4*>(res + pix * p.Ng + ch) : make_uint4(0, 0, 0, 0);
+          }
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           const long long pix = pixel_of(mi);
@@ -983,10 +993,12 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
             o[4 + e] = hi[e] * sc[4 + e] + sh[4 + e];
           }
           if (res != nullptr) {
-            float q[8];
-            Vec16<bf16_t>::load(res + pix * p.Ng + ch, q);
+            const unsigned w4[4] = {rq[mi].x, rq[mi].y, rq[mi].z, rq[mi].w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += q[e];
+            for (int e = 0; e < 4; ++e) {
+              o[2 * e] += __uint_as_float(w4[e] << 16);
+              o[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+            }
           }
           if (p.ep_relu) {
             unsigned bits = 0;
