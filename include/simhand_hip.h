@@ -11,8 +11,13 @@
  *   - every pointer is a DEVICE pointer owned by the caller (a live torch
  *     tensor); no ownership transfer, no allocation inside the library;
  *   - workspaces are caller-allocated after a *_workspace_bytes() query;
- *   - every launch takes an explicit hipStream_t (as void*), is asynchronous
- *     and holds no global mutable state (the optional profiler excepted);
+ *   - every launch takes an explicit hipStream_t (as void*) and is asynchronous.
+ *     Process-global state is limited to (a) the optional event profiler, (b) the
+ *     route counters below and (c) the TEST / TUNING hooks (simhand_*_enable,
+ *     simhand_*_set_*, simhand_*_route ...): atomics that select between
+ *     kernels computing the same result; a product caller never touches them
+ *     (defaults are the measured-best routes), tests restore the defaults in
+ *     try/finally, and simhand_hooks_reset() puts all of them back at once;
  *   - return 0 on success, non-zero on error; simhand_last_error() returns a
  *     thread-local message;
  *   - activations are NHWC, conv weights KRSC ([Cout][R][S][Cin]); dtype enum
@@ -46,6 +51,36 @@ int simhand_abi_version(void);
 const char* simhand_last_error(void);
 /* 0 when a gfx950 device is usable from this process */
 int simhand_device_check(void);
+
+/* ---- kernel-route counters: which hand-written kernel a call was dispatched to.  One atomic counter per route,
+ * bumped at launch time.  Tests use them to PROVE that a parity run exercised a given kernel (e.g. that the bf16
+ * ResNet-50 step really went through the 256x256 LDS-DMA tile kernel, the activation-stationary 1x1 kernel, the
+ * register-resident 3x3 kernel, the all-taps weight gradient, the BatchNorm folds and the two-segment data gradient). */
+enum sh_route {
+  SH_ROUTE_IGEMM128_FWD = 0, SH_ROUTE_IGEMM128_DGRAD = 1,   /* 128 x {64,128} register-staged tile kernel */
+  SH_ROUTE_IGEMM256_FWD = 2, SH_ROUTE_IGEMM256_DGRAD = 3,   /* 256 x 256 LDS-DMA tile kernel */
+  SH_ROUTE_IGEMM256_TAIL = 4,                               /* ragged last round handed to the 128-row kernel */
+  SH_ROUTE_GEMM1X1_FWD = 5, SH_ROUTE_GEMM1X1_FWD_BNACT = 6, SH_ROUTE_GEMM1X1_DGRAD = 7,  /* activation-stationary 1x1 */
+  SH_ROUTE_C64_FWD = 8, SH_ROUTE_C64_DGRAD = 9,             /* 64->64 3x3, filter resident in registers */
+  SH_ROUTE_STEM_FWD = 10,
+  SH_ROUTE_FWD_BNACT = 11,                                  /* any forward with the BN + residual + ReLU epilogue */
+  SH_ROUTE_DGRAD_CONCAT = 12,                               /* data gradient with a second K segment */
+  SH_ROUTE_DGRAD_FUSED_SUMS = 13,                           /* data gradient emitting BN-backward sums / masked store */
+  SH_ROUTE_DGRAD_PARITY = 14,                               /* stride-2 data gradient as 4 parity classes */
+  SH_ROUTE_WGRAD3X3 = 15, SH_ROUTE_WGRAD_PLAIN = 16, SH_ROUTE_WGRAD_GENERIC = 17, SH_ROUTE_WGRAD_STEM = 18,
+  SH_ROUTE_WGRAD_COLSUM = 19,                               /* 1x1 weight gradient that also emits sum(dy) (Gram launches) */
+  SH_ROUTE_BN_FOLD_FWD = 20, SH_ROUTE_BN_FOLD_BWD = 21,     /* Gram-matrix BatchNorm fold (parameter-sized algebra) */
+  SH_ROUTE_BN_APPLY = 22, SH_ROUTE_BN_BWD_APPLY = 23,
+  SH_ROUTE_STEM_BN_POOL = 24,                               /* fused BN + ReLU + MaxPool (fwd or bwd) */
+  SH_ROUTE_NTXENT_FWD = 25, SH_ROUTE_NTXENT_BWD = 26,
+  SH_ROUTE_FP8_FWD = 27, SH_ROUTE_FP8_DGRAD = 28,           /* e4m3 MFMA (K = 128 per instruction) tile kernel */
+  SH_ROUTE_BN_APPLY_GRAM = 29,                              /* BN-apply + ReLU fused into the Gram (x^T x) launch */
+  SH_ROUTE_COUNT = 32
+};
+int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
+int simhand_route_reset(void);
+/* every test / tuning hook back to its default */
+int simhand_hooks_reset(void);
 
 /* ---- optional per-kernel-class HIP-event profiler (used by bench.py) ----- */
 enum sh_prof_class { SH_PROF_CONV_FWD = 0, SH_PROF_CONV_DGRAD = 1, SH_PROF_CONV_WGRAD = 2,

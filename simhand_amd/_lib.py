@@ -27,6 +27,12 @@ WEIGHT_TYPES = {None: 0, "none": 0, "linear": 1, "non_linear": 2, "explicit": 3}
 PP_NORM_IN, PP_NORM_OUT, PP_ANGLE_AS_GIVEN = 1, 2, 4
 PP_FUSED = 3
 PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn", "pool", "loss", "misc")
+# enum sh_route: kernel the library dispatched a call to (index = counter slot)
+ROUTES = ("igemm128_fwd", "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "igemm256_tail", "gemm1x1_fwd", "gemm1x1_fwd_bnact",
+          "gemm1x1_dgrad", "c64_fwd", "c64_dgrad", "stem_fwd", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
+          "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
+          "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram")
+ROUTE_COUNT = 32
 
 
 class SimhandHipError(RuntimeError):
@@ -72,6 +78,9 @@ SIGNATURES = {
     "simhand_abi_version": (_I, []),
     "simhand_last_error": (C.c_char_p, []),
     "simhand_device_check": (_I, []),
+    "simhand_route_counts": (_I, [_P]),
+    "simhand_route_reset": (_I, []),
+    "simhand_hooks_reset": (_I, []),
     "simhand_prof_enable": (_I, [_I]),
     "simhand_prof_set_classes": (_I, [C.c_uint32]),
     "simhand_prof_collect": (_I, [_P, _P, _P, _P]),

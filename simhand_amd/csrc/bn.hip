@@ -964,7 +964,9 @@ static inline int stream_grid(int64_t nvec) {
   return (int)g;
 }
 
-static int g_bn_nt = 1;  // non-temporal loads / stores in the streaming kernels (test hook: simhand_bn_set_nt)
+static hook_t g_bn_nt{1};  // non-temporal loads / stores in the streaming kernels (test hook: simhand_bn_set_nt)
+
+void hooks_reset_bn() { g_bn_nt = 1; }
 
 }  // namespace sh
 
@@ -1034,6 +1036,7 @@ int simhand_bn_apply(const void* y, const float* scale, const float* shift, cons
   SH_REQUIRE(c % ve == 0, "bn_apply: c=%d not a multiple of %d", c, ve);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (residual ? 3 : 2));
+  route_hit(SH_ROUTE_BN_APPLY);
   const int grid = row_grid(m, c / ve);
 #define SH_BN_APPLY(T, NT) bn_apply_kernel<T, NT><<<grid, 256, 0, s>>>((const T*)y, scale, shift, (const T*)residual, relu, (T*)a, relu_mask, m, c)
   if (dtype == SH_F32) { if (g_bn_nt) SH_BN_APPLY(float, true); else SH_BN_APPLY(float, false); }
@@ -1105,6 +1108,7 @@ int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const flo
   SH_REQUIRE(c % ve == 0, "bn_bwd_apply: c=%d not a multiple of %d", c, ve);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (3 + (relu == 1 ? 1 : 0) + (dres ? 1 : 0)));
+  route_hit(SH_ROUTE_BN_BWD_APPLY);
   const float inv_m = (float)(1.0 / (double)m);
   const int grid = row_grid(m, c / ve);
 #define SH_BN_BA(T, NT) bn_bwd_apply_kernel<T, NT><<<grid, 256, 0, s>>>((const T*)da, (const T*)a, (const T*)y, mean, invstd, gamma, dgamma, dbeta, scale, shift, relu, (T*)dy, (T*)dres, m, c, inv_m)
@@ -1124,6 +1128,7 @@ int simhand_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* 
   hipStream_t s = (hipStream_t)stream;
   const double es = dtype == SH_F32 ? 4 : 2;
   ProfScope ps(SH_PROF_BN, s, 0, es * ((double)n * h * w * c + (double)n * ho * wo * c) + (double)n * ho * wo * c);
+  route_hit(SH_ROUTE_STEM_BN_POOL);
   SH_REQUIRE(total < (1ll << 31), "bn_relu_maxpool_fwd: %lld output vectors exceed the 2^31 index range", (long long)total);
   const FastDiv d1 = make_fastdiv((unsigned)(c / ve)), d2 = make_fastdiv((unsigned)wo), d3 = make_fastdiv((unsigned)ho);
   if (dtype == SH_F32)
@@ -1180,6 +1185,7 @@ int simhand_maxpool_bn_bwd_apply(const void* dz, const uint8_t* idx, const void*
   hipStream_t s = (hipStream_t)stream;
   const double es = dtype == SH_F32 ? 4 : 2;
   ProfScope ps(SH_PROF_BN, s, 0, es * (2.0 * (double)m * c + (double)n * ho * wo * c) + (double)n * ho * wo * c);
+  route_hit(SH_ROUTE_STEM_BN_POOL);
   SH_REQUIRE(m < (1ll << 31), "maxpool_bn_bwd_apply: %lld pixels exceed the 2^31 index range", (long long)m);
   const FastDiv dw_ = make_fastdiv((unsigned)w), dh_ = make_fastdiv((unsigned)h);
   const float inv_m = (float)(1.0 / (double)m);
@@ -1236,6 +1242,7 @@ int simhand_bn_fold_fwd(const float* w, int round_bf16, const float* s2, const f
   SH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_fold_fwd: running stats must be given together");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 2.0 * cc * (double)cw * cw, 4.0 * ((double)cc * cw * 2 + (double)cw * cw));
+  route_hit(SH_ROUTE_BN_FOLD_FWD);
   // ws2[c][j] = sum_i W[c][i] S2[i][j]
   {
     int ks, kper;
@@ -1266,6 +1273,7 @@ int simhand_bn_fold_bwd(const float* w, int round_bf16, const float* gmat, const
   SH_REQUIRE(cc % 32 == 0 && cw % 32 == 0 && m >= 1, "bn_fold_bwd: cc=%d / cw=%d must be multiples of 32", cc, cw);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 2.0 * cc * (double)cw * cw, 4.0 * (double)cc * cw * 5);
+  route_hit(SH_ROUTE_BN_FOLD_BWD);
   if (dtype == SH_F32)
     bn_fold_bwd_kernel<float><<<cc, 256, 0, s>>>(w, round_bf16, gmat, s_, ws2, t2, mean, invstd, gamma, cc, cw, m, dgamma, dbeta, dw, (float*)wa, bw, ccoef);
   else

@@ -1,6 +1,8 @@
 // Shared device/host helpers for libsimhand_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -20,6 +22,17 @@ int check_launch(const char* what);
       return 1;                        \
     }                                  \
   } while (0)
+
+// ---- route counters (core.hip): one relaxed atomic increment per launch ----
+void route_hit(int route);
+// test / tuning hooks are relaxed atomics (they only choose between kernels that compute the same result); every file that
+// owns some puts them back to their defaults here (simhand_hooks_reset)
+typedef std::atomic<int> hook_t;
+void hooks_reset_igemm();
+void hooks_reset_c64();
+void hooks_reset_1x1();
+void hooks_reset_wgrad();
+void hooks_reset_bn();
 
 // ---- profiler hooks (prof.hip) ---------------------------------------------
 struct ProfScope {

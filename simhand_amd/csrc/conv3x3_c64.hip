@@ -277,7 +277,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
   }
 }
 
-static int g_use_c64 = 1;
+static hook_t g_use_c64{1};
+void hooks_reset_c64() { g_use_c64 = 1; }
 
 bool c64_supported(int dtype, int cin, int cout, int r, int s, int stride, int pad, int w, long long q_total) {
   return g_use_c64 && dtype == SH_BF16 && cin == 64 && cout == 64 && r == 3 && s == 3 && stride == 1 && pad == 1 && w + 3 <= 64 &&
@@ -304,6 +305,7 @@ int launch_c64(const C64Args& a0, hipStream_t s) {
   const long long steps = (a.q_total + 63) / 64;
   const int b = c64_blocks(a.q_total);
   a.steps_per_block = (int)((steps + b - 1) / b);
+  route_hit(a.dgrad ? SH_ROUTE_C64_DGRAD : SH_ROUTE_C64_FWD);
   if (a.partial == nullptr) conv3x3_c64_kernel<0><<<b, 256, 0, s>>>(a);
   else if (!a.dgrad) conv3x3_c64_kernel<1><<<b, 256, 0, s>>>(a);
   else conv3x3_c64_kernel<2><<<b, 256, 0, s>>>(a);

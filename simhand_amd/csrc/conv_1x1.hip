@@ -372,7 +372,8 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
 bool gemm1x1_supported(int k, int n) { return (k == 64 || k == 128 || k == 256) && n % 64 == 0 && n >= 64; }
 
 // rows per block = 64 * MF; tuned per K on MI355X (scripts/conv_bench.py), overridable for experiments
-static int g_mf[3] = {4, 2, 2};  // K = 64, 128, 256
+static hook_t g_mf[3] = {{4}, {2}, {2}};  // K = 64, 128, 256
+void hooks_reset_1x1() { g_mf[0] = 4; g_mf[1] = 2; g_mf[2] = 2; }
 static int mf_of(int k) { return g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)]; }
 void gemm1x1_set_mf(int k, int mf) { g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)] = mf; }
 
@@ -381,6 +382,7 @@ int gemm1x1_rows_per_block(int k) { return 64 * mf_of(k); }
 int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
   const int mf = mf_of(k);
   const int nblk = ceil_div(a.M, 64 * mf);
+  route_hit(dgrad ? SH_ROUTE_GEMM1X1_DGRAD : (a.ep_scale != nullptr ? SH_ROUTE_GEMM1X1_FWD_BNACT : SH_ROUTE_GEMM1X1_FWD));
 #define SH_G1(KV, MFV)                                                                          \
   do {                                                                                          \
     if (dgrad && a.fpartial != nullptr) gemm1x1_kernel<KV, MFV, true, true><<<nblk, 256, 0, s>>>(a);  \

@@ -1087,7 +1087,9 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
 
 // the 256 x 256 kernel takes the bf16 layers with >= 256 destination channels in multiples of 256 and a reduction long
 // enough (>= 8 k-steps of 64) to amortise its one-block-per-CU prologue / epilogue
-static int g_use_256 = 1;
+static hook_t g_use_256{1};
+static hook_t g_stem_1x1{1};  // bf16 stem forward on the activation-stationary kernel
+static hook_t g_fuse_1x1{0};  // BN-backward sums fused into the short-K 1x1 dgrad (slower: tuning hook)
 static bool use_256(int dtype, int Ng, int Ca, int taps, long long Mg) {
   if (!g_use_256 || dtype != SH_BF16 || Ng % 256 != 0 || Ca % 64 != 0) return false;
   return g_use_256 == 2 || ((long long)taps * Ca >= 512 && Mg >= 256 * 64);  // 2 = forced (tests)
@@ -1105,6 +1107,7 @@ static int launch_igemm(const IgemmArgs& a0, hipStream_t s) {
   IgemmArgs a = a0;
   if (a.lda == 0) a.lda = a.Ca;
   const int nblk = a.classes * a.m_tiles * a.n_tiles;
+  route_hit(DGRAD ? SH_ROUTE_IGEMM128_DGRAD : SH_ROUTE_IGEMM128_FWD);
   if (a.Ng % 128 == 0) {
     igemm_kernel<T, DGRAD, 128><<<nblk, 256, 0, s>>>(a);
   } else {
@@ -1117,7 +1120,7 @@ static int launch_igemm(const IgemmArgs& a0, hipStream_t s) {
 // pay 7 rounds for 6.1 rounds of work.  When the last round would be less than a third full, its m-tiles go to a second
 // launch of the 128-row kernel instead (bit-identical results: same k order, same fp32 MFMA chain), which takes a
 // fraction of a round.  main_m = m-tiles of the 256-row launch, tail128 = 128-row m-tiles of the second one.
-static int g_split256 = 1;
+static hook_t g_split256{1};
 static void split256(long long Mg, int Ng, int classes, int* main_m, int* tail128) {
   static int cus = 0;
   if (cus == 0) {
@@ -1145,8 +1148,10 @@ static int launch_igemm256(IgemmArgs a, hipStream_t s) {
   a.m_tiles = main_m;
   a.n_tiles = a.Ng / 256;
   const int nblk = a.classes * a.m_tiles * a.n_tiles;
+  route_hit(DGRAD ? SH_ROUTE_IGEMM256_DGRAD : SH_ROUTE_IGEMM256_FWD);
   igemm256_kernel<DGRAD><<<nblk, 512, 0, s>>>(a);
   if (tail128 > 0) {
+    route_hit(SH_ROUTE_IGEMM256_TAIL);
     IgemmArgs t = a;
     t.m_tiles = tail128;
     t.n_tiles = a.Ng / 128;
@@ -1180,6 +1185,13 @@ static int check_desc(const sh_conv_desc* d, const char* who) {
 // short-K stride-1 1x1 layers in bf16 go to the activation-stationary kernel (conv_1x1.hip)
 static bool use_1x1(const sh_conv_desc* d, int k, int n) {
   return d->dtype == SH_BF16 && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && gemm1x1_supported(k, n);
+}
+
+void hooks_reset_igemm() {
+  g_use_256 = 1;
+  g_split256 = 1;
+  g_stem_1x1 = 1;
+  g_fuse_1x1 = 0;
 }
 
 }  // namespace sh
@@ -1309,6 +1321,7 @@ int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w
   const double flops = 2.0 * (double)a.Mg * d->cout * d->cin * d->r * d->s;
   const double bytes = 2.0 * ((double)d->n * d->h * d->w * d->cin + (double)a.Mg * d->cout * (residual ? 2 : 1) + (double)d->cout * d->cin * d->r * d->s);
   ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, flops, bytes);
+  route_hit(SH_ROUTE_FWD_BNACT);
   if (use_1x1(d, d->cin, d->cout)) {
     Gemm1x1Args g;
     g.a = (const bf16_t*)x; g.w = (const bf16_t*)w; g.out = (bf16_t*)out; g.bn_partial = nullptr;
@@ -1327,7 +1340,6 @@ int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w
 // operand, so the input is first repacked (simhand_stem_pad_input) to zero-padded NHWC4 [N][h+8][wp][4]; then filter
 // row r of an output pixel is ONE contiguous run of 8 taps x 4 channels (tap 7 and channel 3 carry zero weights) and
 // the stem is a K = 8 rows x 32 = 256 GEMM read straight from that buffer: no im2col matrix (9.9 GB at 2048 x 224^2).
-static int g_stem_1x1 = 1;
 int simhand_stem_geometry(int h, int w, int* hp, int* wp, int* ho, int* wo) {
   SH_REQUIRE(h >= 1 && w >= 1 && hp && wp && ho && wo, "stem_geometry: bad arguments");
   *ho = (h + 6 - 7) / 2 + 1;
@@ -1366,6 +1378,7 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
   const double es = dtype == SH_F32 ? 4 : 2;
   const double bytes = es * ((double)n * hp * wp * 4 + (double)a.Mg * 64 + 64.0 * 256);
   ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, flops, bytes);
+  route_hit(SH_ROUTE_STEM_FWD);
   if (dtype == SH_BF16 && g_stem_1x1) {
     // bf16: the activation-stationary kernel (conv_1x1.hip) with the stem's row addressing -- the layer writes 3.7x what it
     // reads and has only 4 k-steps per tile, the regime that kernel was built for (1.81 -> see DESIGN ms at 2048 x 224^2)
@@ -1460,6 +1473,9 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   const double bytes = es * ((double)d->n * d->h * d->w * d->cin * ((accumulate ? 2 : 1) + (fuse ? 1 : 0)) + (double)mo * d->cout +
                              (double)d->cout * d->cin * d->r * d->s);
   ProfScope ps(SH_PROF_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
+  if (x2 != nullptr) route_hit(SH_ROUTE_DGRAD_CONCAT);
+  if (fuse != nullptr) route_hit(SH_ROUTE_DGRAD_FUSED_SUMS);
+  if (d->stride == 2) route_hit(SH_ROUTE_DGRAD_PARITY);
   if (x2 == nullptr && use_1x1(d, d->cout, d->cin)) {
     Gemm1x1Args g;
     g.a = (const bf16_t*)dy; g.w = (const bf16_t*)wt; g.out = (bf16_t*)dx; g.bn_partial = nullptr;
@@ -1489,7 +1505,6 @@ int simhand_conv2d_dgrad_masked_residual(const sh_conv_desc* d, const void* dy, 
 // tile kernel hides the extra read of y behind its other resident blocks; the activation-stationary short-K 1x1
 // kernel would pay the read's latency once per 64-channel chunk (measured 2-3x slower), so those layers keep the
 // standalone simhand_bn_bwd_partial pass unless forced (simhand_conv2d_dgrad_fuse_1x1).
-static int g_fuse_1x1 = 0;
 int simhand_conv2d_dgrad_fuse_1x1(int on) {
   g_fuse_1x1 = on ? 1 : 0;
   return 0;

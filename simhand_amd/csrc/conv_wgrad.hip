@@ -591,8 +591,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args p) {
       }
 }
 
-static int g_use_wgrad3 = 1;
-static int g_wg3_blocks = 512;  // all-taps 3x3 kernel: two blocks per CU, one round (512 beats 768 by 4-10 %)
+static hook_t g_use_wgrad3{1};
+static hook_t g_wg3_blocks{512};  // all-taps 3x3 kernel: two blocks per CU, one round (512 beats 768 by 4-10 %)
 static bool use_wgrad3(const sh_conv_desc* d) {
   return g_use_wgrad3 && d->dtype == SH_BF16 && d->r == 3 && d->s == 3 && d->stride == 1 && d->pad == 1 && d->w + 3 <= 64 &&
          (long long)d->n * (d->h + 2) * (d->w + 2) < (1ll << 31);
@@ -611,11 +611,11 @@ static void plan3(const sh_conv_desc* d, int* splitk, int* per) {
   *per = (int)(pr * 32);
 }
 
-static int g_use_tr = 1;
+static hook_t g_use_tr{1};
 // blocks a launch aims for (tiles x splits): ONE round of the two blocks a CU holds.  Measured per shape (scripts/wgrad_kpm.py):
 // 512 beats 1024 by 1-7 % and 768 / 1536 (1.5 / 3 rounds: the last one half empty, more split-K partials) by 10-25 %
-static int g_wg_blocks = 512;
-static int g_plain_kpm = 2;  // k-step multiplier of the 1x1 pointer-walking kernel (2 = 64 pixels per barrier)
+static hook_t g_wg_blocks{512};
+static hook_t g_plain_kpm{2};  // k-step multiplier of the 1x1 pointer-walking kernel (2 = 64 pixels per barrier)
 static bool is_plain(const sh_conv_desc* d) {
   return d->dtype == SH_BF16 && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0;
 }
@@ -627,7 +627,8 @@ static void plan(const sh_conv_desc* d, int* bm, int* bn, int* splitk, int* pps)
   const long long tiles = (long long)(d->cout / *bm) * (d->cin / *bn) * d->r * d->s;
   const long long ksteps = (mo + kp - 1) / kp;
   // the pointer-walking 1x1 kernel (64-pixel k-steps, 70 KB of LDS) holds two blocks per CU, the generic one three
-  const int target = (is_plain(d) && g_use_tr && d->dtype == SH_BF16) ? g_wg_blocks : (g_wg_blocks * 3) / 2;
+  const int wgb = g_wg_blocks;
+  const int target = (is_plain(d) && g_use_tr && d->dtype == SH_BF16) ? wgb : (wgb * 3) / 2;
   long long sk = target / tiles;               // never more blocks than one round
   const long long max_sk = (ksteps + 7) / 8;   // at least 8 k-steps per block
   if (sk > max_sk) sk = max_sk;
@@ -636,6 +637,14 @@ static void plan(const sh_conv_desc* d, int* bm, int* bn, int* splitk, int* pps)
   sk = (ksteps + per - 1) / per;
   *splitk = (int)sk;
   *pps = (int)(per * kp);
+}
+
+void hooks_reset_wgrad() {
+  g_use_wgrad3 = 1;
+  g_wg3_blocks = 512;
+  g_use_tr = 1;
+  g_wg_blocks = 512;
+  g_plain_kpm = 2;
 }
 
 }  // namespace sh
@@ -705,6 +714,7 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
     const double flops3 = 2.0 * (double)mo * d->cout * d->cin * 9;
     const double bytes3 = 2.0 * ((double)d->n * d->h * d->w * d->cin + (double)mo * d->cout) + 4.0 * d->cout * d->cin * 9;
     ProfScope ps3(SH_PROF_CONV_WGRAD, s3, flops3, bytes3);
+    route_hit(SH_ROUTE_WGRAD3X3);
     wgrad3x3_kernel<<<sk * (d->cout / 64) * (d->cin / 64), 256, 0, s3>>>(b);
     if (check_launch("conv2d_wgrad (3x3)")) return 1;
     launch_reduce(b.part, (long long)d->cout * d->cin * 9, sk, dw, d->cin, 9, c_real, s3);
@@ -735,6 +745,8 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
     bytes = es * ((double)d->n * stem_hp * stem_wp * 4 + (double)mo * 64) + 4.0 * 64 * 147;
   }
   ProfScope ps(SH_PROF_CONV_WGRAD, s, flops, bytes);
+  route_hit(stem_wp > 0 ? SH_ROUTE_WGRAD_STEM : (plain ? SH_ROUTE_WGRAD_PLAIN : SH_ROUTE_WGRAD_GENERIC));
+  if (dy_colsum != nullptr) route_hit(SH_ROUTE_WGRAD_COLSUM);
 #define SH_WG(T, BM, BN) wgrad_kernel<T, BM, BN><<<nblk, 256, 0, s>>>(a)
   if (stem_wp > 0) {  // cout 64 x 256 virtual channels -> the 64 x 128 tile with the NHWC4 address map
     if (d->dtype == SH_F32) wgrad_kernel<float, 64, 128, true><<<nblk, 256, 0, s>>>(a);

@@ -1,6 +1,7 @@
 // Error plumbing, device check and the per-kernel-class HIP-event profiler.
 #include <stdarg.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -24,6 +25,11 @@ int check_launch(const char* what) {
     return 1;
   }
   return 0;
+}
+
+static std::atomic<long long> g_routes[SH_ROUTE_COUNT];
+void route_hit(int route) {
+  if (route >= 0 && route < SH_ROUTE_COUNT) g_routes[route].fetch_add(1, std::memory_order_relaxed);
 }
 
 // ---- profiler: one event pair per launch, recorded on the launch stream ----
@@ -95,6 +101,29 @@ int simhand_device_check(void) {
     sh::set_error("device is %s; this library is built for gfx950 only", prop.gcnArchName);
     return 2;
   }
+  return 0;
+}
+
+int simhand_route_counts(int64_t* out) {
+  if (!out) {
+    sh::set_error("route_counts: NULL");
+    return 1;
+  }
+  for (int i = 0; i < SH_ROUTE_COUNT; ++i) out[i] = sh::g_routes[i].load(std::memory_order_relaxed);
+  return 0;
+}
+
+int simhand_route_reset(void) {
+  for (int i = 0; i < SH_ROUTE_COUNT; ++i) sh::g_routes[i].store(0, std::memory_order_relaxed);
+  return 0;
+}
+
+int simhand_hooks_reset(void) {
+  sh::hooks_reset_igemm();
+  sh::hooks_reset_c64();
+  sh::hooks_reset_1x1();
+  sh::hooks_reset_wgrad();
+  sh::hooks_reset_bn();
   return 0;
 }
 

@@ -367,7 +367,15 @@ __global__ __launch_bounds__(256) void ntxent_tile_kernel(LossArgs a, const floa
         const float e = expf(t[r] * w * a.inv_t);  // exp(cov * w / temperature), utils.py:412-413
         if (BWD) {
           const float inj = ok ? 1.0f / neg_all[j] : 0.f;
-          p[r] = ok ? w * e * (inv_neg_i + inj) : 0.f;
+          if (wq.wtype == SH_W_EXPLICIT) {
+            // caller-supplied weights need not be symmetric (vanila_*_weights_contrastive_loss takes any (N,N) tensor,
+            // src/models/utils.py:391-501): row j's term uses ITS weight of column i.  Single process only, so lrow == grow.
+            const float wt = ok ? weight_of(D[(size_t)j * a.N + grow], wq) : 0.f;
+            const float et = expf(t[r] * wt * a.inv_t);
+            p[r] = ok ? w * e * inv_neg_i + wt * et * inj : 0.f;
+          } else {
+            p[r] = ok ? w * e * (inv_neg_i + inj) : 0.f;
+          }
         } else {
           rowsum += ok ? e : 0.f;
         }
@@ -583,6 +591,7 @@ int simhand_ntxent_fwd(const sh_ntxent_params* p, const float* Z_all, const floa
   float* neg_partial = (float*)workspace;
   float* loss_rows = neg_partial + (size_t)a.csplit * a.rows_pad;
   ProfScope ps(SH_PROF_LOSS, s, 2.0 * rows * a.N * kDim, 0);
+  route_hit(SH_ROUTE_NTXENT_FWD);
   dim3 grid(a.rows_pad / 64, a.csplit);
   ntxent_tile_kernel<false><<<grid, 256, 0, s>>>(a, Z_all, D_loc, stats, nullptr, neg_partial);
   if (check_launch("ntxent_fwd tile")) return 1;
@@ -605,6 +614,7 @@ int simhand_ntxent_bwd(const sh_ntxent_params* p, const float* Z_all, const floa
   const int rows = 2 * a.map.b_loc;
   float* dz_partial = (float*)workspace;
   ProfScope ps(SH_PROF_LOSS, s, 4.0 * rows * a.N * kDim, 0);
+  route_hit(SH_ROUTE_NTXENT_BWD);
   dim3 grid(a.rows_pad / 64, a.csplit);
   ntxent_tile_kernel<true><<<grid, 256, 0, s>>>(a, Z_all, D_loc, stats, neg_all, dz_partial);
   if (check_launch("ntxent_bwd tile")) return 1;

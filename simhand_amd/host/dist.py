@@ -51,10 +51,34 @@ def shard_pairs(global_pairs: int, rank: int, world: int) -> Tuple[int, int]:
     return rank * b, b
 
 
-def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20) -> None:
+def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Parameters and buffers of rank `src` to every rank (replica consistency does not rest on identical seeding)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    grads: List[torch.Tensor] = [p.grad for p in params if p.grad is not None]
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20) -> None:
+    """SUM all-reduce over a FIXED parameter list: every rank buckets the same tensors in the same order, whatever
+    received a gradient locally.  A trainable parameter without a gradient on this rank contributes zeros (and receives
+    the other ranks' sum); parameters with requires_grad=False are skipped on every rank alike."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    plist = [p for p in params if p.requires_grad]
+    # which parameters have a gradient anywhere: one small MAX all-reduce keeps the bucket layout identical on all ranks
+    has = torch.tensor([1 if p.grad is not None else 0 for p in plist], dtype=torch.int32, device=plist[0].device if plist else "cpu")
+    if has.numel():
+        dist.all_reduce(has, op=dist.ReduceOp.MAX, group=group)
+    keep = has.tolist()
+    grads: List[torch.Tensor] = []
+    for p, k in zip(plist, keep):
+        if not k:
+            continue
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        grads.append(p.grad)
     bucket: List[torch.Tensor] = []
     size = 0
     pending = []

@@ -109,7 +109,7 @@ class ShardedNtxent(torch.autograd.Function):
                     stats[0], stats[1], stats[2] = mm[0], -mm[1], sm[0]
         plan = K.NtxentPlan(B, b_loc, rank * b_loc, cfg.weight_type if weighted or explicit else None,
                             cfg.use_wpos and dpos is not None, cfg.use_wneg and D is not None, cfg.temperature,
-                            cfg.lambda_pos, cfg.lambda_neg)
+                            cfg.lambda_pos, cfg.lambda_neg, dim=Z.shape[1])
         neg_loc, loss = K.ntxent_fwd(plan, Z, D, dpos, stats)
         if world > 1:
             neg_all = _gather_rows(neg_loc.view(rows, 1), b_loc, world, group).view(-1)

@@ -18,55 +18,68 @@ AUG_FLAGS = ["color_drop", "color_jitter", "crop", "cut_out", "flip", "gaussian_
 SOURCES = ["freihand", "interhand", "mpii", "youtube", "ego4d", "100doh", "ah", "ah-exo", "ah-ego"]
 
 
+# (flag, kwargs) in the reference parser's order.  Names, types, defaults and choices are the contract
+# (tests/golden/cli.json); the help texts are this build's own wording.
+_WEIGHT_FLAGS = [
+    ("--experiment_type", dict(type=str, help="model registry key: simclr, peclr, simhand, simhand_w / handclr_w, simclr_w, peclr_w, ...")),
+    ("--weight_type", dict(type=str, help="how joint distances become loss weights: linear | non_linear")),
+    ("--joints_type", dict(type=str, help="which joints feed the weights: original | augmented")),
+    ("--diff_type", dict(type=str, help="joint-distance definition: w_o_abs | w_abs | mpjpe")),
+    ("--pos_neg", dict(type=str, help="which terms are weighted: pos | neg | pos_neg")),
+    ("--non_linear_lambda_pos", dict(type=float, help="sigmoid slope of the positive weights: 5.0 | 2.5 | 1.0")),
+    ("--non_linear_lambda_neg", dict(type=float, help="sigmoid slope of the negative weights: 0.05 | 0.01 | 0.005")),
+    ("--use_pca", dict(action="store_true", default=False, help="project the joints onto 14 PCA components before measuring distances")),
+    ("--resume", dict(action="store_true", help="continue from --resume_path")),
+    ("--resume_path", dict(type=str, help="checkpoint file to continue from")),
+    ("--eval", dict(action="store_true", help="evaluation / visualisation run (not part of this build)")),
+    ("--eval_path", dict(type=str, help="checkpoint file to evaluate")),
+    ("--debug", dict(action="store_true", help="verbose logging")),
+    ("--vis", dict(action="store_true", help="dump intermediate batches for plotting")),
+    ("--vis_save_dir", dict(type=str, default="", help="where --vis dumps go")),
+    ("--datasets_scale", dict(type=str, help="size tag of the pre-training subset, e.g. 1m")),
+]
+_AUG_HELP = {"color_drop": "drop colour channels at random", "color_jitter": "random HSV jitter", "crop": "crop around the hand",
+             "cut_out": "erase a random rectangle", "flip": "random horizontal flip", "gaussian_blur": "random Gaussian blur",
+             "rotate": "random in-plane rotation", "random_crop": "jittered crop position", "resize": "resize to resize_shape",
+             "sobel_filter": "Sobel edge filter", "gaussian_noise": "additive Gaussian noise"}
+_AUG_ORDER = ["color_drop", "color_jitter", "crop", "cut_out", "flip", "gaussian_blur", "rotate", "random_crop", "resize",
+              "sobel_filter", "gaussian_noise"]
+_TRAIN_FLAGS = [
+    ("-tag", dict(action="append", default=[], help="free-form run tag (repeatable)")),
+    ("-batch_size", dict(type=int, help="global batch in pairs")),
+    ("-epochs", dict(type=int, help="epochs to train")),
+    ("-seed", dict(type=int, help="random seed")),
+    ("--gpus", dict(type=str, default="0", help="device ids (ignored by the reference's Trainer as well)")),
+    ("-num_workers", dict(type=int, help="data-loader worker processes")),
+    ("-train_ratio", dict(type=float, help="train share of the train/validation split")),
+    ("-accumulate_grad_batches", dict(type=int, help="micro-batches per optimizer step")),
+    ("-lr", dict(type=float, default=None, help="base learning rate")),
+    ("-optimizer", dict(type=str, default=None, choices=["LARS", "adam"], help="optimizer")),
+    ("--denoiser", dict(action="store_true", default=False, help="denoiser variant of the model")),
+    ("--heatmap", dict(action="store_true", default=False, help="heat-map variant of the model")),
+    ("-sources", dict(action="append", default=[], choices=SOURCES, help="dataset to draw from (repeatable)")),
+    ("-log_interval", dict(type=str, default="epoch", choices=["step", "epoch"], help="logging granularity")),
+    ("-experiment_key", dict(type=str, default=None, help="experiment key of a pre-trained encoder")),
+    ("-checkpoint", dict(type=str, default="", help="checkpoint name to restore")),
+    ("-meta_file", dict(type=str, default=None, help="file that receives the experiment name")),
+    ("-experiment_name", dict(type=str, default="", help="name under which the run is logged")),
+    ("-save_period", dict(type=int, default=1, help="epochs between snapshots")),
+    ("-save_top_k", dict(type=int, default=3, help="how many best checkpoints to keep")),
+    ("--encoder_trainable", dict(action="store_true", default=False, help="fine-tune the encoder in downstream runs")),
+    ("-resnet_size", dict(type=str, default="18", choices=["18", "34", "50", "101", "152"], help="backbone depth")),
+    ("-lr_max_epochs", dict(type=int, default=None, help="epoch count the cosine schedule is stretched over")),
+    ("--use_palm", dict(action="store_true", default=False, help="regress the palm centre instead of the wrist")),
+]
+
+
 def build_parser(description: str = "Script for training baseline supervised model") -> argparse.ArgumentParser:
     p = argparse.ArgumentParser(description=description)
-    p.add_argument("--experiment_type", type=str, help="The training model name.")
-    p.add_argument("--weight_type", type=str, help="Weight type (linear / non_linear)")
-    p.add_argument("--joints_type", type=str, help="joints type (original / augmented)")
-    p.add_argument("--diff_type", type=str, help="joints_differ (w_o_abs / w_abs / mpjpe)")
-    p.add_argument("--pos_neg", type=str, help="pos_neg weighting(pos / neg / pos_neg)")
-    p.add_argument("--non_linear_lambda_pos", type=float, help="non_linear_parm (5.0 / 2.5 / 1.0)")
-    p.add_argument("--non_linear_lambda_neg", type=float, help="non_linear_parm (0.05 / 0.01 / 0.005)")
-    p.add_argument("--use_pca", action="store_true", help="To enable PCA denoise.", default=False)
-    p.add_argument("--resume", action="store_true", help="resume the model training.")
-    p.add_argument("--resume_path", type=str, help="resume the model checkpoints path")
-    p.add_argument("--eval", action="store_true", help="eval the model and visualization.")
-    p.add_argument("--eval_path", type=str, help="eval the model checkpoints path")
-    p.add_argument("--debug", action="store_true", help="Enable debug logging.")
-    p.add_argument("--vis", action="store_true", help="Enable save the intermediate data.")
-    p.add_argument("--vis_save_dir", type=str, help="data visualization save dir", default="")
-    p.add_argument("--datasets_scale", type=str, help="Usage sacle of the pre-trained data set.")
-    helps = {"color_drop": "To enable random color drop", "color_jitter": "To enable random jitter", "crop": "To enable cropping",
-             "cut_out": "To enable random cur out", "flip": "To enable random flipping", "gaussian_blur": "To enable gaussina blur",
-             "rotate": "To rotate samples randomly", "random_crop": "To enable random cropping", "resize": "To enable resizing",
-             "sobel_filter": "To enable sobel filtering", "gaussian_noise": "To add gaussian noise."}
-    for f in ["color_drop", "color_jitter", "crop", "cut_out", "flip", "gaussian_blur", "rotate", "random_crop", "resize",
-              "sobel_filter", "gaussian_noise"]:
-        p.add_argument(f"--{f}", action="store_true", help=helps[f])
-    p.add_argument("-tag", action="append", help="Tag for comet", default=[])
-    p.add_argument("-batch_size", type=int, help="Batch size")
-    p.add_argument("-epochs", type=int, help="Number of epochs")
-    p.add_argument("-seed", type=int, help="To add seed")
-    p.add_argument("--gpus", type=str, default="0", help="gpu ids")
-    p.add_argument("-num_workers", type=int, help="Number of workers for Dataloader.")
-    p.add_argument("-train_ratio", type=float, help="Ratio of train:validation split.")
-    p.add_argument("-accumulate_grad_batches", type=int, help="Number of batches to accumulate gradient.")
-    p.add_argument("-lr", type=float, help="learning rate", default=None)
-    p.add_argument("-optimizer", type=str, help="Select optimizer", default=None, choices=["LARS", "adam"])
-    p.add_argument("--denoiser", action="store_true", help="To enable denoising", default=False)
-    p.add_argument("--heatmap", action="store_true", help="To enable heatmap model", default=False)
-    p.add_argument("-sources", action="append", help="Data sources to use.", default=[], choices=SOURCES)
-    p.add_argument("-log_interval", type=str, help="To enable denoising", default="epoch", choices=["step", "epoch"])
-    p.add_argument("-experiment_key", type=str, help="Experiment key of pretrained encoder", default=None)
-    p.add_argument("-checkpoint", type=str, help="checkpoint name to restore.", default="")
-    p.add_argument("-meta_file", type=str, help="File to save the name of the experiment.", default=None)
-    p.add_argument("-experiment_name", type=str, help="experiment name for logging", default="")
-    p.add_argument("-save_period", type=int, help="interval at which experiments should be saved", default=1)
-    p.add_argument("-save_top_k", type=int, help="Top snapshots to save", default=3)
-    p.add_argument("--encoder_trainable", action="store_true", help="To enable encoder training in SSL", default=False)
-    p.add_argument("-resnet_size", type=str, help="Resnet size", default="18", choices=["18", "34", "50", "101", "152"])
-    p.add_argument("-lr_max_epochs", type=int, help="Top snapshots to save", default=None)
-    p.add_argument("--use_palm", action="store_true", help="To regress plam instead of wrist.", default=False)
+    for flag, kw in _WEIGHT_FLAGS:
+        p.add_argument(flag, **kw)
+    for f in _AUG_ORDER:
+        p.add_argument(f"--{f}", action="store_true", help=_AUG_HELP[f])
+    for flag, kw in _TRAIN_FLAGS:
+        p.add_argument(flag, **kw)
     return p
 
 

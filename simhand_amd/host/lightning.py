@@ -96,6 +96,8 @@ class Trainer:
         self.log_every_n_steps, self.default_root_dir, self.max_steps = log_every_n_steps, default_root_dir, max_steps
         self.global_step = 0
         self.current_epoch = 0
+        self._epoch_complete, self._batches_seen = True, 0
+        self.step_losses: List[torch.Tensor] = []  # detached per-step loss scalars (device tensors: no host sync per step)
         self.history: List[Dict[str, float]] = []
         self.optimizers: list = []
         self.schedulers: list = []
@@ -115,13 +117,16 @@ class Trainer:
     def checkpoint_dict(self, module: LightningModule, epoch: int) -> dict:
         return {
             "epoch": epoch, "global_step": self.global_step, "pytorch-lightning_version": "1.8.0-compatible",
+            # where inside `epoch` the run stood: a checkpoint taken when max_steps ended an epoch early resumes
+            # in the SAME epoch after skipping the batches already consumed
+            "epoch_complete": self._epoch_complete, "batches_seen": self._batches_seen,
             "state_dict": module.state_dict(), "hyper_parameters": module.hparams,
             "optimizer_states": [o.state_dict() for o in self.optimizers],
             "lr_schedulers": [s["scheduler"].state_dict() for s in self.schedulers],
         }
 
     def fit(self, model: LightningModule, train_dataloaders=None, val_dataloaders=None, ckpt_path: Optional[str] = None):
-        from .dist import allreduce_gradients
+        from .dist import allreduce_gradients, broadcast_module_state
 
         model.trainer = self
         if hasattr(model, "set_compute_dtype"):
@@ -131,15 +136,21 @@ class Trainer:
         model.setup("fit")
         opts, scheds = model.configure_optimizers()
         self.optimizers, self.schedulers = opts, scheds
-        start_epoch = 0
+        start_epoch, skip_batches = 0, 0
         if ckpt_path:
-            ck = torch.load(ckpt_path, map_location=device)
+            ck = torch.load(ckpt_path, map_location=device, weights_only=False)
             model.load_state_dict(ck["state_dict"])
             for o, s in zip(opts, ck.get("optimizer_states", [])):
                 o.load_state_dict(s)
             for s, st in zip(scheds, ck.get("lr_schedulers", [])):
                 s["scheduler"].load_state_dict(st)
-            start_epoch, self.global_step = ck.get("epoch", -1) + 1, ck.get("global_step", 0)
+            self.global_step = ck.get("global_step", 0)
+            if ck.get("epoch_complete", True):
+                start_epoch = ck.get("epoch", -1) + 1
+            else:
+                start_epoch, skip_batches = ck.get("epoch", 0), ck.get("batches_seen", 0)
+        # replicas start from rank 0's parameters / buffers whatever each rank's seeding or checkpoint file was
+        broadcast_module_state(model)
         for cb in self.callbacks:
             if isinstance(cb, ModelCheckpoint) and cb.dirpath is None:
                 cb.dirpath = os.path.join(self.default_root_dir, "checkpoints")
@@ -147,7 +158,11 @@ class Trainer:
         for epoch in range(start_epoch, self.max_epochs):
             self.current_epoch = epoch
             outputs = []
+            self._epoch_complete, self._batches_seen = False, 0
             for batch_idx, batch in enumerate(train_dataloaders):
+                self._batches_seen = batch_idx + 1
+                if epoch == start_epoch and batch_idx < skip_batches:
+                    continue  # consumed before the checkpoint was taken (the iterator still advanced its generator)
                 batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
                 out = model.training_step(batch, batch_idx)
                 loss = out["loss"]
@@ -162,11 +177,16 @@ class Trainer:
                     if s.get("interval", "epoch") == "step":
                         s["scheduler"].step()
                 self.global_step += 1
+                self.step_losses.append(loss.detach())
                 outputs.append({k: v.detach() for k, v in out.items() if torch.is_tensor(v)})
                 if self.global_rank == 0 and self.global_step % self.log_every_n_steps == 0:
                     print(f"epoch {epoch} step {self.global_step} contrastive_loss {float(loss):.6f}", flush=True)
                 if 0 < self.max_steps <= self.global_step:
                     break
+            else:
+                self._epoch_complete = True
+            if not outputs:  # resumed exactly at an epoch's end
+                continue
             model.training_epoch_end(outputs)
             metrics = {k: float(v) for k, v in model.train_metrics_epoch.items()}
             metrics["contrastive_loss"] = metrics.get("loss", float("nan"))

@@ -32,7 +32,7 @@ TEMPERATURE = 0.5
 class _PostprocessFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, jx, jy, angle, hw, flags, tx, ty):
-        p = p.contiguous()
+        p = p.contiguous().float()  # the kernels read fp32 rows of 128 (ops refuses anything else)
         ctx.save_for_backward(p)
         ctx.aux = (jx, jy, angle, hw, flags, tx, ty)
         return ops.proj_postprocess_fwd(p, jx, jy, angle, hw, flags, tx, ty)
@@ -41,7 +41,7 @@ class _PostprocessFn(torch.autograd.Function):
     def backward(ctx, dz):
         (p,) = ctx.saved_tensors
         jx, jy, angle, hw, flags, tx, ty = ctx.aux
-        dp = ops.proj_postprocess_bwd(p, jx, jy, angle, hw, dz.contiguous(), flags, tx, ty)
+        dp = ops.proj_postprocess_bwd(p, jx, jy, angle, hw, dz.contiguous().float(), flags, tx, ty)
         return dp, None, None, None, None, None, None, None
 
 

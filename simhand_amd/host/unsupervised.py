@@ -156,6 +156,13 @@ class SimCLR(BaseModel):
         if self.weighted:
             j1, j2 = self._joints(batch)
             if getattr(self.config, "use_pca", False) and type(self).__name__ == "HandCLR_W":
+                if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                        torch.distributed.get_world_size(self.process_group) > 1:
+                    # the reference's PCA basis comes from a randomised torch.pca_lowrank of the batch it sees
+                    # (src/models/utils.py:192-215): per-rank bases would put the gathered joints in incompatible
+                    # coordinates, so the global-negative loss is undefined for this flag
+                    raise NotImplementedError("--use_pca is a single-process option: its per-batch randomised PCA basis "
+                                              "cannot be shared across ranks")
                 j1, j2 = mu.apply_pca(j1), mu.apply_pca(j2)
                 cfg.diff_type = "l2"
             joints = torch.cat((j1, j2), dim=0).to(torch.float32).reshape(z.shape[0], -1).contiguous()

@@ -23,14 +23,28 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+def _ptr(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None) -> C.c_void_p:
+    """Device pointer of a contiguous tensor.  `dtype`: the element type the C entry point reads the buffer as -- a tensor
+    of another dtype would be silently reinterpreted, so it is refused here."""
     if t is None:
         return C.c_void_p(0)
     if not t.is_cuda:
         raise _lib.SimhandHipError("simhand_amd ops need device tensors (there is no CPU path)")
     if not t.is_contiguous():
         raise _lib.SimhandHipError("simhand_amd ops need contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.SimhandHipError(f"simhand_amd op expects a {dtype} tensor, got {t.dtype}")
     return C.c_void_p(t.data_ptr())
+
+
+_F32, _F64, _I64 = torch.float32, torch.float64, torch.int64
+PROJ_DIM = 128  # the post-process / loss kernels view a row as 64 2-D points (output_dim of every *_config.json)
+
+
+def _require_width(t: torch.Tensor, what: str) -> None:
+    if t.dim() != 2 or t.shape[1] != PROJ_DIM:
+        raise _lib.SimhandHipError(f"{what}: rows must be {PROJ_DIM} wide (64 2-D points, output_dim of the reference configs); "
+                                   f"got shape {tuple(t.shape)}")
 
 
 def _lib_dev():
@@ -60,7 +74,7 @@ class NtxentPlan:
 def pos_dist(J_all: torch.Tensor, B: int, mode: str, stats: torch.Tensor) -> torch.Tensor:
     lib = _lib_dev()
     d = torch.empty(B, dtype=torch.float32, device=J_all.device)
-    check(lib.simhand_pos_dist(_ptr(J_all), B, J_all.shape[1], _lib.DIST_MODES[mode], _ptr(d), _ptr(stats), _stream()), "pos_dist")
+    check(lib.simhand_pos_dist(_ptr(J_all, _F32), B, J_all.shape[1], _lib.DIST_MODES[mode], _ptr(d), _ptr(stats, _F64), _stream()), "pos_dist")
     return d
 
 
@@ -70,7 +84,7 @@ def neg_dist(J_all: torch.Tensor, B: int, mode: str, b_loc: int, pair_off: int, 
     D = torch.empty(rows, N, dtype=torch.float32, device=J_all.device)
     nb = lib.simhand_neg_dist_workspace_bytes(rows, N)
     ws = torch.empty(nb, dtype=torch.uint8, device=J_all.device)
-    check(lib.simhand_neg_dist(_ptr(J_all), B, J_all.shape[1], _lib.DIST_MODES[mode], b_loc, pair_off, _ptr(D), _ptr(stats),
+    check(lib.simhand_neg_dist(_ptr(J_all, _F32), B, J_all.shape[1], _lib.DIST_MODES[mode], b_loc, pair_off, _ptr(D), _ptr(stats, _F64),
                                _ptr(ws), nb, _stream()), "neg_dist")
     return D
 
@@ -79,7 +93,7 @@ def weights_from_dist(dist: torch.Tensor, weight_type: str, stats: torch.Tensor,
                       lam: float = 0.0) -> torch.Tensor:
     lib = _lib_dev()
     w = torch.empty_like(dist)
-    check(lib.simhand_weights_from_dist(_ptr(dist), dist.numel(), _lib.WEIGHT_TYPES[weight_type], _ptr(stats), int(positive),
+    check(lib.simhand_weights_from_dist(_ptr(dist, _F32), dist.numel(), _lib.WEIGHT_TYPES[weight_type], _ptr(stats, _F64), int(positive),
                                         float(mean_count), float(lam or 0.0), _ptr(w), _stream()), "weights_from_dist")
     return w
 
@@ -87,10 +101,11 @@ def weights_from_dist(dist: torch.Tensor, weight_type: str, stats: torch.Tensor,
 def ntxent_fwd(plan: NtxentPlan, Z_all, D_loc, d_pos, stats) -> Tuple[torch.Tensor, torch.Tensor]:
     lib = _lib_dev()
     dev = Z_all.device
+    _require_width(Z_all, "ntxent_fwd")
     neg = torch.empty(plan.rows, dtype=torch.float32, device=dev)
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
-    check(lib.simhand_ntxent_fwd(C.byref(plan.p), _ptr(Z_all), _ptr(D_loc), _ptr(d_pos), _ptr(stats), _ptr(neg), _ptr(loss),
+    check(lib.simhand_ntxent_fwd(C.byref(plan.p), _ptr(Z_all, _F32), _ptr(D_loc, _F32), _ptr(d_pos, _F32), _ptr(stats, _F64), _ptr(neg), _ptr(loss),
                                  _ptr(ws), plan.ws_bytes, _stream()), "ntxent_fwd")
     return neg, loss
 
@@ -98,9 +113,10 @@ def ntxent_fwd(plan: NtxentPlan, Z_all, D_loc, d_pos, stats) -> Tuple[torch.Tens
 def ntxent_bwd(plan: NtxentPlan, Z_all, D_loc, d_pos, stats, neg_all, dloss) -> torch.Tensor:
     lib = _lib_dev()
     dev = Z_all.device
+    _require_width(Z_all, "ntxent_bwd")
     dZ = torch.empty(plan.rows, plan.p.dim, dtype=torch.float32, device=dev)
     ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
-    check(lib.simhand_ntxent_bwd(C.byref(plan.p), _ptr(Z_all), _ptr(D_loc), _ptr(d_pos), _ptr(stats), _ptr(neg_all), _ptr(dloss),
+    check(lib.simhand_ntxent_bwd(C.byref(plan.p), _ptr(Z_all, _F32), _ptr(D_loc, _F32), _ptr(d_pos, _F32), _ptr(stats, _F64), _ptr(neg_all, _F32), _ptr(dloss, _F32),
                                  _ptr(dZ), _ptr(ws), plan.ws_bytes, _stream()), "ntxent_bwd")
     return dZ
 
@@ -108,27 +124,31 @@ def ntxent_bwd(plan: NtxentPlan, Z_all, D_loc, d_pos, stats, neg_all, dloss) -> 
 # ------------------------------------------------------------------ post-process
 def proj_postprocess_fwd(P, jx, jy, angle, hw, flags: int = _lib.PP_FUSED, tx=None, ty=None) -> torch.Tensor:
     lib = _lib_dev()
+    _require_width(P, "proj_postprocess_fwd")
     Z = torch.empty_like(P)
-    check(lib.simhand_proj_postprocess_fwd(_ptr(P), P.shape[0], _ptr(jx), _ptr(jy), _ptr(tx), _ptr(ty), _ptr(angle), int(hw[0]),
+    check(lib.simhand_proj_postprocess_fwd(_ptr(P, _F32), P.shape[0], _ptr(jx, _I64), _ptr(jy, _I64), _ptr(tx, _F32), _ptr(ty, _F32), _ptr(angle, _F64), int(hw[0]),
                                            int(hw[1]), flags, _ptr(Z), _stream()), "proj_postprocess_fwd")
     return Z
 
 
 def proj_postprocess_bwd(P, jx, jy, angle, hw, dZ, flags: int = _lib.PP_FUSED, tx=None, ty=None) -> torch.Tensor:
     lib = _lib_dev()
+    _require_width(P, "proj_postprocess_bwd")
+    _require_width(dZ, "proj_postprocess_bwd (dZ)")
     dP = torch.empty_like(P)
-    check(lib.simhand_proj_postprocess_bwd(_ptr(P), P.shape[0], _ptr(jx), _ptr(jy), _ptr(tx), _ptr(ty), _ptr(angle), int(hw[0]),
-                                           int(hw[1]), flags, _ptr(dZ), _ptr(dP), _stream()), "proj_postprocess_bwd")
+    check(lib.simhand_proj_postprocess_bwd(_ptr(P, _F32), P.shape[0], _ptr(jx, _I64), _ptr(jy, _I64), _ptr(tx, _F32), _ptr(ty, _F32), _ptr(angle, _F64), int(hw[0]),
+                                           int(hw[1]), flags, _ptr(dZ, _F32), _ptr(dP), _stream()), "proj_postprocess_bwd")
     return dP
 
 
 def proj_stats(P: torch.Tensor) -> torch.Tensor:
     """8 batch-mean statistics of one view's raw head output (rows x 128)."""
     lib = _lib_dev()
+    _require_width(P, "proj_stats")
     n = P.shape[0]
     ws = torch.empty(n, 8, dtype=torch.float32, device=P.device)
     out = torch.empty(8, dtype=torch.float32, device=P.device)
-    check(lib.simhand_proj_stats(_ptr(P), n, _ptr(ws), _ptr(out), _stream()), "proj_stats")
+    check(lib.simhand_proj_stats(_ptr(P, _F32), n, _ptr(ws), _ptr(out), _stream()), "proj_stats")
     return out
 
 
@@ -698,6 +718,23 @@ def lars_adam_multi(plan: LarsAdamPlan, records: "np.ndarray", betas=(0.9, 0.999
     check(lib.simhand_lars_adam_multi(_ptr(table), len(records), _ptr(plan.chunks), plan.n_chunks, _ptr(plan.partials), betas[0],
                                       betas[1], adam_eps, lars_eta, lars_eps, int(lars_clip), plan.total, _stream()),
           "lars_adam_multi")
+
+
+# ----------------------------------------------------------------- route counters
+def route_reset() -> None:
+    _lib.load().simhand_route_reset()
+
+
+def route_counts() -> dict:
+    """{route name: launches since the last reset} -- which hand-written kernel each call was dispatched to."""
+    buf = (C.c_int64 * _lib.ROUTE_COUNT)()
+    check(_lib.load().simhand_route_counts(buf), "route_counts")
+    return {name: int(buf[i]) for i, name in enumerate(_lib.ROUTES)}
+
+
+def hooks_reset() -> None:
+    """Every test / tuning hook of the library back to its default."""
+    _lib.load().simhand_hooks_reset()
 
 
 # --------------------------------------------------------------------- profiler
