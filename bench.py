@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: hand-image-pairs/s of the SiMHand contrastive training step.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without WORLD_SIZE: spawns its own N ranks (RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1] / [2]): ResNet-50 `handclr_w`, bf16 MFMA kernels, per-GPU batch
@@ -20,6 +20,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -49,8 +51,32 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "32"])
     ap.add_argument("--experiment", default="handclr_w", choices=["handclr_w", "peclr_w", "simclr"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs in the CPU-baseline sample")
+    ap.add_argument("--cpu-pairs", type=int, default=32, help="pairs in the CPU-baseline sample (SURVEY 8d: 32)")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="also time the other SURVEY 8d CPU points (ResNet-18 B=32 = BASELINE configs[0], ResNet-50 B=128): minutes of CPU time")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, one process per GPU, before this process
+    has touched the GPU (children are fresh interpreters, nothing is exec'ed over an initialised runtime).  Rank 0
+    inherits stdout and prints the JSON line."""
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE=str(args.gpus), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def make_model(args, world):
@@ -87,32 +113,73 @@ def device_batch(b, size, seed, device):
     }
 
 
-def cpu_baseline(args):
-    """The oracle (CPU port of the reference step, torch fp32) on all host cores, bounded sample."""
+def host_cpu():
+    """CPU model, sockets x cores (physical) and hardware threads of this host, from lscpu."""
+    info = {"model": "unknown", "physical_cores": None, "threads": os.cpu_count()}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {ln.split(":", 1)[0].strip(): ln.split(":", 1)[1].strip() for ln in out.splitlines() if ":" in ln}
+        info["model"] = kv.get("Model name", "unknown")
+        info["physical_cores"] = int(kv.get("Socket(s)", "1")) * int(kv.get("Core(s) per socket", "0")) or None
+    except Exception:  # noqa: BLE001 -- lscpu missing: keep the defaults
+        pass
+    return info
+
+
+def _cpu_point(exp, resnet, pairs, size, wcfg, budget_s):
+    """One CPU reference point: the oracle step (fwd + bwd, then LARS/Adam timed separately) -- median of up to 5 timed
+    steps after 2 warm-ups; the timed steps stop early once `budget_s` of wall time is spent (never fewer than 1)."""
     from oracle import step as orc
     from oracle.optim import LARSWrapperOracle
 
-    b = args.cpu_pairs
     torch.manual_seed(5)
-    wcfg = dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg") if args.experiment != "simclr" else {}
-    exp = {"handclr_w": "simhand_w", "peclr_w": "peclr_w", "simclr": "simclr"}[args.experiment]
-    model = orc.StepOracle(exp, args.resnet, AUG, **wcfg).train()
+    model = orc.StepOracle(exp, resnet, AUG, **wcfg).train()
     adam = torch.optim.Adam(model.parameters(), lr=3.2e-3, weight_decay=1e-6)
     opt = LARSWrapperOracle(adam)
-    batch = orc.synthetic_batch(b, size=args.image_size, seed=5)
-    cores = torch.get_num_threads()
-    times = []
-    for i in range(3):
+    batch = orc.synthetic_batch(pairs, size=size, seed=5)
+    fb, op = [], []
+    t_start = time.perf_counter()
+    for i in range(7):
         t0 = time.perf_counter()
         adam.zero_grad(set_to_none=True)
         loss = model.contrastive_step(batch)
         loss.backward()
+        t1 = time.perf_counter()
         opt.step()
-        times.append(time.perf_counter() - t0)
-    t = min(times[1:])
-    return {"value": b / t, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"oracle.StepOracle ResNet-{args.resnet} {args.experiment} fp32, {b} pairs of {args.image_size}x{args.image_size}, "
-                      f"fwd+bwd+LARS/Adam, best of 2 steps after 1 warm-up ({t * 1e3:.0f} ms/step)"}
+        t2 = time.perf_counter()
+        if i >= 2:
+            fb.append(t1 - t0)
+            op.append(t2 - t1)
+        if i >= 2 and time.perf_counter() - t_start > budget_s:
+            break
+    fb.sort()
+    op.sort()
+    tf, to = fb[len(fb) // 2], op[len(op) // 2]
+    return {"pairs_per_s": pairs / tf, "pairs_per_s_incl_optimizer": pairs / (tf + to), "fwd_bwd_ms": tf * 1e3, "optimizer_ms": to * 1e3,
+            "pairs": pairs, "timed_steps": len(fb), "resnet": resnet, "image_size": size}
+
+
+def cpu_baseline(args):
+    """The oracle (CPU port of the reference step, torch fp32, validated against the reference's golden vectors) on the
+    host cores.  Headline point: the benchmarked network at 32 pairs.  --cpu-full adds BASELINE configs[0]
+    (ResNet-18, 32 pairs) and the 128-pair point."""
+    wcfg = dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg") if args.experiment != "simclr" else {}
+    exp = {"handclr_w": "simhand_w", "peclr_w": "peclr_w", "simclr": "simclr"}[args.experiment]
+    cpu = host_cpu()
+    threads = torch.get_num_threads()
+    pt = _cpu_point(exp, args.resnet, args.cpu_pairs, args.image_size, wcfg, budget_s=25.0)
+    res = {"value": pt["pairs_per_s"], "unit": "pairs/s", "cores": threads, "kind": "port",
+           "cpu_model": cpu["model"], "physical_cores": cpu["physical_cores"], "hardware_threads": cpu["threads"],
+           "optimizer_ms": pt["optimizer_ms"], "fwd_bwd_ms": pt["fwd_bwd_ms"],
+           "sample": f"oracle.StepOracle ResNet-{args.resnet} {args.experiment} fp32, {pt['pairs']} pairs of {args.image_size}x{args.image_size}, "
+                     f"fwd+bwd (optimizer timed separately: {pt['optimizer_ms']:.0f} ms), median of {pt['timed_steps']} steps after 2 warm-ups "
+                     f"({pt['fwd_bwd_ms']:.0f} ms/step), {threads} torch threads on {cpu['model']} ({cpu['physical_cores']} physical cores)"}
+    if args.cpu_full:
+        res["points"] = {
+            "configs[0] ResNet-18 B=32": _cpu_point(exp, "18", 32, args.image_size, wcfg, budget_s=60.0),
+            f"ResNet-{args.resnet} B=128": _cpu_point(exp, args.resnet, 128, args.image_size, wcfg, budget_s=240.0),
+        }
+    return res
 
 
 def main():
@@ -120,11 +187,13 @@ def main():
     from simhand_amd import _lib, ops
     from simhand_amd.host import dist as shdist
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))  # nothing above touched the GPU: the ranks are ordinary child processes
     rank, local, world = shdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     _lib.require_device()
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", torch.cuda.current_device())  # = LOCAL_RANK (init_from_env set it)
     model = make_model(args, world).to(device).train()
 
     class _T:
@@ -209,7 +278,9 @@ def main():
                                    f"{args.per_gpu_batch} pairs/GPU of 2x{args.image_size}x{args.image_size}x3, linear MPJPE weighting, "
                                    f"crop+rotate un-warp, global negatives",
                        "global_batch": global_pairs, "per_gpu_batch": args.per_gpu_batch, "image_size": args.image_size,
-                       "parallelism": f"dp{world}", "loss": final_loss},
+                       "parallelism": f"dp{world}", "loss": final_loss,
+                       "world_size_backend": dist.get_world_size() if world > 1 else 1,
+                       "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "launches": d["count"], "avg_launch_ms": d["ms"] / max(1, d["count"]),
                          "all_conv_tflops": all_conv_flops / (all_conv_ms * 1e-3) / 1e12 if all_conv_ms > 0 else 0.0,

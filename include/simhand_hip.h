@@ -84,7 +84,8 @@ int simhand_hooks_reset(void);
 
 /* ---- optional per-kernel-class HIP-event profiler (used by bench.py) ----- */
 enum sh_prof_class { SH_PROF_CONV_FWD = 0, SH_PROF_CONV_DGRAD = 1, SH_PROF_CONV_WGRAD = 2,
-                     SH_PROF_BN = 3, SH_PROF_POOL = 4, SH_PROF_LOSS = 5, SH_PROF_MISC = 6, SH_PROF_NCLASS = 7 };
+                     SH_PROF_BN = 3, SH_PROF_POOL = 4, SH_PROF_LOSS = 5, SH_PROF_MISC = 6,
+                     SH_PROF_OPT = 7 /* LARS + Adam update */, SH_PROF_NCLASS = 8 };
 int simhand_prof_enable(int on);
 /* bit c set = launches of class c record their event pair (default: all).  An event pair costs ~1-3 us of queue time per
  * launch, so a timed region records only the class it needs. */

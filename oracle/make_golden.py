@@ -295,14 +295,74 @@ def golden_cli() -> None:
         json.dump(res, f, indent=1, sort_keys=True)
 
 
+def golden_sharded() -> None:
+    """Row a13: what the RCCL path must equal.  The reference's HandCLR_W applied SHARD BY SHARD
+    (same weights; train-mode BatchNorm statistics per shard, as in its DataParallel replicas), the shards' projections
+    concatenated in the reference row order cat(all view-1, all view-2), then the reference's own
+    get_weights_linear + vanila_weights_contrastive_loss over the GLOBAL batch -- for R in {1, 2, 4, 8} at
+    B_glob = 32 (64 x 64 images, restated RN18 through the torchvision shim, seed 5)."""
+    mu = ref_import.models_utils()
+    aug = ["color_jitter", "crop", "random_crop", "resize", "rotate"]
+    wcfg = dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg")
+    b, size, seed = 32, 64, 5
+    batch = step.synthetic_batch(b, size=size, seed=seed)
+    cfg = ref_import.EasyDict(resnet_size="18", projection_head_input_dim=512, projection_head_hidden_dim=512, output_dim=128,
+                              augmentation=aug, joints_type="augmented", use_pca=False, non_linear_lambda_pos=5.0,
+                              non_linear_lambda_neg=0.05, **wcfg)
+    res, arrays = {"B": b, "size": size, "seed": seed, "config": wcfg, "augmentation": aug, "ranks": {}}, {}
+    j1, j2 = batch["joints1_aug"][:, :, :2], batch["joints2_aug"][:, :, :2]
+    for ranks in (1, 2, 4, 8):
+        torch.manual_seed(seed)
+        with ref_import.quiet():
+            model = ref_import.step_class("HandCLR_W")(cfg, None, "train")
+            model.train()
+            bl = b // ranks
+            zs1, zs2 = [], []
+            for r in range(ranks):
+                sub = {k: v[r * bl:(r + 1) * bl].clone() for k, v in batch.items()}
+                p1, p2 = model.get_transformed_projections(sub)
+                zs1.append(p1)
+                zs2.append(p2)
+            z1, z2 = torch.cat(zs1), torch.cat(zs2)
+            wp, wn = mu.get_weights_linear(j1, j2, "mpjpe")
+            loss = mu.vanila_weights_contrastive_loss(z1, z2, wp, wn)
+            loss.backward()
+        # the restatement, sharded the same way, must agree before the numbers are committed
+        torch.manual_seed(seed)
+        orc = step.StepOracle("simhand_w", "18", aug, **wcfg).train()
+        lo, _ = step.sharded_step(orc, batch, ranks)
+        lo.backward()
+        assert abs(lo.item() - loss.item()) < 1e-5 * abs(loss.item()), (ranks, lo.item(), loss.item())
+        gref = dict(model.named_parameters())
+        for k, p in orc.named_parameters():
+            if p.grad is None:
+                continue
+            err, den = (p.grad - gref[k].grad).abs().max(), gref[k].grad.abs().max()
+            assert err < 5e-3 * den or err < 1e-6, (ranks, k, float(err), float(den))
+        res["ranks"][str(ranks)] = {
+            "loss": float(loss.detach()),
+            "param_checksum": float(sum(p.double().abs().sum() for p in model.parameters())),
+            "grad_norms": {k: float(p.grad.norm()) for k, p in model.named_parameters() if p.grad is not None},
+        }
+        arrays[f"R{ranks}.z"] = _np(torch.cat((z1, z2)))
+        arrays[f"R{ranks}.dW_head3"] = _np(gref["projection_head.3.weight"].grad)
+    np.savez_compressed(os.path.join(OUT, "sharded_rn18.npz"), **arrays)
+    with open(os.path.join(OUT, "sharded_rn18.json"), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "sharded":  # only the a13 fixture
+        golden_sharded()
+        return
     mu = ref_import.models_utils()
     golden_loss(mu)
     golden_pca(mu)
     golden_postprocess()
     golden_step()
+    golden_sharded()
     golden_cli()
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):

@@ -436,6 +436,50 @@ class StepOracle(nn.Module):
         return ntxent(z[:b], z[b:], wp, wn)
 
 
+def sharded_step(model: "StepOracle", batch: Dict[str, Tensor], ranks: int) -> Tuple[Tensor, Tensor]:
+    """what R data-parallel ranks must compute together.  Encoder + head + un-warp run shard by shard
+    (contiguous pair ranges, both views of a pair in one shard; train-mode BatchNorm statistics per shard, as in the
+    reference's DataParallel replicas, src/experiments/main.py:152-163), the projections are concatenated in the
+    reference's row order cat(all view-1, all view-2) and the weights + NT-Xent run ONCE over the global batch
+    (== the reference's single-device loss at the global batch).  Returns (loss, z (2B,128))."""
+    b = batch["transformed_image1"].shape[0]
+    if b % ranks:
+        raise ValueError(f"global batch {b} is not divisible by {ranks} ranks")
+    bl = b // ranks
+    hw = tuple(batch["transformed_image1"].shape[-2:])
+    z1s, z2s = [], []
+    for r in range(ranks):
+        sub = {k: v[r * bl:(r + 1) * bl] for k, v in batch.items()}
+        x = torch.cat((sub["transformed_image1"], sub["transformed_image2"]), dim=0)
+        _, p = model.embed(x)
+        if model.unwarps:
+            jx = jy = ang = None
+            if "crop" in model.augmentation:
+                jx = torch.cat((sub["jitter_x_1"], sub["jitter_x_2"]))
+                jy = torch.cat((sub["jitter_y_1"], sub["jitter_y_2"]))
+            if "rotate" in model.augmentation:
+                ang = torch.cat((sub["angle_1"], sub["angle_2"]))
+            z = transformed_projections(p, jx, jy, ang, hw)
+        else:
+            z = rownorm(p)
+        z1s.append(z[:bl])
+        z2s.append(z[bl:])
+    z1, z2 = torch.cat(z1s), torch.cat(z2s)
+    wp = wn = None
+    if model.weighted:
+        j1 = batch["joints1_aug"][:, :, :2]
+        j2 = batch["joints2_aug"][:, :, :2]
+        if model.weight_type == "linear":
+            wp, wn = weights_linear(j1, j2, model.diff_type)
+        else:
+            wp, wn = weights_nonlinear(j1, j2, model.lambda_pos, model.lambda_neg, model.diff_type)
+        if model.pos_neg == "pos":
+            wn = None
+        elif model.pos_neg == "neg":
+            wp = None
+    return ntxent(z1, z2, wp, wn), torch.cat((z1, z2))
+
+
 # --------------------------------------------------------------------------
 # synthetic batch (SURVEY 8d) -- shared by tests, smoke() and bench.py
 # --------------------------------------------------------------------------

@@ -26,7 +26,7 @@ DIST_MODES = {"mpjpe": 0, "w_abs": 1, "w_o_abs": 2, "l2": 3}
 WEIGHT_TYPES = {None: 0, "none": 0, "linear": 1, "non_linear": 2, "explicit": 3}
 PP_NORM_IN, PP_NORM_OUT, PP_ANGLE_AS_GIVEN = 1, 2, 4
 PP_FUSED = 3
-PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn", "pool", "loss", "misc")
+PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn", "pool", "loss", "misc", "optimizer")
 # enum sh_route: kernel the library dispatched a call to (index = counter slot)
 ROUTES = ("igemm128_fwd", "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "igemm256_tail", "gemm1x1_fwd", "gemm1x1_fwd_bnact",
           "gemm1x1_dgrad", "c64_fwd", "c64_dgrad", "stem_fwd", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",

@@ -740,6 +740,8 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
   const double es = d->dtype == SH_F32 ? 4 : 2;
   double flops = 2.0 * (double)mo * d->cout * d->cin * d->r * d->s;
   double bytes = es * ((double)d->n * d->h * d->w * d->cin + (double)mo * d->cout) + 4.0 * d->cout * d->cin * d->r * d->s;
+  if (x == dy) flops = 0.0;  // Gram launch of the BatchNorm fold (a^T a): its time stays in the class, its FLOPs are not
+                             // algorithmic work of the layer graph and are not counted towards any roofline figure
   if (stem_wp > 0) {  // algorithmic figures of the 7x7x3 stem, not of its padded K = 256 lowering
     flops = 2.0 * (double)mo * 64 * 147;
     bytes = es * ((double)d->n * stem_hp * stem_wp * 4 + (double)mo * 64) + 4.0 * 64 * 147;

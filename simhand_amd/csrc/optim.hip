@@ -151,7 +151,7 @@ extern "C" {
 
 int simhand_sumsq_partial(const float* x, int64_t count, float* partial, int nblk, sh_stream_t stream) {
   SH_REQUIRE(x && partial && count >= 0 && nblk >= 1, "sumsq_partial: bad arguments");
-  ProfScope ps(SH_PROF_MISC, (hipStream_t)stream, 0, (double)count * 4);
+  ProfScope ps(SH_PROF_OPT, (hipStream_t)stream, 0, (double)count * 4);
   sumsq_partial_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(x, count, partial);
   return check_launch("sumsq_partial");
 }
@@ -168,7 +168,7 @@ int simhand_lars_adam_step(float* param, const float* grad, float* exp_avg, floa
   int64_t g = (count + 255) / 256;
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
-  ProfScope ps(SH_PROF_MISC, (hipStream_t)stream, 0, (double)count * 28);
+  ProfScope ps(SH_PROF_OPT, (hipStream_t)stream, 0, (double)count * 28);
   lars_adam_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, count, p_sumsq, g_sumsq, nblk_norm, lr,
                                                             beta1, beta2, adam_eps, weight_decay, lars_eta, lars_eps, lars_clip, use_lars,
                                                             bc1, bc2_sqrt);
@@ -183,7 +183,7 @@ int simhand_lars_adam_multi(const sh_opt_tensor* tensors, int n_tensors, const i
   SH_REQUIRE(tensors && chunks && norm_partials, "lars_adam_multi: NULL pointer");
   SH_REQUIRE(n_tensors >= 1 && n_chunks >= 1, "lars_adam_multi: empty tables");
   hipStream_t st = (hipStream_t)stream;
-  ProfScope ps(SH_PROF_MISC, st, 0, (double)total_elems * 36);
+  ProfScope ps(SH_PROF_OPT, st, 0, (double)total_elems * 36);
   opt_norms_kernel<<<n_chunks, 256, 0, st>>>(tensors, (const int2*)chunks, norm_partials, norm_partials + n_chunks);
   opt_update_kernel<<<n_chunks, 256, 0, st>>>(tensors, (const int2*)chunks, norm_partials, norm_partials + n_chunks, beta1, beta2,
                                               adam_eps, lars_eta, lars_eps, lars_clip);

@@ -28,3 +28,17 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _library_hooks_back_to_default(request):
+    """The library's test / tuning hooks (kernel-route switches) are process-global: whatever a test does with them, and
+    however it ends, the next test starts from the defaults."""
+    yield
+    if "gpu" in request.keywords:
+        import torch
+
+        if torch.cuda.is_available():
+            from simhand_amd import ops
+
+            ops.hooks_reset()

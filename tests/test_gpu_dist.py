@@ -1,24 +1,58 @@
-"""GPU: the N > 1 path on real kernels.  World size 2 and 4 on ONE GPU (gloo transports the collectives because
-RCCL refuses two ranks per device): sharded HIP step + gradient all-reduce == oracle with per-shard BatchNorm
-statistics and the global NT-Xent."""
+"""GPU: the N > 1 path on real kernels.
+
+* gloo, R in {1, 2, 4, 8} ranks sharing ONE GPU (RCCL refuses two ranks per device, so gloo carries the collectives): the
+  sharded HIP step + gradient all-reduce == the reference's numbers for that R (tests/golden/sharded_rn18.*, B_glob = 32).
+* nccl (= RCCL), one rank per device: the same check over the real backend; needs >= 2 GPUs, skipped on a 1-GPU box.
+* bench.py --gpus N launches its own ranks (the driver runs plain `python bench.py --gpus 8` on an 8-GPU node)."""
+import json
 import os
 import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_step_matches_oracle(world):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29620 + world), WORLD_SIZE=str(world), OMP_NUM_THREADS="4",
+def _run(world, backend, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), OMP_NUM_THREADS="4",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     worker = os.path.join(ROOT, "tests", "_dist_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+    procs = [subprocess.Popen([sys.executable, worker, ROOT, backend], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
         assert f"rank {r} ok" in o
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_sharded_step_matches_reference_golden(world):
+    _run(world, "gloo", 29620 + world)
+
+
+def test_sharded_step_over_rccl():
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("RCCL needs one device per rank: this box has a single GPU (the gloo test covers the same arithmetic)")
+    _run(min(n, 8) if min(n, 8) in (2, 4, 8) else 2, "nccl", 29641)
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment spawns its own ranks and prints ONE JSON line
+    with n_gpus = 2 and the world size the backend reports.  On a 1-GPU box the ranks share the device over gloo
+    (SIMHAND_SHARE_GPU=1: same code path, no RCCL); with >= 2 GPUs it runs over RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.device_count() < 2:
+        env["SIMHAND_SHARE_GPU"] = "1"
+    env["MASTER_PORT"] = "29655"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--per-gpu-batch", "8",
+                          "--resnet", "18", "--image-size", "64", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 16 and res["config"]["world_size_backend"] == 2
+    assert res["value"] > 0 and res["scaling"] == "weak"

@@ -217,3 +217,60 @@ def test_sharded_loss_and_grad_allreduce_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
         assert f"rank {r} ok" in o
+
+
+def _torchvision_resnet_keys(layers, bottleneck):
+    """The state-dict key list of torchvision.models.resnet{18,34,50,101,152} (v0.13), written out from its published
+    module structure: conv1, bn1, layer1..4 (blocks with conv/bn pairs and an optional downsample = Sequential(conv, bn)), fc."""
+    bn = lambda p: [f"{p}.weight", f"{p}.bias", f"{p}.running_mean", f"{p}.running_var", f"{p}.num_batches_tracked"]  # noqa: E731
+    keys = ["conv1.weight"] + bn("bn1")
+    inplanes, exp = 64, 4 if bottleneck else 1
+    for li, (n, planes, stride) in enumerate(zip(layers, (64, 128, 256, 512), (1, 2, 2, 2)), start=1):
+        for b in range(n):
+            p = f"layer{li}.{b}"
+            for c in range(1, (3 if bottleneck else 2) + 1):
+                keys += [f"{p}.conv{c}.weight"] + bn(f"{p}.bn{c}")
+            if b == 0 and (stride != 1 or inplanes != planes * exp):
+                keys += [f"{p}.downsample.0.weight"] + bn(f"{p}.downsample.1")
+            inplanes = planes * exp
+    return keys + ["fc.weight", "fc.bias"]
+
+
+def test_checkpoint_lookup_and_torchvision_export(tmp_path, monkeypatch):
+    """src/models/utils.py:504-540 (get_latest_checkpoint / get_encoder_state_dict) and src/models/port_model.py:7-48
+    (positional copy onto torchvision's key order), on a Lightning-style checkpoint of the step model's state dict."""
+    import torch
+
+    from oracle import step as orc
+    from simhand_amd.host import export
+
+    for size, layers, bott in (("50", [3, 4, 6, 3], True), ("18", [2, 2, 2, 2], False), ("152", [3, 8, 36, 3], True)):
+        assert list(export.torchvision_resnet(size).state_dict().keys()) == _torchvision_resnet_keys(layers, bott), size
+    assert len(_torchvision_resnet_keys([3, 4, 6, 3], True)) == 320  # torchvision resnet50: 320 entries
+    torch.manual_seed(0)
+    om = orc.StepOracle("simhand_w", "50", [], weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg")
+    monkeypatch.setenv("SAVED_MODELS_BASE_PATH", str(tmp_path))
+    ckdir = tmp_path / "exp1" / "checkpoints"
+    ckdir.mkdir(parents=True)
+    for ep in (0, 3, 12):
+        sd = {k: v.clone() + ep for k, v in om.state_dict().items()}
+        torch.save({"state_dict": sd, "epoch": ep}, ckdir / f"epoch={ep}.ckpt")
+    assert export.get_latest_checkpoint("exp1") == str(ckdir / "epoch=12.ckpt")  # numeric, not lexicographic, order
+    assert export.get_latest_checkpoint("exp1", "epoch=3.ckpt") == str(ckdir / "epoch=3.ckpt")
+    enc = export.get_encoder_state_dict("exp1", "epoch=3.ckpt")
+    want = {k[8:]: v + 3 for k, v in om.state_dict().items() if "encoder" in k}
+    assert list(enc.keys()) == list(want.keys()) and all(k.startswith(("features.", "final_layer.")) for k in enc)
+    assert all(torch.equal(enc[k], want[k]) for k in enc)
+    out = tmp_path / "resnet50_simhand.pth"
+    tv = export.export_torchvision_state_dict(str(ckdir / "epoch=0.ckpt"), str(out), 50)
+    assert list(tv.keys()) == _torchvision_resnet_keys([3, 4, 6, 3], True)
+    src = [(k, v) for k, v in om.state_dict().items() if "features" in k]
+    for (dk, dv), (sk, sv) in zip(tv.items(), src):  # 318 encoder tensors by position; fc keeps its own init
+        assert torch.equal(dv, sv), (dk, sk)
+    assert torch.equal(torch.load(out)["layer1.0.downsample.0.weight"], om.state_dict()["encoder.features.4.0.downsample.0.weight"])
+    with pytest.raises(ValueError):  # a ResNet-50 checkpoint does not fit a ResNet-18
+        export.peclr_to_torchvision(export.torchvision_resnet(18), str(ckdir / "epoch=0.ckpt"))
+    hub = export.resnet50_simhand(pretrained=True, path=str(out))
+    assert torch.equal(hub.state_dict()["conv1.weight"], om.state_dict()["encoder.features.0.weight"])
+    with pytest.raises(ValueError):
+        export.resnet50_simhand(pretrained=True)
