@@ -51,7 +51,8 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "32"])
     ap.add_argument("--experiment", default="handclr_w", choices=["handclr_w", "peclr_w", "simclr"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=32, help="pairs in the CPU-baseline sample (SURVEY 8d: 32)")
+    ap.add_argument("--cpu-pairs", type=int, default=16,
+                    help="pairs in the default CPU-baseline sample (bounded to ~20-30 s; --cpu-full times the SURVEY 8d points 32 / 128)")
     ap.add_argument("--cpu-full", action="store_true",
                     help="also time the other SURVEY 8d CPU points (ResNet-18 B=32 = BASELINE configs[0], ResNet-50 B=128): minutes of CPU time")
     return ap.parse_args()
@@ -126,9 +127,9 @@ def host_cpu():
     return info
 
 
-def _cpu_point(exp, resnet, pairs, size, wcfg, budget_s):
+def _cpu_point(exp, resnet, pairs, size, wcfg, budget_s, warm=2):
     """One CPU reference point: the oracle step (fwd + bwd, then LARS/Adam timed separately) -- median of up to 5 timed
-    steps after 2 warm-ups; the timed steps stop early once `budget_s` of wall time is spent (never fewer than 1)."""
+    steps after `warm` warm-ups; the timed steps stop early once `budget_s` of wall time is spent (never fewer than 1)."""
     from oracle import step as orc
     from oracle.optim import LARSWrapperOracle
 
@@ -139,7 +140,7 @@ def _cpu_point(exp, resnet, pairs, size, wcfg, budget_s):
     batch = orc.synthetic_batch(pairs, size=size, seed=5)
     fb, op = [], []
     t_start = time.perf_counter()
-    for i in range(7):
+    for i in range(warm + 5):
         t0 = time.perf_counter()
         adam.zero_grad(set_to_none=True)
         loss = model.contrastive_step(batch)
@@ -147,16 +148,16 @@ def _cpu_point(exp, resnet, pairs, size, wcfg, budget_s):
         t1 = time.perf_counter()
         opt.step()
         t2 = time.perf_counter()
-        if i >= 2:
+        if i >= warm:
             fb.append(t1 - t0)
             op.append(t2 - t1)
-        if i >= 2 and time.perf_counter() - t_start > budget_s:
+        if i >= warm and time.perf_counter() - t_start > budget_s:
             break
     fb.sort()
     op.sort()
     tf, to = fb[len(fb) // 2], op[len(op) // 2]
     return {"pairs_per_s": pairs / tf, "pairs_per_s_incl_optimizer": pairs / (tf + to), "fwd_bwd_ms": tf * 1e3, "optimizer_ms": to * 1e3,
-            "pairs": pairs, "timed_steps": len(fb), "resnet": resnet, "image_size": size}
+            "pairs": pairs, "timed_steps": len(fb), "warmups": warm, "resnet": resnet, "image_size": size}
 
 
 def cpu_baseline(args):
@@ -167,17 +168,18 @@ def cpu_baseline(args):
     exp = {"handclr_w": "simhand_w", "peclr_w": "peclr_w", "simclr": "simclr"}[args.experiment]
     cpu = host_cpu()
     threads = torch.get_num_threads()
-    pt = _cpu_point(exp, args.resnet, args.cpu_pairs, args.image_size, wcfg, budget_s=25.0)
+    pt = _cpu_point(exp, args.resnet, args.cpu_pairs, args.image_size, wcfg, budget_s=20.0, warm=1)
     res = {"value": pt["pairs_per_s"], "unit": "pairs/s", "cores": threads, "kind": "port",
            "cpu_model": cpu["model"], "physical_cores": cpu["physical_cores"], "hardware_threads": cpu["threads"],
            "optimizer_ms": pt["optimizer_ms"], "fwd_bwd_ms": pt["fwd_bwd_ms"],
            "sample": f"oracle.StepOracle ResNet-{args.resnet} {args.experiment} fp32, {pt['pairs']} pairs of {args.image_size}x{args.image_size}, "
-                     f"fwd+bwd (optimizer timed separately: {pt['optimizer_ms']:.0f} ms), median of {pt['timed_steps']} steps after 2 warm-ups "
+                     f"fwd+bwd (optimizer timed separately: {pt['optimizer_ms']:.0f} ms), median of {pt['timed_steps']} steps after {pt['warmups']} warm-up "
                      f"({pt['fwd_bwd_ms']:.0f} ms/step), {threads} torch threads on {cpu['model']} ({cpu['physical_cores']} physical cores)"}
     if args.cpu_full:
         res["points"] = {
             "configs[0] ResNet-18 B=32": _cpu_point(exp, "18", 32, args.image_size, wcfg, budget_s=60.0),
-            f"ResNet-{args.resnet} B=128": _cpu_point(exp, args.resnet, 128, args.image_size, wcfg, budget_s=240.0),
+            f"ResNet-{args.resnet} B=32": _cpu_point(exp, args.resnet, 32, args.image_size, wcfg, budget_s=120.0),
+            f"ResNet-{args.resnet} B=128": _cpu_point(exp, args.resnet, 128, args.image_size, wcfg, budget_s=400.0),
         }
     return res
 
