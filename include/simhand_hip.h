@@ -75,6 +75,7 @@ enum sh_route {
   SH_ROUTE_NTXENT_FWD = 25, SH_ROUTE_NTXENT_BWD = 26,
   SH_ROUTE_FP8_FWD = 27, SH_ROUTE_FP8_DGRAD = 28,           /* e4m3 MFMA (K = 128 per instruction) tile kernel */
   SH_ROUTE_BN_APPLY_GRAM = 29,                              /* BN-apply + ReLU fused into the Gram (x^T x) launch */
+  SH_ROUTE_WGRAD_BNBWD = 30,                                /* BN-backward apply fused into the 1x1 weight gradient's dy loader */
   SH_ROUTE_COUNT = 32
 };
 int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
@@ -289,6 +290,27 @@ int simhand_conv2d_wgrad(const sh_conv_desc* d, const void* x, const void* dy, f
 int simhand_conv2d_wgrad_splits(const sh_conv_desc* d);
 int simhand_conv2d_wgrad_colsum(const sh_conv_desc* d, const void* x, const void* dy, float* dw, float* dy_colsum, void* workspace,
                                 size_t workspace_bytes, sh_stream_t stream);
+/* BatchNorm passes fused into the operand loaders of the bf16 1x1 / stride-1 weight-gradient kernel (its tiles are staged
+ * global -> registers -> LDS, so a per-channel transform between load and store costs VALU only):
+ *  simhand_bn_apply_gram: y = raw conv output [m][c] of a conv + BN (+ReLU) unit whose activation feeds a FOLDED 1x1
+ *    convolution (simhand_conv2d_fwd_bnact).  One launch writes a = act(y*scale + shift), s2 = a^T a [c][c] fp32 and
+ *    colsum_partial [simhand_conv2d_wgrad_splits(d)][2][c] (row 0 = sum a) -- the stand-alone simhand_bn_apply pass over y
+ *    and the separate Gram launch's read of a are gone.  d = the c -> c 1x1 descriptor over the m pixels.
+ *  simhand_conv2d_wgrad_bnbwd: weight gradient of a conv whose output y feeds a BN (+ReLU): the dy operand is computed on
+ *    the fly as dy = coef_a * (da * [y*scale + shift > 0]) - coef_b * y + coef_c  (BatchNorm backward with its sums already
+ *    reduced: coef_a = gamma invstd, coef_b = coef_a invstd dgamma / M, coef_c = -coef_a dbeta / M + mean coef_b; see
+ *    simhand_bn_bwd_coefs) and written to dy_out for the data gradient that follows -- the stand-alone
+ *    simhand_bn_bwd_apply pass is gone.  dw_oihw as simhand_conv2d_wgrad_oihw (c_real = 0: KRSC fp32).
+ * Replaces (reference): native_batch_norm / native_batch_norm_backward around conv2 / conv1 of torchvision's Bottleneck
+ * (src/models/resnet_model.py:13-58). */
+int simhand_bn_apply_gram(const sh_conv_desc* d, const void* y, const float* scale, const float* shift, int relu, void* a, float* s2,
+                          float* colsum_partial, void* workspace, size_t workspace_bytes, sh_stream_t stream);
+int simhand_conv2d_wgrad_bnbwd(const sh_conv_desc* d, const void* x, const void* da, const void* y, const float* scale, const float* shift,
+                               const float* coef_a, const float* coef_b, const float* coef_c, int relu, void* dy_out, float* dw_oihw,
+                               int c_real, void* workspace, size_t workspace_bytes, sh_stream_t stream);
+/* coefficient vectors of the line above from the finished BatchNorm-backward sums */
+int simhand_bn_bwd_coefs(const float* mean, const float* invstd, const float* gamma, const float* dgamma, const float* dbeta, int64_t m,
+                         int c, float* coef_a, float* coef_b, float* coef_c, sh_stream_t stream);
 /* Same, but the split-K reduction writes the gradient directly in the reference's nn.Conv2d.weight.grad layout
  * OIHW fp32 [cout][c_real][r][s]; c_real <= cin drops zero-padded input channels (the im2col'd stem: cin = 192
  * columns, c_real = 147 = 3*7*7 -> exactly weight.grad.view(64, 147)). */

@@ -1,0 +1,125 @@
+"""Per-layer table for the 23 distinct convolution shapes of ResNet-50 @224^2 at the benchmarked
+batch (2048 images): forward / data gradient / weight gradient through the library's own dispatch -- kernel route,
+microseconds, TFLOP/s, algorithmic GB/s, the bound that applies (HBM below the 397 FLOP/B ridge of 2.5 PF / 6.3 TB/s,
+MFMA above) and the fraction of that bound.  Runs ON THE GPU BOX:
+
+    python scripts/layer_table.py [--images 2048] [--out profiles/r02_layer_table.md]
+
+Timing: HIP events on torch's current stream (the stream the kernels are launched on), median of 5 after 2 warm-ups.
+The forward of the layers whose BatchNorm is folded (1x1, cout >= 2 cin) is timed in the form the engine runs
+(simhand_conv2d_fwd_bnact: BN + residual + ReLU epilogue); the data gradient is the plain store form (the engine's
+variants add epilogue reads that are listed in DESIGN 3)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from simhand_amd import ops  # noqa: E402
+
+SHAPES = [  # (cin, cout, k, stride, hin, count)
+    (64, 64, 1, 1, 56, 1), (64, 64, 3, 1, 56, 3), (64, 256, 1, 1, 56, 4), (256, 64, 1, 1, 56, 2), (256, 128, 1, 1, 56, 1),
+    (128, 128, 3, 2, 56, 1), (128, 512, 1, 1, 28, 4), (256, 512, 1, 2, 56, 1), (512, 128, 1, 1, 28, 3), (128, 128, 3, 1, 28, 3),
+    (512, 256, 1, 1, 28, 1), (256, 256, 3, 2, 28, 1), (256, 1024, 1, 1, 14, 6), (512, 1024, 1, 2, 28, 1), (1024, 256, 1, 1, 14, 5),
+    (256, 256, 3, 1, 14, 5), (1024, 512, 1, 1, 14, 1), (512, 512, 3, 2, 14, 1), (512, 2048, 1, 1, 7, 3), (1024, 2048, 1, 2, 14, 1),
+    (2048, 512, 1, 1, 7, 2), (512, 512, 3, 1, 7, 2),
+]
+PEAK_TF, PEAK_GB = 2500.0, 6300.0  # dense bf16 MFMA; achievable HBM copy rate (MI355X_MICROARCH.md)
+
+
+def timed(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def route_of(fn):
+    ops.route_reset()
+    fn()
+    torch.cuda.synchronize()
+    skip = ("fwd_bnact", "dgrad_fused_sums", "dgrad_parity", "dgrad_concat", "wgrad_colsum")
+    return "+".join(k for k, v in ops.route_counts().items() if v and k not in skip)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=2048)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--alternates", action="store_true", help="also time every op under the other kernel routes (tuning hooks)")
+    args = ap.parse_args()
+    from simhand_amd import _lib
+    lib = _lib.load()
+    alts = {"default": lambda: None, "no256": lambda: lib.simhand_igemm256_enable(0), "force256": lambda: lib.simhand_igemm256_enable(2),
+            "no_c64": lambda: lib.simhand_conv3x3_c64_enable(0), "no_wgrad3": lambda: lib.simhand_wgrad3x3_enable(0),
+            "notail": lambda: lib.simhand_igemm256_split_tail(0)}
+    n, dt, dev = args.images, torch.bfloat16, "cuda"
+    rows = ["| layer (cin,cout,k,s,Hin) x count | op | kernel route | us | TFLOP/s | GB/s (algorithmic) | bound | fraction of bound |",
+            "|---|---|---|---|---|---|---|---|"]
+    tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    for cin, cout, k, s, h, cnt in SHAPES:
+        pad = 1 if k == 3 else 0
+        d = ops.conv_desc(n, h, h, cin, cout, k, k, s, pad, dt)
+        x = torch.randn(n, h, h, cin, device=dev).to(dt)
+        w = torch.randn(cout, cin, k, k, device=dev) * (2.0 / (cin * k * k)) ** 0.5
+        wk, wc = ops.pack_krsc(w, dt), ops.pack_crsk(w, dt)
+        dy = torch.randn(n, d.ho, d.wo, cout, device=dev).to(dt)
+        m = n * d.ho * d.wo
+        flops = 2.0 * m * cout * cin * k * k
+        folded = k == 1 and cout >= 2 * cin
+        if folded:
+            st = ops.BNState(cout, dev)
+            st.scale.fill_(1.0)
+            st.shift.fill_(0.0)
+            res = torch.randn(n, d.ho, d.wo, cout, device=dev).to(dt) if s == 1 and cout == 4 * cin else None
+            f_fwd = lambda: ops.conv2d_fwd_bnact(d, x, wk, st, res is not None, res, want_mask=res is not None)  # noqa: E731
+            b_fwd = 2.0 * (x.numel() + m * cout * (2 if res is not None else 1) + wk.numel()) + (m * cout / 8 if res is not None else 0)
+        else:
+            f_fwd = lambda: ops.conv2d_fwd(d, x, wk, want_stats=True)  # noqa: E731
+            b_fwd = 2.0 * (x.numel() + m * cout + wk.numel())
+        f_dg = lambda: ops.conv2d_dgrad(d, dy, wc)  # noqa: E731
+        b_dg = 2.0 * (x.numel() + m * cout + wk.numel())
+        f_wg = lambda: ops.conv2d_wgrad_oihw(d, x, dy, (cout, cin, k, k))  # noqa: E731
+        b_wg = 2.0 * (x.numel() + m * cout) + 4.0 * wk.numel()
+        for op, fn, by in (("fwd" + (" +bnact" if folded else ""), f_fwd, b_fwd), ("dgrad", f_dg, b_dg), ("wgrad", f_wg, b_wg)):
+            us = timed(fn)
+            rt = route_of(fn)
+            tf, gb = flops / us / 1e6, by / us / 1e3
+            ai = flops / by
+            bound = "MFMA" if ai >= PEAK_TF * 1e3 / PEAK_GB else "HBM"
+            frac = tf / PEAK_TF if bound == "MFMA" else gb / PEAK_GB
+            rows.append(f"| ({cin},{cout},{k},{s},{h}) x{cnt} | {op} | {rt} | {us:.0f} | {tf:.0f} | {gb:.0f} | {bound} ({ai:.0f} FLOP/B) | {frac:.2f} |")
+            tot[op.split()[0]] += us * cnt
+            if args.alternates:
+                for an, setter in alts.items():
+                    if an == "default":
+                        continue
+                    ops.hooks_reset()
+                    setter()
+                    rt2 = route_of(fn)
+                    if rt2 != rt:
+                        us2 = timed(fn)
+                        rows.append(f"|   alt {an} | {op} | {rt2} | {us2:.0f} | {flops / us2 / 1e6:.0f} | {by / us2 / 1e3:.0f} | | {us2 / us:.2f}x time |")
+                ops.hooks_reset()
+        del x, dy
+        torch.cuda.empty_cache()
+    rows.append("")
+    rows.append(f"sum over the 52 non-stem convolutions of ResNet-50 (count-weighted): fwd {tot['fwd']/1e3:.1f} ms, dgrad {tot['dgrad']/1e3:.1f} ms, "
+                f"wgrad {tot['wgrad']/1e3:.1f} ms at {n} images")
+    text = "\n".join(rows)
+    print(text)
+    if args.out:
+        open(args.out, "w").write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()

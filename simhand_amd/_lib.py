@@ -31,7 +31,7 @@ PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn", "pool", "loss", "m
 ROUTES = ("igemm128_fwd", "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "igemm256_tail", "gemm1x1_fwd", "gemm1x1_fwd_bnact",
           "gemm1x1_dgrad", "c64_fwd", "c64_dgrad", "stem_fwd", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
           "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
-          "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram")
+          "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram", "wgrad_bnbwd")
 ROUTE_COUNT = 32
 
 
@@ -111,6 +111,9 @@ SIGNATURES = {
     "simhand_conv2d_wgrad_splits": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_wgrad_colsum": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _S, _P]),
     "simhand_conv2d_wgrad_oihw": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _S, _P]),
+    "simhand_bn_apply_gram": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _P, _P, _P, _S, _P]),
+    "simhand_conv2d_wgrad_bnbwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _S, _P]),
+    "simhand_bn_bwd_coefs": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
     "simhand_wgrad_set_tr": (_I, [_I]),
     "simhand_wgrad_plain_kpm": (_I, [_I]),
     "simhand_wgrad_target_blocks": (_I, [_I, _I]),

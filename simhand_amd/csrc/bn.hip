@@ -968,11 +968,32 @@ static hook_t g_bn_nt{1};  // non-temporal loads / stores in the streaming kerne
 
 void hooks_reset_bn() { g_bn_nt = 1; }
 
+__global__ void bn_bwd_coefs_kernel(const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta, float inv_m, int c,
+                                    float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  // dy = gamma invstd (g - mean(g) - xhat mean(g xhat)),  xhat = (y - mean) invstd   ->   A g - B y + C
+  const float a = gamma[i] * invstd[i];
+  const float b = a * invstd[i] * dgamma[i] * inv_m;
+  ca[i] = a;
+  cb[i] = b;
+  cc[i] = -a * dbeta[i] * inv_m + mean[i] * b;
+}
+
 }  // namespace sh
 
 using namespace sh;
 
 extern "C" {
+
+int simhand_bn_bwd_coefs(const float* mean, const float* invstd, const float* gamma, const float* dgamma, const float* dbeta, int64_t m, int c,
+                         float* coef_a, float* coef_b, float* coef_c, sh_stream_t stream) {
+  SH_REQUIRE(mean && invstd && gamma && dgamma && dbeta && coef_a && coef_b && coef_c && m >= 1 && c >= 1, "bn_bwd_coefs: bad arguments");
+  bn_bwd_coefs_kernel<<<ceil_div(c, 256), 256, 0, (hipStream_t)stream>>>(mean, invstd, gamma, dgamma, dbeta, (float)(1.0 / (double)m), c,
+                                                                         coef_a, coef_b, coef_c);
+  return check_launch("bn_bwd_coefs");
+}
 
 int simhand_bn_set_nt(int on) {
   g_bn_nt = on ? 1 : 0;

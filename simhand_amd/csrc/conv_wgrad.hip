@@ -39,6 +39,21 @@ struct WgradArgs {
                         // (emitted by the cin-tile-0 blocks from the tiles they stage anyway), row 1 = 0; null = off
   int stem_hp, stem_wp; // > 0: x is the zero-padded NHWC4 stem input [N][hp][wp][4]; Cin = 256 virtual channels
                         // = 8 filter rows x (8 taps x 4 channels), row r of output pixel (ho, wo) at (2ho + r, 2wo)
+  // PLAIN kernel, XFORM != 0: the operand chunks are TRANSFORMED in registers between the global load and the LDS store,
+  // and the transformed dy operand is also written out (by the cin-tile-0 blocks: every element exactly once).
+  //   XFORM 1 (Gram launch, x == dy == raw conv output y of a conv + BN + ReLU unit): v = max(y * xs + xh, 0) on BOTH operands
+  //           -> dw = a^T a, dy_colsum = sum a, xout = a.  The stand-alone BatchNorm-apply pass over y disappears.
+  //   XFORM 2 (weight gradient of the conv whose OUTPUT feeds the BN): dy operand = BatchNorm backward of (da, y):
+  //           v = xa * (da * [y * xs + xh > 0]) - xb * y + xc  -> dw = dy^T x, xout = dy.  The stand-alone
+  //           BatchNorm-backward-apply pass disappears (dy2 = the raw conv output y laid out like dy).
+  const float* xs = nullptr;   // [Cout] scale  (gamma * invstd)
+  const float* xh = nullptr;   // [Cout] shift  (beta - mean * scale)
+  const float* xa = nullptr;   // XFORM 2: [Cout] A = gamma * invstd
+  const float* xb = nullptr;   // XFORM 2: [Cout] B = A * invstd * dgamma / M
+  const float* xc = nullptr;   // XFORM 2: [Cout] C = -A * dbeta / M + mean * B
+  const void* dy2 = nullptr;   // XFORM 2: y
+  void* xout = nullptr;        // transformed dy operand [Mo][Cout]
+  int xrelu = 1;               // XFORM 1 / 2: the unit has a ReLU
 };
 
 __device__ __forceinline__ int xcd_remap_w(int bid, int nblk) {
@@ -95,8 +110,9 @@ __device__ __forceinline__ uint4 frag_bf16_scalar(const char* tile, int stride, 
 // per 16 MFMAs on addressing and is VALU-issue-bound.
 // KPM: k-step = KPM x the base 32 (bf16) / 16 (fp32) pixels.  PLAIN uses 2: one barrier (~250 cycles) per 32 MFMAs of a
 // wave instead of per 16.
-template <typename T, int BM, int BN, bool STEM = false, bool PLAIN = false, int KPM = 1>
+template <typename T, int BM, int BN, bool STEM = false, bool PLAIN = false, int KPM = 1, int XFORM = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
+  static_assert(XFORM == 0 || (PLAIN && sizeof(T) == 2), "operand transforms exist for the bf16 1x1 pointer-walking kernel only");
   constexpr int KP = WgCfg<T>::KP * KPM;
   constexpr int SA = BM * (int)sizeof(T) + WgCfg<T>::PAD;  // dy tile row stride (bytes)
   constexpr int SB = BN * (int)sizeof(T) + WgCfg<T>::PAD;  // x tile row stride
@@ -168,6 +184,52 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   // PLAIN + dy_colsum: every chunk of this thread is the same 8 channels k0 + (tid % CPR_A) * 8 .. (CPR_A divides 256)
   const bool want_colsum = PLAIN && sizeof(T) == 2 && p.dy_colsum != nullptr && nt_i == 0;
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // XFORM: this thread's chunks always cover the same 8 channels (CPR_A / CPR_B divide 256): coefficients in registers
+  float ca_s[8], ca_h[8], ca_a[8], ca_b[8], ca_c[8], cb_s[8], cb_h[8];
+  const char* pdy2[NA];
+  char* pout[NA];
+  const bool x_writes = XFORM != 0 && nt_i == 0 && p.xout != nullptr;
+  const bool x_diag = XFORM == 1 && BM == BN && mt_i == nt_i;  // Gram diagonal tile: both operands are the same columns
+  if constexpr (XFORM != 0) {
+    const int cha = k0 + (tid % CPR_A) * VE;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ca_s[e] = p.xs[cha + e];
+      ca_h[e] = p.xh[cha + e];
+      ca_a[e] = XFORM == 2 ? p.xa[cha + e] : 0.f;
+      ca_b[e] = XFORM == 2 ? p.xb[cha + e] : 0.f;
+      ca_c[e] = XFORM == 2 ? p.xc[cha + e] : 0.f;
+    }
+    if constexpr (XFORM == 1) {
+      const int chb = c0 + (tid % CPR_B) * VE;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        cb_s[e] = p.xs[chb + e];
+        cb_h[e] = p.xh[chb + e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const long long off = (pix_begin + rowa[i]) * (long long)p.Cout + k0 + (tid + 256 * i - rowa[i] * CPR_A) * VE;
+      pdy2[i] = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.dy2) + off);
+      pout[i] = reinterpret_cast<char*>(reinterpret_cast<T*>(p.xout) + off);
+    }
+  }
+  auto bn_relu8 = [&](uint4 v, const float (&sc)[8], const float (&sh)[8]) __attribute__((always_inline)) -> uint4 {
+    const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+    unsigned o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float lo = __uint_as_float(w4[q] << 16) * sc[2 * q] + sh[2 * q];
+      float hi = __uint_as_float(w4[q] & 0xffff0000u) * sc[2 * q + 1] + sh[2 * q + 1];
+      if (p.xrelu) {
+        lo = fmaxf(lo, 0.f);
+        hi = fmaxf(hi, 0.f);
+      }
+      o[q] = pack_bf16x2(lo, hi);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+  };
   const unsigned step_dy = (unsigned)KP * (unsigned)p.Cout * (unsigned)sizeof(T);
   const unsigned step_x = (unsigned)KP * (unsigned)p.Cin * (unsigned)sizeof(T);
   const int rows_total = (int)(pix_end - pix_begin);  // <= pix_per_split
@@ -178,8 +240,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
       const int left = rows_total - ks * KP;  // rows of this k-step inside the block's pixel range
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        ra[i] = rowa[i] < left ? *reinterpret_cast<const uint4*>(pdy[i]) : make_uint4(0, 0, 0, 0);
+        const bool live = rowa[i] < left;
+        ra[i] = live ? *reinterpret_cast<const uint4*>(pdy[i]) : make_uint4(0, 0, 0, 0);
         pdy[i] += step_dy;
+        if constexpr (XFORM == 1) {
+          ra[i] = live ? bn_relu8(ra[i], ca_s, ca_h) : make_uint4(0, 0, 0, 0);  // rows past the range must stay zero
+        } else if constexpr (XFORM == 2) {
+          const uint4 yv = live ? *reinterpret_cast<const uint4*>(pdy2[i]) : make_uint4(0, 0, 0, 0);
+          pdy2[i] += step_dy;
+          const unsigned g4[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w}, y4[4] = {yv.x, yv.y, yv.z, yv.w};
+          unsigned o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float r2[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const int e = 2 * q + hh;
+              const float g = hh == 0 ? __uint_as_float(g4[q] << 16) : __uint_as_float(g4[q] & 0xffff0000u);
+              const float y = hh == 0 ? __uint_as_float(y4[q] << 16) : __uint_as_float(y4[q] & 0xffff0000u);
+              const bool on = !p.xrelu || (y * ca_s[e] + ca_h[e] > 0.f);
+              r2[hh] = ca_a[e] * (on ? g : 0.f) - ca_b[e] * y + ca_c[e];
+            }
+            o[q] = pack_bf16x2(r2[0], r2[1]);
+          }
+          ra[i] = live ? make_uint4(o[0], o[1], o[2], o[3]) : make_uint4(0, 0, 0, 0);
+        }
+        if constexpr (XFORM != 0) {
+          if (x_writes && live) *reinterpret_cast<uint4*>(pout[i]) = ra[i];
+          pout[i] += step_dy;
+        }
       }
       if (want_colsum) {  // block-uniform
 #pragma unroll
@@ -194,7 +283,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
       }
 #pragma unroll
       for (int i = 0; i < NBL; ++i) {
+        if constexpr (XFORM == 1 && BM == BN) {
+          if (x_diag) {  // block-uniform: the Gram tile on the diagonal reuses the transformed dy chunks
+            rb[i] = ra[i];
+            px[i] += step_x;
+            continue;
+          }
+        }
         rb[i] = rowb[i] < left ? *reinterpret_cast<const uint4*>(px[i]) : make_uint4(0, 0, 0, 0);
+        if constexpr (XFORM == 1) rb[i] = rowb[i] < left ? bn_relu8(rb[i], cb_s, cb_h) : make_uint4(0, 0, 0, 0);
         if constexpr (STEM) {
           px[i] += 2 * KP * 4 * (int)sizeof(T);
           swo[i] += KP;
@@ -685,8 +782,17 @@ size_t simhand_conv2d_wgrad_workspace_bytes(const sh_conv_desc* d) {
   return (size_t)sk * d->cout * d->cin * d->r * d->s * sizeof(float);
 }
 
+struct WgXform {  // operand transform of the 1x1 pointer-walking kernel (see WgradArgs)
+  int mode;        // 1 = BN-apply (+ReLU) Gram, 2 = BN-backward apply on the dy operand
+  const float *scale, *shift, *ca, *cb, *cc;
+  const void* y;   // mode 2
+  void* out;
+  int relu;
+};
+
 static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, float* dw, int c_real, void* workspace,
-                      size_t workspace_bytes, sh_stream_t stream, int stem_hp = 0, int stem_wp = 0, float* dy_colsum = nullptr) {
+                      size_t workspace_bytes, sh_stream_t stream, int stem_hp = 0, int stem_wp = 0, float* dy_colsum = nullptr,
+                      const WgXform* xf = nullptr) {
   SH_REQUIRE(d != nullptr, "conv2d_wgrad: desc is NULL");
   SH_REQUIRE(x && dy && dw && workspace, "conv2d_wgrad: NULL pointer");
   SH_REQUIRE(d->dtype == SH_F32 || d->dtype == SH_BF16, "conv2d_wgrad: bad dtype %d", d->dtype);
@@ -735,6 +841,10 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
   a.dy_colsum = dy_colsum;
   const bool plain = d->dtype == SH_BF16 && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && a.use_tr && stem_wp == 0;
   SH_REQUIRE(dy_colsum == nullptr || plain, "conv2d_wgrad_colsum: only for bf16 1x1 / stride-1 convolutions");
+  SH_REQUIRE(xf == nullptr || (plain && g_plain_kpm == 2), "fused BatchNorm operand transforms: only for bf16 1x1 / stride-1 convolutions");
+  if (xf != nullptr) {
+    a.xs = xf->scale; a.xh = xf->shift; a.xa = xf->ca; a.xb = xf->cb; a.xc = xf->cc; a.dy2 = xf->y; a.xout = xf->out; a.xrelu = xf->relu;
+  }
   hipStream_t s = (hipStream_t)stream;
   const int nblk = a.splitk * d->r * d->s * a.mt * a.nt;
   const double es = d->dtype == SH_F32 ? 4 : 2;
@@ -765,10 +875,24 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
     if (g_plain_kpm == 2) wgrad_kernel<bf16_t, BM, BN, false, true, 2><<<nblk, 256, 0, s>>>(a); \
     else wgrad_kernel<bf16_t, BM, BN, false, true><<<nblk, 256, 0, s>>>(a);                  \
   } while (0)
-    if (bm == 128 && bn == 128) SH_WGP(128, 128);
+#define SH_WGX(BM, BN, XF) wgrad_kernel<bf16_t, BM, BN, false, true, 2, XF><<<nblk, 256, 0, s>>>(a)
+    if (xf != nullptr && xf->mode == 1) {
+      route_hit(SH_ROUTE_BN_APPLY_GRAM);
+      if (bm == 128 && bn == 128) SH_WGX(128, 128, 1);
+      else if (bm == 128) SH_WGX(128, 64, 1);
+      else if (bn == 128) SH_WGX(64, 128, 1);
+      else SH_WGX(64, 64, 1);
+    } else if (xf != nullptr) {
+      route_hit(SH_ROUTE_WGRAD_BNBWD);
+      if (bm == 128 && bn == 128) SH_WGX(128, 128, 2);
+      else if (bm == 128) SH_WGX(128, 64, 2);
+      else if (bn == 128) SH_WGX(64, 128, 2);
+      else SH_WGX(64, 64, 2);
+    } else if (bm == 128 && bn == 128) SH_WGP(128, 128);
     else if (bm == 128) SH_WGP(128, 64);
     else if (bn == 128) SH_WGP(64, 128);
     else SH_WGP(64, 64);
+#undef SH_WGX
 #undef SH_WGP
   } else {
     if (bm == 128 && bn == 128) SH_WG(bf16_t, 128, 128);
@@ -800,6 +924,24 @@ int simhand_conv2d_wgrad_colsum(const sh_conv_desc* d, const void* x, const void
                                 size_t workspace_bytes, sh_stream_t stream) {
   SH_REQUIRE(dy_colsum != nullptr, "conv2d_wgrad_colsum: NULL dy_colsum");
   return wgrad_impl(d, x, dy, dw, 0, workspace, workspace_bytes, stream, 0, 0, dy_colsum);
+}
+
+int simhand_bn_apply_gram(const sh_conv_desc* d, const void* y, const float* scale, const float* shift, int relu, void* a, float* s2,
+                          float* colsum_partial, void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+  SH_REQUIRE(d != nullptr && d->cin == d->cout, "bn_apply_gram: the descriptor must be the c -> c 1x1 Gram descriptor");
+  SH_REQUIRE(y && scale && shift && a && s2 && colsum_partial, "bn_apply_gram: NULL pointer");
+  WgXform xf = {1, scale, shift, nullptr, nullptr, nullptr, nullptr, a, relu};
+  return wgrad_impl(d, y, y, s2, 0, workspace, workspace_bytes, stream, 0, 0, colsum_partial, &xf);
+}
+
+int simhand_conv2d_wgrad_bnbwd(const sh_conv_desc* d, const void* x, const void* da, const void* y, const float* scale, const float* shift,
+                               const float* coef_a, const float* coef_b, const float* coef_c, int relu, void* dy_out, float* dw_oihw,
+                               int c_real, void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+  SH_REQUIRE(d != nullptr, "conv2d_wgrad_bnbwd: desc is NULL");
+  SH_REQUIRE(x && da && y && scale && shift && coef_a && coef_b && coef_c && dy_out && dw_oihw, "conv2d_wgrad_bnbwd: NULL pointer");
+  SH_REQUIRE(c_real >= 0 && c_real <= d->cin, "conv2d_wgrad_bnbwd: c_real=%d outside [0, cin=%d]", c_real, d->cin);
+  WgXform xf = {2, scale, shift, coef_a, coef_b, coef_c, y, dy_out, relu};
+  return wgrad_impl(d, x, da, dw_oihw, c_real, workspace, workspace_bytes, stream, 0, 0, nullptr, &xf);
 }
 
 int simhand_conv2d_wgrad_oihw(const sh_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int c_real, void* workspace,

@@ -139,6 +139,11 @@ class ResNetEngine:
         self.concat_fold = True
         # the folds need every block's incoming gradient in masked form, which only the all-1x1 tails of Bottleneck nets give
         self._bottleneck = all(isinstance(b, Bottleneck) for li in (4, 5, 6, 7) for b in features[li])
+        # BN-apply (+ReLU) of the unit in front of a folded conv runs inside the Gram launch the fold needs anyway
+        self.fuse_apply_gram = True
+        # BN-backward apply of a 1x1 / stride-1 unit without residual runs inside that unit's weight-gradient launch
+        self.fuse_bwd_apply_wgrad = True
+        self._gram = None  # (activation tensor, a^T a, sum a) of the unit just applied that way
 
     # -- weights -------------------------------------------------------------
     def _pack(self, conv: nn.Conv2d, need_t: bool, stem: bool = False) -> _Packed:
@@ -186,8 +191,12 @@ class ResNetEngine:
         m = n * d.ho * d.wo
         s2 = t2 = ws2 = None
         if training:
-            dww = ops.conv_desc(n, d.ho, d.wo, cin, cin, 1, 1, 1, 0, self.dtype)
-            s2, t2 = ops.conv2d_wgrad_colsum(dww, x_in, x_in)                # x^T x (fp32) and sum x ride on one kernel
+            if self._gram is not None and self._gram[0] is x_in:            # came out of the producer's fused BN-apply + Gram launch
+                s2, t2 = self._gram[1], self._gram[2]
+            else:
+                dww = ops.conv_desc(n, d.ho, d.wo, cin, cin, 1, 1, 1, 0, self.dtype)
+                s2, t2 = ops.conv2d_wgrad_colsum(dww, x_in, x_in)            # x^T x (fp32) and sum x ride on one kernel
+            self._gram = None
             # sum y = W . sum x, sum y^2 = rowdot(W S2, W) with the weights the MFMAs see -> statistics, running stats, W S2
             st, ws2 = ops.bn_fold_fwd(conv.weight.detach().view(cout, cin), True, s2, t2, m, bn.weight.detach(), bn.bias.detach(),
                                       bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum)
@@ -205,7 +214,9 @@ class ResNetEngine:
             save.append(u)
         return a
 
-    def _conv_bn(self, conv, bn, x, relu, residual, training, save: Optional[list], need_dgrad=True):
+    def _conv_bn(self, conv, bn, x, relu, residual, training, save: Optional[list], need_dgrad=True, gram_next=False):
+        """gram_next: the activation feeds a folded 1x1 convolution (which needs a^T a and sum a): BatchNorm-apply + ReLU then
+        run inside that Gram launch (ops.bn_apply_gram) instead of as a pass of their own."""
         if self._fold_fwd_ok(conv, relu, residual):
             return self._conv_bn_folded(conv, bn, x, relu, residual, training, save)
         n, h, w, cin = x.shape
@@ -218,6 +229,9 @@ class ResNetEngine:
         mask = None
         if save is not None and residual is not None and relu:
             a, mask = ops.bn_apply(y, st, m, conv.out_channels, relu, residual, want_mask=True)
+        elif gram_next and training and residual is None and self.fuse_apply_gram and self.dtype == torch.bfloat16:
+            a, s2, t2 = ops.bn_apply_gram(y, st, relu)
+            self._gram = (a, s2, t2)
         else:
             a = ops.bn_apply(y, st, m, conv.out_channels, relu, residual)
         if save is not None:
@@ -267,8 +281,11 @@ class ResNetEngine:
                 inp = x
                 units = blk.units()
                 t = inp
-                for conv, bn in units[:-1]:
-                    t = self._conv_bn(conv, bn, t, True, None, training, saved)
+                last_conv = units[-1][0]
+                for ui, (conv, bn) in enumerate(units[:-1]):
+                    # the unit in front of a folded stride-1 conv3: its BN-apply rides on the Gram launch
+                    gram_next = (ui == len(units) - 2 and last_conv.stride == (1, 1) and self._fold_fwd_ok(last_conv, True, inp))
+                    t = self._conv_bn(conv, bn, t, True, None, training, saved, gram_next=gram_next)
                 idn = inp
                 dsaved: Optional[list] = [] if want_ctx else None
                 if blk.downsample is not None:
@@ -405,12 +422,18 @@ class ResNetEngine:
         c = d.cout
         if u.y is None:
             raise RuntimeError("this unit ran the folded forward (its raw conv output was never stored): its backward must be folded too")
+        w = u.conv.weight
+        fuse_apply = (self.fuse_bwd_apply_wgrad and self.dtype == torch.bfloat16 and not u.stem and relu_mask is None and not u.has_res
+                      and u.conv.kernel_size == (1, 1) and u.conv.stride == (1, 1) and u.conv.padding == (0, 0))
         dy, _, dg, db = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, False,
-                                        mask_from_y=u.relu and not u.has_res, relu_mask=relu_mask, raw_partial=raw_partial)
+                                        mask_from_y=u.relu and not u.has_res, relu_mask=relu_mask, raw_partial=raw_partial,
+                                        apply=not fuse_apply)
         grads[u.bn.weight] = dg
         grads[u.bn.bias] = db
-        w = u.conv.weight
-        if u.stem:
+        if fuse_apply:
+            coefs = ops.bn_bwd_coefs(u.st, u.bn.weight.detach(), dg, db, m)
+            grads[w], dy = ops.conv2d_wgrad_bnbwd(d, u.x, da, u.y, u.st, coefs, u.relu, tuple(w.shape))
+        elif u.stem:
             grads[w] = ops.stem_conv_wgrad(u.x, dy, d.h, d.w)
         else:
             grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))  # split-K reduce writes weight.grad's layout

@@ -288,6 +288,46 @@ def conv2d_wgrad_colsum(d: ConvDesc, x, dy):
     return dw, bn_channel_sums(part, d.cout)
 
 
+def bn_apply_gram(y: torch.Tensor, st: "BNState", relu: bool = True):
+    """a = act(y*scale + shift), s2 = a^T a (fp32 [c][c]) and sum a ([c]) in ONE launch of the 1x1 weight-gradient kernel
+    (bf16; the BatchNorm-apply runs in its operand loader).  y: [n][h][w][c] raw conv output."""
+    lib = _lib_dev()
+    n, h, w, c = y.shape
+    d = conv_desc(n, h, w, c, c, 1, 1, 1, 0, y.dtype)
+    nb = lib.simhand_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty(nb, dtype=torch.uint8, device=y.device)
+    a = torch.empty_like(y)
+    s2 = torch.empty(c, c, dtype=torch.float32, device=y.device)
+    part = torch.empty(lib.simhand_conv2d_wgrad_splits(C.byref(d)), 2, c, dtype=torch.float32, device=y.device)
+    check(lib.simhand_bn_apply_gram(C.byref(d), _ptr(y, torch.bfloat16), _ptr(st.scale), _ptr(st.shift), int(relu), _ptr(a), _ptr(s2), _ptr(part),
+                                    _ptr(ws), nb, _stream()), "bn_apply_gram")
+    return a, s2, bn_channel_sums(part, c)
+
+
+def bn_bwd_coefs(st: "BNState", gamma, dgamma, dbeta, m: int):
+    """(A, B, C) with dy = A * g - B * y + C: the BatchNorm backward once its sums are reduced (simhand_bn_bwd_coefs)."""
+    lib = _lib_dev()
+    c = gamma.numel()
+    buf = torch.empty(3, c, dtype=torch.float32, device=gamma.device)
+    check(lib.simhand_bn_bwd_coefs(_ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(dgamma), _ptr(dbeta), m, c, _ptr(buf[0]), _ptr(buf[1]),
+                                   _ptr(buf[2]), _stream()), "bn_bwd_coefs")
+    return buf[0], buf[1], buf[2]
+
+
+def conv2d_wgrad_bnbwd(d: ConvDesc, x, da, y, st: "BNState", coefs, relu: bool, shape):
+    """Weight gradient (OIHW fp32, `shape`) of a 1x1 / stride-1 conv whose output y feeds a BN (+ReLU), with the BatchNorm
+    backward apply fused into the dy loader; also returns dy (written once, for the data gradient)."""
+    lib = _lib_dev()
+    nb = lib.simhand_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    dw = torch.empty(shape, dtype=torch.float32, device=x.device)
+    dy = torch.empty_like(y)
+    c_real = dw[0].numel() // (d.r * d.s)
+    check(lib.simhand_conv2d_wgrad_bnbwd(C.byref(d), _ptr(x), _ptr(da), _ptr(y), _ptr(st.scale), _ptr(st.shift), _ptr(coefs[0]), _ptr(coefs[1]),
+                                         _ptr(coefs[2]), int(relu), _ptr(dy), _ptr(dw), c_real, _ptr(ws), nb, _stream()), "conv2d_wgrad_bnbwd")
+    return dw, dy
+
+
 def conv2d_wgrad_oihw(d: ConvDesc, x, dy, shape) -> torch.Tensor:
     """fp32 gradient directly in the nn.Conv2d.weight.grad layout `shape` = (cout, c, r, s); for the im2col'd stem
     `d` is the 1x1 descriptor over the padded columns and shape = (64, 3, 7, 7) (147 real columns)."""
@@ -463,7 +503,7 @@ def bn_apply(y, st: BNState, m: int, c: int, relu: bool, residual=None, out=None
 
 
 def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_dres: bool, mask_from_y: bool = False,
-                relu_mask=None, raw_partial=None):
+                relu_mask=None, raw_partial=None, apply: bool = True):
     """Returns (dy, dres or None, dgamma, dbeta).  raw_partial: (sum g, sum g*y) tiles from conv2d_dgrad_fused -- the
     standalone partial-sum pass is skipped.  mask_from_y: the unit had no residual add, so the ReLU mask is
     recomputed from y (the stored activation is not read).  relu_mask: bit mask from bn_apply(want_mask=True) --
@@ -487,6 +527,8 @@ def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_d
         check(lib.simhand_bn_bwd_partial(_ptr(da), _ptr(aa), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift), mode, m, c,
                                          dt(y.dtype), _ptr(part), _stream()), "bn_bwd_partial")
         check(lib.simhand_bn_bwd_finalize(_ptr(part), nblk, c, _ptr(dg), _ptr(db), _stream()), "bn_bwd_finalize")
+    if not apply:  # sums only: the caller fuses the apply into a consumer (conv2d_wgrad_bnbwd)
+        return None, None, dg, db
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
     check(lib.simhand_bn_bwd_apply(_ptr(da), _ptr(aa), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(dg), _ptr(db),

@@ -39,6 +39,15 @@ def record_hip_relu_masks(store: list):
             store.append(((res[0] if want_mask else res) > 0).cpu())
         return res
 
+    orig_gram = ops.bn_apply_gram
+
+    def bn_apply_gram(y, st, relu=True):
+        res = orig_gram(y, st, relu)
+        if relu:
+            store.append((res[0] > 0).cpu())
+        return res
+
+    ops.bn_apply_gram = bn_apply_gram
     ops.bn_apply = bn_apply
     ops.bn_relu_maxpool_fwd = bn_relu_maxpool_fwd
     ops.conv2d_fwd_bnact = conv2d_fwd_bnact
@@ -48,6 +57,7 @@ def record_hip_relu_masks(store: list):
         ops.bn_apply = orig
         ops.bn_relu_maxpool_fwd = orig_stem
         ops.conv2d_fwd_bnact = orig_fused
+        ops.bn_apply_gram = orig_gram
 
 
 @contextlib.contextmanager

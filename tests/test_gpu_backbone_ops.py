@@ -755,3 +755,72 @@ def test_conv_fwd_bnact_epilogue_and_gram_statistics(shape, with_res):
     assert (sum_y2.double() - ref2).abs().max().item() <= 1e-3 * ref2.abs().max().item()
     xs = x_in.float().view(m, cin)
     assert torch.allclose(t2, xs.sum(0), rtol=1e-4, atol=1e-2) and torch.allclose(s2, xs.t() @ xs, rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("n,h,c,relu", [(3, 13, 64, True), (2, 20, 128, True), (5, 9, 256, True), (2, 7, 512, False), (1, 5, 64, True)])
+def test_bn_apply_fused_into_the_gram_launch(n, h, c, relu):
+    """simhand_bn_apply_gram: a = act(y*scale + shift), a^T a and sum a in one launch of the 1x1 weight-gradient kernel ==
+    simhand_bn_apply followed by the Gram launch (simhand_conv2d_wgrad_colsum with x = dy = a).  Ragged pixel counts, one to
+    sixteen Gram tiles (c = 512: off-diagonal tiles transform both operands)."""
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(n * 100 + c)
+    dt = torch.bfloat16
+    m = n * h * h
+    y = (torch.randn(n, h, h, c, generator=g) * 1.5 + 0.2).to(DEV).to(dt)
+    st = ops.BNState(c, DEV)
+    st.scale.copy_(torch.rand(c, generator=g) + 0.5)
+    st.shift.copy_(torch.randn(c, generator=g) * 0.3)
+    want_a = ops.bn_apply(y.view(m, c), st, m, c, relu).view(n, h, h, c)
+    d = ops.conv_desc(n, h, h, c, c, 1, 1, 1, 0, dt)
+    want_s2, want_t2 = ops.conv2d_wgrad_colsum(d, want_a, want_a)
+    ops.route_reset()
+    a, s2, t2 = ops.bn_apply_gram(y, st, relu)
+    assert ops.route_counts()["bn_apply_gram"] == 1
+    assert torch.equal(a, want_a)                      # same fp32 expression, same rounding
+    _check(s2.cpu(), want_s2.cpu(), 1e-5, "a^T a")     # same bf16 operands, fp32 accumulate: split-K order only
+    _check(t2.cpu(), want_t2.cpu(), 1e-5, "sum a")
+    # against plain torch fp32
+    ref = y.float().cpu().view(m, c) * st.scale.cpu() + st.shift.cpu()
+    ref = (ref.clamp_min(0) if relu else ref).to(dt).float()
+    _check(s2.cpu(), ref.t() @ ref, 1e-3, "a^T a vs torch")
+
+
+@pytest.mark.parametrize("n,h,cin,cout,relu", [(3, 13, 256, 64, True), (2, 20, 512, 128, True), (2, 9, 1024, 256, True), (1, 7, 64, 64, False)])
+def test_bn_backward_apply_fused_into_the_1x1_weight_gradient(n, h, cin, cout, relu):
+    """simhand_conv2d_wgrad_bnbwd: dy = A (da [bn(y) > 0]) - B y + C computed in the weight-gradient kernel's dy loader ==
+    simhand_bn_bwd_apply followed by simhand_conv2d_wgrad_oihw; the dy it writes == the stand-alone pass's."""
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(cin + cout + h)
+    dt = torch.bfloat16
+    m = n * h * h
+    x = torch.randn(n, h, h, cin, generator=g).to(DEV).to(dt)
+    y = (torch.randn(n, h, h, cout, generator=g) * 1.3 + 0.1).to(DEV).to(dt)
+    da = torch.randn(n, h, h, cout, generator=g).to(DEV).to(dt)
+    gamma = (torch.rand(cout, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(cout, generator=g) * 0.2).to(DEV)
+    part = ops.bn_partial_stats(y.view(m, cout), m, cout)
+    st = ops.bn_finalize(part, m, cout, gamma, beta, torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV),
+                         torch.zeros(1, dtype=torch.int64, device=DEV))
+    want_dy, _, dg, db = ops.bn_backward(da.view(m, cout), None, y.view(m, cout), st, gamma, m, cout, relu, False, mask_from_y=relu)
+    d = ops.conv_desc(n, h, h, cin, cout, 1, 1, 1, 0, dt)
+    want_dw = ops.conv2d_wgrad_oihw(d, x, want_dy.view(n, h, h, cout), (cout, cin, 1, 1))
+    _, _, dg2, db2 = ops.bn_backward(da.view(m, cout), None, y.view(m, cout), st, gamma, m, cout, relu, False, mask_from_y=relu, apply=False)
+    assert torch.equal(dg, dg2) and torch.equal(db, db2)
+    coefs = ops.bn_bwd_coefs(st, gamma, dg, db, m)
+    ops.route_reset()
+    dw, dy = ops.conv2d_wgrad_bnbwd(d, x, da, y, st, coefs, relu, (cout, cin, 1, 1))
+    assert ops.route_counts()["wgrad_bnbwd"] == 1
+    # the fused form evaluates A g - B y + C, the stand-alone pass gamma invstd (g - mean g - xhat mean(g xhat)): same value,
+    # different association -> agreement to bf16 round-off of the stored dy
+    _check(dy.float().cpu().view(m, cout), want_dy.float().cpu(), 1e-2, "dy")
+    _check(dw.cpu(), want_dw.cpu(), 1e-2, "dw")
+    # and against torch autograd in fp32
+    yt = y.float().cpu().view(m, cout).requires_grad_(True)
+    out = F.batch_norm(yt, None, None, gamma.cpu(), beta.cpu(), training=True, eps=1e-5)
+    if relu:
+        out = F.relu(out)
+    out.backward(da.float().cpu().view(m, cout))
+    _check(dy.float().cpu().view(m, cout), yt.grad, 2e-2, "dy vs autograd")
+    _check(dw.cpu().view(cout, cin), yt.grad.t() @ x.float().cpu().view(m, cin), 2e-2, "dw vs autograd")
