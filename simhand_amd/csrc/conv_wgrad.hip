@@ -146,6 +146,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   const unsigned hw = (unsigned)(p.Ho * p.Wo);
 
   uint4 ra[NA], rb[NBL];
+  uint4 ry[XFORM == 2 ? NA : 1];  // XFORM 2: the raw conv output chunks next to the incoming-gradient chunks in ra
+  int live_rows = 0;              // rows of the staged k-step that lie inside the block's pixel range
   // PLAIN: per-thread row pointers of k-step 0 (chunk i = tile row (tid + 256 i) / CPR, 16-B chunk (tid + 256 i) % CPR)
   const char* pdy[NA];
   const char* px[NBL];
@@ -243,55 +245,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
         const bool live = rowa[i] < left;
         ra[i] = live ? *reinterpret_cast<const uint4*>(pdy[i]) : make_uint4(0, 0, 0, 0);
         pdy[i] += step_dy;
-        if constexpr (XFORM == 1) {
-          ra[i] = live ? bn_relu8(ra[i], ca_s, ca_h) : make_uint4(0, 0, 0, 0);  // rows past the range must stay zero
-        } else if constexpr (XFORM == 2) {
-          const uint4 yv = live ? *reinterpret_cast<const uint4*>(pdy2[i]) : make_uint4(0, 0, 0, 0);
+        if constexpr (XFORM == 2) {
+          ry[i] = live ? *reinterpret_cast<const uint4*>(pdy2[i]) : make_uint4(0, 0, 0, 0);
           pdy2[i] += step_dy;
-          const unsigned g4[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w}, y4[4] = {yv.x, yv.y, yv.z, yv.w};
-          unsigned o[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float r2[2];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-              const int e = 2 * q + hh;
-              const float g = hh == 0 ? __uint_as_float(g4[q] << 16) : __uint_as_float(g4[q] & 0xffff0000u);
-              const float y = hh == 0 ? __uint_as_float(y4[q] << 16) : __uint_as_float(y4[q] & 0xffff0000u);
-              const bool on = !p.xrelu || (y * ca_s[e] + ca_h[e] > 0.f);
-              r2[hh] = ca_a[e] * (on ? g : 0.f) - ca_b[e] * y + ca_c[e];
-            }
-            o[q] = pack_bf16x2(r2[0], r2[1]);
-          }
-          ra[i] = live ? make_uint4(o[0], o[1], o[2], o[3]) : make_uint4(0, 0, 0, 0);
-        }
-        if constexpr (XFORM != 0) {
-          if (x_writes && live) *reinterpret_cast<uint4*>(pout[i]) = ra[i];
-          pout[i] += step_dy;
         }
       }
-      if (want_colsum) {  // block-uniform
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-          const unsigned w4[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            csum[2 * q] += __uint_as_float(w4[q] << 16);
-            csum[2 * q + 1] += __uint_as_float(w4[q] & 0xffff0000u);
-          }
-        }
-      }
+      live_rows = left;  // the transforms / column sums run in store_step, AFTER the MFMAs that cover these loads' latency
 #pragma unroll
       for (int i = 0; i < NBL; ++i) {
         if constexpr (XFORM == 1 && BM == BN) {
-          if (x_diag) {  // block-uniform: the Gram tile on the diagonal reuses the transformed dy chunks
-            rb[i] = ra[i];
+          if (x_diag) {  // block-uniform: the Gram tile on the diagonal reuses the transformed dy chunks (store_step)
             px[i] += step_x;
             continue;
           }
         }
         rb[i] = rowb[i] < left ? *reinterpret_cast<const uint4*>(px[i]) : make_uint4(0, 0, 0, 0);
-        if constexpr (XFORM == 1) rb[i] = rowb[i] < left ? bn_relu8(rb[i], cb_s, cb_h) : make_uint4(0, 0, 0, 0);
         if constexpr (STEM) {
           px[i] += 2 * KP * 4 * (int)sizeof(T);
           swo[i] += KP;
@@ -350,6 +318,57 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   auto store_step = [&](int buf) __attribute__((always_inline)) {
     char* dA = sA + buf * (KP * SA);
     char* dB = sB + buf * (KP * SB);
+    if constexpr (XFORM != 0) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const bool live = rowa[i] < live_rows;
+        if constexpr (XFORM == 1) {
+          ra[i] = live ? bn_relu8(ra[i], ca_s, ca_h) : make_uint4(0, 0, 0, 0);  // rows past the range must stay zero
+        } else {
+          const unsigned g4[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w}, y4[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+          unsigned o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float r2[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const int e = 2 * q + hh;
+              const float g = hh == 0 ? __uint_as_float(g4[q] << 16) : __uint_as_float(g4[q] & 0xffff0000u);
+              const float y = hh == 0 ? __uint_as_float(y4[q] << 16) : __uint_as_float(y4[q] & 0xffff0000u);
+              const bool on = !p.xrelu || (y * ca_s[e] + ca_h[e] > 0.f);
+              r2[hh] = ca_a[e] * (on ? g : 0.f) - ca_b[e] * y + ca_c[e];
+            }
+            o[q] = pack_bf16x2(r2[0], r2[1]);
+          }
+          ra[i] = live ? make_uint4(o[0], o[1], o[2], o[3]) : make_uint4(0, 0, 0, 0);
+        }
+        if (x_writes && live) *reinterpret_cast<uint4*>(pout[i]) = ra[i];
+        pout[i] += step_dy;
+      }
+      if constexpr (XFORM == 1) {
+#pragma unroll
+        for (int i = 0; i < NBL; ++i) {
+          if constexpr (BM == BN) {
+            if (x_diag) {
+              rb[i] = ra[i];
+              continue;
+            }
+          }
+          rb[i] = rowb[i] < live_rows ? bn_relu8(rb[i], cb_s, cb_h) : make_uint4(0, 0, 0, 0);
+        }
+      }
+    }
+    if (want_colsum) {  // block-uniform; after the MFMAs so that the loads' latency is covered
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const unsigned w4[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          csum[2 * q] += __uint_as_float(w4[q] << 16);
+          csum[2 * q + 1] += __uint_as_float(w4[q] & 0xffff0000u);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int id = tid + 256 * i;

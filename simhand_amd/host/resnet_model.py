@@ -23,6 +23,7 @@ OIHW fp32 -> KRSC / CRSK compute dtype when the parameter version changes.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -140,9 +141,11 @@ class ResNetEngine:
         # the folds need every block's incoming gradient in masked form, which only the all-1x1 tails of Bottleneck nets give
         self._bottleneck = all(isinstance(b, Bottleneck) for li in (4, 5, 6, 7) for b in features[li])
         # BN-apply (+ReLU) of the unit in front of a folded conv runs inside the Gram launch the fold needs anyway
-        self.fuse_apply_gram = True
+        self.fuse_apply_gram = os.environ.get("SIMHAND_FUSE_GRAM", "1") == "1"  # env: A/B timing only
         # BN-backward apply of a 1x1 / stride-1 unit without residual runs inside that unit's weight-gradient launch
-        self.fuse_bwd_apply_wgrad = True
+        # (off: measured on MI355X at 2048 x 224^2 the BatchNorm class drops 4.3 ms but the weight-gradient class grows 8.5 ms --
+        # every cin tile of the launch re-derives the dy operand from TWO tensors; kept for the experiment record)
+        self.fuse_bwd_apply_wgrad = os.environ.get("SIMHAND_FUSE_BWDW", "0") == "1"
         self._gram = None  # (activation tensor, a^T a, sum a) of the unit just applied that way
 
     # -- weights -------------------------------------------------------------
