@@ -35,6 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+FP8_DENSE_PEAK_TFLOPS = 5000.0   # ~5 PF dense fp8 (block-scaled K = 128 MFMA)
 F32_PEAK_TFLOPS = 157.3
 AUG = ["color_jitter", "crop", "random_crop", "resize", "rotate"]
 TRAIN_GFLOP_PER_PAIR = {"18": 21.77, "50": 49.06, "152": 138.15}  # BASELINE.md section 3 (@224)
@@ -48,7 +49,8 @@ def parse():
     ap.add_argument("--per-gpu-batch", type=int, default=1024, help="pairs per GPU (BASELINE config: 1024)")
     ap.add_argument("--resnet", default="50", choices=["18", "34", "50", "101", "152"])
     ap.add_argument("--image-size", type=int, default=224)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "32", "fp8"],
+                    help="fp8 = BASELINE configs[4] slice: bf16 storage, e4m3 forward operands on the MFMA-bound layers (parity n/a)")
     ap.add_argument("--experiment", default="handclr_w", choices=["handclr_w", "peclr_w", "simclr"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16,
@@ -92,7 +94,7 @@ def make_model(args, world):
     cls = {"handclr_w": unsupervised.HandCLR_W, "peclr_w": unsupervised.PeCLR_W, "simclr": unsupervised.SimCLR}[args.experiment]
     torch.manual_seed(5)
     model = cls(cfg, None, "train")
-    model.set_compute_dtype(torch.bfloat16 if args.precision == "bf16" else torch.float32)
+    model.set_compute_dtype(torch.float32 if args.precision == "32" else torch.bfloat16, fp8=args.precision == "fp8")
     return model
 
 
@@ -263,7 +265,7 @@ def main():
         conv = {k: prof[k] for k in conv_classes}
         dom = max(conv, key=lambda k: conv[k]["ms"])
         d = conv[dom]  # measured in the timed region
-        peak = BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else F32_PEAK_TFLOPS
+        peak = {"bf16": BF16_DENSE_PEAK_TFLOPS, "fp8": FP8_DENSE_PEAK_TFLOPS, "32": F32_PEAK_TFLOPS}[args.precision]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
         breakdown, bsteps = (warm_prof, 1) if warm_prof is not None else (prof, args.steps)
         all_conv_flops = sum(breakdown[k]["flops"] for k in conv_classes)
@@ -275,12 +277,12 @@ def main():
         res = {
             "metric": "hand-image-pairs/sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"bf16": "bf16", "32": "f32", "fp8": "fp8-e4m3 forward operands / bf16"}[args.precision], "data": "synthetic",
             "config": {"workload": f"ResNet-{args.resnet} {args.experiment} contrastive step (fwd+bwd+allreduce+LARS/Adam), "
                                    f"{args.per_gpu_batch} pairs/GPU of 2x{args.image_size}x{args.image_size}x3, linear MPJPE weighting, "
                                    f"crop+rotate un-warp, global negatives",
                        "global_batch": global_pairs, "per_gpu_batch": args.per_gpu_batch, "image_size": args.image_size,
-                       "parallelism": f"dp{world}", "loss": final_loss,
+                       "parallelism": f"dp{world}", "loss": final_loss, "parity": "n/a (the reference has no fp8 path)" if args.precision == "fp8" else "oracle",
                        "world_size_backend": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

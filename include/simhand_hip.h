@@ -35,7 +35,7 @@ extern "C" {
 
 typedef void* sh_stream_t; /* hipStream_t */
 
-enum sh_dtype { SH_F32 = 0, SH_BF16 = 1 };
+enum sh_dtype { SH_F32 = 0, SH_BF16 = 1, SH_FP8_E4M3 = 2 /* OCP e4m3fn; operands of the simhand_*_fp8 entry points only */ };
 
 /* joint-distance definitions of get_weights_* (src/models/utils.py:218-388) */
 enum sh_dist_mode {
@@ -440,6 +440,28 @@ int simhand_avgpool_bwd(const void* dy, void* dx, int n, int hw, int c, int dtyp
 
 /* column sums of [M][C] (Linear bias gradient); partial: (2*simhand_bn_stat_blocks(m,c) + 1) * c floats */
 int simhand_colsum(const void* x, int64_t m, int c, int dtype, float* partial, float* out, sh_stream_t stream);
+
+/* ===========================================================================
+ * FP8 first slice (BASELINE configs[4], "next" row 8f-4 mixed-precision policy).  The reference has no fp8 path
+ * (fp16 autocast + GradScaler, src/experiments/main.py:158-159): parity n/a, the gate is agreement with the bf16 path.
+ *   per-tensor scaling: q = e4m3(clamp(v * scale, +-448)).  A scale lives in a device `state` vector of
+ *   simhand_fp8_state_floats(history) floats: [0] scale, [1] 1/scale, [2] ring position, [3] updates, [4..] amax ring.
+ *   simhand_fp8_amax folds max|x| into *amax_bits (uint bits of a non-negative float, atomicMax: exact and deterministic);
+ *   simhand_fp8_scale_update consumes *amax_bits: delayed = 0 -> scale = 448 / (amax * margin_pow2) (current scaling),
+ *   delayed = 1 -> amax enters the ring and scale = 448 / (max(ring) * margin_pow2) (what the NEXT quantize call uses);
+ *   simhand_fp8_quantize converts with state[0] and (optionally) records the tensor's own amax for that next update.
+ *   simhand_conv2d_fwd_fp8: y (bf16) = conv(q_x, q_w) / (scale_x scale_w) on v_mfma_scale_f32_16x16x128_f8f6f4 (all block
+ *   scales 2^0), + the fused BatchNorm partial sums [ceil(n*ho*wo/128)][2][cout] of simhand_conv2d_fwd.  Needs cin, cout
+ *   multiples of 128 (simhand_conv2d_fwd_fp8_supported).  x_q [n][h][w][cin], w_q KRSC, both e4m3.
+ * =========================================================================== */
+int simhand_fp8_state_floats(int history);
+int simhand_fp8_amax(const void* x, int64_t count, int dtype, uint32_t* amax_bits, sh_stream_t stream);
+int simhand_fp8_scale_update(float* state, uint32_t* amax_new_bits, int history, float margin_pow2, int delayed, sh_stream_t stream);
+int simhand_fp8_quantize(const void* x, void* q, int64_t count, int dtype, const float* state, uint32_t* amax_bits, sh_stream_t stream);
+int simhand_fp8_pack_krsc(const float* w_oihw, void* q, int k, int c, int r, int s, const float* state, sh_stream_t stream);
+int simhand_conv2d_fwd_fp8_supported(const sh_conv_desc* d);
+int simhand_conv2d_fwd_fp8(const sh_conv_desc* d, const void* x_q, const void* w_q, const float* x_state, const float* w_state, void* y,
+                           float* bn_partial, sh_stream_t stream);
 
 /* ===========================================================================
  * Optimizer ("next" row 8f-1): LARSWrapper(Adam) step, pl_bolts 0.2.2 semantics

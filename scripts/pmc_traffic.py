@@ -24,9 +24,9 @@ for tot, k, cnt, rd, wr in rows[:25]:
 lines.append(f"\nall kernels: read {sum(r[3] for r in rows)/1e9:.1f} GB, write {sum(r[4] for r in rows)/1e9:.1f} GB over the profiled run (2 steps: 1 warm-up + 1 timed)")
 open(sys.argv[3], "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
-cls = {"conv_fwd": (r"igemm_kernel<unsigned short, false", r"gemm1x1_kernel<\d+, \d+, false"),
-       "conv_dgrad": (r"igemm_kernel<unsigned short, true", r"gemm1x1_kernel<\d+, \d+, true"),
-       "conv_wgrad": (r"wgrad_kernel<unsigned short",)}
+cls = {"conv_fwd": (r"igemm_kernel<unsigned short, false", r"igemm256_kernel<false", r"gemm1x1_kernel<\d+, \d+, false", r"conv3x3_c64_kernel<[01]>"),
+       "conv_dgrad": (r"igemm_kernel<unsigned short, true", r"igemm256_kernel<true", r"gemm1x1_kernel<\d+, \d+, true", r"conv3x3_c64_kernel<2>"),
+       "conv_wgrad": (r"wgrad_kernel<unsigned short", r"wgrad3x3_kernel")}
 out = {}
 for c, pats in cls.items():
     sel = [r for r in rows if any(re.search(p, r[1]) for p in pats)]

@@ -13,10 +13,14 @@ python scripts/rocpd_stats.py /tmp/prof_kt/kt_results.db "$out/${tag}_bench_b102
 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_f -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_w -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/w.log 2>&1
 python scripts/pmc_traffic.py /tmp/prof_f/f_results.db /tmp/prof_w/w_results.db "$out/${tag}_bench_b1024_hbm_traffic.md" "$out/hbm_traffic.json" > /dev/null
-tail -3 /tmp/f.log /tmp/w.log | cut -c1-200
+# matrix-core utilisation (own pass: counters only, program directly after --)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d /tmp/prof_m -o m -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/m.log 2>&1
+python scripts/pmc_mfma.py /tmp/prof_m/m_results.db "$out/${tag}_bench_b1024_mfma_util.md" /tmp/prof_kt/kt_results.db > /dev/null || tail -5 /tmp/m.log
+python scripts/layer_table.py --out "$out/${tag}_layer_table.md" > /dev/null 2>&1
+tail -3 /tmp/f.log /tmp/w.log /tmp/m.log | cut -c1-200
 # the bench line last: its roofline.traffic reads the PMC-derived bytes per launch written just above
 cp "$out/hbm_traffic.json" "$root/profiles/hbm_traffic.json"
-python bench.py > "$out/${tag}_bench_b1024.log" 2>&1
+python bench.py --cpu-full > "$out/${tag}_bench_b1024.log" 2>&1
 tail -1 "$out/${tag}_bench_b1024.log" > "$out/${tag}_bench_b1024.json"
 cat "$out/${tag}_bench_b1024.json"
 ls -la "$out"

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SIMHAND_LIB") or os.path.join(_HERE, "libsimhand_hip.so")
 
 # enums of include/simhand_hip.h
-SH_F32, SH_BF16 = 0, 1
+SH_F32, SH_BF16, SH_FP8_E4M3 = 0, 1, 2
 DIST_MODES = {"mpjpe": 0, "w_abs": 1, "w_o_abs": 2, "l2": 3}
 WEIGHT_TYPES = {None: 0, "none": 0, "linear": 1, "non_linear": 2, "explicit": 3}
 PP_NORM_IN, PP_NORM_OUT, PP_ANGLE_AS_GIVEN = 1, 2, 4
@@ -164,6 +164,13 @@ SIGNATURES = {
     "simhand_sumsq_partial": (_I, [_P, _L, _P, _I, _P]),
     "simhand_opt_chunk_elems": (_I, []),
     "simhand_lars_adam_multi": (_I, [_P, _I, _P, _I, _P, _F, _F, _F, _F, _F, _I, _L, _P]),
+    "simhand_fp8_state_floats": (_I, [_I]),
+    "simhand_fp8_amax": (_I, [_P, _L, _I, _P, _P]),
+    "simhand_fp8_scale_update": (_I, [_P, _P, _I, _F, _I, _P]),
+    "simhand_fp8_quantize": (_I, [_P, _P, _L, _I, _P, _P, _P]),
+    "simhand_fp8_pack_krsc": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "simhand_conv2d_fwd_fp8_supported": (_I, [C.POINTER(ConvDesc)]),
+    "simhand_conv2d_fwd_fp8": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "simhand_lars_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P]),
 }
 

@@ -29,8 +29,10 @@ class BaseModel(LightningModule):
         self.plot_params: dict = {}
         self.train_iters_per_epoch = 1
 
-    def set_compute_dtype(self, dtype: torch.dtype) -> None:
-        self.encoder.set_compute_dtype(dtype)
+    def set_compute_dtype(self, dtype: torch.dtype, fp8: bool = False) -> None:
+        """dtype: storage / kernel dtype of the encoder (fp32 parity mode or bf16); fp8: e4m3 forward operands for the
+        matrix-core-bound layers on top of bf16 (BASELINE configs[4])."""
+        self.encoder.set_compute_dtype(dtype, fp8=fp8)
 
     def exclude_from_wt_decay(self, named_params: Iterator[Tuple[str, torch.Tensor]], weight_decay: float,
                               skip_list: List[str] = ["bias", "bn"]) -> List[Dict[str, Union[list, float]]]:

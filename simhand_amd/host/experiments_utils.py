@@ -90,7 +90,7 @@ def add_build_flags(p: argparse.ArgumentParser) -> argparse.ArgumentParser:
     """Additive flags of this build: none of them changes a reference default."""
     p.add_argument("--synthetic", action="store_true", help="train on the SURVEY 8d synthetic batch schema (no dataset on disk)")
     p.add_argument("--synthetic_samples", type=int, default=None, help="samples per synthetic epoch (default 4 global batches)")
-    p.add_argument("--precision", type=str, default=None, choices=["32", "bf16", "16"],
+    p.add_argument("--precision", type=str, default=None, choices=["32", "bf16", "16", "fp8"],
                    help="kernel dtype: 32 = exact-fp32 MFMA, bf16/16 = bf16 MFMA (overrides training_config.json's 16)")
     p.add_argument("--image_size", type=int, default=None, help="synthetic image side (default: resize_shape or 224)")
     p.add_argument("--max_steps", type=int, default=-1, help="stop after this many optimizer steps")

@@ -86,9 +86,15 @@ class ModelCheckpoint:
 
 
 class Trainer:
-    """fit loop for the contrastive step classes.  precision: 32 -> fp32 kernels,
-    "bf16" / 16 -> bf16 MFMA kernels (the reference's fp16 AMP has no GradScaler
-    equivalent here: bf16 keeps the fp32 exponent range, master weights stay fp32)."""
+    """fit loop for the contrastive step classes.  Mixed-precision policy (the reference runs fp16 autocast +
+    GradScaler, main.py:158-159):
+      precision 32        -> exact-fp32 MFMA kernels, fp32 storage (parity mode);
+      precision "bf16"/16 -> bf16 storage + bf16 MFMA, fp32 accumulators, fp32 BatchNorm statistics / loss / optimizer, fp32
+                             master weights.  No loss scaling: bf16 has fp32's exponent range, so the overflow the reference's
+                             GradScaler guards against cannot occur;
+      precision "fp8"     -> as bf16, plus e4m3 forward operands (per-tensor scales: weights current, activations delayed
+                             with a 16-entry amax ring and 1 bit of margin, ops.FP8Scaler) for the matrix-core-bound layers.
+    tests/test_gpu_fp8.py / test_gpu_main.py hold the multi-step stability evidence."""
 
     def __init__(self, max_epochs: int = 1, precision=32, callbacks: Optional[list] = None, log_every_n_steps: int = 5,
                  default_root_dir: str = ".", max_steps: int = -1, logger=None, **_ignored):
@@ -114,6 +120,10 @@ class Trainer:
     def compute_dtype(self) -> torch.dtype:
         return torch.float32 if str(self.precision) == "32" else torch.bfloat16
 
+    @property
+    def fp8(self) -> bool:
+        return str(self.precision) == "fp8"
+
     def checkpoint_dict(self, module: LightningModule, epoch: int) -> dict:
         return {
             "epoch": epoch, "global_step": self.global_step, "pytorch-lightning_version": "1.8.0-compatible",
@@ -130,7 +140,7 @@ class Trainer:
 
         model.trainer = self
         if hasattr(model, "set_compute_dtype"):
-            model.set_compute_dtype(self.compute_dtype)
+            model.set_compute_dtype(self.compute_dtype, fp8=self.fp8)
         device = torch.device("cuda", torch.cuda.current_device())
         model.to(device)
         model.setup("fit")

@@ -128,9 +128,14 @@ class _Unit:
 
 
 class ResNetEngine:
-    def __init__(self, features: nn.Sequential, dtype: torch.dtype = torch.float32):
+    def __init__(self, features: nn.Sequential, dtype: torch.dtype = torch.float32, fp8: bool = False):
         self.features = features
         self.dtype = dtype
+        # fp8 slice (BASELINE configs[4]): bf16 storage everywhere, e4m3 operands + the scaled K = 128 MFMA for the FORWARD of
+        # the matrix-core-bound layers (3x3, and 1x1 with >= 512 input channels) whose BatchNorm is not folded; data / weight
+        # gradients stay bf16.  Scales: ops.FP8Scaler (per-tensor; weights current, activations delayed).
+        self.fp8 = fp8
+        self._fp8_sites: Dict[int, tuple] = {}  # id(conv.weight) -> (activation scaler, weight scaler, packed weights, version)
         self._packs: Dict[int, _Packed] = {}
         # BN-backward partial sums of a unit fused into the epilogue of the dgrad that produces its incoming gradient
         self.fuse_bn_bwd = True
@@ -217,6 +222,23 @@ class ResNetEngine:
             save.append(u)
         return a
 
+    def _fp8_ok(self, conv, d) -> bool:
+        return (self.fp8 and self.dtype == torch.bfloat16 and (conv.kernel_size == (3, 3) or conv.in_channels >= 512)
+                and ops.conv2d_fwd_fp8_supported(d))
+
+    def _conv_fwd_fp8(self, conv, d, x, training):
+        w = conv.weight
+        site = self._fp8_sites.get(id(w))
+        ver = (w._version, w.data_ptr())
+        if site is None:
+            site = [ops.FP8Scaler(x.device, delayed=True), ops.FP8Scaler(x.device, delayed=False), None, None]
+            self._fp8_sites[id(w)] = site
+        if site[3] != ver:  # new parameter version: re-pack (and re-scale) the e4m3 weights
+            site[2] = site[1].pack_weights(w)
+            site[3] = ver
+        xq = site[0].quantize(x)
+        return ops.conv2d_fwd_fp8(d, xq, site[2], site[0], site[1], want_stats=training)
+
     def _conv_bn(self, conv, bn, x, relu, residual, training, save: Optional[list], need_dgrad=True, gram_next=False):
         """gram_next: the activation feeds a folded 1x1 convolution (which needs a^T a and sum a): BatchNorm-apply + ReLU then
         run inside that Gram launch (ops.bn_apply_gram) instead of as a pass of their own."""
@@ -226,7 +248,10 @@ class ResNetEngine:
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         d = ops.conv_desc(n, h, w, cin, conv.out_channels, k, k, s, p, self.dtype)
         pk = self._pack(conv, need_t=save is not None and need_dgrad)
-        y, part = ops.conv2d_fwd(d, x, pk.krsc, want_stats=training)
+        if self._fp8_ok(conv, d):
+            y, part = self._conv_fwd_fp8(conv, d, x, training)
+        else:
+            y, part = ops.conv2d_fwd(d, x, pk.krsc, want_stats=training)
         m = n * d.ho * d.wo
         st = self._bn(bn, part, m, conv.out_channels, training)
         mask = None
@@ -554,8 +579,8 @@ class ResNetModel(nn.Module):
         self.out_features = m.fc.in_features
         self.engine = ResNetEngine(self.features, compute_dtype)
 
-    def set_compute_dtype(self, dtype: torch.dtype) -> None:
-        self.engine = ResNetEngine(self.features, dtype)
+    def set_compute_dtype(self, dtype: torch.dtype, fp8: bool = False) -> None:
+        self.engine = ResNetEngine(self.features, dtype, fp8=fp8)
 
     def forward(self, x) -> Tensor:
         """x: image batch, or a tuple of batches (the two views) encoded as their concatenation -- the stem reads each

@@ -708,6 +708,74 @@ def colsum(x: torch.Tensor, m: int, c: int) -> torch.Tensor:
     return out
 
 
+# -------------------------------------------------------------------------- fp8
+FP8_HISTORY = 16
+
+
+class FP8Scaler:
+    """Per-tensor scale of one quantisation site (a weight tensor or an activation edge) -- the mixed-precision policy of
+    the fp8 slice (the reference's fp16 GradScaler, src/experiments/main.py:158-159, has no fp8 analogue):
+
+    * e4m3 for forward operands, value range +-448; q = e4m3(clamp(v * scale));
+    * weights: CURRENT scaling -- amax of the fp32 master at pack time (weights change once per optimizer step);
+    * activations: DELAYED scaling -- the scale used now comes from the amax ring (last FP8_HISTORY calls, max), the tensor's
+      own amax is recorded by the same quantize pass for the next call: one pass over the tensor, no host sync.  The first
+      call has no history and falls back to a current-scaling pre-pass.  margin = 1 bit of headroom (scale / 2);
+    * everything the scale touches stays on the device (state vector), nothing is read back per step."""
+
+    def __init__(self, device, delayed: bool, margin_bits: int = 1):
+        lib = _lib_dev()
+        self.delayed, self.margin = delayed, float(2 ** margin_bits)
+        self.state = torch.zeros(lib.simhand_fp8_state_floats(FP8_HISTORY), dtype=torch.float32, device=device)
+        self.state[0] = 1.0
+        self.state[1] = 1.0
+        self.amax_bits = torch.zeros(1, dtype=torch.int32, device=device)
+        self.calls = 0
+
+    def _update(self, delayed: bool):
+        check(_lib_dev().simhand_fp8_scale_update(_ptr(self.state), _ptr(self.amax_bits), FP8_HISTORY, self.margin, int(delayed), _stream()),
+              "fp8_scale_update")
+
+    def quantize(self, x: torch.Tensor) -> torch.Tensor:
+        """x (bf16 / fp32, contiguous, numel % 16 == 0) -> uint8 tensor of e4m3 codes with this site's scale."""
+        lib = _lib_dev()
+        q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        if not self.delayed or self.calls == 0:
+            check(lib.simhand_fp8_amax(_ptr(x), x.numel(), dt(x.dtype), _ptr(self.amax_bits), _stream()), "fp8_amax")
+            self._update(self.delayed)  # current scaling (and, for a delayed site, the ring's first entry)
+            check(lib.simhand_fp8_quantize(_ptr(x), _ptr(q), x.numel(), dt(x.dtype), _ptr(self.state), None, _stream()), "fp8_quantize")
+        else:
+            check(lib.simhand_fp8_quantize(_ptr(x), _ptr(q), x.numel(), dt(x.dtype), _ptr(self.state), _ptr(self.amax_bits), _stream()),
+                  "fp8_quantize")
+            self._update(True)  # this call's amax enters the ring: the scale of the NEXT call
+        self.calls += 1
+        return q
+
+    def pack_weights(self, w_oihw: torch.Tensor) -> torch.Tensor:
+        lib = _lib_dev()
+        k, c, r, s = w_oihw.shape
+        wq = torch.empty(k, r * s * c, dtype=torch.uint8, device=w_oihw.device)
+        w = w_oihw.detach().contiguous()
+        check(lib.simhand_fp8_amax(_ptr(w, _F32), w.numel(), _lib.SH_F32, _ptr(self.amax_bits), _stream()), "fp8_amax")
+        self._update(False)
+        check(lib.simhand_fp8_pack_krsc(_ptr(w), _ptr(wq), k, c, r, s, _ptr(self.state), _stream()), "fp8_pack_krsc")
+        return wq
+
+
+def conv2d_fwd_fp8_supported(d: ConvDesc) -> bool:
+    return bool(_lib.load().simhand_conv2d_fwd_fp8_supported(C.byref(d)))
+
+
+def conv2d_fwd_fp8(d: ConvDesc, x_q, w_q, x_scaler: FP8Scaler, w_scaler: FP8Scaler, want_stats: bool = True):
+    """y (bf16) = conv(x_q, w_q) / (scale_x * scale_w) on the e4m3 scaled-MFMA kernel; BN partial sums as conv2d_fwd."""
+    lib = _lib_dev()
+    y = torch.empty(d.n, d.ho, d.wo, d.cout, dtype=torch.bfloat16, device=x_q.device)
+    part = torch.empty((d.n * d.ho * d.wo + 127) // 128, 2, d.cout, dtype=torch.float32, device=x_q.device) if want_stats else None
+    check(lib.simhand_conv2d_fwd_fp8(C.byref(d), _ptr(x_q, torch.uint8), _ptr(w_q, torch.uint8), _ptr(x_scaler.state), _ptr(w_scaler.state), _ptr(y),
+                                     _ptr(part), _stream()), "conv2d_fwd_fp8")
+    return y, part
+
+
 # -------------------------------------------------------------------- optimizer
 def lars_adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, weight_decay: float, use_lars: bool,
                    betas=(0.9, 0.999), adam_eps: float = 1e-8, lars_eta: float = 0.02, lars_eps: float = 1e-8,

@@ -1,0 +1,127 @@
+"""GPU: the fp8 slice (BASELINE configs[4]: ResNet-50 simclr fp8).  The reference has no fp8 path (fp16 autocast,
+src/experiments/main.py:158-159), so there is nothing to be bit-compatible with -- "parity: n/a".  What is checked:
+  * the e4m3 quantiser against torch's float8_e4m3fn cast (bit-exact codes) and the scale bookkeeping (current / delayed);
+  * the scaled-MFMA convolution against an fp32 convolution of the SAME dequantised operands (the matrix instruction's
+    products of e4m3 values are exact in fp32: only the summation order differs);
+  * the SimCLR ResNet-50 step with fp8 forward operands against the bf16 step: loss band, embedding cosine, and a
+    multi-step run (optimizer in the loop) that stays finite and tracks the bf16 trajectory."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import step as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+AUG = ["color_jitter", "crop", "random_crop", "resize", "rotate"]
+
+
+def _deq(q: torch.Tensor) -> torch.Tensor:
+    return q.cpu().view(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_quantiser_matches_torch_float8_cast_and_scale_policy(dtype):
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(4, 33, 16, generator=g) * 3.0).to(dtype)
+    x[0, 0, 0] = 70.0  # the amax
+    xd = x.to(DEV)
+    sc = ops.FP8Scaler(DEV, delayed=False, margin_bits=0)
+    q = sc.quantize(xd)
+    scale = float(sc.state[0])
+    assert abs(scale - 448.0 / 70.0) <= 1e-6 * scale and abs(float(sc.state[1]) * scale - 1.0) < 1e-6
+    want = (x.float() * scale).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q.cpu(), want)
+    assert float(_deq(q).abs().max()) == 448.0
+    # delayed scaling: call 1 calibrates, call 2 still uses call 1's amax and records its own, call 3 sees max(ring)
+    sd = ops.FP8Scaler(DEV, delayed=True, margin_bits=1)
+    sd.quantize(xd)
+    s1 = float(sd.state[0])
+    assert abs(s1 - 448.0 / 140.0) <= 1e-6 * s1
+    q2 = sd.quantize((xd.float() * 4).to(dtype))  # 4x larger tensor, old scale: saturates instead of overflowing
+    assert torch.isfinite(_deq(q2)).all() and float(_deq(q2).abs().max()) == 448.0
+    s2 = float(sd.state[0])
+    assert abs(s2 - 448.0 / 560.0) <= 1e-5 * s2  # ring max = 280 now
+    sd.quantize(xd)
+    assert abs(float(sd.state[0]) - s2) <= 1e-6 * s2  # the ring remembers the large tensor
+
+
+@pytest.mark.parametrize("shape", [(2, 14, 14, 128, 128, 3, 1, 1), (3, 9, 9, 256, 128, 3, 2, 1), (2, 7, 7, 512, 256, 1, 1, 0),
+                                   (1, 5, 5, 128, 256, 3, 1, 1), (5, 6, 6, 1024, 128, 1, 1, 0)])
+def test_fp8_conv_forward_against_fp32_conv_of_the_dequantised_operands(shape):
+    from simhand_amd import ops
+
+    n, h, w, cin, cout, k, s, p = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16).to(DEV)
+    wt = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(DEV)
+    d = ops.conv_desc(n, h, w, cin, cout, k, k, s, p, torch.bfloat16)
+    assert ops.conv2d_fwd_fp8_supported(d)
+    sx, sw = ops.FP8Scaler(DEV, delayed=True), ops.FP8Scaler(DEV, delayed=False)
+    xq, wq = sx.quantize(x), sw.pack_weights(wt)
+    ops.route_reset()
+    y, part = ops.conv2d_fwd_fp8(d, xq, wq, sx, sw)
+    assert ops.route_counts()["fp8_fwd"] == 1
+    xdq = _deq(xq).permute(0, 3, 1, 2) * float(sx.state[1])
+    wdq = _deq(wq).view(cout, k, k, cin).permute(0, 3, 1, 2) * float(sw.state[1])
+    want = F.conv2d(xdq, wdq, stride=s, padding=p).permute(0, 2, 3, 1)
+    err = (y.float().cpu() - want).abs().max() / want.abs().max()
+    assert err <= 1e-2, err  # output rounded to bf16
+    m = n * d.ho * d.wo
+    sums = part.sum(dim=0).cpu()
+    flat = want.reshape(m, cout)
+    assert (sums[0] - flat.sum(0)).abs().max() <= 1e-3 * flat.abs().sum(0).max()
+    assert (sums[1] - (flat * flat).sum(0)).abs().max() <= 1e-3 * (flat * flat).sum(0).max()
+    # and against the unquantised bf16 convolution: e4m3 keeps 3 mantissa bits -> a few percent
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wt.cpu(), stride=s, padding=p).permute(0, 2, 3, 1)
+    rel = (y.float().cpu() - ref).norm() / ref.norm()
+    assert rel <= 6e-2, rel
+
+
+def test_simclr_rn50_step_fp8_tracks_bf16_over_several_steps():
+    from simhand_amd import ops
+    from tests.test_gpu_configs import _oracle, _product
+
+    b, img = 8, 224
+    om = _oracle("simclr", "50", {}, 31, 0.1)
+    batch = {k: v.to(DEV) for k, v in orc.synthetic_batch(b, size=img, seed=31).items()}
+
+    class _T:
+        max_epochs, world_size = 100, 1
+
+    runs = {}
+    for mode in ("bf16", "fp8"):
+        model = _product("SimCLR", "50", {}, om, torch.bfloat16, b)
+        model.set_compute_dtype(torch.bfloat16, fp8=(mode == "fp8"))
+        model.trainer = _T()
+        model.setup("fit")
+        (opt,), _ = model.configure_optimizers()
+        for grp in opt.param_groups:
+            grp["lr"] = 1e-3
+        ops.route_reset()
+        losses, z0 = [], None
+        for i in range(5):
+            opt.zero_grad(set_to_none=True)
+            out = model.training_step(batch, i)
+            out["loss"].backward()
+            if i == 0:
+                with torch.no_grad():
+                    z0 = torch.cat(model.get_transformed_projections(batch)).float().cpu()
+                grads_ok = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+                assert grads_ok
+            opt.step()
+            losses.append(float(out["loss"]))
+        runs[mode] = (losses, z0, ops.route_counts()["fp8_fwd"])
+    lb, zb, nb = runs["bf16"]
+    lf, zf, nf = runs["fp8"]
+    assert nb == 0 and nf >= 5 * 13, (nb, nf)  # 13 3x3 layers + the 1x1 layers with >= 512 input channels, every step
+    print("bf16", lb, "fp8", lf)
+    assert all(l == l and abs(l) < 1e4 for l in lf)
+    assert abs(lf[0] - lb[0]) <= 1e-2 * abs(lb[0]), (lf[0], lb[0])
+    cos = F.cosine_similarity(zb.double(), zf.double(), dim=1)
+    assert float(cos.mean()) >= 0.99 and float(cos.min()) >= 0.95, (float(cos.mean()), float(cos.min()))
+    for a, c in zip(lf, lb):
+        assert abs(a - c) <= 3e-2 * abs(c), (lf, lb)
+    assert abs(lf[-1] - lf[0]) > 1e-4  # the optimizer moved the fp8 run too
