@@ -464,6 +464,23 @@ int simhand_conv2d_fwd_fp8(const sh_conv_desc* d, const void* x_q, const void* w
                            float* bn_partial, sh_stream_t stream);
 
 /* ===========================================================================
+ * GPU batch producer ("next" row 8f-2): the per-sample augmentation chain of the contrastive recipes for a whole batch.
+ * Replaces (reference): SampleAugmenter.transform_sample with rotate / crop (+random_crop) / resize / color_jitter
+ * (src/data_loader/sample_augmenter.py:50-136, :173-318, :424-474), ToTensor + Normalize (src/data_loader/utils.py:279-285)
+ * and the angle / jitter bookkeeping of Data_Set.get_random_augment_param (src/data_loader/data_set.py:804-838).
+ *   images [n][h][w][3] uint8; joints [n][21][3] fp32 (x, y, depth) in image pixels;
+ *   draws (made by the caller): angle [n] degrees or NULL (rotate off), crop_margin [n], jitter [n][2] int32 (the
+ *   override / drawn crop-box jitter), hsab [n][4] = hue, saturation, alpha, beta factors or NULL (color_jitter off);
+ *   out_images [n][3][out_h][out_w] fp32 normalised; joints_aug [n][21][3]; rec [n][6] int32 = jitter_x, jitter_y (the
+ *   batch entries of App. B), origin_x, origin_y, crop width, crop height.
+ * OpenCV's own rounding is un-vendored: resampling / colour arithmetic follow the published definitions (oracle/augment.py
+ * says what is pinned). */
+size_t simhand_augment_workspace_bytes(int n);
+int simhand_augment_batch(const uint8_t* images, const float* joints, const float* angle, const float* crop_margin, const int32_t* jitter,
+                          const float* hsab, int n, int h, int w, int out_w, int out_h, float* out_images, float* joints_aug, int32_t* rec,
+                          void* workspace, size_t workspace_bytes, sh_stream_t stream);
+
+/* ===========================================================================
  * Optimizer ("next" row 8f-1): LARSWrapper(Adam) step, pl_bolts 0.2.2 semantics
  * (call site src/models/base_model.py:59-106) -- PARITY UNPINNED, restated from
  * the published source.  One launch per parameter tensor group element.

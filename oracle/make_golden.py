@@ -351,11 +351,54 @@ def golden_sharded() -> None:
         json.dump(res, f, indent=1, sort_keys=True)
 
 
+def golden_augment() -> None:
+    """Row 8f-2 (batch producer): the part of the reference's augmenter that does NOT go through OpenCV, executed as the
+    reference's own code -- SampleAugmenter.get_crop_size (sample_augmenter.py:424-474) and crop_sample's joint / jitter
+    bookkeeping (:173-195) for given jitters and crop margins, incl. boxes clamped at the image origin."""
+    import importlib
+
+    from oracle import augment
+
+    ref_import.install()
+    with ref_import.quiet():
+        sa = importlib.import_module("src.data_loader.sample_augmenter")
+    cfg = json.load(open(os.path.join(ref_import.REFERENCE_ROOT, "src", "experiments", "config", "training_config.json")))
+    flags = ref_import.EasyDict(cfg["augmentation_flags"])
+    params = ref_import.EasyDict(cfg["augmentation_params"])
+    aug = sa.SampleAugmenter(flags, params)
+    g = torch.Generator().manual_seed(77)
+    cases = []
+    for i in range(24):
+        centre = torch.rand(2, generator=g) * 160 + (10 if i % 4 == 0 else 40)   # some hands near the top-left corner
+        j = torch.cat((centre + torch.randn(21, 2, generator=g) * (8 + 3 * (i % 5)), torch.ones(21, 1)), dim=1)
+        jitter = [int(torch.randint(0, 20, (1,), generator=g)), int(torch.randint(0, 20, (1,), generator=g))]
+        margin = float(0.9 + 0.6 * torch.rand(1, generator=g))
+        ox, oy, side = aug.get_crop_size(j.clone(), jitter, margin)
+        want = {"origin_x": int(ox), "origin_y": int(oy), "side": int(side), "jitter_x": int(aug.jitter_x), "jitter_y": int(aug.jitter_y)}
+        got = augment.crop_box(j[:, :2].numpy(), jitter, margin)
+        assert all(got[k] == v for k, v in want.items()), (i, got, want)
+        img = np.zeros((224, 224, 3), dtype=np.uint8)
+        crop, jc, shift = aug.crop_sample(img, j.clone(), jitter)  # random_crop flag: margin drawn inside -> only shapes / shift are kept
+        cases.append({"joints": j.numpy().tolist(), "jitter": jitter, "crop_margin": margin, **want})
+        # rotation centre of rotate_sample (:256-259): get_crop_size(joints, [0, 0], 0.0)
+        ox0, oy0, s0 = aug.get_crop_size(j.clone(), [0, 0], 0.0)
+        cases[-1]["rot_center"] = [int(ox0 + s0 / 2), int(oy0 + s0 / 2)]
+    with open(os.path.join(OUT, "augment_crop.json"), "w") as f:
+        json.dump({"cases": cases, "resize_shape": list(params.resize_shape), "crop_box_jitter": list(params.crop_box_jitter),
+                   "crop_margin_range": list(params.crop_margin_range), "angle_range": [params.min_angle, params.max_angle],
+                   "hue_factor_range": list(params.hue_factor_range), "sat_factor_range": list(params.sat_factor_range),
+                   "value_factor_alpha_range": list(params.value_factor_alpha_range),
+                   "value_factor_beta_range": list(params.value_factor_beta_range)}, f, indent=1, sort_keys=True)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "sharded":  # only the a13 fixture
         golden_sharded()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "augment":  # only the 8f-2 fixture
+        golden_augment()
         return
     mu = ref_import.models_utils()
     golden_loss(mu)
@@ -363,6 +406,7 @@ def main() -> None:
     golden_postprocess()
     golden_step()
     golden_sharded()
+    golden_augment()
     golden_cli()
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):

@@ -12,18 +12,26 @@ import sqlite3
 import sys
 
 cur = sqlite3.connect(sys.argv[1]).cursor()
-acc = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.Counter()
-seen = set()
 cols = [r[1] for r in cur.execute("pragma table_info(pmc_events)")]
-idc = "dispatch_id" if "dispatch_id" in cols else ("id" if "id" in cols else None)
+print("pmc_events columns:", cols)
+idc = next((c for c in cols if "dispatch" in c.lower()), None)
+# one row per (dispatch, counter, hardware instance -- e.g. one per XCD): counters that COUNT work add up over the instances,
+# GRBM_GUI_ACTIVE (chip-busy cycles, the same wall clock seen by every instance) is taken once per dispatch (max)
+per_disp = collections.defaultdict(lambda: collections.defaultdict(list))
 q = f"select name, counter_name, counter_value{', ' + idc if idc else ''} from pmc_events"
+auto_id = collections.Counter()
 for row in cur.execute(q):
     name = re.sub(r"\(.*", "", row[0])
-    acc[name][row[1]] += row[2]
-    key = (name, row[3]) if idc else None
-    if row[1] == "GRBM_GUI_ACTIVE":
-        cnt[name] += 1
+    did = row[3] if idc else None
+    per_disp[(name, did)][row[1]].append(row[2])
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.Counter()
+for (name, did), d in per_disp.items():
+    inst = max(1, len(d.get("GRBM_GUI_ACTIVE", [0])))
+    n_disp = 1 if idc else max(1, inst // 8)  # without a dispatch id: assume the 8 XCD instances per dispatch
+    for k, v in d.items():
+        acc[name][k] += (max(v) if idc else sum(v) / (inst / n_disp)) if k == "GRBM_GUI_ACTIVE" else sum(v)
+    cnt[name] += n_disp
 dur = {}
 if len(sys.argv) > 3:
     c2 = sqlite3.connect(sys.argv[3]).cursor()

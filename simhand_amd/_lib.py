@@ -171,6 +171,8 @@ SIGNATURES = {
     "simhand_fp8_pack_krsc": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "simhand_conv2d_fwd_fp8_supported": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_fwd_fp8": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "simhand_augment_workspace_bytes": (_S, [_I]),
+    "simhand_augment_batch": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _S, _P]),
     "simhand_lars_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P]),
 }
 

@@ -83,12 +83,14 @@ def build_parser(description: str = "Script for training baseline supervised mod
     return p
 
 
-BUILD_ONLY_FLAGS = ("synthetic", "synthetic_samples", "precision", "image_size", "max_steps", "out_dir")
+BUILD_ONLY_FLAGS = ("synthetic", "synthetic_raw", "synthetic_samples", "precision", "image_size", "max_steps", "out_dir")
 
 
 def add_build_flags(p: argparse.ArgumentParser) -> argparse.ArgumentParser:
     """Additive flags of this build: none of them changes a reference default."""
     p.add_argument("--synthetic", action="store_true", help="train on the SURVEY 8d synthetic batch schema (no dataset on disk)")
+    p.add_argument("--synthetic_raw", action="store_true",
+                   help="synthetic RAW frames + joints through the GPU batch producer (the reference's augmentation chain on the device)")
     p.add_argument("--synthetic_samples", type=int, default=None, help="samples per synthetic epoch (default 4 global batches)")
     p.add_argument("--precision", type=str, default=None, choices=["32", "bf16", "16", "fp8"],
                    help="kernel dtype: 32 = exact-fp32 MFMA, bf16/16 = bf16 MFMA (overrides training_config.json's 16)")

@@ -73,13 +73,21 @@ def main(argv=None):
     say(f"Train parameters {pformat(dict(train_param))}")
     seed_everything(train_param.seed)
 
-    if not args.synthetic:
-        raise SystemExit("dataset readers (src/data_loader/*) are outside this build's scope: pass --synthetic "
-                         "to train on the synthetic batch schema, or feed Trainer.fit() your own iterable of batch dicts")
+    if not (args.synthetic or args.synthetic_raw):
+        raise SystemExit("dataset readers (src/data_loader/*) are outside this build's scope: pass --synthetic (ready batches) or "
+                         "--synthetic_raw (raw frames through the GPU batch producer), or feed Trainer.fit() your own iterable of batch dicts")
     size = args.image_size or (train_param.augmentation_params.resize_shape[0] if train_param.augmentation_flags.resize else 224)
     samples = args.synthetic_samples or 4 * train_param.batch_size
-    device = torch.device("cuda", local)
-    data = SyntheticPairs(samples, train_param.batch_size, size, rank, world, train_param.seed, device)
+    device = torch.device("cuda", torch.cuda.current_device())
+    if args.synthetic_raw:
+        from .data import GpuAugmenter, SyntheticRawPairs
+
+        if args.image_size:
+            train_param.augmentation_params.resize_shape = [args.image_size, args.image_size]
+        augmenter = GpuAugmenter(train_param.augmentation_flags, train_param.augmentation_params)
+        data = SyntheticRawPairs(augmenter, samples, train_param.batch_size, rank, world, train_param.seed, device)
+    else:
+        data = SyntheticPairs(samples, train_param.batch_size, size, rank, world, train_param.seed, device)
 
     model_param = update_model_params(model_param, args, samples, train_param)
     model_param.augmentation = [k for k, v in train_param.augmentation_flags.items() if v]

@@ -776,6 +776,25 @@ def conv2d_fwd_fp8(d: ConvDesc, x_q, w_q, x_scaler: FP8Scaler, w_scaler: FP8Scal
     return y, part
 
 
+# ---------------------------------------------------------------- batch producer
+def augment_batch(images_u8: torch.Tensor, joints: torch.Tensor, angle, crop_margin, jitter, hsab, out_hw=(128, 128)):
+    """images [n][h][w][3] uint8, joints [n][21][3] fp32, angle [n] fp32 or None, crop_margin [n] fp32, jitter [n][2] int32,
+    hsab [n][4] fp32 or None -> (images [n][3][oh][ow] fp32 normalised, joints_aug [n][21][3], rec [n][6] int32)."""
+    lib = _lib_dev()
+    n, h, w, _ = images_u8.shape
+    oh, ow = out_hw
+    dev = images_u8.device
+    out = torch.empty(n, 3, oh, ow, dtype=torch.float32, device=dev)
+    ja = torch.empty(n, 21, 3, dtype=torch.float32, device=dev)
+    rec = torch.empty(n, 6, dtype=torch.int32, device=dev)
+    nb = lib.simhand_augment_workspace_bytes(n)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    check(lib.simhand_augment_batch(_ptr(images_u8, torch.uint8), _ptr(joints, _F32), _ptr(angle, _F32), _ptr(crop_margin, _F32),
+                                    _ptr(jitter, torch.int32), _ptr(hsab, _F32), n, h, w, ow, oh, _ptr(out), _ptr(ja), _ptr(rec), _ptr(ws), nb,
+                                    _stream()), "augment_batch")
+    return out, ja, rec
+
+
 # -------------------------------------------------------------------- optimizer
 def lars_adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, weight_decay: float, use_lars: bool,
                    betas=(0.9, 0.999), adam_eps: float = 1e-8, lars_eta: float = 0.02, lars_eps: float = 1e-8,
