@@ -481,6 +481,25 @@ int simhand_augment_batch(const uint8_t* images, const float* joints, const floa
                           void* workspace, size_t workspace_bytes, sh_stream_t stream);
 
 /* ===========================================================================
+ * Thin RCCL wrappers behind an opaque communicator handle -- the exchange steps of the path for a caller
+ * that does not go through torch.distributed: all-gather of the projection / joint rows into the reference row order,
+ * all-reduce of the distance statistics (MAX / MIN / SUM) and of the parameter gradients (SUM).
+ * Replaces (reference): nn.DataParallel's scatter / gather / reduce-add under strategy="dp" (src/experiments/main.py:152-163).
+ * librccl.so is resolved at run time (the copy the process already mapped, else dlopen); every entry point returns an
+ * error if it cannot be loaded.  simhand_comm_init binds the communicator to the CURRENT HIP device; rank 0 creates the id
+ * and hands its SH_COMM_ID_BYTES to the other ranks over any side channel.  `count` = elements PER RANK for all_gather.
+ * =========================================================================== */
+#define SH_COMM_ID_BYTES 128
+enum sh_comm_dtype { SH_COMM_F32 = 0, SH_COMM_F64 = 1, SH_COMM_BF16 = 2, SH_COMM_I64 = 3 };
+enum sh_comm_op { SH_COMM_SUM = 0, SH_COMM_MAX = 1, SH_COMM_MIN = 2 };
+int simhand_comm_unique_id(uint8_t* id /*[SH_COMM_ID_BYTES]*/);
+int simhand_comm_init(const uint8_t* id, int world, int rank, void** comm);
+int simhand_comm_destroy(void* comm);
+int simhand_comm_world(void* comm, int* world, int* rank);
+int simhand_comm_all_gather(void* comm, const void* send, void* recv, int64_t count, int dtype, sh_stream_t stream);
+int simhand_comm_all_reduce(void* comm, const void* send, void* recv, int64_t count, int dtype, int op, sh_stream_t stream);
+
+/* ===========================================================================
  * Optimizer ("next" row 8f-1): LARSWrapper(Adam) step, pl_bolts 0.2.2 semantics
  * (call site src/models/base_model.py:59-106) -- PARITY UNPINNED, restated from
  * the published source.  One launch per parameter tensor group element.

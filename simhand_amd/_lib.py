@@ -173,6 +173,12 @@ SIGNATURES = {
     "simhand_conv2d_fwd_fp8": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "simhand_augment_workspace_bytes": (_S, [_I]),
     "simhand_augment_batch": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _S, _P]),
+    "simhand_comm_unique_id": (_I, [_P]),
+    "simhand_comm_init": (_I, [_P, _I, _I, C.POINTER(_P)]),
+    "simhand_comm_destroy": (_I, [_P]),
+    "simhand_comm_world": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
+    "simhand_comm_all_gather": (_I, [_P, _P, _P, _L, _I, _P]),
+    "simhand_comm_all_reduce": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "simhand_lars_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P]),
 }
 

@@ -42,6 +42,71 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
     return rank, local, world
 
 
+class RcclComm:
+    """A communicator over the C ABI's thin RCCL wrappers (``simhand_comm_*``, include/simhand_hip.h) -- the exchange steps
+    of the path without torch.distributed in the data path.  Pass it as ``model.process_group`` (or as the ``group`` of
+    ``ShardedNtxent`` / ``allreduce_gradients``) and the all-gathers / all-reduces of the step go RCCL -> xGMI directly on
+    the current HIP stream.  One communicator per process, bound to the current device at construction."""
+
+    _DT = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.int64: 3}
+    _OP = {"sum": 0, "max": 1, "min": 2}
+
+    def __init__(self, id_bytes: bytes, world: int, rank: int):
+        import ctypes as C
+
+        from .. import _lib
+
+        self._lib, self._C = _lib.load(), C
+        _lib.require_device()
+        handle = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(id_bytes)
+        _lib.check(self._lib.simhand_comm_init(buf, world, rank, C.byref(handle)), "comm_init")
+        self._h = handle
+        w, r = C.c_int(), C.c_int()
+        _lib.check(self._lib.simhand_comm_world(self._h, C.byref(w), C.byref(r)), "comm_world")
+        self.world, self.rank = w.value, r.value
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        from .. import _lib
+
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.load().simhand_comm_unique_id(buf), "comm_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def from_torch_distributed(cls, group=None) -> "RcclComm":
+        """Bootstrap over an existing torch.distributed group (any backend): rank 0's id travels by broadcast_object_list."""
+        box = [cls.unique_id() if dist.get_rank(group) == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(box[0], dist.get_world_size(group), dist.get_rank(group))
+
+    def _stream(self):
+        return self._C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def all_gather_into(self, out: torch.Tensor, x: torch.Tensor) -> None:
+        from .. import _lib
+
+        assert out.is_contiguous() and x.is_contiguous() and out.numel() == x.numel() * self.world and out.dtype == x.dtype
+        _lib.check(self._lib.simhand_comm_all_gather(self._h, self._C.c_void_p(x.data_ptr()), self._C.c_void_p(out.data_ptr()), x.numel(),
+                                                     self._DT[x.dtype], self._stream()), "comm_all_gather")
+
+    def all_reduce_(self, t: torch.Tensor, op: str = "sum") -> torch.Tensor:
+        from .. import _lib
+
+        assert t.is_contiguous()
+        _lib.check(self._lib.simhand_comm_all_reduce(self._h, self._C.c_void_p(t.data_ptr()), self._C.c_void_p(t.data_ptr()), t.numel(),
+                                                     self._DT[t.dtype], self._OP[op], self._stream()), "comm_all_reduce")
+        return t
+
+    def close(self) -> None:
+        if self._h is not None:
+            self._lib.simhand_comm_destroy(self._h)
+            self._h = None
+
+
 def shard_pairs(global_pairs: int, rank: int, world: int) -> Tuple[int, int]:
     """(first pair, number of pairs) of this rank; the global batch must divide evenly
     (the loss kernel's row map assumes equal shards)."""
@@ -64,13 +129,20 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
     """SUM all-reduce over a FIXED parameter list: every rank buckets the same tensors in the same order, whatever
     received a gradient locally.  A trainable parameter without a gradient on this rank contributes zeros (and receives
     the other ranks' sum); parameters with requires_grad=False are skipped on every rank alike."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    abi = isinstance(group, RcclComm)
+    if abi:
+        if group.world == 1:
+            return
+    elif not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
     plist = [p for p in params if p.requires_grad]
     # which parameters have a gradient anywhere: one small MAX all-reduce keeps the bucket layout identical on all ranks
-    has = torch.tensor([1 if p.grad is not None else 0 for p in plist], dtype=torch.int32, device=plist[0].device if plist else "cpu")
+    has = torch.tensor([1 if p.grad is not None else 0 for p in plist], dtype=torch.int64, device=plist[0].device if plist else "cpu")
     if has.numel():
-        dist.all_reduce(has, op=dist.ReduceOp.MAX, group=group)
+        if abi:
+            group.all_reduce_(has, "max")
+        else:
+            dist.all_reduce(has, op=dist.ReduceOp.MAX, group=group)
     keep = has.tolist()
     grads: List[torch.Tensor] = []
     for p, k in zip(plist, keep):
@@ -88,7 +160,11 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
         if not bucket:
             return
         flat = torch.cat([g.reshape(-1) for g in bucket])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        if abi:  # stream-ordered on the current stream: nothing to wait for on the host
+            group.all_reduce_(flat, "sum")
+            work = None
+        else:
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
         pending.append((work, flat, bucket))
         bucket, size = [], 0
 
@@ -99,7 +175,8 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
             flush()
     flush()
     for work, flat, bucket_ in pending:
-        work.wait()
+        if work is not None:
+            work.wait()
         off = 0
         for g in bucket_:
             n = g.numel()

@@ -52,7 +52,14 @@ class LossConfig:
                           lambda_neg=float(getattr(config, "non_linear_lambda_neg", 0.0) or 0.0))
 
 
+def _is_abi(group) -> bool:
+    """`group` is a simhand_amd.host.dist.RcclComm (the C ABI's thin RCCL wrappers) instead of a torch.distributed group."""
+    return group is not None and hasattr(group, "all_gather_into")
+
+
 def _world(group):
+    if _is_abi(group):
+        return group.world, group.rank
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(group), dist.get_rank(group)
     return 1, 0
@@ -65,9 +72,20 @@ def _gather_rows(x_loc: Tensor, b_loc: int, world: int, group) -> Tensor:
         return x_loc
     B = b_loc * world
     out = torch.empty(2 * B, x_loc.shape[1], dtype=x_loc.dtype, device=x_loc.device)
-    dist.all_gather_into_tensor(out[:B], x_loc[:b_loc].contiguous(), group=group)
-    dist.all_gather_into_tensor(out[B:], x_loc[b_loc:].contiguous(), group=group)
+    if _is_abi(group):
+        group.all_gather_into(out[:B], x_loc[:b_loc].contiguous())
+        group.all_gather_into(out[B:], x_loc[b_loc:].contiguous())
+    else:
+        dist.all_gather_into_tensor(out[:B], x_loc[:b_loc].contiguous(), group=group)
+        dist.all_gather_into_tensor(out[B:], x_loc[b_loc:].contiguous(), group=group)
     return out
+
+
+def _all_reduce(t: Tensor, op: str, group) -> Tensor:
+    if _is_abi(group):
+        return group.all_reduce_(t, op)
+    dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op], group=group)
+    return t
 
 
 class ShardedNtxent(torch.autograd.Function):
@@ -102,10 +120,8 @@ class ShardedNtxent(torch.autograd.Function):
             if cfg.use_wneg:
                 D = K.neg_dist(J, B, mode, b_loc, rank * b_loc, stats)
                 if world > 1:
-                    mm = torch.stack((stats[0], -stats[1]))
-                    dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=group)
-                    sm = stats[2:3].clone()
-                    dist.all_reduce(sm, op=dist.ReduceOp.SUM, group=group)
+                    mm = _all_reduce(torch.stack((stats[0], -stats[1])), "max", group)
+                    sm = _all_reduce(stats[2:3].clone(), "sum", group)
                     stats[0], stats[1], stats[2] = mm[0], -mm[1], sm[0]
         plan = K.NtxentPlan(B, b_loc, rank * b_loc, cfg.weight_type if weighted or explicit else None,
                             cfg.use_wpos and dpos is not None, cfg.use_wneg and D is not None, cfg.temperature,
@@ -113,7 +129,7 @@ class ShardedNtxent(torch.autograd.Function):
         neg_loc, loss = K.ntxent_fwd(plan, Z, D, dpos, stats)
         if world > 1:
             neg_all = _gather_rows(neg_loc.view(rows, 1), b_loc, world, group).view(-1)
-            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce(loss, "sum", group)
         else:
             neg_all = neg_loc
         ctx.k, ctx.plan = K, plan

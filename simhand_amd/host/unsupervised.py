@@ -156,8 +156,9 @@ class SimCLR(BaseModel):
         if self.weighted:
             j1, j2 = self._joints(batch)
             if getattr(self.config, "use_pca", False) and type(self).__name__ == "HandCLR_W":
-                if torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                        torch.distributed.get_world_size(self.process_group) > 1:
+                from .dist_loss import _world
+
+                if _world(self.process_group)[0] > 1:
                     # the reference's PCA basis comes from a randomised torch.pca_lowrank of the batch it sees
                     # (src/models/utils.py:192-215): per-rank bases would put the gathered joints in incompatible
                     # coordinates, so the global-negative loss is undefined for this flag

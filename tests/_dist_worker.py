@@ -40,6 +40,19 @@ loss.backward()
 shdist.allreduce_gradients(model.parameters(), bucket_bytes=1 << 20)
 torch.cuda.synchronize()
 
+if BACKEND == "nccl" and world > 1:
+    # the same step with every exchange routed through the C ABI's RCCL wrappers (simhand_comm_*) instead of torch.distributed
+    comm = shdist.RcclComm.from_torch_distributed()
+    assert (comm.world, comm.rank) == (world, rank)
+    model.zero_grad()
+    model.process_group = comm
+    loss_abi = model.training_step(shard, 0)["loss"]
+    loss_abi.backward()
+    shdist.allreduce_gradients(model.parameters(), group=comm, bucket_bytes=1 << 20)
+    torch.cuda.synchronize()
+    assert abs(loss_abi.item() - loss.item()) <= 1e-6 * abs(loss.item()), (loss_abi.item(), loss.item())
+    comm.close()
+
 if rank == 0:
     want = meta["ranks"][str(world)]
     assert abs(loss.item() - want["loss"]) <= 1e-4 * abs(want["loss"]), (loss.item(), want["loss"])

@@ -56,3 +56,39 @@ def test_bench_self_launch_two_ranks():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 16 and res["config"]["world_size_backend"] == 2
     assert res["value"] > 0 and res["scaling"] == "weak"
+
+
+def test_rccl_wrappers_run_on_one_gpu():
+    """The C ABI's thin RCCL wrappers (simhand_comm_*): a one-rank communicator on this GPU runs real RCCL all-gather /
+    all-reduce launches on the current stream, and the sharded loss routed through it equals the plain single-process loss."""
+    from oracle import step as orc
+    from simhand_amd.host import dist as shdist
+    from simhand_amd.host import dist_loss
+
+    comm = shdist.RcclComm(shdist.RcclComm.unique_id(), 1, 0)
+    try:
+        assert (comm.world, comm.rank) == (1, 0)
+        x = torch.arange(24, dtype=torch.float32, device="cuda").view(6, 4)
+        out = torch.empty_like(x)
+        comm.all_gather_into(out, x)
+        t = torch.tensor([1.5, -2.0], dtype=torch.float64, device="cuda")
+        comm.all_reduce_(t, "max")
+        b16 = torch.ones(8, dtype=torch.bfloat16, device="cuda")
+        comm.all_reduce_(b16, "sum")
+        i64 = torch.tensor([3, 4], dtype=torch.int64, device="cuda")
+        comm.all_reduce_(i64, "min")
+        torch.cuda.synchronize()
+        assert torch.equal(out, x) and t.tolist() == [1.5, -2.0] and b16.float().sum().item() == 8 and i64.tolist() == [3, 4]
+        g = torch.Generator().manual_seed(4)
+        z = torch.nn.functional.normalize(torch.randn(16, 128, generator=g)).to("cuda").requires_grad_(True)
+        j = (torch.rand(16, 42, generator=g) * 128).to("cuda")
+        cfg = dist_loss.LossConfig(weight_type="linear", diff_type="mpjpe", use_wpos=True, use_wneg=True)
+        la = dist_loss.ShardedNtxent.apply(z, j, cfg, comm, None, None)
+        lb = dist_loss.ShardedNtxent.apply(z, j, cfg, None, None, None)
+        assert torch.equal(la, lb)
+        p = torch.nn.Parameter(torch.ones(5, device="cuda"))
+        p.grad = torch.full((5,), 2.0, device="cuda")
+        shdist.allreduce_gradients([p], group=comm)  # world 1: a no-op by contract
+        assert p.grad.tolist() == [2.0] * 5
+    finally:
+        comm.close()
