@@ -75,7 +75,8 @@ enum sh_route {
   SH_ROUTE_NTXENT_FWD = 25, SH_ROUTE_NTXENT_BWD = 26,
   SH_ROUTE_FP8_FWD = 27, SH_ROUTE_FP8_DGRAD = 28,           /* e4m3 MFMA (K = 128 per instruction) tile kernel */
   SH_ROUTE_BN_APPLY_GRAM = 29,                              /* BN-apply + ReLU fused into the Gram (x^T x) launch */
-  SH_ROUTE_WGRAD_BNBWD = 30,                                /* BN-backward apply fused into the 1x1 weight gradient's dy loader */
+  SH_ROUTE_WGRAD_BNBWD = 30,
+  SH_ROUTE_NTXENT_FUSED_DIST = 31,                          /* loss tile kernel computing the joint distances in-tile (no D block) */                                /* BN-backward apply fused into the 1x1 weight gradient's dy loader */
   SH_ROUTE_COUNT = 32
 };
 int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
@@ -152,6 +153,18 @@ int simhand_ntxent_fwd(const sh_ntxent_params* p, const float* Z_all, const floa
 int simhand_ntxent_bwd(const sh_ntxent_params* p, const float* Z_all, const float* D_loc, const float* d_pos,
                        const double* stats, const float* neg_all, const float* dloss, float* dZ_loc,
                        void* workspace, size_t workspace_bytes, sh_stream_t stream);
+
+/* FUSED form (north star: "the B x B cosine-similarity matrix + adaptive MPJPE-weighted softmax-cross-entropy as one
+ * LDS-tiled kernel"): the joint-distance tile is computed inside the loss tile kernel next to the similarity tile, from
+ * J_all [N][F] (column tile staged in LDS, the lane's own row in registers) -- NO [rows_loc][N] distance block exists in HBM.
+ * The statistics (max / min / sum of D) still come from simhand_neg_dist, called with D_loc = NULL (statistics only).
+ * Distances are evaluated in the same operation order as simhand_neg_dist: results are bit-identical to the D-block form. */
+int simhand_ntxent_fwd_fused(const sh_ntxent_params* p, const float* Z_all, const float* J_all, int F, int dist_mode, const float* d_pos,
+                             const double* stats, float* neg_loc, float* loss_part, void* workspace, size_t workspace_bytes,
+                             sh_stream_t stream);
+int simhand_ntxent_bwd_fused(const sh_ntxent_params* p, const float* Z_all, const float* J_all, int F, int dist_mode, const float* d_pos,
+                             const double* stats, const float* neg_all, const float* dloss, float* dZ_loc, void* workspace,
+                             size_t workspace_bytes, sh_stream_t stream);
 
 /* ===========================================================================
  * Projection post-process (per row of 128 = 64 2-D points)

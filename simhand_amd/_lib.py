@@ -31,7 +31,7 @@ PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn", "pool", "loss", "m
 ROUTES = ("igemm128_fwd", "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "igemm256_tail", "gemm1x1_fwd", "gemm1x1_fwd_bnact",
           "gemm1x1_dgrad", "c64_fwd", "c64_dgrad", "stem_fwd", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
           "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
-          "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram", "wgrad_bnbwd")
+          "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram", "wgrad_bnbwd", "ntxent_fused_dist")
 ROUTE_COUNT = 32
 
 
@@ -92,6 +92,8 @@ SIGNATURES = {
     "simhand_ntxent_workspace_bytes":(_S, [C.POINTER(NtxentParams)]),
     "simhand_ntxent_fwd": (_I, [C.POINTER(NtxentParams), _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_ntxent_bwd": (_I, [C.POINTER(NtxentParams), _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "simhand_ntxent_fwd_fused": (_I, [C.POINTER(NtxentParams), _P, _P, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
+    "simhand_ntxent_bwd_fused": (_I, [C.POINTER(NtxentParams), _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_proj_postprocess_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "simhand_proj_postprocess_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "simhand_proj_stats": (_I, [_P, _I, _P, _P, _P]),

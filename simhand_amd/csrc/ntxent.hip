@@ -125,6 +125,25 @@ __global__ __launch_bounds__(1024) void pos_dist_kernel(const float* __restrict_
   }
 }
 
+// One joint distance, evaluated in exactly the order of neg_dist_kernel (accumulate over joints, then / nj or sqrt), so the
+// in-tile (fused) and the materialised D agree bit for bit.  ji: this lane's row in registers, jj: the other row in LDS.
+template <int MODE>
+__device__ __forceinline__ float pair_dist(const float (&ji)[kMaxF], const float* __restrict__ jj, int F) {
+  float acc = 0.f;
+  if (MODE == SH_DIST_L2) {
+#pragma unroll 2
+    for (int f = 0; f < F; ++f) {
+      const float t = ji[f] - jj[f];
+      acc += t * t;
+    }
+    return sqrtf(acc);
+  }
+  const int nj = F / 2;
+#pragma unroll 3
+  for (int j = 0; j < nj; ++j) acc = pair_accum<MODE>(acc, ji[2 * j] - jj[2 * j], ji[2 * j + 1] - jj[2 * j + 1]);
+  return MODE == SH_DIST_MPJPE ? acc / (float)nj : sqrtf(acc);
+}
+
 // D row block, src/models/utils.py:237-253 (PCA :280-293).  64x64 tile per block,
 // 4x4 register block per thread.
 template <int MODE>
@@ -195,7 +214,7 @@ __global__ __launch_bounds__(256) void neg_dist_kernel(const float* __restrict__
       const int gc = c0 + tx + 16 * b;
       float d = MODE == SH_DIST_MPJPE ? acc[a][b] / inv_nj : sqrtf(acc[a][b]);
       if (lr < rows_loc && gc < N) {
-        D[(size_t)lr * N + gc] = d;
+        if (D != nullptr) D[(size_t)lr * N + gc] = d;  // null: statistics only (the loss kernels recompute d in their tiles)
         vmax = fmaxf(vmax, d);
         vmin = fminf(vmin, d);
         if (d != d) vmax = vmin = d;
@@ -308,11 +327,16 @@ __device__ __forceinline__ void stage_z_tile(float* zj, const float* __restrict_
 
 // BWD = false: neg_partial[cs][lrow] = sum over this column range of exp(w s / t), j != i
 // BWD = true : dz_partial[cs][lrow][128] = sum_j w e (1/neg_i + 1/neg_j) z_j
-template <bool BWD>
+// DMODE < 0: the joint distances come from the materialised row block D.  DMODE = sh_dist_mode: FUSED -- the distance tile
+// is computed here, next to the similarity tile, from the joint rows (J_all [N][F] staged in LDS per column tile, this lane's
+// own row in registers); no [rows_loc][N] block exists in HBM (north star: "one LDS-tiled kernel").
+template <bool BWD, int DMODE = -1>
 __global__ __launch_bounds__(256) void ntxent_tile_kernel(LossArgs a, const float* __restrict__ Z,
                                                           const float* __restrict__ D, const double* __restrict__ stats,
-                                                          const float* __restrict__ neg_all, float* __restrict__ out) {
+                                                          const float* __restrict__ neg_all, float* __restrict__ out,
+                                                          const float* __restrict__ J = nullptr, int F = 0) {
   __shared__ __attribute__((aligned(16))) float zj[kTJ * kLds];
+  __shared__ float jjt[DMODE >= 0 ? kTJ * (kMaxF + 1) : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int li = lane & 15, g = lane >> 4;
   const int rows_loc = 2 * a.map.b_loc;
@@ -327,6 +351,11 @@ __global__ __launch_bounds__(256) void ntxent_tile_kernel(LossArgs a, const floa
     zi[c] = rvalid ? *reinterpret_cast<const float4*>(Z + (size_t)grow * kDim + 16 * c + 4 * g) : make_float4(0, 0, 0, 0);
   float inv_neg_i = 0.f;
   if (BWD) inv_neg_i = rvalid ? 1.0f / neg_all[grow] : 0.f;
+  float ji[kMaxF];
+  if constexpr (DMODE >= 0) {
+#pragma unroll
+    for (int f = 0; f < kMaxF; ++f) ji[f] = (rvalid && f < F) ? J[(size_t)grow * F + f] : 0.f;
+  }
 
   float rowsum = 0.f;
   f32x4 dz[8];
@@ -340,6 +369,13 @@ __global__ __launch_bounds__(256) void ntxent_tile_kernel(LossArgs a, const floa
     const int j0 = jt * kTJ;
     __syncthreads();
     stage_z_tile(zj, Z, j0, a.N);
+    if constexpr (DMODE >= 0) {
+      if (wq.wtype != SH_W_NONE)
+        for (int idx = threadIdx.x; idx < kTJ * F; idx += 256) {
+          const int r = idx / F, f = idx - r * F;
+          jjt[r * (kMaxF + 1) + f] = j0 + r < a.N ? J[(size_t)(j0 + r) * F + f] : 0.f;
+        }
+    }
     __syncthreads();
 #pragma unroll 1
     for (int js = 0; js < 4; ++js) {
@@ -361,7 +397,9 @@ __global__ __launch_bounds__(256) void ntxent_tile_kernel(LossArgs a, const floa
         const bool ok = rvalid && j < a.N && j != grow;
         float w = 1.0f;
         if (wq.wtype != SH_W_NONE) {
-          const float d = ok ? D[(size_t)lrow * a.N + j] : 0.f;
+          float d;
+          if constexpr (DMODE >= 0) d = ok ? pair_dist<DMODE>(ji, jjt + (js * 16 + 4 * g + r) * (kMaxF + 1), F) : 0.f;
+          else d = ok ? D[(size_t)lrow * a.N + j] : 0.f;
           w = weight_of(d, wq);
         }
         const float e = expf(t[r] * w * a.inv_t);  // exp(cov * w / temperature), utils.py:412-413
@@ -513,6 +551,26 @@ static int make_args(const sh_ntxent_params* p, LossArgs* a) {
   return 0;
 }
 
+// launch the tile kernel for the fused-distance mode `dm`
+template <bool BWD>
+static void launch_tile_fused(int dm, dim3 grid, hipStream_t s, const LossArgs& a, const float* Z, const double* stats, const float* neg_all,
+                              float* out, const float* J, int F) {
+  switch (dm) {
+    case SH_DIST_MPJPE: ntxent_tile_kernel<BWD, SH_DIST_MPJPE><<<grid, 256, 0, s>>>(a, Z, nullptr, stats, neg_all, out, J, F); break;
+    case SH_DIST_W_ABS: ntxent_tile_kernel<BWD, SH_DIST_W_ABS><<<grid, 256, 0, s>>>(a, Z, nullptr, stats, neg_all, out, J, F); break;
+    case SH_DIST_W_O_ABS: ntxent_tile_kernel<BWD, SH_DIST_W_O_ABS><<<grid, 256, 0, s>>>(a, Z, nullptr, stats, neg_all, out, J, F); break;
+    default: ntxent_tile_kernel<BWD, SH_DIST_L2><<<grid, 256, 0, s>>>(a, Z, nullptr, stats, neg_all, out, J, F); break;
+  }
+}
+
+static int check_fused(const LossArgs& a, const float* J_all, int F, int dist_mode, const char* who) {
+  SH_REQUIRE(a.wtype != SH_W_EXPLICIT, "%s: explicit weight tensors have no joints to fuse", who);
+  SH_REQUIRE(!a.use_wneg || J_all, "%s: J_all required when negatives are weighted", who);
+  SH_REQUIRE(F >= 1 && F <= kMaxF && dist_mode >= 0 && dist_mode <= SH_DIST_L2 && (dist_mode == SH_DIST_L2 || F % 2 == 0), "%s: bad F=%d / dist_mode=%d",
+             who, F, dist_mode);
+  return 0;
+}
+
 }  // namespace sh
 
 using namespace sh;
@@ -535,7 +593,7 @@ size_t simhand_neg_dist_workspace_bytes(int rows_loc, int N) {
 
 int simhand_neg_dist(const float* J_all, int B, int F, int dist_mode, int b_loc, int pair_off, float* D_loc, double* stats,
                      void* workspace, size_t workspace_bytes, sh_stream_t stream) {
-  SH_REQUIRE(J_all && D_loc && stats && workspace, "neg_dist: NULL pointer");
+  SH_REQUIRE(J_all && stats && workspace, "neg_dist: NULL pointer");  // D_loc may be NULL: statistics only
   SH_REQUIRE(B >= 1 && F >= 1 && F <= kMaxF, "neg_dist: bad B=%d F=%d", B, F);
   SH_REQUIRE(b_loc >= 1 && pair_off >= 0 && pair_off + b_loc <= B, "neg_dist: bad partition");
   SH_REQUIRE(dist_mode >= 0 && dist_mode <= SH_DIST_L2, "neg_dist: bad dist_mode %d", dist_mode);
@@ -546,7 +604,7 @@ int simhand_neg_dist(const float* J_all, int B, int F, int dist_mode, int b_loc,
   dim3 grid(ceil_div(N, 64), ceil_div(rows, 64));
   RowMap map{B, b_loc, pair_off};
   double* partial = (double*)workspace;
-  ProfScope ps(SH_PROF_LOSS, s, 0, (double)rows * N * 4);
+  ProfScope ps(SH_PROF_LOSS, s, 0, D_loc ? (double)rows * N * 4 : 0.0);
   switch (dist_mode) {
     case SH_DIST_MPJPE: neg_dist_kernel<SH_DIST_MPJPE><<<grid, 256, 0, s>>>(J_all, map, N, F, D_loc, partial); break;
     case SH_DIST_W_ABS: neg_dist_kernel<SH_DIST_W_ABS><<<grid, 256, 0, s>>>(J_all, map, N, F, D_loc, partial); break;
@@ -599,6 +657,52 @@ int simhand_ntxent_fwd(const sh_ntxent_params* p, const float* Z_all, const floa
   if (check_launch("ntxent_fwd finalize")) return 1;
   sum_rows_kernel<<<1, 1024, 0, s>>>(loss_rows, rows, 1.0 / (double)a.N, loss_part);
   return check_launch("ntxent_fwd sum");
+}
+
+int simhand_ntxent_fwd_fused(const sh_ntxent_params* p, const float* Z_all, const float* J_all, int F, int dist_mode, const float* d_pos,
+                             const double* stats, float* neg_loc, float* loss_part, void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+  LossArgs a;
+  if (make_args(p, &a)) return 1;
+  SH_REQUIRE(Z_all && stats && neg_loc && loss_part && workspace, "ntxent_fwd_fused: NULL pointer");
+  if (check_fused(a, J_all, F, dist_mode, "ntxent_fwd_fused")) return 1;
+  SH_REQUIRE(!a.use_wpos || d_pos, "ntxent_fwd_fused: d_pos required when positives are weighted");
+  SH_REQUIRE(workspace_bytes >= simhand_ntxent_workspace_bytes(p), "ntxent_fwd_fused: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int rows = 2 * a.map.b_loc;
+  float* neg_partial = (float*)workspace;
+  float* loss_rows = neg_partial + (size_t)a.csplit * a.rows_pad;
+  ProfScope ps(SH_PROF_LOSS, s, 2.0 * rows * a.N * kDim, 0);
+  route_hit(SH_ROUTE_NTXENT_FWD);
+  route_hit(SH_ROUTE_NTXENT_FUSED_DIST);
+  dim3 grid(a.rows_pad / 64, a.csplit);
+  launch_tile_fused<false>(dist_mode, grid, s, a, Z_all, stats, nullptr, neg_partial, J_all, F);
+  if (check_launch("ntxent_fwd_fused tile")) return 1;
+  ntxent_fwd_finalize_kernel<<<ceil_div(rows, 4), 256, 0, s>>>(a, Z_all, d_pos, stats, neg_partial, neg_loc, loss_rows);
+  if (check_launch("ntxent_fwd_fused finalize")) return 1;
+  sum_rows_kernel<<<1, 1024, 0, s>>>(loss_rows, rows, 1.0 / (double)a.N, loss_part);
+  return check_launch("ntxent_fwd_fused sum");
+}
+
+int simhand_ntxent_bwd_fused(const sh_ntxent_params* p, const float* Z_all, const float* J_all, int F, int dist_mode, const float* d_pos,
+                             const double* stats, const float* neg_all, const float* dloss, float* dZ_loc, void* workspace,
+                             size_t workspace_bytes, sh_stream_t stream) {
+  LossArgs a;
+  if (make_args(p, &a)) return 1;
+  SH_REQUIRE(Z_all && stats && neg_all && dZ_loc && workspace, "ntxent_bwd_fused: NULL pointer");
+  if (check_fused(a, J_all, F, dist_mode, "ntxent_bwd_fused")) return 1;
+  SH_REQUIRE(!a.use_wpos || d_pos, "ntxent_bwd_fused: d_pos required when positives are weighted");
+  SH_REQUIRE(workspace_bytes >= simhand_ntxent_workspace_bytes(p), "ntxent_bwd_fused: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int rows = 2 * a.map.b_loc;
+  float* dz_partial = (float*)workspace;
+  ProfScope ps(SH_PROF_LOSS, s, 4.0 * rows * a.N * kDim, 0);
+  route_hit(SH_ROUTE_NTXENT_BWD);
+  route_hit(SH_ROUTE_NTXENT_FUSED_DIST);
+  dim3 grid(a.rows_pad / 64, a.csplit);
+  launch_tile_fused<true>(dist_mode, grid, s, a, Z_all, stats, neg_all, dz_partial, J_all, F);
+  if (check_launch("ntxent_bwd_fused tile")) return 1;
+  ntxent_bwd_finalize_kernel<<<ceil_div((int64_t)rows * 32, 256), 256, 0, s>>>(a, Z_all, d_pos, stats, dz_partial, dloss, dZ_loc);
+  return check_launch("ntxent_bwd_fused finalize");
 }
 
 int simhand_ntxent_bwd(const sh_ntxent_params* p, const float* Z_all, const float* D_loc, const float* d_pos,

@@ -40,6 +40,10 @@ class LossConfig:
     lambda_pos: float = 0.0
     lambda_neg: float = 0.0
     kernels: Any = None                    # test hook only; None -> simhand_amd.ops (HIP)
+    # True: the joint distances are computed inside the loss tile kernels (no [rows_loc][N] block in HBM -- the north star's
+    # "one LDS-tiled kernel"); False: one distance pass materialises the row block, both loss passes read it (3x fewer sqrt);
+    # None: False while the block stays below FUSE_DIST_BYTES, True above (bit-identical results either way)
+    fuse_dist: Optional[bool] = None
 
     @staticmethod
     def from_model_config(config, weighted: bool) -> "LossConfig":
@@ -50,6 +54,9 @@ class LossConfig:
                           use_wpos=pos_neg in ("pos_neg", "pos"), use_wneg=pos_neg in ("pos_neg", "neg"),
                           lambda_pos=float(getattr(config, "non_linear_lambda_pos", 0.0) or 0.0),
                           lambda_neg=float(getattr(config, "non_linear_lambda_neg", 0.0) or 0.0))
+
+
+FUSE_DIST_BYTES = 1 << 30  # materialised distance row blocks above 1 GiB switch to the fused kernels
 
 
 def _is_abi(group) -> bool:
@@ -109,6 +116,7 @@ class ShardedNtxent(torch.autograd.Function):
         Z = _gather_rows(z_loc, b_loc, world, group)
         stats = torch.zeros(8, dtype=torch.float64, device=z_loc.device)
         D = dpos = None
+        fused_dist = False
         if explicit:
             dpos = None if pos_w is None else pos_w.contiguous().float()
             D = None if neg_w is None else neg_w.contiguous().float()
@@ -118,27 +126,39 @@ class ShardedNtxent(torch.autograd.Function):
             if cfg.use_wpos:
                 dpos = K.pos_dist(J, B, mode, stats)
             if cfg.use_wneg:
-                D = K.neg_dist(J, B, mode, b_loc, rank * b_loc, stats)
+                fused_dist = cfg.fuse_dist if cfg.fuse_dist is not None else (4 * rows * 2 * B > FUSE_DIST_BYTES)
+                fused_dist = bool(fused_dist) and hasattr(K, "ntxent_fwd_fused")
+                if fused_dist:
+                    K.neg_dist(J, B, mode, b_loc, rank * b_loc, stats, stats_only=True)
+                else:
+                    D = K.neg_dist(J, B, mode, b_loc, rank * b_loc, stats)
                 if world > 1:
                     mm = _all_reduce(torch.stack((stats[0], -stats[1])), "max", group)
                     sm = _all_reduce(stats[2:3].clone(), "sum", group)
                     stats[0], stats[1], stats[2] = mm[0], -mm[1], sm[0]
         plan = K.NtxentPlan(B, b_loc, rank * b_loc, cfg.weight_type if weighted or explicit else None,
-                            cfg.use_wpos and dpos is not None, cfg.use_wneg and D is not None, cfg.temperature,
+                            cfg.use_wpos and dpos is not None, cfg.use_wneg and (D is not None or fused_dist), cfg.temperature,
                             cfg.lambda_pos, cfg.lambda_neg, dim=Z.shape[1])
-        neg_loc, loss = K.ntxent_fwd(plan, Z, D, dpos, stats)
+        fused_j = J if fused_dist else None
+        if fused_j is not None:
+            neg_loc, loss = K.ntxent_fwd_fused(plan, Z, fused_j, cfg.diff_type, dpos, stats)
+        else:
+            neg_loc, loss = K.ntxent_fwd(plan, Z, D, dpos, stats)
         if world > 1:
             neg_all = _gather_rows(neg_loc.view(rows, 1), b_loc, world, group).view(-1)
             _all_reduce(loss, "sum", group)
         else:
             neg_all = neg_loc
-        ctx.k, ctx.plan = K, plan
-        ctx.save_for_backward(Z, D, dpos, stats, neg_all)
+        ctx.k, ctx.plan, ctx.fused_mode = K, plan, (cfg.diff_type if fused_j is not None else None)
+        ctx.save_for_backward(Z, D if fused_j is None else fused_j, dpos, stats, neg_all)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, dloss):
         Z, D, dpos, stats, neg_all = ctx.saved_tensors
         g = dloss.reshape(1).float().contiguous()
-        dz = ctx.k.ntxent_bwd(ctx.plan, Z, D, dpos, stats, neg_all, g)
+        if ctx.fused_mode is not None:  # `D` holds J_all: the distances are recomputed in the backward tiles
+            dz = ctx.k.ntxent_bwd_fused(ctx.plan, Z, D, ctx.fused_mode, dpos, stats, neg_all, g)
+        else:
+            dz = ctx.k.ntxent_bwd(ctx.plan, Z, D, dpos, stats, neg_all, g)
         return dz, None, None, None, None, None

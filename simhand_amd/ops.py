@@ -78,10 +78,12 @@ def pos_dist(J_all: torch.Tensor, B: int, mode: str, stats: torch.Tensor) -> tor
     return d
 
 
-def neg_dist(J_all: torch.Tensor, B: int, mode: str, b_loc: int, pair_off: int, stats: torch.Tensor) -> torch.Tensor:
+def neg_dist(J_all: torch.Tensor, B: int, mode: str, b_loc: int, pair_off: int, stats: torch.Tensor, stats_only: bool = False):
+    """D row block [rows_loc][N] + its max / min / sum into stats[0..2]; stats_only: no block is written (returns None) --
+    the fused loss kernels recompute the distances in their tiles."""
     lib = _lib_dev()
     rows, N = 2 * b_loc, 2 * B
-    D = torch.empty(rows, N, dtype=torch.float32, device=J_all.device)
+    D = None if stats_only else torch.empty(rows, N, dtype=torch.float32, device=J_all.device)
     nb = lib.simhand_neg_dist_workspace_bytes(rows, N)
     ws = torch.empty(nb, dtype=torch.uint8, device=J_all.device)
     check(lib.simhand_neg_dist(_ptr(J_all, _F32), B, J_all.shape[1], _lib.DIST_MODES[mode], b_loc, pair_off, _ptr(D), _ptr(stats, _F64),
@@ -108,6 +110,31 @@ def ntxent_fwd(plan: NtxentPlan, Z_all, D_loc, d_pos, stats) -> Tuple[torch.Tens
     check(lib.simhand_ntxent_fwd(C.byref(plan.p), _ptr(Z_all, _F32), _ptr(D_loc, _F32), _ptr(d_pos, _F32), _ptr(stats, _F64), _ptr(neg), _ptr(loss),
                                  _ptr(ws), plan.ws_bytes, _stream()), "ntxent_fwd")
     return neg, loss
+
+
+def ntxent_fwd_fused(plan: NtxentPlan, Z_all, J_all, mode: str, d_pos, stats) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ntxent_fwd with the joint-distance tile computed inside the loss kernel (no D block in HBM)."""
+    lib = _lib_dev()
+    dev = Z_all.device
+    _require_width(Z_all, "ntxent_fwd_fused")
+    neg = torch.empty(plan.rows, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.simhand_ntxent_fwd_fused(C.byref(plan.p), _ptr(Z_all, _F32), _ptr(J_all, _F32), J_all.shape[1], _lib.DIST_MODES[mode], _ptr(d_pos, _F32),
+                                       _ptr(stats, _F64), _ptr(neg), _ptr(loss), _ptr(ws), plan.ws_bytes, _stream()), "ntxent_fwd_fused")
+    return neg, loss
+
+
+def ntxent_bwd_fused(plan: NtxentPlan, Z_all, J_all, mode: str, d_pos, stats, neg_all, dloss) -> torch.Tensor:
+    lib = _lib_dev()
+    dev = Z_all.device
+    _require_width(Z_all, "ntxent_bwd_fused")
+    dZ = torch.empty(plan.rows, plan.p.dim, dtype=torch.float32, device=dev)
+    ws = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.simhand_ntxent_bwd_fused(C.byref(plan.p), _ptr(Z_all, _F32), _ptr(J_all, _F32), J_all.shape[1], _lib.DIST_MODES[mode], _ptr(d_pos, _F32),
+                                       _ptr(stats, _F64), _ptr(neg_all, _F32), _ptr(dloss, _F32), _ptr(dZ), _ptr(ws), plan.ws_bytes, _stream()),
+          "ntxent_bwd_fused")
+    return dZ
 
 
 def ntxent_bwd(plan: NtxentPlan, Z_all, D_loc, d_pos, stats, neg_all, dloss) -> torch.Tensor:

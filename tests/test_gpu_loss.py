@@ -18,8 +18,9 @@ DIFFS = ("mpjpe", "w_abs", "w_o_abs")
 DEV = "cuda"
 
 
-def _hip_loss(z1, z2, j1, j2, diff, weight_type, pos_neg, ranks=1, lam=(5.0, 0.05), backward=True):
-    """Run the HIP loss for all `ranks` row shards on one GPU; returns (loss, dz (N,128))."""
+def _hip_loss(z1, z2, j1, j2, diff, weight_type, pos_neg, ranks=1, lam=(5.0, 0.05), backward=True, fused=False):
+    """Run the HIP loss for all `ranks` row shards on one GPU; returns (loss, dz (N,128)).  fused: the distance tiles are
+    computed inside the loss kernels (simhand_ntxent_*_fused), no D row block."""
     from simhand_amd import ops
 
     B = z1.shape[0]
@@ -41,7 +42,7 @@ def _hip_loss(z1, z2, j1, j2, diff, weight_type, pos_neg, ranks=1, lam=(5.0, 0.0
         D = None
         if weighted:
             d_pos = ops.pos_dist(J, B, mode, stats)
-            D = ops.neg_dist(J, B, mode, b_loc, r * b_loc, stats)
+            D = ops.neg_dist(J, B, mode, b_loc, r * b_loc, stats, stats_only=fused and use_wneg)
         stats_r.append(stats)
         D_r.append(D)
         plans.append(ops.NtxentPlan(B, b_loc, r * b_loc, weight_type, use_wpos, use_wneg, 0.5, lam[0], lam[1]))
@@ -54,7 +55,10 @@ def _hip_loss(z1, z2, j1, j2, diff, weight_type, pos_neg, ranks=1, lam=(5.0, 0.0
     neg_all = torch.empty(N, dtype=torch.float32, device=DEV)
     loss = torch.zeros(1, dtype=torch.float32, device=DEV)
     for r in range(ranks):
-        neg, lp = ops.ntxent_fwd(plans[r], Z, D_r[r], d_pos, glob)
+        if fused and use_wneg:
+            neg, lp = ops.ntxent_fwd_fused(plans[r], Z, J, mode, d_pos, glob)
+        else:
+            neg, lp = ops.ntxent_fwd(plans[r], Z, D_r[r], d_pos, glob)
         neg_all[r * b_loc:(r + 1) * b_loc] = neg[:b_loc]
         neg_all[B + r * b_loc:B + (r + 1) * b_loc] = neg[b_loc:]
         loss += lp
@@ -62,7 +66,10 @@ def _hip_loss(z1, z2, j1, j2, diff, weight_type, pos_neg, ranks=1, lam=(5.0, 0.0
     if backward:
         dz = torch.empty(N, 128, dtype=torch.float32, device=DEV)
         for r in range(ranks):
-            d = ops.ntxent_bwd(plans[r], Z, D_r[r], d_pos, glob, neg_all, None)
+            if fused and use_wneg:
+                d = ops.ntxent_bwd_fused(plans[r], Z, J, mode, d_pos, glob, neg_all, None)
+            else:
+                d = ops.ntxent_bwd(plans[r], Z, D_r[r], d_pos, glob, neg_all, None)
             dz[r * b_loc:(r + 1) * b_loc] = d[:b_loc]
             dz[B + r * b_loc:B + (r + 1) * b_loc] = d[b_loc:]
         dz = dz.cpu()
@@ -193,3 +200,76 @@ def test_projection_stats_against_reference_golden(golden_dir):
         for i, k in enumerate(order):
             want = float(g[f"stat.{name}{k}"])
             assert abs(out[i] - want) <= 1e-6 + 1e-5 * abs(want), (name, k, out[i], want)
+
+
+@pytest.mark.parametrize("B,ranks", [(5, 1), (96, 4), (200, 8), (1024, 2)])
+@pytest.mark.parametrize("wt,diff,mode", [("linear", "mpjpe", "pos_neg"), ("non_linear", "w_abs", "neg"), ("linear", "w_o_abs", "pos_neg")])
+def test_fused_distance_loss_is_bit_identical_to_the_row_block_form(B, ranks, wt, diff, mode):
+    """North-star form: similarity tile + joint-distance tile + weighted softmax-cross-entropy in ONE LDS-tiled kernel, no
+    [rows][N] distance block in HBM.  The in-tile distances follow simhand_neg_dist's operation order, so loss and gradient
+    equal the row-block path bit for bit (which the golden / oracle tests above pin to the reference)."""
+    from simhand_amd import ops
+
+    gen = torch.Generator().manual_seed(77 + B)
+    z1 = torch.nn.functional.normalize(torch.randn(B, 128, generator=gen))
+    z2 = torch.nn.functional.normalize(torch.randn(B, 128, generator=gen))
+    j1 = torch.rand(B, 21, 2, generator=gen) * 224
+    j2 = j1 + torch.randn(B, 21, 2, generator=gen) * 8
+    la, dza = _hip_loss(z1, z2, j1, j2, diff, wt, mode, ranks=ranks, lam=(2.5, 0.01))
+    ops.route_reset()
+    lb, dzb = _hip_loss(z1, z2, j1, j2, diff, wt, mode, ranks=ranks, lam=(2.5, 0.01), fused=True)
+    assert ops.route_counts()["ntxent_fused_dist"] == 2 * ranks
+    assert la == lb and torch.equal(dza, dzb)
+    # PCA features (plain L2 over 14 columns)
+    f1, f2 = torch.randn(B, 14, generator=gen), torch.randn(B, 14, generator=gen)
+    lc, dzc = _hip_loss(z1, z2, f1, f2, "mpjpe", wt, mode, ranks=ranks, lam=(2.5, 0.01))
+    ld, dzd = _hip_loss(z1, z2, f1, f2, "mpjpe", wt, mode, ranks=ranks, lam=(2.5, 0.01), fused=True)
+    assert lc == ld and torch.equal(dzc, dzd)
+
+
+def test_fused_distance_through_the_autograd_surface_and_timing():
+    """LossConfig.fuse_dist routes ShardedNtxent through the fused kernels; prints both forms' time at the BASELINE sizes
+    (N = 2048 single GPU; 2048 local rows x N = 16 384 = one rank of the 8-GPU config)."""
+    import time
+
+    from simhand_amd.host import dist_loss
+
+    gen = torch.Generator().manual_seed(5)
+    for B, b_loc in ((1024, 1024), (8192, 1024)):
+        z = torch.nn.functional.normalize(torch.randn(2 * B, 128, generator=gen)).to(DEV)
+        J = (torch.rand(2 * B, 42, generator=gen) * 224).to(DEV)
+        res = {}
+        for fused in (False, True):
+            cfg = dist_loss.LossConfig(weight_type="linear", diff_type="mpjpe", use_wpos=True, use_wneg=True, fuse_dist=fused)
+            if b_loc == B:
+                zz = z.clone().requires_grad_(True)
+                loss = dist_loss.ShardedNtxent.apply(zz, J, cfg, None, None, None)
+                loss.backward()
+                res[fused] = (loss.item(), zz.grad.clone())
+            # timing of one rank's work (rows 0 .. 2 b_loc of N) through the raw ops
+            from simhand_amd import ops
+            stats = torch.zeros(8, dtype=torch.float64, device=DEV)
+            plan = ops.NtxentPlan(B, b_loc, 0, "linear", True, True)
+            dpos = ops.pos_dist(J, B, "mpjpe", stats)
+
+            def run():
+                D = ops.neg_dist(J, B, "mpjpe", b_loc, 0, stats, stats_only=fused)
+                if fused:
+                    neg, _ = ops.ntxent_fwd_fused(plan, z, J, "mpjpe", dpos, stats)
+                else:
+                    neg, _ = ops.ntxent_fwd(plan, z, D, dpos, stats)
+                neg_all = neg if b_loc == B else torch.ones(2 * B, device=DEV)
+                if fused:
+                    ops.ntxent_bwd_fused(plan, z, J, "mpjpe", dpos, stats, neg_all, None)
+                else:
+                    ops.ntxent_bwd(plan, z, D, dpos, stats, neg_all, None)
+
+            run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize()
+            print(f"loss path N={2 * B} rows={2 * b_loc} fused={fused}: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms")
+        if b_loc == B:
+            assert res[False][0] == res[True][0] and torch.equal(res[False][1], res[True][1])
