@@ -843,6 +843,17 @@ static inline void fold_split(int tiles, int k, int* ks, int* kper) {
   *kper = per;
 }
 
+// Centred second moments of the (narrow) input: S2c = a^T a - (sum a)(sum a)^T / M  (fp64 arithmetic on the fp32 sums).  The
+// batch variance of y_c = W_c . a is then W_c S2c W_c^T / M directly -- the E[y^2] - mean^2 cancellation of a channel whose
+// mean dwarfs its spread happens here, on the INPUT's statistics (post-ReLU activations: mean ~ std), not on the outputs'.
+__global__ __launch_bounds__(256) void fold_center_kernel(const float* __restrict__ s2, const float* __restrict__ t2, int cw, double inv_m,
+                                                          float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)cw * cw) return;
+  const int j = (int)(i / cw), k = (int)(i - (int64_t)j * cw);
+  out[i] = (float)((double)s2[i] - (double)t2[j] * (double)t2[k] * inv_m);
+}
+
 __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restrict__ w, int round_bf16, const float* __restrict__ s2,
                                                           const float* __restrict__ t2, int cc, int cw, int64_t m,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -850,21 +861,26 @@ __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restric
                                                           float* __restrict__ running_var, int64_t* __restrict__ nbt,
                                                           float* __restrict__ mean_o, float* __restrict__ invstd_o,
                                                           float* __restrict__ scale_o, float* __restrict__ shift_o,
-                                                          const float* __restrict__ ws2) {
+                                                          float* __restrict__ ws2) {
   __shared__ double red[256];
+  __shared__ double s_mean;
   const int c = blockIdx.x;
   double sy = 0.0, sy2 = 0.0;
-  for (int j = threadIdx.x; j < cw; j += 256) {  // ws2 = W S2 comes from fold_sgemm_kernel
+  for (int j = threadIdx.x; j < cw; j += 256) {  // ws2 holds W S2c (CENTRED Gram) from fold_sgemm_kernel
     const float wv = fold_w(w, c * cw + j, round_bf16);
     sy += (double)wv * (double)t2[j];
     sy2 += (double)ws2[(int64_t)c * cw + j] * (double)wv;
   }
   sy = block_sum256(sy, red);
   sy2 = block_sum256(sy2, red);
+  if (threadIdx.x == 0) s_mean = sy / (double)m;
+  __syncthreads();
+  // the backward's algebra wants the UN-centred product: W S2 = W S2c + (W t2) t2^T / M = ws2c + mean_c t2
+  for (int j = threadIdx.x; j < cw; j += 256) ws2[(int64_t)c * cw + j] = (float)((double)ws2[(int64_t)c * cw + j] + s_mean * (double)t2[j]);
   if (threadIdx.x == 0) {
     if (c == 0 && nbt) nbt[0] += 1;
-    const double mean = sy / (double)m;
-    double var = sy2 / (double)m - mean * mean;
+    const double mean = s_mean;
+    double var = sy2 / (double)m;  // no subtraction of mean^2: the second moments are centred already
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = (gamma ? gamma[c] : 1.0f) * invstd;
@@ -1251,7 +1267,7 @@ size_t simhand_bn_fold_workspace_bytes(int cc, int cw) {
   fold_split(ceil_div(cw, 64) * ceil_div(cc, 64), cw, &ks1, &kp1);
   fold_split(ceil_div(cw, 64) * ceil_div(cw, 64), cc, &ks2, &kp2);
   const size_t a = (size_t)ks1 * cc * cw, b = (size_t)ks2 * cw * cw;
-  return (a > b ? a : b) * sizeof(float);
+  return ((a > b ? a : b) + (size_t)cw * cw) * sizeof(float);  // + the centred Gram matrix of the forward fold
 }
 
 int simhand_bn_fold_fwd(const float* w, int round_bf16, const float* s2, const float* t2, int cc, int cw, int64_t m, const float* gamma,
@@ -1269,9 +1285,12 @@ int simhand_bn_fold_fwd(const float* w, int round_bf16, const float* s2, const f
     int ks, kper;
     const int tiles = ceil_div(cw, 64) * ceil_div(cc, 64);
     fold_split(tiles, cw, &ks, &kper);
-    SH_REQUIRE(ks == 1 || (workspace && workspace_bytes >= (size_t)ks * cc * cw * sizeof(float)), "bn_fold_fwd: workspace too small");
+    SH_REQUIRE(workspace && workspace_bytes >= simhand_bn_fold_workspace_bytes(cc, cw), "bn_fold_fwd: workspace too small");
+    float* s2c = (float*)workspace + (workspace_bytes / sizeof(float) - (size_t)cw * cw);  // the tail of the workspace
+    fold_center_kernel<<<ceil_div((int64_t)cw * cw, 256), 256, 0, s>>>(s2, t2, cw, 1.0 / (double)m, s2c);
+    if (check_launch("bn_fold_fwd centre")) return 1;
     float* dst = ks > 1 ? (float*)workspace : ws2;
-    fold_sgemm_kernel<float, 0><<<dim3(ceil_div(cw, 64), ceil_div(cc, 64), ks), 256, 0, s>>>(w, cw, 1, round_bf16, s2, cw, 1, cc, cw, cw, dst,
+    fold_sgemm_kernel<float, 0><<<dim3(ceil_div(cw, 64), ceil_div(cc, 64), ks), 256, 0, s>>>(w, cw, 1, round_bf16, s2c, cw, 1, cc, cw, cw, dst,
                                                                                              nullptr, cw, kper);
     if (check_launch("bn_fold_fwd gemm")) return 1;
     if (ks > 1) {

@@ -824,3 +824,35 @@ def test_bn_backward_apply_fused_into_the_1x1_weight_gradient(n, h, cin, cout, r
     out.backward(da.float().cpu().view(m, cout))
     _check(dy.float().cpu().view(m, cout), yt.grad, 2e-2, "dy vs autograd")
     _check(dw.cpu().view(cout, cin), yt.grad.t() @ x.float().cpu().view(m, cin), 2e-2, "dw vs autograd")
+
+
+@pytest.mark.parametrize("offset", [0.0, 5.0, 40.0])
+@pytest.mark.parametrize("cin,cout", [(64, 256), (256, 1024)])
+def test_folded_statistics_survive_large_channel_means(offset, cin, cout):
+    """the fold derives Var[y_c] from parameter-sized matrices of the input; with |mean| >> std the textbook
+    E[y^2] - mean^2 loses digits.  The fold therefore CENTRES the input's second moments first (fold_center_kernel: a^T a -
+    (sum a)(sum a)^T / M in fp64) and takes W S2c W^T directly.  Stress: inputs with a common offset of 0 / 5 / 40 standard
+    deviations (output channel means up to several hundred times their spread), statistics against an fp64 two-pass
+    reference of the SAME bf16 operands; the un-centred product the backward uses (W S2) must survive the round trip."""
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(cin + int(offset))
+    dt = torch.bfloat16
+    n, h = 4, 24
+    m = n * h * h
+    x = (torch.randn(n, h, h, cin, generator=g) + offset).to(dt).to(DEV)
+    wt = (torch.randn(cout, cin, generator=g) / math.sqrt(cin)).to(DEV)
+    d = ops.conv_desc(n, h, h, cin, cin, 1, 1, 1, 0, dt)
+    s2, t2 = ops.conv2d_wgrad_colsum(d, x, x)
+    gamma, beta = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+    st, ws2 = ops.bn_fold_fwd(wt, True, s2, t2, m, gamma, beta, None, None, None)
+    w64 = wt.to(dt).double().cpu()
+    y = x.double().cpu().view(m, cin) @ w64.t()
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    ratio = float((mean.abs() / var.sqrt()).max())
+    assert (st.mean.cpu().double() - mean).abs().max() <= 1e-5 * mean.abs().max() + 1e-6
+    rel = ((st.invstd.cpu().double() - 1 / (var + 1e-5).sqrt()).abs() * (var + 1e-5).sqrt()).max()
+    print(f"offset {offset}: max |mean|/std of an output channel {ratio:.0f}, invstd relative error {float(rel):.2e}")
+    assert rel <= 2e-3, (offset, ratio, float(rel))
+    want_ws2 = w64 @ (x.double().cpu().view(m, cin).t() @ x.double().cpu().view(m, cin))
+    assert (ws2.cpu().double() - want_ws2).abs().max() <= 1e-4 * want_ws2.abs().max()

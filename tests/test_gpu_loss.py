@@ -273,3 +273,35 @@ def test_fused_distance_through_the_autograd_surface_and_timing():
             print(f"loss path N={2 * B} rows={2 * b_loc} fused={fused}: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms")
         if b_loc == B:
             assert res[False][0] == res[True][0] and torch.equal(res[False][1], res[True][1])
+
+
+def test_explicit_asymmetric_negative_weights_gradient():
+    """The functional surface takes ANY (N,N) neg_weights tensor, like the reference (src/models/utils.py:391-427, :468-501):
+    for a non-symmetric one the column term of dL/dz must use w_ji, not w_ij.  Checked against autograd of the
+    oracle in fp64."""
+    from simhand_amd.host import model_utils as mu
+
+    g = torch.Generator().manual_seed(12)
+    B = 24
+    z1 = torch.nn.functional.normalize(torch.randn(B, 128, generator=g))
+    z2 = torch.nn.functional.normalize(torch.randn(B, 128, generator=g))
+    wn = torch.rand(2 * B, 2 * B, generator=g)          # deliberately NOT symmetric
+    wp = torch.rand(B, generator=g)
+    assert (wn - wn.t()).abs().max() > 0.5
+    a, b = z1.double().requires_grad_(True), z2.double().requires_grad_(True)
+    want = orc.ntxent(a, b, wp.double(), wn.double())
+    want.backward()
+    for fn, args in ((mu.vanila_weights_contrastive_loss, (wp.to(DEV), wn.to(DEV))), (mu.vanila_neg_weights_contrastive_loss, (wn.to(DEV),))):
+        x1, x2 = z1.to(DEV).requires_grad_(True), z2.to(DEV).requires_grad_(True)
+        loss = fn(x1, x2, *args)
+        loss.backward()
+        if len(args) == 2:
+            assert abs(loss.item() - want.item()) <= 1e-5 * abs(want.item())
+            _close_grad(x1.grad.cpu().numpy(), a.grad.float().numpy(), "asymmetric dz1")
+            _close_grad(x2.grad.cpu().numpy(), b.grad.float().numpy(), "asymmetric dz2")
+        else:
+            c, d = z1.double().requires_grad_(True), z2.double().requires_grad_(True)
+            w2 = orc.ntxent(c, d, None, wn.double())
+            w2.backward()
+            assert abs(loss.item() - w2.item()) <= 1e-5 * abs(w2.item())
+            _close_grad(x1.grad.cpu().numpy(), c.grad.float().numpy(), "asymmetric (neg only) dz1")
