@@ -110,6 +110,12 @@ __device__ __forceinline__ uint4 frag_bf16_scalar(const char* tile, int stride, 
 // per 16 MFMAs on addressing and is VALU-issue-bound.
 // KPM: k-step = KPM x the base 32 (bf16) / 16 (fp32) pixels.  PLAIN uses 2: one barrier (~250 cycles) per 32 MFMAs of a
 // wave instead of per 16.
+// SH_WGRAD_PF2 = 1: two k-steps of operand loads in flight in the 1x1 pointer-walking kernel.  Measured on MI355X (round 2,
+// scripts/wg_ab.py): the 128 x 128 tile then needs > 256 VGPRs (scratch spills: 2-2.5x slower), the tiles that still fit gain
+// nothing -- in isolation these launches already run at 5.5-6.1 TB/s on the 56^2 / 28^2 layers.  Kept off.
+#ifndef SH_WGRAD_PF2
+#define SH_WGRAD_PF2 0
+#endif
 template <typename T, int BM, int BN, bool STEM = false, bool PLAIN = false, int KPM = 1, int XFORM = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   static_assert(XFORM == 0 || (PLAIN && sizeof(T) == 2), "operand transforms exist for the bf16 1x1 pointer-walking kernel only");
@@ -145,9 +151,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   const T* __restrict__ dys = reinterpret_cast<const T*>(p.dy);
   const unsigned hw = (unsigned)(p.Ho * p.Wo);
 
-  uint4 ra[NA], rb[NBL];
-  uint4 ry[XFORM == 2 ? NA : 1];  // XFORM 2: the raw conv output chunks next to the incoming-gradient chunks in ra
-  int live_rows = 0;              // rows of the staged k-step that lie inside the block's pixel range
+  // staging registers of one k-step (a second set only with SH_WGRAD_PF2, see above)
+  struct Regs {
+    uint4 a[NA], b[NBL];
+    uint4 y[XFORM == 2 ? NA : 1];  // XFORM 2: the raw conv output chunks next to the incoming-gradient chunks in a
+    int live;                      // rows of the staged k-step that lie inside the block's pixel range
+  };
+  Regs r0, r1;
+  r0.live = r1.live = 0;
   // PLAIN: per-thread row pointers of k-step 0 (chunk i = tile row (tid + 256 i) / CPR, 16-B chunk (tid + 256 i) % CPR)
   const char* pdy[NA];
   const char* px[NBL];
@@ -237,20 +248,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
   const int rows_total = (int)(pix_end - pix_begin);  // <= pix_per_split
   const long long stem_row_skip = ((long long)2 * p.stem_wp - 2 * p.Wo) * 4 * (long long)sizeof(T);             // bytes, at a row wrap
   const long long stem_img_skip = ((long long)p.stem_hp - 2 * p.Ho) * p.stem_wp * 4 * (long long)sizeof(T);  // bytes, at an image wrap
-  auto load_step = [&](int ks) __attribute__((always_inline)) {
+  auto load_step = [&](int ks, Regs& R) __attribute__((always_inline)) {
     if constexpr (PLAIN || STEM) {
       const int left = rows_total - ks * KP;  // rows of this k-step inside the block's pixel range
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const bool live = rowa[i] < left;
-        ra[i] = live ? *reinterpret_cast<const uint4*>(pdy[i]) : make_uint4(0, 0, 0, 0);
+        R.a[i] = live ? *reinterpret_cast<const uint4*>(pdy[i]) : make_uint4(0, 0, 0, 0);
         pdy[i] += step_dy;
         if constexpr (XFORM == 2) {
-          ry[i] = live ? *reinterpret_cast<const uint4*>(pdy2[i]) : make_uint4(0, 0, 0, 0);
+          R.y[i] = live ? *reinterpret_cast<const uint4*>(pdy2[i]) : make_uint4(0, 0, 0, 0);
           pdy2[i] += step_dy;
         }
       }
-      live_rows = left;  // the transforms / column sums run in store_step, AFTER the MFMAs that cover these loads' latency
+      R.live = left;  // the transforms / column sums run in store_step, AFTER the MFMAs that cover these loads' latency
 #pragma unroll
       for (int i = 0; i < NBL; ++i) {
         if constexpr (XFORM == 1 && BM == BN) {
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
             continue;
           }
         }
-        rb[i] = rowb[i] < left ? *reinterpret_cast<const uint4*>(px[i]) : make_uint4(0, 0, 0, 0);
+        R.b[i] = rowb[i] < left ? *reinterpret_cast<const uint4*>(px[i]) : make_uint4(0, 0, 0, 0);
         if constexpr (STEM) {
           px[i] += 2 * KP * 4 * (int)sizeof(T);
           swo[i] += KP;
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
       const unsigned m = base + row;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (m < endu) v = *reinterpret_cast<const uint4*>(dys + (unsigned long long)m * (unsigned)p.Cout + (k0 + ch * VE));
-      ra[i] = v;
+      R.a[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
@@ -312,20 +323,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
           }
         }
       }
-      rb[i] = v;
+      R.b[i] = v;
     }
   };
-  auto store_step = [&](int buf) __attribute__((always_inline)) {
+  auto store_step = [&](int buf, Regs& R) __attribute__((always_inline)) {
     char* dA = sA + buf * (KP * SA);
     char* dB = sB + buf * (KP * SB);
     if constexpr (XFORM != 0) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const bool live = rowa[i] < live_rows;
+        const bool live = rowa[i] < R.live;
         if constexpr (XFORM == 1) {
-          ra[i] = live ? bn_relu8(ra[i], ca_s, ca_h) : make_uint4(0, 0, 0, 0);  // rows past the range must stay zero
+          R.a[i] = live ? bn_relu8(R.a[i], ca_s, ca_h) : make_uint4(0, 0, 0, 0);  // rows past the range must stay zero
         } else {
-          const unsigned g4[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w}, y4[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+          const unsigned g4[4] = {R.a[i].x, R.a[i].y, R.a[i].z, R.a[i].w}, y4[4] = {R.y[i].x, R.y[i].y, R.y[i].z, R.y[i].w};
           unsigned o[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -340,9 +351,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
             }
             o[q] = pack_bf16x2(r2[0], r2[1]);
           }
-          ra[i] = live ? make_uint4(o[0], o[1], o[2], o[3]) : make_uint4(0, 0, 0, 0);
+          R.a[i] = live ? make_uint4(o[0], o[1], o[2], o[3]) : make_uint4(0, 0, 0, 0);
         }
-        if (x_writes && live) *reinterpret_cast<uint4*>(pout[i]) = ra[i];
+        if (x_writes && live) *reinterpret_cast<uint4*>(pout[i]) = R.a[i];
         pout[i] += step_dy;
       }
       if constexpr (XFORM == 1) {
@@ -350,18 +361,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
         for (int i = 0; i < NBL; ++i) {
           if constexpr (BM == BN) {
             if (x_diag) {
-              rb[i] = ra[i];
+              R.b[i] = R.a[i];
               continue;
             }
           }
-          rb[i] = rowb[i] < live_rows ? bn_relu8(rb[i], cb_s, cb_h) : make_uint4(0, 0, 0, 0);
+          R.b[i] = rowb[i] < R.live ? bn_relu8(R.b[i], cb_s, cb_h) : make_uint4(0, 0, 0, 0);
         }
       }
     }
     if (want_colsum) {  // block-uniform; after the MFMAs so that the loads' latency is covered
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const unsigned w4[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+        const unsigned w4[4] = {R.a[i].x, R.a[i].y, R.a[i].z, R.a[i].w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           csum[2 * q] += __uint_as_float(w4[q] << 16);
@@ -373,13 +384,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
     for (int i = 0; i < NA; ++i) {
       const int id = tid + 256 * i;
       const int row = id / CPR_A, ch = id - row * CPR_A;
-      *reinterpret_cast<uint4*>(dA + row * SA + ch * 16) = ra[i];
+      *reinterpret_cast<uint4*>(dA + row * SA + ch * 16) = R.a[i];
     }
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
       const int id = tid + 256 * i;
       const int row = id / CPR_B, ch = id - row * CPR_B;
-      *reinterpret_cast<uint4*>(dB + row * SB + ch * 16) = rb[i];
+      *reinterpret_cast<uint4*>(dB + row * SB + ch * 16) = R.b[i];
     }
   };
 
@@ -389,14 +400,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) {
-    load_step(0);
-    store_step(0);
-  }
-  __syncthreads();
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) load_step(ks + 1);
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* tA = sA + buf * (KP * SA);
     const char* tB = sB + buf * (KP * SB);
     if constexpr (sizeof(T) == 2) {
@@ -441,8 +445,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
           for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
       }
     }
-    if (ks + 1 < nk) store_step(buf ^ 1);
-    __syncthreads();
+  };
+  constexpr bool PF2 = PLAIN && sizeof(T) == 2 && SH_WGRAD_PF2;
+  if (nk > 0) {
+    load_step(0, r0);
+    store_step(0, r0);
+  }
+  if (PF2 && nk > 1) load_step(1, r1);
+  __syncthreads();
+  if constexpr (!PF2) {
+    for (int ks = 0; ks < nk; ++ks) {
+      const int buf = ks & 1;
+      if (ks + 1 < nk) load_step(ks + 1, r0);
+      compute(buf);
+      if (ks + 1 < nk) store_step(buf ^ 1, r0);
+      __syncthreads();
+    }
+  } else {
+    // LDS buffer 0 / register set r0 carry the even k-steps, buffer 1 / r1 the odd ones
+    for (int ks = 0; ks < nk; ks += 2) {
+      if (ks + 2 < nk) load_step(ks + 2, r0);
+      compute(0);
+      if (ks + 1 < nk) store_step(1, r1);
+      __syncthreads();
+      if (ks + 1 >= nk) break;
+      if (ks + 3 < nk) load_step(ks + 3, r1);
+      compute(1);
+      if (ks + 2 < nk) store_step(0, r0);
+      __syncthreads();
+    }
   }
 
   if (want_colsum) {
