@@ -199,6 +199,7 @@ def main():
     _lib.require_device()
     device = torch.device("cuda", torch.cuda.current_device())  # = LOCAL_RANK (init_from_env set it)
     model = make_model(args, world).to(device).train()
+    shdist.broadcast_module_state(model)  # replicas start from rank 0's parameters (a no-op at N = 1)
 
     class _T:
         max_epochs, world_size = 100, world
@@ -293,7 +294,7 @@ def main():
             "kernel_ms_per_step": {k: v["ms"] / bsteps for k, v in breakdown.items()},
             "kernel_ms_source": "last warm-up step (events on every launch)" if warm_prof is not None else "timed region",
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU reference is timed at N = 1 only (the other ranks would idle behind it)
             res["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(res), flush=True)
     if world > 1:
