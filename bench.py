@@ -209,12 +209,16 @@ def main():
     (opt,), (sched,) = model.configure_optimizers()
     batch = device_batch(args.per_gpu_batch, args.image_size, 5 + rank, device)
     params = [p for p in model.parameters()]
+    reducer = None
+    if world > 1:  # backbone gradients go out block by block during the backward pass; the head's follow in allreduce_gradients
+        reducer = shdist.OverlappedGradReducer()
+        model.encoder.engine.grad_reducer = reducer
 
     def step(i):
         opt.zero_grad(set_to_none=True)
         out = model.training_step(batch, i)
         out["loss"].backward()
-        shdist.allreduce_gradients(params)
+        shdist.allreduce_gradients(params, skip=reducer.reduced if reducer is not None else None)
         opt.step()
         sched["scheduler"].step()
         return out["loss"]

@@ -116,6 +116,64 @@ def shard_pairs(global_pairs: int, rank: int, world: int) -> Tuple[int, int]:
     return rank * b, b
 
 
+class OverlappedGradReducer:
+    """Gradient all-reduce OVERLAPPED with the backward pass (north star: "all-reduce of gradients ... overlapped with
+    backward").  The backbone is one hand-written backward (`ResNetEngine.backward`) that finishes its parameter gradients
+    block by block, last stage first; each finished group is handed to ``submit``: full buckets are flattened and go out as
+    asynchronous SUM all-reduces (RCCL runs them on its own stream, behind an event on the launch stream) while the earlier
+    blocks' kernels keep the compute stream busy.  ``finish`` (end of the backbone's backward) waits and scatters the sums
+    back into the gradient tensors, so what autograd hands to ``p.grad`` is already reduced; ``reduced`` tells
+    ``allreduce_gradients`` which parameters are done.  xGMI is point to point (7 links x ~153 GB/s per GPU): a ResNet-50's
+    98.5 MB of fp32 gradients are ~1-3 ms of ring time per step -- hidden behind ~80 ms of backward instead of appended."""
+
+    def __init__(self, group=None, bucket_bytes: int = 32 << 20):
+        self.group, self.bucket_bytes = group, bucket_bytes
+        self.reduced = set()
+        self._bucket: List[torch.Tensor] = []
+        self._size = 0
+        self._pending = []
+
+    def active(self) -> bool:
+        if isinstance(self.group, RcclComm):
+            return self.group.world > 1
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _flush(self) -> None:
+        if not self._bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in self._bucket])
+        if isinstance(self.group, RcclComm):
+            self.group.all_reduce_(flat, "sum")  # stream-ordered
+            work = None
+        else:
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((work, flat, self._bucket))
+        self._bucket, self._size = [], 0
+
+    def submit(self, pairs) -> None:
+        """pairs: iterable of (parameter, finished gradient tensor)."""
+        for p, g in pairs:
+            if g is None:
+                continue
+            self.reduced.add(id(p))
+            self._bucket.append(g)
+            self._size += g.numel() * g.element_size()
+            if self._size >= self.bucket_bytes:
+                self._flush()
+
+    def finish(self) -> None:
+        self._flush()
+        for work, flat, bucket in self._pending:
+            if work is not None:
+                work.wait()
+            off = 0
+            for g in bucket:
+                n = g.numel()
+                g.copy_(flat[off:off + n].view_as(g))
+                off += n
+        self._pending = []
+
+
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Parameters and buffers of rank `src` to every rank (replica consistency does not rest on identical seeding)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -125,17 +183,20 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) ->
             dist.broadcast(t.data, src=src, group=group)
 
 
-def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20) -> None:
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20, skip=None) -> None:
     """SUM all-reduce over a FIXED parameter list: every rank buckets the same tensors in the same order, whatever
     received a gradient locally.  A trainable parameter without a gradient on this rank contributes zeros (and receives
-    the other ranks' sum); parameters with requires_grad=False are skipped on every rank alike."""
+    the other ranks' sum); parameters with requires_grad=False are skipped on every rank alike.  skip: ids of parameters an
+    OverlappedGradReducer already reduced during this step's backward (the set is emptied)."""
     abi = isinstance(group, RcclComm)
     if abi:
         if group.world == 1:
             return
     elif not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    plist = [p for p in params if p.requires_grad]
+    plist = [p for p in params if p.requires_grad and not (skip and id(p) in skip)]  # skip: already reduced during backward
+    if skip:
+        skip.clear()
     # which parameters have a gradient anywhere: one small MAX all-reduce keeps the bucket layout identical on all ranks
     has = torch.tensor([1 if p.grad is not None else 0 for p in plist], dtype=torch.int64, device=plist[0].device if plist else "cpu")
     if has.numel():

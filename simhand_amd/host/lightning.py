@@ -136,7 +136,7 @@ class Trainer:
         }
 
     def fit(self, model: LightningModule, train_dataloaders=None, val_dataloaders=None, ckpt_path: Optional[str] = None):
-        from .dist import allreduce_gradients, broadcast_module_state
+        from .dist import OverlappedGradReducer, allreduce_gradients, broadcast_module_state
 
         model.trainer = self
         if hasattr(model, "set_compute_dtype"):
@@ -164,6 +164,10 @@ class Trainer:
         for cb in self.callbacks:
             if isinstance(cb, ModelCheckpoint) and cb.dirpath is None:
                 cb.dirpath = os.path.join(self.default_root_dir, "checkpoints")
+        reducer = None
+        if self.world_size > 1 and hasattr(getattr(model, "encoder", None), "engine"):
+            reducer = OverlappedGradReducer(getattr(model, "process_group", None))
+            model.encoder.engine.grad_reducer = reducer  # backbone gradients are all-reduced during the backward pass
         model.train()
         for epoch in range(start_epoch, self.max_epochs):
             self.current_epoch = epoch
@@ -180,7 +184,8 @@ class Trainer:
                     o.zero_grad(set_to_none=True)
                 loss.backward()
                 if self.world_size > 1:
-                    allreduce_gradients(model.parameters())
+                    allreduce_gradients(model.parameters(), group=getattr(model, "process_group", None),
+                                        skip=reducer.reduced if reducer is not None else None)
                 for o in opts:
                     o.step()
                 for s in scheds:

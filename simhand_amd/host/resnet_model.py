@@ -152,6 +152,8 @@ class ResNetEngine:
         # every cin tile of the launch re-derives the dy operand from TWO tensors; kept for the experiment record)
         self.fuse_bwd_apply_wgrad = os.environ.get("SIMHAND_FUSE_BWDW", "0") == "1"
         self._gram = None  # (activation tensor, a^T a, sum a) of the unit just applied that way
+        # multi-GPU: host.dist.OverlappedGradReducer -- finished parameter gradients go out block by block during backward
+        self.grad_reducer = None
 
     # -- weights -------------------------------------------------------------
     def _pack(self, conv: nn.Conv2d, need_t: bool, stem: bool = False) -> _Packed:
@@ -486,6 +488,8 @@ class ResNetEngine:
 
     def backward(self, ctx: dict, d_enc: Tensor) -> Dict[nn.Parameter, Tensor]:
         grads: Dict[nn.Parameter, Tensor] = {}
+        red = self.grad_reducer if (self.grad_reducer is not None and self.grad_reducer.active()) else None
+        sent = 0  # gradients of `grads` (insertion order) already handed to the reducer
         g = d_enc.contiguous() if d_enc.dtype == self.dtype else ops.cast(d_enc.contiguous(), self.dtype)
         dz = ops.avgpool_bwd(g, ctx["last_shape"])
         blocks = ctx["blocks"]
@@ -529,12 +533,19 @@ class ResNetEngine:
                                              prev_masked_store=fold)
                 dz_masked = fold
             saved.clear()
+            if red is not None:  # this block's parameter gradients are final: their all-reduce overlaps the blocks below
+                items = list(grads.items())
+                red.submit(items[sent:])
+                sent = len(items)
         # stem: the pooled gradient is gathered through the winner index inside the BatchNorm-backward passes
         u = ctx["stem"]
         dy, dg, db = ops.maxpool_bn_backward(dz, ctx["pool_idx"], u.y, u.st, u.bn.weight.detach(), ywin=ctx.get("pool_ywin"))
         grads[u.bn.weight] = dg
         grads[u.bn.bias] = db
         grads[u.conv.weight] = ops.stem_conv_wgrad(u.x, dy, u.desc.h, u.desc.w)
+        if red is not None:
+            red.submit(list(grads.items())[sent:])
+            red.finish()  # waits for the buckets still in flight and scatters the sums back: what autograd receives is reduced
         return grads
 
 

@@ -35,9 +35,14 @@ model = _product("HandCLR_W", "18", wcfg, om)
 shdist.broadcast_module_state(model)
 off, b = shdist.shard_pairs(B, rank, world)
 shard = {k: v[off:off + b].to(dev) for k, v in batch.items()}
+reducer = shdist.OverlappedGradReducer(bucket_bytes=1 << 20)  # several buckets even for ResNet-18
+model.encoder.engine.grad_reducer = reducer
 loss = model.training_step(shard, 0)["loss"]
 loss.backward()
-shdist.allreduce_gradients(model.parameters(), bucket_bytes=1 << 20)
+n_overlapped = len(reducer.reduced)
+assert (n_overlapped > 50) == (world > 1), n_overlapped  # every backbone gradient went out during backward (world > 1)
+shdist.allreduce_gradients(model.parameters(), bucket_bytes=1 << 20, skip=reducer.reduced)
+assert not reducer.reduced
 torch.cuda.synchronize()
 
 if BACKEND == "nccl" and world > 1:
@@ -46,9 +51,10 @@ if BACKEND == "nccl" and world > 1:
     assert (comm.world, comm.rank) == (world, rank)
     model.zero_grad()
     model.process_group = comm
+    model.encoder.engine.grad_reducer = shdist.OverlappedGradReducer(comm, bucket_bytes=1 << 20)
     loss_abi = model.training_step(shard, 0)["loss"]
     loss_abi.backward()
-    shdist.allreduce_gradients(model.parameters(), group=comm, bucket_bytes=1 << 20)
+    shdist.allreduce_gradients(model.parameters(), group=comm, bucket_bytes=1 << 20, skip=model.encoder.engine.grad_reducer.reduced)
     torch.cuda.synchronize()
     assert abs(loss_abi.item() - loss.item()) <= 1e-6 * abs(loss.item()), (loss_abi.item(), loss.item())
     comm.close()

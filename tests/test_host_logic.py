@@ -201,6 +201,21 @@ p[0].grad = torch.full((5,), float(rank + 1)); p[1].grad = torch.full((3, 2), 10
 shdist.allreduce_gradients(p, bucket_bytes=16)
 tot = sum(range(1, world + 1))
 assert torch.equal(p[0].grad, torch.full((5,), float(tot))) and torch.equal(p[1].grad, torch.full((3, 2), 10.0 * tot))
+# overlapped reducer: groups handed over "block by block" go out as asynchronous buckets, finish() scatters the sums back into
+# the very tensors that were submitted; what it reduced is skipped (once) by allreduce_gradients
+q = [torch.nn.Parameter(torch.zeros(n)) for n in (7, 3, 11, 2)]
+gr = [torch.full((p_.numel(),), float((rank + 1) * (i + 1))) for i, p_ in enumerate(q)]
+red = shdist.OverlappedGradReducer(bucket_bytes=32)
+assert red.active()
+red.submit([(q[0], gr[0]), (q[1], gr[1])]); red.submit([(q[2], gr[2])]); red.finish()
+for i in range(3):
+    assert torch.equal(gr[i], torch.full_like(gr[i], float(tot * (i + 1)))), (rank, i, gr[i])
+    q[i].grad = gr[i]
+q[3].grad = gr[3]
+assert red.reduced == {id(q[0]), id(q[1]), id(q[2])}
+shdist.allreduce_gradients(q, bucket_bytes=16, skip=red.reduced)
+assert not red.reduced
+assert torch.equal(q[0].grad, torch.full((7,), float(tot))) and torch.equal(q[3].grad, torch.full((2,), 4.0 * tot))
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
