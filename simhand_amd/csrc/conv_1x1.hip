@@ -18,6 +18,8 @@
 // channels of a pixel per tile pair; BatchNorm partial sums use DPP row reductions + a double-buffered LDS slab.
 #include "conv_1x1.h"
 
+#include <stdlib.h>
+
 namespace sh {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16_frag_t;
@@ -46,7 +48,9 @@ __device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
 // EP (forward only): BatchNorm + residual + ReLU epilogue (Gemm1x1Args::ep_*): scale / shift are cached in LDS and the
 // residual chunk of the NEXT 64 channels is prefetched into registers while the current chunk's MFMAs run -- otherwise
 // every chunk would expose a global-load latency (measured 1.6x the HBM-bound time).
-template <int K, int MF, bool DGRAD, bool FUSE = false, bool EP = false>
+// PF (data gradient, accumulate 2 only): the residual-gradient rows and both bit masks of the NEXT 64 channels are requested
+// while the current chunk's MFMAs run (masks as one 8-byte load per pixel row instead of two byte loads per mask)
+template <int K, int MF, bool DGRAD, bool FUSE = false, bool EP = false, bool PF = false>
 #ifndef SH_G1_FUSE_MINB
 #define SH_G1_FUSE_MINB 3
 #endif
@@ -144,6 +148,23 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
     }
     if (p.ep_res != nullptr) load_res(0);
   }
+
+  // ---- PF: residual gradient + masks of chunk 0
+  uint4 pg[PF ? MF : 1][2];
+  uint2 pm[PF ? MF : 1], pk[PF ? MF : 1];
+  auto load_pf = [&](int nc2) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mi = 0; mi < (PF ? MF : 1); ++mi) {
+      const long long row = mbase + mi * 16 + li;
+      const bool ok = row < p.M;
+      const long long r = ok ? row : 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) pg[mi][j] = *reinterpret_cast<const uint4*>(p.res_grad + r * p.N + nc2 * 64 + j * 32 + g * 8);
+      pm[mi] = *reinterpret_cast<const uint2*>(p.res_mask + r * (p.N >> 3) + nc2 * 8);
+      pk[mi] = p.fmode == 4 ? *reinterpret_cast<const uint2*>(p.fmask + r * (p.N >> 3) + nc2 * 8) : make_uint2(0xffffffffu, 0xffffffffu);
+    }
+  };
+  if constexpr (PF) load_pf(0);
 
   // ---- fragment read offsets: weight row chan_of(ni, li) = (ni>>1)*32 + (li>>2)*8 + (ni&1)*4 + (li&3); key == li -------
   const int fkey = CPR == 16 ? li : (((li & 3) >> 1) | ((li >> 2) << 1));
@@ -251,9 +272,16 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
           v.y = pack_bf16x2(lo[2], lo[3]);
           v.z = pack_bf16x2(hi[0], hi[1]);
           v.w = pack_bf16x2(hi[2], hi[3]);
-          if (DGRAD && p.accumulate == 2) {
-            const uint4 o = *reinterpret_cast<const uint4*>(p.res_grad + row * p.N + ch);
-            const unsigned bits = p.res_mask[row * (p.N >> 3) + (ch >> 3)];
+          if (DGRAD && (PF || p.accumulate == 2)) {
+            uint4 o;
+            unsigned bits;
+            if constexpr (PF) {
+              o = pg[mi][j];
+              bits = ((j == 0 ? pm[mi].x : pm[mi].y) >> (8 * g)) & 0xffu;
+            } else {
+              o = *reinterpret_cast<const uint4*>(p.res_grad + row * p.N + ch);
+              bits = p.res_mask[row * (p.N >> 3) + (ch >> 3)];
+            }
             const unsigned m0w = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
             const unsigned m1w = ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
             const unsigned m2w = ((bits & 16u) ? 0x0000ffffu : 0u) | ((bits & 32u) ? 0xffff0000u : 0u);
@@ -269,7 +297,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
             v.z = add_bf16x2_g1(v.z, o.z);
             v.w = add_bf16x2_g1(v.w, o.w);
           }
-          if (DGRAD && p.fmode == 4) {  // the stored gradient is the masked one
+          if (DGRAD && (PF || p.fmode == 4)) {  // the stored gradient is the masked one
             v.x &= ((keep & 1u) ? 0x0000ffffu : 0u) | ((keep & 2u) ? 0xffff0000u : 0u);
             v.y &= ((keep & 4u) ? 0x0000ffffu : 0u) | ((keep & 8u) ? 0xffff0000u : 0u);
             v.z &= ((keep & 16u) ? 0x0000ffffu : 0u) | ((keep & 32u) ? 0xffff0000u : 0u);
@@ -337,10 +365,14 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
 #pragma unroll
               for (int j = 0; j < 2; ++j) {
                 unsigned keep = 0xffu;
-                if (DGRAD && p.fmode == 4) keep = p.fmask[row * (p.N >> 3) + ((n0 + j * 32 + g * 8) >> 3)];  // masked store, no sums
+                if constexpr (PF) keep = ((j == 0 ? pk[mi].x : pk[mi].y) >> (8 * g)) & 0xffu;
+                else if (DGRAD && p.fmode == 4) keep = p.fmask[row * (p.N >> 3) + ((n0 + j * 32 + g * 8) >> 3)];  // masked store, no sums
                 store_chunk(mi, j, row, keep);
               }
             }
+          }
+          if constexpr (PF) {
+            if (nc + 1 < nch) load_pf(nc + 1);  // lands under the next chunk's MFMAs
           }
           if constexpr (EP) {
             if (p.ep_res != nullptr && nc + 1 < nch) load_res(nc + 1);  // lands under the next chunk's MFMAs
@@ -377,6 +409,12 @@ void hooks_reset_1x1() { g_mf[0] = 4; g_mf[1] = 2; g_mf[2] = 2; }
 static int mf_of(int k) { return g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)]; }
 void gemm1x1_set_mf(int k, int mf) { g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)] = mf; }
 
+// accumulate-2 data gradient with prefetched residual rows / masks (per K; test / tuning hook, env for A/B timing)
+static int pf_of(int k) {
+  static const int env = getenv("SIMHAND_G1_PF") ? atoi(getenv("SIMHAND_G1_PF")) : 7;  // bit 0: K = 64, 1: 128, 2: 256
+  return (env >> (k == 64 ? 0 : (k == 128 ? 1 : 2))) & 1;
+}
+
 int gemm1x1_rows_per_block(int k) { return 64 * mf_of(k); }
 
 int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
@@ -386,6 +424,7 @@ int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
 #define SH_G1(KV, MFV)                                                                          \
   do {                                                                                          \
     if (dgrad && a.fpartial != nullptr) gemm1x1_kernel<KV, MFV, true, true><<<nblk, 256, 0, s>>>(a);  \
+    else if (dgrad && a.accumulate == 2 && pf_of(KV)) gemm1x1_kernel<KV, MFV, true, false, false, true><<<nblk, 256, 0, s>>>(a);  \
     else if (dgrad) gemm1x1_kernel<KV, MFV, true><<<nblk, 256, 0, s>>>(a);                      \
     else if (a.ep_scale != nullptr) gemm1x1_kernel<KV, MFV, false, false, true><<<nblk, 256, 0, s>>>(a);  \
     else gemm1x1_kernel<KV, MFV, false><<<nblk, 256, 0, s>>>(a);                                \

@@ -856,11 +856,35 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         fa[(grp + 1) & 1][0] = *reinterpret_cast<const uint4*>(st + fa_base + (2 * nq) * 16 * 128 + fo);
         fa[(grp + 1) & 1][1] = *reinterpret_cast<const uint4*>(st + fa_base + (2 * nq + 1) * 16 * 128 + fo);
       }
+#ifndef SH_DMA_SCHED
+#define SH_DMA_SCHED 1
+#endif
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[2 * q][ni] = Mma<T>::run(fb[kk][ni], fa[grp & 1][0], acc[2 * q][ni]);
+#if SH_DMA_SCHED == 4  // between the two MFMA quads of the group, first half of the step
+      if (grp < 4) { dma_part(2 * grp); dma_part(2 * grp + 1); }
+#elif SH_DMA_SCHED == 5  // one between the quads, one after
+      if (grp < 4) dma_part(2 * grp);
+#elif SH_DMA_SCHED == 6  // 3,3,2
+      if (grp < 2) { dma_part(3 * grp); dma_part(3 * grp + 1); dma_part(3 * grp + 2); } else if (grp == 2) { dma_part(6); dma_part(7); }
+#endif
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[2 * q + 1][ni] = Mma<T>::run(fb[kk][ni], fa[grp & 1][1], acc[2 * q + 1][ni]);
+#if SH_DMA_SCHED == 5
+      if (grp < 4) dma_part(2 * grp + 1);
+#endif
+#ifndef SH_DMA_SCHED
+#define SH_DMA_SCHED 1
+#endif
+#if SH_DMA_SCHED == 0
       dma_part(grp);
+#elif SH_DMA_SCHED == 1  // two per group in the first half of the step: the last DMA has half a step to land
+      if (grp < 4) { dma_part(2 * grp); dma_part(2 * grp + 1); }
+#elif SH_DMA_SCHED == 2
+      if (grp < 2) { dma_part(4 * grp); dma_part(4 * grp + 1); dma_part(4 * grp + 2); dma_part(4 * grp + 3); }
+#elif SH_DMA_SCHED == 3  // 2,2,1,1,1,1
+      if (grp < 2) { dma_part(2 * grp); dma_part(2 * grp + 1); } else if (grp < 6) dma_part(grp + 2);
+#endif
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS is reused by the epilogues
