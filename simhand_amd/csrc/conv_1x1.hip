@@ -48,9 +48,18 @@ __device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
 // EP (forward only): BatchNorm + residual + ReLU epilogue (Gemm1x1Args::ep_*): scale / shift are cached in LDS and the
 // residual chunk of the NEXT 64 channels is prefetched into registers while the current chunk's MFMAs run -- otherwise
 // every chunk would expose a global-load latency (measured 1.6x the HBM-bound time).
-// PF (data gradient, accumulate 2 only): the residual-gradient rows and both bit masks of the NEXT 64 channels are requested
-// while the current chunk's MFMAs run (masks as one 8-byte load per pixel row instead of two byte loads per mask)
-template <int K, int MF, bool DGRAD, bool FUSE = false, bool EP = false, bool PF = false>
+// EP == 2: the same with residual, ReLU and bit mask all present and M a multiple of the block's rows (the conv3 of every
+// identity block): no conditional anywhere near a global load or store, see the note on vmcnt below.
+// PF (data gradient; accumulate 2, masked store, full blocks): residual-gradient rows and both bit masks of the chunk are
+// requested when the chunk's MFMAs start (masks as one 8-byte load per pixel row instead of two byte loads per mask).
+//
+// vmcnt: vector-memory operations retire IN ORDER, and hipcc's waitcnt pass takes the most conservative pending state over all
+// paths that reach a point.  A conditional load or store in the loop body therefore turns the counted waits for the weight tile
+// (the youngest loads but for the epilogue's) into vmcnt(0): the block drains its queue once per chunk and the HBM latency of
+// the prefetched rows is exposed instead of hidden under the MFMAs -- these kernels' MFMA time and HBM time ADDED UP.  The fast
+// variants (EP == 2, PF) keep the body branch-free, request the epilogue's rows right AFTER the chunk's first weight-tile fetch
+// (so that waiting for the tile does not wait for them), and the last step re-fetches tile 0 instead of skipping the fetch.
+template <int K, int MF, bool DGRAD, bool FUSE = false, int EP = 0, bool PF = false>
 #ifndef SH_G1_FUSE_MINB
 #define SH_G1_FUSE_MINB 3
 #endif
@@ -63,6 +72,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
   constexpr int NBL = 64 * CPR / 256;     // staged chunks per thread and step
   constexpr int ROWB = KC * 2;            // bytes per weight-tile row
   constexpr int BT = 64 * ROWB;           // bytes per weight tile
+  constexpr bool FAST = EP == 2 || PF;
   __shared__ __attribute__((aligned(16))) char sB[2 * BT];
   __shared__ float red[2][4][2][64];
   __shared__ __attribute__((aligned(16))) float s_ep[EP ? 2 * 2048 : 4];  // [2][N <= 2048]: scale, shift
@@ -137,8 +147,8 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
     for (int mi = 0; mi < (EP ? MF : 1); ++mi) {
       const long long row = mbase + mi * 16 + li;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        rq[mi][j] = row < p.M ? *reinterpret_cast<const uint4*>(p.ep_res + row * p.N + nc2 * 64 + j * 32 + g * 8) : make_uint4(0, 0, 0, 0);
+      for (int j = 0; j < 2; ++j)  // rows beyond M read row 0 (never stored): no branch around the load
+        rq[mi][j] = *reinterpret_cast<const uint4*>(p.ep_res + (FAST || row < p.M ? row : 0) * p.N + nc2 * 64 + j * 32 + g * 8);
     }
   };
   if constexpr (EP) {
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
       s_ep[i] = p.ep_scale[i];
       s_ep[2048 + i] = p.ep_shift[i];
     }
-    if (p.ep_res != nullptr) load_res(0);
+    if (EP == 1 && p.ep_res != nullptr) load_res(0);
   }
 
   // ---- PF: residual gradient + masks of chunk 0
@@ -155,16 +165,13 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
   auto load_pf = [&](int nc2) __attribute__((always_inline)) {
 #pragma unroll
     for (int mi = 0; mi < (PF ? MF : 1); ++mi) {
-      const long long row = mbase + mi * 16 + li;
-      const bool ok = row < p.M;
-      const long long r = ok ? row : 0;
+      const long long r = mbase + mi * 16 + li;
 #pragma unroll
       for (int j = 0; j < 2; ++j) pg[mi][j] = *reinterpret_cast<const uint4*>(p.res_grad + r * p.N + nc2 * 64 + j * 32 + g * 8);
       pm[mi] = *reinterpret_cast<const uint2*>(p.res_mask + r * (p.N >> 3) + nc2 * 8);
-      pk[mi] = p.fmode == 4 ? *reinterpret_cast<const uint2*>(p.fmask + r * (p.N >> 3) + nc2 * 8) : make_uint2(0xffffffffu, 0xffffffffu);
+      pk[mi] = *reinterpret_cast<const uint2*>(p.fmask + r * (p.N >> 3) + nc2 * 8);
     }
   };
-  if constexpr (PF) load_pf(0);
 
   // ---- fragment read offsets: weight row chan_of(ni, li) = (ni>>1)*32 + (li>>2)*8 + (ni&1)*4 + (li&3); key == li -------
   const int fkey = CPR == 16 ? li : (((li & 3) >> 1) | ((li >> 2) << 1));
@@ -182,6 +189,9 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   SH_G1_STORE(sB);
+  // everything the prologue requested (A rows, coefficients) is waited for HERE, explicitly: a load still pending on the loop's
+  // entry path would make every iteration drain the queue down to that path's count (see the note on vmcnt above)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
 
   int s = 0;
@@ -190,9 +200,17 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
     for (int ks = 0; ks < KSTEPS; ++ks, ++s) {
       const int buf = s & 1;
       const bool more = s + 1 < total;
-      if (more) {  // next weight tile: (nc, ks + 1) or (nc + 1, 0)
-        const long long off = ks + 1 < KSTEPS ? (long long)nc * 64 * K + (ks + 1) * KC : (long long)(nc + 1) * 64 * K;
+      {  // next weight tile: (nc, ks + 1) or (nc + 1, 0); after the last one tile 0 again (unused)
+        const long long off = !more ? 0ll : (ks + 1 < KSTEPS ? (long long)nc * 64 * K + (ks + 1) * KC : (long long)(nc + 1) * 64 * K);
         SH_G1_LOAD(off);
+      }
+      if constexpr (FAST) {  // this chunk's epilogue rows: younger than the tile fetch above, a whole chunk of MFMAs to land
+        __builtin_amdgcn_sched_barrier(0);  // the machine scheduler would hoist them above the tile fetch
+        if (ks == 0) {
+          if constexpr (EP == 2) load_res(nc);
+          else load_pf(nc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       const char* cB = sB + buf * BT;
 #pragma unroll
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
         const int n0 = nc * 64;
         // ---- BatchNorm partial sums of the fp32 accumulators: lane holds pixel li of each 16-row group, channels
         //      chan_of(ni, 4g + r); rows beyond M are exact zeros
-        if (!DGRAD && p.bn_partial != nullptr) {
+        if (!FAST && !DGRAD && p.bn_partial != nullptr) {
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -233,7 +251,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
         // ---- 64 channels out: two 16-B vectors per lane and pixel (channels n0 + j*32 + g*8 .. +8)
         auto store_chunk = [&](int mi, int j, long long row, unsigned keep = 0xffu) __attribute__((always_inline)) -> uint4 {
           f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
-          if (DGRAD && p.bias != nullptr) {
+          if (!FAST && DGRAD && p.bias != nullptr) {
             const int chb = n0 + j * 32 + g * 8;
             const float4 b0 = *reinterpret_cast<const float4*>(p.bias + chb), b1 = *reinterpret_cast<const float4*>(p.bias + chb + 4);
             lo[0] += b0.x; lo[1] += b0.y; lo[2] += b0.z; lo[3] += b0.w;
@@ -247,7 +265,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
             const float4 h0 = *reinterpret_cast<const float4*>(s_ep + 2048 + ch), h1 = *reinterpret_cast<const float4*>(s_ep + 2048 + ch + 4);
             float o[8] = {lo[0] * s0.x + h0.x, lo[1] * s0.y + h0.y, lo[2] * s0.z + h0.z, lo[3] * s0.w + h0.w,
                           hi[0] * s1.x + h1.x, hi[1] * s1.y + h1.y, hi[2] * s1.z + h1.z, hi[3] * s1.w + h1.w};
-            if (p.ep_res != nullptr) {
+            if (EP == 2 || p.ep_res != nullptr) {
               const unsigned w4[4] = {rq[mi][j].x, rq[mi][j].y, rq[mi][j].z, rq[mi][j].w};  // prefetched a chunk ago
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
@@ -255,14 +273,14 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
                 o[2 * i + 1] += __uint_as_float(w4[i] & 0xffff0000u);
               }
             }
-            if (p.ep_relu) {
+            if (EP == 2 || p.ep_relu) {
               unsigned bits = 0;
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 bits |= (o[e] > 0.f ? 1u : 0u) << e;
                 o[e] = o[e] > 0.f ? o[e] : 0.f;
               }
-              if (p.ep_mask != nullptr) p.ep_mask[row * (p.N >> 3) + (ch >> 3)] = (unsigned char)bits;
+              if (EP == 2 || p.ep_mask != nullptr) p.ep_mask[row * (p.N >> 3) + (ch >> 3)] = (unsigned char)bits;
             }
             Vec16<bf16_t>::store(dst, o);
             return make_uint4(0, 0, 0, 0);
@@ -361,7 +379,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
 #pragma unroll
           for (int mi = 0; mi < MF; ++mi) {
             const long long row = mbase + mi * 16 + li;
-            if (row < p.M) {
+            if (FAST || row < p.M) {
 #pragma unroll
               for (int j = 0; j < 2; ++j) {
                 unsigned keep = 0xffu;
@@ -371,10 +389,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
               }
             }
           }
-          if constexpr (PF) {
-            if (nc + 1 < nch) load_pf(nc + 1);  // lands under the next chunk's MFMAs
-          }
-          if constexpr (EP) {
+          if constexpr (EP == 1) {
             if (p.ep_res != nullptr && nc + 1 < nch) load_res(nc + 1);  // lands under the next chunk's MFMAs
           }
         }
@@ -383,13 +398,13 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-      if (more) {
+      {
         char* dB = sB + (buf ^ 1) * BT;
         SH_G1_STORE(dB);
       }
       __syncthreads();
       float* stat_out = DGRAD ? (FUSE ? p.fpartial : nullptr) : p.bn_partial;
-      if (ks == KSTEPS - 1 && stat_out != nullptr && tid < 128) {
+      if (!FAST && ks == KSTEPS - 1 && stat_out != nullptr && tid < 128) {
         const int which = tid >> 6, c = tid & 63;
         const float v = (red[nc & 1][0][which][c] + red[nc & 1][1][which][c]) + (red[nc & 1][2][which][c] + red[nc & 1][3][which][c]);
         stat_out[((long long)blockIdx.x * 2 + which) * p.N + nc * 64 + c] = v;
@@ -409,7 +424,7 @@ void hooks_reset_1x1() { g_mf[0] = 4; g_mf[1] = 2; g_mf[2] = 2; }
 static int mf_of(int k) { return g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)]; }
 void gemm1x1_set_mf(int k, int mf) { g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)] = mf; }
 
-// accumulate-2 data gradient with prefetched residual rows / masks (per K; test / tuning hook, env for A/B timing)
+// the branch-free variants (EP == 2, PF) per K; env for A/B timing against the generic kernels
 static int pf_of(int k) {
   static const int env = getenv("SIMHAND_G1_PF") ? atoi(getenv("SIMHAND_G1_PF")) : 7;  // bit 0: K = 64, 1: 128, 2: 256
   return (env >> (k == 64 ? 0 : (k == 128 ? 1 : 2))) & 1;
@@ -418,15 +433,23 @@ static int pf_of(int k) {
 int gemm1x1_rows_per_block(int k) { return 64 * mf_of(k); }
 
 int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
-  const int mf = mf_of(k);
+  int mf = mf_of(k);
+  // the branch-free BN + residual + ReLU epilogue at K = 64 wants 128-row blocks (its rows are requested one short chunk ahead:
+  // more resident blocks hide what the 32 MFMAs of a chunk cannot; measured 1.53 ms against 2.05 with 256 rows, 1.64 generic)
+  if (!dgrad && k == 64 && mf == 4 && a.ep_scale != nullptr && a.ep_res != nullptr && a.ep_relu && a.ep_mask != nullptr && a.M % 128 == 0 && pf_of(64))
+    mf = 2;
   const int nblk = ceil_div(a.M, 64 * mf);
+  const bool full = a.M % (64 * mf) == 0;
   route_hit(dgrad ? SH_ROUTE_GEMM1X1_DGRAD : (a.ep_scale != nullptr ? SH_ROUTE_GEMM1X1_FWD_BNACT : SH_ROUTE_GEMM1X1_FWD));
 #define SH_G1(KV, MFV)                                                                          \
   do {                                                                                          \
     if (dgrad && a.fpartial != nullptr) gemm1x1_kernel<KV, MFV, true, true><<<nblk, 256, 0, s>>>(a);  \
-    else if (dgrad && a.accumulate == 2 && pf_of(KV)) gemm1x1_kernel<KV, MFV, true, false, false, true><<<nblk, 256, 0, s>>>(a);  \
+    else if (dgrad && a.accumulate == 2 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && full && pf_of(KV))  \
+      gemm1x1_kernel<KV, MFV, true, false, 0, true><<<nblk, 256, 0, s>>>(a);                    \
     else if (dgrad) gemm1x1_kernel<KV, MFV, true><<<nblk, 256, 0, s>>>(a);                      \
-    else if (a.ep_scale != nullptr) gemm1x1_kernel<KV, MFV, false, false, true><<<nblk, 256, 0, s>>>(a);  \
+    else if (a.ep_scale != nullptr && a.ep_res != nullptr && a.ep_relu && a.ep_mask != nullptr && full && pf_of(KV))  \
+      gemm1x1_kernel<KV, MFV, false, false, 2><<<nblk, 256, 0, s>>>(a);                         \
+    else if (a.ep_scale != nullptr) gemm1x1_kernel<KV, MFV, false, false, 1><<<nblk, 256, 0, s>>>(a);  \
     else gemm1x1_kernel<KV, MFV, false><<<nblk, 256, 0, s>>>(a);                                \
   } while (0)
   if (k == 64) {
