@@ -142,6 +142,10 @@ struct Pixel {
 #ifndef SH_IGEMM_MINB
 #define SH_IGEMM_MINB 3
 #endif
+// 128 B of zeros: halo / out-of-range / past-the-end operand loads read it instead of being skipped -- a conditional global
+// load in a main loop makes hipcc's waitcnt pass drain the whole queue (it merges the pending state of both paths)
+__device__ uint4 g_zero_page[8];
+
 template <typename T, bool DGRAD, int BN>
 __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void igemm_kernel(IgemmArgs p) {
   constexpr int KE = 128 / (int)sizeof(T);  // elements of k per step
@@ -263,7 +267,8 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
   int l_cs = 0, l_tr = 0, l_ts = 0;
   // staging registers as named scalars: an array here ends up in scratch / promoted to LDS (hipcc 7.2)
   uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2 = make_uint4(0, 0, 0, 0), rb3 = make_uint4(0, 0, 0, 0);
-  auto load_step = [&]() __attribute__((always_inline)) {
+  const char* zsrc = reinterpret_cast<const char*>(g_zero_page) + (tid & 7) * 16;
+  auto load_step = [&](bool live) __attribute__((always_inline)) {
     if (DGRAD && p.a2 != nullptr && l_cs == cs1) {
       // second K segment (1x1 / stride 1: pixel index == m): re-base the row and weight pointers so that the same
       // l_cs * KE offsets walk a2 / w2; dead rows keep their h0 = -2^20
@@ -279,21 +284,25 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
     const int hoff = dh * l_tr, woff = dh * l_ts;
     const int aoff = (hoff * p.Ws + woff) * p.lda + l_cs * KE;                              // elements, |.| < 2^31
     const int boff = ((r0 + rstep * l_tr) * p.S + (s0 + rstep * l_ts)) * p.lda + l_cs * KE;
+    // branch-free: halo pixels, dead rows and the step past the end (live == false) read the zero page
     auto load_a = [&](const T* pa, int h0, int w0) __attribute__((always_inline)) -> uint4 {
-      const bool ok = (unsigned)(h0 + hoff) < (unsigned)p.Hs && (unsigned)(w0 + woff) < (unsigned)p.Ws;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *reinterpret_cast<const uint4*>(pa + aoff);
-      return v;
+      const bool ok = live && (unsigned)(h0 + hoff) < (unsigned)p.Hs && (unsigned)(w0 + woff) < (unsigned)p.Ws;
+      const char* src = ok ? reinterpret_cast<const char*>(pa + aoff) : zsrc;
+      return *reinterpret_cast<const uint4*>(src);
     };
     ra0 = load_a(pa0, h00, w00);
     ra1 = load_a(pa1, h01, w01);
     ra2 = load_a(pa2, h02, w02);
     ra3 = load_a(pa3, h03, w03);
-    rb0 = *reinterpret_cast<const uint4*>(pb0 + boff);
-    rb1 = *reinterpret_cast<const uint4*>(pb0 + wrow32 + boff);
+    auto load_b = [&](long long row_off) __attribute__((always_inline)) -> uint4 {
+      const char* src = live ? reinterpret_cast<const char*>(pb0 + row_off + boff) : zsrc;  // (a re-based pb0 alone is not a valid address)
+      return *reinterpret_cast<const uint4*>(src);
+    };
+    rb0 = load_b(0);
+    rb1 = load_b(wrow32);
     if (NB == 4) {
-      rb2 = *reinterpret_cast<const uint4*>(pb0 + 2 * wrow32 + boff);
-      rb3 = *reinterpret_cast<const uint4*>(pb0 + 3 * wrow32 + boff);
+      rb2 = load_b(2 * wrow32);
+      rb3 = load_b(3 * wrow32);
     }
     if (++l_cs == csteps) {
       l_cs = 0;
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) {
-    load_step();
+    load_step(true);
     store_step(0);
   }
   __syncthreads();
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = NBUF == 2 ? (ks & 1) : 0;
 #if SH_ABL != 2
-    if (ks + 1 < nk) load_step();  // global loads in flight under the MFMAs
+    load_step(ks + 1 < nk);  // global loads in flight under the MFMAs (unconditional: see g_zero_page)
 #endif
     const char* cA = sA + buf * (128 * 128) + fa_base;
     const char* cB = sB + buf * (BN * 128);
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
     if (NBUF == 1) __syncthreads();  // single buffer: every wave is done reading before the tile is overwritten
 #endif
 #if SH_ABL != 1
-    if (ks + 1 < nk) store_step(NBUF == 2 ? (buf ^ 1) : 0);
+    store_step(NBUF == 2 ? (buf ^ 1) : 0);  // after the last step: zeros into a tile nobody reads again
 #else
     asm volatile("" ::"v"(ra0.x), "v"(ra1.x), "v"(ra2.x), "v"(ra3.x), "v"(rb0.x), "v"(rb1.x), "v"(rb2.x), "v"(rb3.x));
 #endif
@@ -657,8 +666,6 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
 //   * per k-step: issue the next step's 8 DMA instructions, s_waitcnt vmcnt(8) (this step has landed), barrier,
 //     64 MFMAs per wave from the current stage, barrier.  No ordinary global loads in the loop.
 // Fragment layout, weight-row permutation and the epilogues are those of igemm_kernel (MI = 8 row tiles per wave).
-__device__ uint4 g_zero_page[8];
-
 template <bool DGRAD>
 __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   typedef bf16_t T;
