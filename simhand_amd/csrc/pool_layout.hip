@@ -301,6 +301,32 @@ __global__ __launch_bounds__(256) void oihw_to_crsk_kernel(const float* __restri
   }
 }
 
+// every conv weight of the net in ONE launch (was two launches per convolution and step: ~0.5 ms of 5-us kernels): block b works
+// on PACK_CHUNK consecutive KRSC elements of tensor chunks[b].x, starting at element chunks[b].y * PACK_CHUNK, and writes the
+// KRSC copy and -- when the item has one -- the CRSK copy (the data-gradient operand) from a single read of the fp32 master
+constexpr int PACK_CHUNK = 4096;
+template <typename T>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const sh_pack_item* __restrict__ items, const int2* __restrict__ chunks) {
+  const int2 ck = chunks[blockIdx.x];
+  const sh_pack_item it = items[ck.x];
+  const int c = it.c, r = it.r, s = it.s, k = it.k;
+  const int row = c * r * s;
+  const int64_t total = (int64_t)k * row;
+  const float* __restrict__ src = it.src;
+  T* __restrict__ krsc = reinterpret_cast<T*>(it.krsc);
+  T* __restrict__ crsk = reinterpret_cast<T*>(it.crsk);
+  const int64_t base = (int64_t)ck.y * PACK_CHUNK;
+  for (int j = threadIdx.x; j < PACK_CHUNK; j += 256) {
+    const int64_t i = base + j;
+    if (i >= total) break;
+    const int col = (int)(i % row), ko = (int)(i / row);
+    const int ci = col % c, rs = col / c;
+    const float v = src[(((int64_t)ko * c + ci) * r + rs / s) * s + rs % s];
+    Elem<T>::store(krsc + i, v);
+    if (crsk != nullptr) Elem<T>::store(crsk + ((int64_t)ci * r * s + rs) * k + ko, v);
+  }
+}
+
 __global__ __launch_bounds__(256) void krsc_to_oihw_kernel(const float* __restrict__ src, float* __restrict__ dst, int k, int c,
                                                            int r, int s, int k_pad) {
   const int64_t total = (int64_t)k * c * r * s;
@@ -536,6 +562,17 @@ int simhand_oihw_f32_to_krsc(const float* src, void* dst, int k, int c, int r, i
   SH_DISPATCH(dtype, (oihw_to_krsc_kernel<float><<<stream_grid(total), 256, 0, st>>>(src, (float*)dst, k, c, r, s, k_pad)),
               (oihw_to_krsc_kernel<bf16_t><<<stream_grid(total), 256, 0, st>>>(src, (bf16_t*)dst, k, c, r, s, k_pad)));
   return check_launch("oihw_to_krsc");
+}
+
+int simhand_pack_chunk_elems(void) { return PACK_CHUNK; }
+
+int simhand_pack_weights_multi(const sh_pack_item* items, const int32_t* chunks, int n_chunks, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(items && chunks && n_chunks >= 1, "pack_weights_multi: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_MISC, st, 0, (double)n_chunks * PACK_CHUNK * 8);
+  SH_DISPATCH(dtype, (pack_multi_kernel<float><<<n_chunks, 256, 0, st>>>(items, (const int2*)chunks)),
+              (pack_multi_kernel<bf16_t><<<n_chunks, 256, 0, st>>>(items, (const int2*)chunks)));
+  return check_launch("pack_weights_multi");
 }
 
 int simhand_oihw_f32_to_crsk(const float* src, void* dst, int k, int c, int r, int s, int dtype, sh_stream_t stream) {

@@ -119,7 +119,7 @@ class _Backbone(nn.Module):
 # engine
 # --------------------------------------------------------------------------
 class _Packed:
-    __slots__ = ("krsc", "crsk", "version")
+    __slots__ = ("krsc", "crsk", "version", "w", "stem")
 
 
 class _Unit:
@@ -137,6 +137,7 @@ class ResNetEngine:
         self.fp8 = fp8
         self._fp8_sites: Dict[int, tuple] = {}  # id(conv.weight) -> (activation scaler, weight scaler, packed weights, version)
         self._packs: Dict[int, _Packed] = {}
+        self._pack_plan = None  # (key, ops.PackPlan) of the one-launch re-pack
         # BN-backward partial sums of a unit fused into the epilogue of the dgrad that produces its incoming gradient
         self.fuse_bn_bwd = True
         # bottleneck conv3 + bn3: BatchNorm backward folded into the 1x1 conv's own gradients (_unit3_bwd_folded)
@@ -168,10 +169,25 @@ class ResNetEngine:
                 p.krsc = ops.pack_krsc(w.detach(), self.dtype)
             p.crsk = None
             p.version = ver
+            p.w, p.stem = w, stem
             self._packs[id(w)] = p
         if need_t and p.crsk is None:
             p.crsk = ops.pack_crsk(w.detach(), self.dtype)
         return p
+
+    def _repack_stale(self) -> None:
+        """After an optimizer step every packed copy is stale: re-pack all of them (KRSC, and CRSK where a data gradient asked for
+        one before) in ONE launch instead of two per convolution (ops.pack_weights_multi); _pack() then finds them current."""
+        stale = [p for p in self._packs.values()
+                 if not p.stem and p.version != (p.w._version, p.w.data_ptr(), self.dtype) and p.version[1:] == (p.w.data_ptr(), self.dtype)]
+        if len(stale) < 2:
+            return
+        key = tuple((p.w.data_ptr(), p.krsc.data_ptr(), 0 if p.crsk is None else p.crsk.data_ptr()) for p in stale)
+        if self._pack_plan is None or self._pack_plan[0] != key:
+            self._pack_plan = (key, ops.PackPlan([(p.w.detach(), p.krsc, p.crsk) for p in stale], self.dtype))
+        ops.pack_weights_multi(self._pack_plan[1])
+        for p in stale:
+            p.version = (p.w._version, p.w.data_ptr(), self.dtype)
 
     # -- forward ---------------------------------------------------------------
     def _bn(self, bn: nn.BatchNorm2d, part, m, c, training):
@@ -281,6 +297,7 @@ class ResNetEngine:
         n = sum(v.shape[0] for v in views)
         h, w = views[0].shape[-2:]
         ctx: Optional[dict] = {"units": [], "blocks": []} if want_ctx else None
+        self._repack_stale()
         # stem: direct 7x7/2 conv from the zero-padded NHWC4 copy of the batch (0.9 GB at 2048 x 224^2 -- an im2col
         # matrix would be 9.9 GB); the same copy feeds the stem's weight gradient
         xp = ops.stem_pad_input(tuple(v.contiguous() for v in views), self.dtype)

@@ -384,6 +384,36 @@ def pack_crsk(w_oihw: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return out
 
 
+PACK_ITEM_DTYPE = np.dtype([("src", "<u8"), ("krsc", "<u8"), ("crsk", "<u8"), ("k", "<i4"), ("c", "<i4"), ("r", "<i4"), ("s", "<i4")])  # == sh_pack_item
+
+
+class PackPlan:
+    """Device tables for ``pack_weights_multi``: entries = [(fp32 OIHW master, KRSC buffer, CRSK buffer or None)]; the tables hold raw
+    pointers, so a plan is valid as long as those tensors are (the caller keys its cache on their data_ptr()s)."""
+
+    def __init__(self, entries, dtype: torch.dtype):
+        lib = _lib_dev()
+        ch = lib.simhand_pack_chunk_elems()
+        rec = np.zeros(len(entries), dtype=PACK_ITEM_DTYPE)
+        pairs = []
+        for i, (w, krsc, crsk) in enumerate(entries):
+            k, c, r, s = w.shape
+            assert w.dtype == torch.float32 and w.is_contiguous() and krsc.dtype == dtype and krsc.numel() == w.numel()
+            assert crsk is None or (crsk.dtype == dtype and crsk.numel() == w.numel())
+            rec[i] = (w.data_ptr(), krsc.data_ptr(), 0 if crsk is None else crsk.data_ptr(), k, c, r, s)
+            pairs.extend((i, j) for j in range((w.numel() + ch - 1) // ch))
+        dev = entries[0][0].device
+        self.dtype = dtype
+        self.n_chunks = len(pairs)
+        self.items = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        self.chunks = torch.tensor(pairs, dtype=torch.int32).reshape(-1, 2).contiguous().to(dev)
+
+
+def pack_weights_multi(plan: PackPlan) -> None:
+    check(_lib_dev().simhand_pack_weights_multi(_ptr(plan.items), _ptr(plan.chunks), plan.n_chunks, dt(plan.dtype), _stream()),
+          "pack_weights_multi")
+
+
 def unpack_krsc_grad(dw: torch.Tensor, shape, k_pad: Optional[int] = None) -> torch.Tensor:
     lib = _lib_dev()
     k, c, r, s = shape

@@ -856,3 +856,49 @@ def test_folded_statistics_survive_large_channel_means(offset, cin, cout):
     assert rel <= 2e-3, (offset, ratio, float(rel))
     want_ws2 = w64 @ (x.double().cpu().view(m, cin).t() @ x.double().cpu().view(m, cin))
     assert (ws2.cpu().double() - want_ws2).abs().max() <= 1e-4 * want_ws2.abs().max()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_weights_multi_equals_the_per_tensor_packers(dtype):
+    """One launch re-packs every conv weight (KRSC + optional CRSK): bit-identical to oihw_to_krsc / oihw_to_crsk per tensor,
+    including items that span several chunks and items without a data-gradient copy."""
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 64, 1, 1), (128, 64, 3, 3), (256, 1024, 1, 1), (64, 16, 3, 3), (512, 512, 3, 3)]
+    ws = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    entries = []
+    for i, w in enumerate(ws):
+        k, c, r, s = w.shape
+        krsc = torch.full((k, c * r * s), 7.0, device=DEV).to(dtype)
+        crsk = None if i == 1 else torch.full((c, r * s * k), 7.0, device=DEV).to(dtype)
+        entries.append((w, krsc, crsk))
+    ops.pack_weights_multi(ops.PackPlan(entries, dtype))
+    torch.cuda.synchronize()
+    for w, krsc, crsk in entries:
+        assert torch.equal(krsc, ops.pack_krsc(w, dtype))
+        if crsk is not None:
+            assert torch.equal(crsk, ops.pack_crsk(w, dtype))
+
+
+def test_engine_repacks_all_weights_in_one_launch_after_an_update():
+    """ResNetEngine._repack_stale: after the parameters change, the next forward re-packs every conv weight through the
+    multi-tensor launch and sees the new values (same output as a fresh engine)."""
+    from types import SimpleNamespace
+
+    from simhand_amd.host.resnet_model import ResNetModel
+
+    torch.manual_seed(3)
+    cfg = SimpleNamespace(model=SimpleNamespace(backend_model="resnet50", pretrained=False))
+    m = ResNetModel(cfg, "pretraining", torch.bfloat16).to(DEV).train()
+    x = torch.randn(4, 3, 64, 64, device=DEV)
+    m(x).sum().backward()  # first step: lazy per-tensor packs (forward + data-gradient copies)
+    with torch.no_grad():
+        for p in m.features.parameters():
+            p.mul_(1.5)
+    m.zero_grad()
+    y1 = m(x)
+    assert m.engine._pack_plan is not None and len(m.engine._pack_plan[0]) > 40
+    m.set_compute_dtype(torch.bfloat16)  # fresh engine: packs everything lazily from the updated masters
+    y2 = m(x)
+    assert torch.equal(y1, y2)
