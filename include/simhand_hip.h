@@ -540,9 +540,11 @@ typedef struct sh_opt_tensor {
 } sh_opt_tensor;
 int simhand_opt_chunk_elems(void);
 
-/* Every convolution weight of the net re-packed in ONE launch: item = fp32 OIHW master -> KRSC rows [k][r*s*c] (forward / weight
- * gradient order) and, when crsk is not NULL, CRSK [c][r*s*k] (data-gradient operand), both in `dtype`.  items and chunks are
- * DEVICE arrays; chunk j = (item index, chunk number within that item), simhand_pack_chunk_elems() KRSC elements each.
+/* Every convolution weight of the net re-packed in TWO launches: item = fp32 OIHW master -> KRSC rows [k][r*s*c] (forward / weight
+ * gradient order) and, when crsk is not NULL, CRSK [c][r*s*k] (data-gradient operand), both in `dtype`.  items, chunks and
+ * crsk_tiles are DEVICE arrays; chunk j = (item index, chunk number within that item), simhand_pack_chunk_elems() KRSC elements
+ * each; crsk_tiles j = (item index, tile number): the CRSK copies are 64 x 64 tile transposes of the KRSC copies, tile number =
+ * (tap * (k / 64) + k_tile) * (c / 64) + c_tile (items with a CRSK copy need k % 64 == 0 and c % 64 == 0).
  * Replaces (reference): nothing -- torch keeps one weight layout; here the packed copies follow every optimizer step
  * (src/models/base_model.py:59-106 is where the reference's parameters change). */
 typedef struct sh_pack_item {
@@ -552,7 +554,8 @@ typedef struct sh_pack_item {
   int32_t k, c, r, s;
 } sh_pack_item;
 int simhand_pack_chunk_elems(void);
-int simhand_pack_weights_multi(const sh_pack_item* items, const int32_t* chunks, int n_chunks, int dtype, sh_stream_t stream);
+int simhand_pack_weights_multi(const sh_pack_item* items, const int32_t* chunks, int n_chunks, const int32_t* crsk_tiles, int n_tiles,
+                               int dtype, sh_stream_t stream);
 int simhand_lars_adam_multi(const sh_opt_tensor* tensors, int n_tensors, const int32_t* chunks, int n_chunks, float* norm_partials,
                             float beta1, float beta2, float adam_eps, float lars_eta, float lars_eps, int lars_clip,
                             int64_t total_elems, sh_stream_t stream);

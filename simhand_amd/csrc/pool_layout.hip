@@ -323,8 +323,31 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const sh_pack_item* __r
     const int ci = col % c, rs = col / c;
     const float v = src[(((int64_t)ko * c + ci) * r + rs / s) * s + rs % s];
     Elem<T>::store(krsc + i, v);
-    if (crsk != nullptr) Elem<T>::store(crsk + ((int64_t)ci * r * s + rs) * k + ko, v);
   }
+}
+
+// CRSK copies from the KRSC copies just written, as 64 x 64 tile transposes through LDS (both sides in 128-B+ runs; a scatter from
+// the KRSC index space costs 0.3 ms per step): block = (item, tile); tile = (tap, 64 output channels, 64 input channels)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_crsk_tiles_kernel(const sh_pack_item* __restrict__ items, const int2* __restrict__ tiles) {
+  __shared__ T tile[64][64 + 2];
+  const int2 tk = tiles[blockIdx.x];
+  const sh_pack_item it = items[tk.x];
+  const int c = it.c, k = it.k, rs_n = it.r * it.s;
+  const int ct = c / 64, kt = k / 64;
+  int t = tk.y;
+  const int ci0 = (t % ct) * 64;
+  t /= ct;
+  const int ko0 = (t % kt) * 64;
+  const int rs = t / kt;
+  const T* __restrict__ krsc = reinterpret_cast<const T*>(it.krsc);
+  T* __restrict__ crsk = reinterpret_cast<T*>(it.crsk);
+  const int col = threadIdx.x & 63, row4 = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int rr = row4; rr < 64; rr += 4) tile[rr][col] = krsc[((int64_t)(ko0 + rr) * rs_n + rs) * c + ci0 + col];
+  __syncthreads();
+#pragma unroll 4
+  for (int rr = row4; rr < 64; rr += 4) crsk[((int64_t)(ci0 + rr) * rs_n + rs) * k + ko0 + col] = tile[col][rr];
 }
 
 __global__ __launch_bounds__(256) void krsc_to_oihw_kernel(const float* __restrict__ src, float* __restrict__ dst, int k, int c,
@@ -566,12 +589,17 @@ int simhand_oihw_f32_to_krsc(const float* src, void* dst, int k, int c, int r, i
 
 int simhand_pack_chunk_elems(void) { return PACK_CHUNK; }
 
-int simhand_pack_weights_multi(const sh_pack_item* items, const int32_t* chunks, int n_chunks, int dtype, sh_stream_t stream) {
-  SH_REQUIRE(items && chunks && n_chunks >= 1, "pack_weights_multi: bad arguments");
+int simhand_pack_weights_multi(const sh_pack_item* items, const int32_t* chunks, int n_chunks, const int32_t* crsk_tiles, int n_tiles,
+                               int dtype, sh_stream_t stream) {
+  SH_REQUIRE(items && chunks && n_chunks >= 1 && (n_tiles == 0 || crsk_tiles), "pack_weights_multi: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(SH_PROF_MISC, st, 0, (double)n_chunks * PACK_CHUNK * 8);
   SH_DISPATCH(dtype, (pack_multi_kernel<float><<<n_chunks, 256, 0, st>>>(items, (const int2*)chunks)),
               (pack_multi_kernel<bf16_t><<<n_chunks, 256, 0, st>>>(items, (const int2*)chunks)));
+  if (n_tiles > 0) {
+    SH_DISPATCH(dtype, (pack_crsk_tiles_kernel<float><<<n_tiles, 256, 0, st>>>(items, (const int2*)crsk_tiles)),
+                (pack_crsk_tiles_kernel<bf16_t><<<n_tiles, 256, 0, st>>>(items, (const int2*)crsk_tiles)));
+  }
   return check_launch("pack_weights_multi");
 }
 

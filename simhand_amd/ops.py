@@ -395,23 +395,26 @@ class PackPlan:
         lib = _lib_dev()
         ch = lib.simhand_pack_chunk_elems()
         rec = np.zeros(len(entries), dtype=PACK_ITEM_DTYPE)
-        pairs = []
+        pairs, tiles = [], []
         for i, (w, krsc, crsk) in enumerate(entries):
             k, c, r, s = w.shape
             assert w.dtype == torch.float32 and w.is_contiguous() and krsc.dtype == dtype and krsc.numel() == w.numel()
-            assert crsk is None or (crsk.dtype == dtype and crsk.numel() == w.numel())
+            assert crsk is None or (crsk.dtype == dtype and crsk.numel() == w.numel() and k % 64 == 0 and c % 64 == 0)
             rec[i] = (w.data_ptr(), krsc.data_ptr(), 0 if crsk is None else crsk.data_ptr(), k, c, r, s)
             pairs.extend((i, j) for j in range((w.numel() + ch - 1) // ch))
+            if crsk is not None:  # 64 x 64 tile transposes of the KRSC copy, one per (tap, k tile, c tile)
+                tiles.extend((i, j) for j in range(r * s * (k // 64) * (c // 64)))
         dev = entries[0][0].device
         self.dtype = dtype
-        self.n_chunks = len(pairs)
+        self.n_chunks, self.n_tiles = len(pairs), len(tiles)
         self.items = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
         self.chunks = torch.tensor(pairs, dtype=torch.int32).reshape(-1, 2).contiguous().to(dev)
+        self.tiles = torch.tensor(tiles or [(0, 0)], dtype=torch.int32).reshape(-1, 2).contiguous().to(dev)
 
 
 def pack_weights_multi(plan: PackPlan) -> None:
-    check(_lib_dev().simhand_pack_weights_multi(_ptr(plan.items), _ptr(plan.chunks), plan.n_chunks, dt(plan.dtype), _stream()),
-          "pack_weights_multi")
+    check(_lib_dev().simhand_pack_weights_multi(_ptr(plan.items), _ptr(plan.chunks), plan.n_chunks, _ptr(plan.tiles), plan.n_tiles,
+                                                dt(plan.dtype), _stream()), "pack_weights_multi")
 
 
 def unpack_krsc_grad(dw: torch.Tensor, shape, k_pad: Optional[int] = None) -> torch.Tensor:

@@ -865,7 +865,7 @@ def test_pack_weights_multi_equals_the_per_tensor_packers(dtype):
     from simhand_amd import ops
 
     g = torch.Generator().manual_seed(11)
-    shapes = [(64, 64, 1, 1), (128, 64, 3, 3), (256, 1024, 1, 1), (64, 16, 3, 3), (512, 512, 3, 3)]
+    shapes = [(64, 64, 1, 1), (128, 64, 3, 3), (256, 1024, 1, 1), (64, 128, 3, 3), (512, 512, 3, 3)]
     ws = [torch.randn(s, generator=g).to(DEV) for s in shapes]
     entries = []
     for i, w in enumerate(ws):
