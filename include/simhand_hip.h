@@ -75,9 +75,10 @@ enum sh_route {
   SH_ROUTE_NTXENT_FWD = 25, SH_ROUTE_NTXENT_BWD = 26,
   SH_ROUTE_FP8_FWD = 27, SH_ROUTE_FP8_DGRAD = 28,           /* e4m3 MFMA (K = 128 per instruction) tile kernel */
   SH_ROUTE_BN_APPLY_GRAM = 29,                              /* BN-apply + ReLU fused into the Gram (x^T x) launch */
-  SH_ROUTE_WGRAD_BNBWD = 30,
-  SH_ROUTE_NTXENT_FUSED_DIST = 31,                          /* loss tile kernel computing the joint distances in-tile (no D block) */                                /* BN-backward apply fused into the 1x1 weight gradient's dy loader */
-  SH_ROUTE_COUNT = 32
+  SH_ROUTE_WGRAD_BNBWD = 30,                                /* BN-backward apply fused into the 1x1 weight gradient's dy loader */
+  SH_ROUTE_NTXENT_FUSED_DIST = 31,                          /* loss tile kernel computing the joint distances in-tile (no D block) */
+  SH_ROUTE_DGRAD_DYSRC = 32,                                /* BN-backward apply fused into the 1x1 data gradient's dy loader */
+  SH_ROUTE_COUNT = 33
 };
 int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
 int simhand_route_reset(void);
@@ -281,6 +282,25 @@ int simhand_conv2d_dgrad_fused(const sh_conv_desc* d, const void* dy, const void
  * accumulated in fp32 in one pass -- the two terms of the folded BatchNorm backward's input gradient
  * (g (diag(A) W) - a (W^T diag(B) W)) without a second launch re-reading and re-writing dx.  Only where
  * simhand_conv2d_dgrad_concat_ok(d, c2) says so (bf16 1x1 / stride 1, c2 a multiple of 64); x2 = NULL: off. */
+/* dy_src: the `dy` operand is DERIVED on load instead of read -- dy = coef_a * (da [y*scale + shift > 0]) - coef_b * y + coef_c (the
+ * BatchNorm-backward apply of the unit this convolution belongs to, its sums already reduced: simhand_bn_bwd_coefs) -- and
+ * written once to dy_out for the weight gradient that follows: the stand-alone simhand_bn_bwd_apply pass over the unit is gone
+ * (2 reads + 1 write of a dy-sized tensor become 1 extra read + 1 write inside this launch).  The `dy` argument of
+ * simhand_conv2d_dgrad_ex is then ignored.  Only where simhand_conv2d_dgrad_dysrc_ok(d) says so (the bf16 1x1 / stride-1 layers
+ * the activation-stationary kernel takes, single reduction segment).  relu = 0: no gate.
+ * Replaces (reference): native_batch_norm_backward in front of conv1's input gradient in torchvision's Bottleneck
+ * (src/models/resnet_model.py:13-58). */
+typedef struct sh_dy_src {
+  const void* da;
+  const void* y;
+  const float* scale;
+  const float* shift;
+  const float* coef_a;
+  const float* coef_b;
+  const float* coef_c;
+  int32_t relu;
+  void* dy_out;
+} sh_dy_src;
 typedef struct sh_dgrad_opts {
   int32_t accumulate;
   const void* res_grad;
@@ -290,8 +310,10 @@ typedef struct sh_dgrad_opts {
   const void* x2;
   const void* wt2;
   int32_t c2;
+  const sh_dy_src* dy_src;
 } sh_dgrad_opts;
 int simhand_conv2d_dgrad_concat_ok(const sh_conv_desc* d, int c2);
+int simhand_conv2d_dgrad_dysrc_ok(const sh_conv_desc* d);
 int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, const sh_dgrad_opts* opts, sh_stream_t stream);
 
 /* dw (fp32, KRSC) = sum over output pixels of dy (x) patches(x); deterministic two-stage split-K */

@@ -31,8 +31,9 @@ PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn", "pool", "loss", "m
 ROUTES = ("igemm128_fwd", "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "igemm256_tail", "gemm1x1_fwd", "gemm1x1_fwd_bnact",
           "gemm1x1_dgrad", "c64_fwd", "c64_dgrad", "stem_fwd", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
           "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
-          "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram", "wgrad_bnbwd", "ntxent_fused_dist")
-ROUTE_COUNT = 32
+          "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram", "wgrad_bnbwd", "ntxent_fused_dist",
+          "dgrad_dysrc")
+ROUTE_COUNT = 33
 
 
 class SimhandHipError(RuntimeError):
@@ -53,10 +54,17 @@ class BnBwdFuse(C.Structure):
                 ("relu_mode", C.c_int32), ("partial", C.c_void_p)]
 
 
+class DySrc(C.Structure):
+    """sh_dy_src (include/simhand_hip.h)."""
+    _fields_ = [("da", C.c_void_p), ("y", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("coef_a", C.c_void_p),
+                ("coef_b", C.c_void_p), ("coef_c", C.c_void_p), ("relu", C.c_int32), ("dy_out", C.c_void_p)]
+
+
 class DgradOpts(C.Structure):
     """sh_dgrad_opts (include/simhand_hip.h)."""
     _fields_ = [("accumulate", C.c_int32), ("res_grad", C.c_void_p), ("res_mask", C.c_void_p), ("bias", C.c_void_p),
-                ("fuse", C.POINTER(BnBwdFuse)), ("x2", C.c_void_p), ("wt2", C.c_void_p), ("c2", C.c_int32)]
+                ("fuse", C.POINTER(BnBwdFuse)), ("x2", C.c_void_p), ("wt2", C.c_void_p), ("c2", C.c_int32),
+                ("dy_src", C.POINTER(DySrc))]
 
 
 class ConvDesc(C.Structure):
@@ -149,6 +157,7 @@ SIGNATURES = {
     "simhand_conv3x3_c64_enable": (_I, [_I]),
     "simhand_stem_conv_route": (_I, [_I]),
     "simhand_igemm256_split_tail": (_I, [_I]),
+    "simhand_conv2d_dgrad_dysrc_ok": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_dgrad_concat_ok": (_I, [C.POINTER(ConvDesc), _I]),
     "simhand_conv2d_fwd_bnact": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "simhand_conv2d_dgrad_ex": (_I, [C.POINTER(ConvDesc), _P, _P, _P, C.POINTER(DgradOpts), _P]),

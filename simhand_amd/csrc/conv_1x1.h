@@ -31,6 +31,17 @@ struct Gemm1x1Args {
   // K = 256 forward only: the direct 7x7/2 stem.  a = zero-padded NHWC4 input [n][stem_hp][stem_wp][4]; row m = output pixel
   // (img, ho, wo); its k-slice j (32 elements) is filter row j: 8 taps x 4 channels contiguous at padded (2 ho + j, 2 wo).
   // stem_wp = 0: off
+  // data gradient only: the A operand is DERIVED on load instead of read -- dy = xf_a * (a [y*xf_s + xf_h > 0]) - xf_b * y + xf_c per
+  // channel (the BatchNorm-backward apply of the unit whose conv this is the data gradient of; a = incoming gradient, xf_y = the
+  // unit's raw conv output) -- and written to xf_out for the weight gradient that follows.  xf_y null = off
+  const bf16_t* xf_y = nullptr;
+  const float* xf_s = nullptr;
+  const float* xf_h = nullptr;
+  const float* xf_a = nullptr;
+  const float* xf_b = nullptr;
+  const float* xf_c = nullptr;
+  bf16_t* xf_out = nullptr;
+  int xf_relu = 0;
   int stem_hp = 0, stem_wp = 0;
   FastDiv div_hw = {1, 0, 0}, div_w = {1, 0, 0};  // ho * wo, wo
 };

@@ -139,6 +139,59 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
 #pragma unroll
     for (int j = 0; j < KF; ++j) afr[mi][j] = ok ? *reinterpret_cast<const uint4*>(pr + j * jstride) : make_uint4(0, 0, 0, 0);
   }
+  if constexpr (DGRAD) {
+    if (p.xf_y != nullptr) {  // block-uniform, prologue only: BatchNorm-backward apply on the freshly loaded gradient rows
+      // all y rows are requested before the first one is used (one exposed round trip, not MF * KF of them); the per-channel
+      // coefficients depend on the k-slice only and are fetched once per slice
+      uint4 yfr[MF][KF];
+#pragma unroll
+      for (int mi = 0; mi < MF; ++mi) {
+        const long long row = mbase + mi * 16 + li;
+        const bf16_t* py = p.xf_y + (row < p.M ? row : 0) * K + g * 8;
+#pragma unroll
+        for (int j = 0; j < KF; ++j) yfr[mi][j] = *reinterpret_cast<const uint4*>(py + j * 32);
+      }
+#pragma unroll
+      for (int j = 0; j < KF; ++j) {
+        const int kc = j * 32 + g * 8;
+        float cs[8], ch[8], ca[8], cb[8], cc[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+          const float4 t0 = *reinterpret_cast<const float4*>(p.xf_s + kc + e), t1 = *reinterpret_cast<const float4*>(p.xf_h + kc + e);
+          const float4 t2 = *reinterpret_cast<const float4*>(p.xf_a + kc + e), t3 = *reinterpret_cast<const float4*>(p.xf_b + kc + e);
+          const float4 t4 = *reinterpret_cast<const float4*>(p.xf_c + kc + e);
+          cs[e] = t0.x; cs[e + 1] = t0.y; cs[e + 2] = t0.z; cs[e + 3] = t0.w;
+          ch[e] = t1.x; ch[e + 1] = t1.y; ch[e + 2] = t1.z; ch[e + 3] = t1.w;
+          ca[e] = t2.x; ca[e + 1] = t2.y; ca[e + 2] = t2.z; ca[e + 3] = t2.w;
+          cb[e] = t3.x; cb[e + 1] = t3.y; cb[e + 2] = t3.z; cb[e + 3] = t3.w;
+          cc[e] = t4.x; cc[e + 1] = t4.y; cc[e + 2] = t4.z; cc[e + 3] = t4.w;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MF; ++mi) {
+          const long long row = mbase + mi * 16 + li;
+          const bool ok = row < p.M;
+          const unsigned g4[4] = {afr[mi][j].x, afr[mi][j].y, afr[mi][j].z, afr[mi][j].w};
+          const unsigned y4[4] = {yfr[mi][j].x, yfr[mi][j].y, yfr[mi][j].z, yfr[mi][j].w};
+          unsigned o4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float r2[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const int e = 2 * q + hh;
+              const float gv = hh == 0 ? __uint_as_float(g4[q] << 16) : __uint_as_float(g4[q] & 0xffff0000u);
+              const float yy = hh == 0 ? __uint_as_float(y4[q] << 16) : __uint_as_float(y4[q] & 0xffff0000u);
+              const bool on = !p.xf_relu || (yy * cs[e] + ch[e] > 0.f);
+              r2[hh] = ca[e] * (on ? gv : 0.f) - cb[e] * yy + cc[e];  // same expression as the weight-gradient loader's (XFORM 2)
+            }
+            o4[q] = pack_bf16x2(r2[0], r2[1]);
+          }
+          afr[mi][j] = ok ? make_uint4(o4[0], o4[1], o4[2], o4[3]) : make_uint4(0, 0, 0, 0);
+          if (ok) *reinterpret_cast<uint4*>(p.xf_out + row * K + g * 8 + j * 32) = afr[mi][j];
+        }
+      }
+    }
+  }
 
   // ---- EP: coefficients to LDS (visible after the first barrier below), residual rows of chunk 0 to registers -------
   uint4 rq[EP ? MF : 1][2];

@@ -1448,8 +1448,16 @@ static bool concat_ok(const sh_conv_desc* d, int c2) {
 
 static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
                       const unsigned char* res_mask, sh_stream_t stream, const sh_bn_bwd_fuse* fuse = nullptr,
-                      const float* bias = nullptr, const void* x2 = nullptr, const void* wt2 = nullptr, int c2 = 0) {
+                      const float* bias = nullptr, const void* x2 = nullptr, const void* wt2 = nullptr, int c2 = 0,
+                      const sh_dy_src* src = nullptr) {
   if (check_desc(d, "conv2d_dgrad")) return 1;
+  if (src != nullptr) {
+    SH_REQUIRE(src->da && src->y && src->scale && src->shift && src->coef_a && src->coef_b && src->coef_c && src->dy_out,
+               "conv2d_dgrad_ex: dy_src has a NULL member");
+    SH_REQUIRE(x2 == nullptr && use_1x1(d, d->cout, d->cin),
+               "conv2d_dgrad_ex: dy_src needs a layer simhand_conv2d_dgrad_dysrc_ok accepts and a single reduction segment");
+    dy = src->da;
+  }
   SH_REQUIRE(dy && wt && dx, "conv2d_dgrad: NULL pointer");
   SH_REQUIRE(x2 == nullptr || (wt2 != nullptr && concat_ok(d, c2)),
              "conv2d_dgrad_ex: a second reduction segment needs wt2 and a layer simhand_conv2d_dgrad_concat_ok accepts");
@@ -1513,6 +1521,11 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
     g.M = a.Mg; g.N = d->cin; g.accumulate = accumulate; g.res_grad = (const bf16_t*)res_grad; g.res_mask = res_mask;
     g.fy = (const bf16_t*)a.fy; g.fscale = a.fscale; g.fshift = a.fshift; g.fmask = a.fmask; g.fmode = a.fmode; g.fpartial = a.fpartial;
     g.bias = a.bias;
+    if (src != nullptr) {
+      g.xf_y = (const bf16_t*)src->y; g.xf_s = src->scale; g.xf_h = src->shift; g.xf_a = src->coef_a; g.xf_b = src->coef_b;
+      g.xf_c = src->coef_c; g.xf_out = (bf16_t*)src->dy_out; g.xf_relu = src->relu;
+      route_hit(SH_ROUTE_DGRAD_DYSRC);
+    }
     launch_gemm1x1(g, d->cout, true, (hipStream_t)stream);
     return check_launch("conv2d_dgrad (1x1)");
   }
@@ -1564,8 +1577,10 @@ int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* w
   SH_REQUIRE(o != nullptr, "conv2d_dgrad_ex: opts is NULL");
   SH_REQUIRE(o->accumulate >= 0 && o->accumulate <= 2, "conv2d_dgrad_ex: accumulate mode %d", o->accumulate);
   SH_REQUIRE(o->accumulate != 2 || (o->res_grad && o->res_mask), "conv2d_dgrad_ex: accumulate 2 needs res_grad / res_mask");
-  return dgrad_impl(d, dy, wt, dx, o->accumulate, o->res_grad, o->res_mask, stream, o->fuse, o->bias, o->x2, o->wt2, o->c2);
+  return dgrad_impl(d, dy, wt, dx, o->accumulate, o->res_grad, o->res_mask, stream, o->fuse, o->bias, o->x2, o->wt2, o->c2, o->dy_src);
 }
+
+int simhand_conv2d_dgrad_dysrc_ok(const sh_conv_desc* d) { return d != nullptr && use_1x1(d, d->cout, d->cin) ? 1 : 0; }
 
 int simhand_conv2d_dgrad_concat_ok(const sh_conv_desc* d, int c2) {
   if (!d) return 0;

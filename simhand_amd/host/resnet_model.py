@@ -152,6 +152,11 @@ class ResNetEngine:
         # (off: measured on MI355X at 2048 x 224^2 the BatchNorm class drops 4.3 ms but the weight-gradient class grows 8.5 ms --
         # every cin tile of the launch re-derives the dy operand from TWO tensors; kept for the experiment record)
         self.fuse_bwd_apply_wgrad = os.environ.get("SIMHAND_FUSE_BWDW", "0") == "1"
+        # BN-backward apply of a Bottleneck's conv1 + bn1 runs in the A-operand load of conv1's DATA gradient (the activation-
+        # stationary kernel loads each gradient row exactly once, straight into MFMA operand registers): the stand-alone pass
+        # (2 reads + 1 write of the narrow tensor) becomes 1 extra read + 1 write inside that launch; the weight gradient then
+        # reads the dy it wrote (env: A/B timing only)
+        self.fuse_bwd_apply_dgrad = os.environ.get("SIMHAND_FUSE_BWDD", "1") == "1"
         self._gram = None  # (activation tensor, a^T a, sum a) of the unit just applied that way
         # multi-GPU: host.dist.OverlappedGradReducer -- finished parameter gradients go out block by block during backward
         self.grad_reducer = None
@@ -472,11 +477,24 @@ class ResNetEngine:
         w = u.conv.weight
         fuse_apply = (self.fuse_bwd_apply_wgrad and self.dtype == torch.bfloat16 and not u.stem and relu_mask is None and not u.has_res
                       and u.conv.kernel_size == (1, 1) and u.conv.stride == (1, 1) and u.conv.padding == (0, 0))
+        fuse_dg = (self.fuse_bwd_apply_dgrad and not fuse_apply and self.dtype == torch.bfloat16 and not u.stem and relu_mask is None
+                   and not u.has_res and need_dx and prev is not None and prev_masked_store and u.conv.kernel_size == (1, 1)
+                   and u.conv.stride == (1, 1) and u.conv.padding == (0, 0) and ops.conv2d_dgrad_dysrc_ok(d))
         dy, _, dg, db = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, False,
                                         mask_from_y=u.relu and not u.has_res, relu_mask=relu_mask, raw_partial=raw_partial,
-                                        apply=not fuse_apply)
+                                        apply=not (fuse_apply or fuse_dg))
         grads[u.bn.weight] = dg
         grads[u.bn.bias] = db
+        if fuse_dg:
+            # data gradient FIRST: it derives dy from (da, y) while loading its operand rows and writes it out for the weight gradient
+            coefs = ops.bn_bwd_coefs(u.st, u.bn.weight.detach(), dg, db, m)
+            pk = self._pack(u.conv, need_t=True)
+            dy = torch.empty_like(u.y)
+            dxm, _ = ops.conv2d_dgrad_ex(d, None, pk.crsk, dx=dx_into, accumulate=dx_into is not None, res_grad=res_grad, res_mask=res_mask,
+                                         fuse_mode=4, prev_mask=prev.mask, want_sums=False,
+                                         dy_src=(da.contiguous(), u.y, u.st, coefs, u.relu, dy))
+            grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))
+            return dxm, None
         if fuse_apply:
             coefs = ops.bn_bwd_coefs(u.st, u.bn.weight.detach(), dg, db, m)
             grads[w], dy = ops.conv2d_wgrad_bnbwd(d, u.x, da, u.y, u.st, coefs, u.relu, tuple(w.shape))

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BnBwdFuse, ConvDesc, DgradOpts, NtxentParams, check
+from ._lib import BnBwdFuse, ConvDesc, DgradOpts, DySrc, NtxentParams, check
 
 _DT = {torch.float32: _lib.SH_F32, torch.bfloat16: _lib.SH_BF16}
 
@@ -252,16 +252,26 @@ def conv2d_dgrad_fused(d: ConvDesc, dy, wt, prev_y, prev_st: Optional["BNState"]
 
 def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accumulate: bool = False, res_grad=None, res_mask=None,
                     bias=None, fuse_mode: Optional[int] = None, prev_y=None, prev_st: Optional["BNState"] = None, prev_mask=None,
-                    want_sums: bool = True, x2=None, wt2=None):
+                    want_sums: bool = True, x2=None, wt2=None, dy_src=None):
     """General data gradient (simhand_conv2d_dgrad_ex): optional accumulate / masked-residual merge, fp32 per-channel
     bias, and epilogue fusion.  fuse_mode: None = none; 0 / 2 / 3 = BN-backward sums of the previous unit (no ReLU /
     mask from prev_y*scale+shift / bit mask); 4 = store the gradient masked by prev_mask and emit its channel sums.
     x2 / wt2: second reduction segment, dx = dy wt^T + x2 wt2^T in one pass (only where conv2d_dgrad_concat_ok).
+    dy_src = (da, y, BNState, (coef_a, coef_b, coef_c), relu, dy_out): the dy operand is derived on load as the BatchNorm-backward
+    apply of the unit (sh_dy_src; `dy` is ignored, pass None) and written to dy_out; only where conv2d_dgrad_dysrc_ok.
     Returns (dx, partial or None)."""
     lib = _lib_dev()
+    ref = dy if dy is not None else dy_src[0]
     if dx is None:
-        dx = torch.empty(d.n, d.h, d.w, d.cin, dtype=dy.dtype, device=dy.device)
+        dx = torch.empty(d.n, d.h, d.w, d.cin, dtype=ref.dtype, device=ref.device)
     o = DgradOpts()
+    if dy_src is not None:
+        da, ysrc, st_, coefs, relu_, dy_out = dy_src
+        sdy = DySrc()
+        sdy.da, sdy.y, sdy.scale, sdy.shift = _ptr(da, torch.bfloat16), _ptr(ysrc, torch.bfloat16), _ptr(st_.scale), _ptr(st_.shift)
+        sdy.coef_a, sdy.coef_b, sdy.coef_c, sdy.relu, sdy.dy_out = _ptr(coefs[0]), _ptr(coefs[1]), _ptr(coefs[2]), int(relu_), _ptr(dy_out, torch.bfloat16)
+        o.dy_src = C.pointer(sdy)
+        dy = da
     o.accumulate = 2 if res_grad is not None else int(accumulate)
     o.res_grad = _ptr(res_grad)
     o.res_mask = _ptr(res_mask)
@@ -272,7 +282,7 @@ def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accu
     if fuse_mode is not None:
         if want_sums or fuse_mode != 4:  # mode 4 may store the masked gradient without emitting its sums
             nblk = lib.simhand_conv2d_dgrad_stat_blocks(C.byref(d), o.accumulate, fuse_mode, int(o.c2))
-            part = torch.empty(nblk, 2, d.cin, dtype=torch.float32, device=dy.device)
+            part = torch.empty(nblk, 2, d.cin, dtype=torch.float32, device=ref.device)
         f = BnBwdFuse()
         f.y = _ptr(prev_y)
         f.mask = _ptr(prev_mask)
@@ -283,6 +293,10 @@ def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accu
         o.fuse = C.pointer(f)
     check(lib.simhand_conv2d_dgrad_ex(C.byref(d), _ptr(dy), _ptr(wt), _ptr(dx), C.byref(o), _stream()), "conv2d_dgrad_ex")
     return dx, part
+
+
+def conv2d_dgrad_dysrc_ok(d: ConvDesc) -> bool:
+    return bool(_lib_dev().simhand_conv2d_dgrad_dysrc_ok(C.byref(d)))
 
 
 def conv2d_dgrad_concat_ok(d: ConvDesc, c2: int) -> bool:

@@ -902,3 +902,46 @@ def test_engine_repacks_all_weights_in_one_launch_after_an_update():
     m.set_compute_dtype(torch.bfloat16)  # fresh engine: packs everything lazily from the updated masters
     y2 = m(x)
     assert torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("n,h,cin,cout,relu,masked", [(3, 13, 256, 64, True, True), (2, 20, 512, 128, True, True), (2, 16, 1024, 256, True, False),
+                                                       (1, 7, 256, 64, False, False)])
+def test_bn_backward_apply_fused_into_the_1x1_data_gradient(n, h, cin, cout, relu, masked):
+    """sh_dy_src: dy = A (da [bn(y) > 0]) - B y + C derived in the data gradient's operand load == simhand_bn_bwd_apply followed by
+    the plain data gradient (same residual merge / masked store); the dy it writes == the stand-alone pass's (bf16 round-off:
+    the fused form evaluates A g - B y + C, the pass gamma invstd (g - mean g - xhat mean(g xhat)))."""
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(cin + cout + h)
+    dt = torch.bfloat16
+    m = n * h * h
+    y = (torch.randn(n, h, h, cout, generator=g) * 1.3 + 0.1).to(DEV).to(dt)
+    da = torch.randn(n, h, h, cout, generator=g).to(DEV).to(dt)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.05).to(DEV)
+    gamma = (torch.rand(cout, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(cout, generator=g) * 0.2).to(DEV)
+    part = ops.bn_partial_stats(y.view(m, cout), m, cout)
+    st = ops.bn_finalize(part, m, cout, gamma, beta, torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV),
+                         torch.zeros(1, dtype=torch.int64, device=DEV))
+    want_dy, _, dg, db = ops.bn_backward(da.view(m, cout), None, y.view(m, cout), st, gamma, m, cout, relu, False, mask_from_y=relu)
+    d = ops.conv_desc(n, h, h, cin, cout, 1, 1, 1, 0, dt)
+    assert ops.conv2d_dgrad_dysrc_ok(d)
+    wt = ops.pack_crsk(w, dt)
+    kw = {}
+    if masked:  # identity-block form: + residual gradient through its mask, stored through the block-below's mask
+        one = ops.BNState(cin, DEV); one.scale.fill_(1.0); one.shift.fill_(0.0)
+        rg = torch.randn(n, h, h, cin, generator=g).to(DEV).to(dt)
+        _, rmask = ops.bn_apply(torch.randn(m, cin, generator=g).to(DEV).to(dt), one, m, cin, True, None, want_mask=True)
+        _, pmask = ops.bn_apply(torch.randn(m, cin, generator=g).to(DEV).to(dt), one, m, cin, True, None, want_mask=True)
+        kw = dict(res_grad=rg, res_mask=rmask, fuse_mode=4, prev_mask=pmask, want_sums=False)
+    want_dx, _ = ops.conv2d_dgrad_ex(d, want_dy.view(n, h, h, cout), wt, **kw)
+    coefs = ops.bn_bwd_coefs(st, gamma, dg, db, m)
+    dy = torch.empty_like(y)
+    ops.route_reset()
+    dx, _ = ops.conv2d_dgrad_ex(d, None, wt, dy_src=(da, y, st, coefs, relu, dy), **kw)
+    assert ops.route_counts()["dgrad_dysrc"] == 1
+    _check(dy.float().cpu().view(m, cout), want_dy.float().cpu(), 1e-2, "dy")
+    # dx from the dy the kernel itself derived: compare against the plain data gradient of THAT dy (bit-identical operands)
+    ref_dx, _ = ops.conv2d_dgrad_ex(d, dy, wt, **kw)
+    assert torch.equal(dx, ref_dx)
+    _check(dx.float().cpu(), want_dx.float().cpu(), 2e-2, "dx")
