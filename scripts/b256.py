@@ -20,5 +20,8 @@ for cin, cout, k, s, h in SH:
     wk, wt = ops.pack_krsc(w, dt), ops.pack_crsk(w, dt)
     fl = 2.0 * N * d.ho * d.wo * cout * cin * k * k
     tf = ev(lambda: ops.conv2d_fwd(d, x, wk, True)); td = ev(lambda: ops.conv2d_dgrad(d, dy, wt))
-    out.append(f"{(cin,cout,k,s,h)}: fwd {tf:6.1f} us {fl/tf/1e6:5.0f} TF | dgrad {td:6.1f} us {fl/td/1e6:5.0f} TF")
+    st = ops.BNState(cin, x.device); st.scale.fill_(1.0); st.shift.fill_(0.0)
+    dxb = torch.empty_like(x)
+    tdf = ev(lambda: ops.conv2d_dgrad_fused(d, dy, wt, x, st, None, dx=dxb))
+    out.append(f"{(cin,cout,k,s,h)}: fwd {tf:6.1f} us {fl/tf/1e6:5.0f} TF | dgrad {td:6.1f} us {fl/td/1e6:5.0f} TF | dgrad+sums {tdf:6.1f} us")
 print("\n".join(out))

@@ -602,16 +602,31 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
           sh[e] = p.fmode == 2 ? p.fshift[ch + e] : 0.f;
           s1[e] = s2[e] = 0.f;
         }
+        // the four y rows / mask bytes of this channel group are requested together, branch-free (rows past the range read row 0)
+        uint4 yq[4];
+        unsigned bq[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const long long pc = pixs[mi] < 0 ? 0 : pixs[mi];
+          yq[mi] = p.fmode != 4 ? *reinterpret_cast<const uint4*>(fy + pc * p.Ng + ch) : make_uint4(0, 0, 0, 0);
+          bq[mi] = p.fmode >= 3 ? (unsigned)p.fmask[pc * (p.Ng / VE) + ch / VE] : 0xffu;
+        }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           const long long pix = pixs[mi];
           if (pix < 0) continue;
           float yy[VE], gg[VE];
+          if (sizeof(T) == 4) {
+            yy[0] = __uint_as_float(yq[mi].x); yy[1] = __uint_as_float(yq[mi].y); yy[2] = __uint_as_float(yq[mi].z); yy[3] = __uint_as_float(yq[mi].w);
+          } else {
+            const unsigned y4[4] = {yq[mi].x, yq[mi].y, yq[mi].z, yq[mi].w};
 #pragma unroll
-          for (int e = 0; e < VE; ++e) yy[e] = 0.f;
-          if (p.fmode != 4) Vec16<T>::load(fy + pix * p.Ng + ch, yy);
-          unsigned bits = 0xffu;
-          if (p.fmode >= 3) bits = p.fmask[pix * (p.Ng / VE) + ch / VE];
+            for (int i = 0; i < 4; ++i) {
+              yy[(2 * i) % VE] = __uint_as_float(y4[i] << 16);
+              yy[(2 * i + 1) % VE] = __uint_as_float(y4[i] & 0xffff0000u);
+            }
+          }
+          const unsigned bits = bq[mi];
           const uint4 v = chunk_out(mi, j, pix, bits);
           if (sizeof(T) == 4) {
             gg[0] = __uint_as_float(v.x); gg[1] = __uint_as_float(v.y); gg[2] = __uint_as_float(v.z); gg[3] = __uint_as_float(v.w);
@@ -1069,16 +1084,23 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
           sh[e] = p.fmode == 2 ? p.fshift[ch + e] : 0.f;
           s1[e] = s2[e] = 0.f;
         }
+        // all y rows / mask bytes of this 32-channel group are requested before the first one is used (rows past the range read row
+        // 0, branch-free): one exposed round trip per group instead of one per 16-pixel row -- the block is alone on its CU
+        uint4 yq[MI];
+        unsigned bq[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const long long pix = pixel_of(mi);
+          const long long pc = pix < 0 ? 0 : pix;
+          yq[mi] = p.fmode != 4 ? *reinterpret_cast<const uint4*>(fy + pc * p.Ng + ch) : make_uint4(0, 0, 0, 0);
+          bq[mi] = p.fmode >= 3 ? (unsigned)p.fmask[pc * (p.Ng / VE) + ch / VE] : 0xffu;
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           const long long pix = pixel_of(mi);
           if (pix < 0) continue;
-          float yy[VE];
-#pragma unroll
-          for (int e = 0; e < VE; ++e) yy[e] = 0.f;
-          if (p.fmode != 4) Vec16<T>::load(fy + pix * p.Ng + ch, yy);
-          unsigned bits = 0xffu;
-          if (p.fmode >= 3) bits = p.fmask[pix * (p.Ng / VE) + ch / VE];
+          const unsigned y4[4] = {yq[mi].x, yq[mi].y, yq[mi].z, yq[mi].w};
+          const unsigned bits = bq[mi];
           const uint4 v = chunk_out(mi, j, pix, bits);
           const unsigned w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -1087,12 +1109,13 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
             for (int h = 0; h < 2; ++h) {
               const int e = 2 * i + h;
               const float gq = h == 0 ? __uint_as_float(w4[i] << 16) : __uint_as_float(w4[i] & 0xffff0000u);
+              const float yy = h == 0 ? __uint_as_float(y4[i] << 16) : __uint_as_float(y4[i] & 0xffff0000u);
               bool on = true;
-              if (p.fmode == 2) on = yy[e] * sc[e] + sh[e] > 0.f;
+              if (p.fmode == 2) on = yy * sc[e] + sh[e] > 0.f;
               else if (p.fmode == 3) on = (bits >> e) & 1u;  // mode 4: the value is already masked
               const float gv = on ? gq : 0.f;
               s1[e] += gv;
-              s2[e] += gv * yy[e];
+              s2[e] += gv * yy;
             }
           }
         }
