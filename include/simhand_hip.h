@@ -226,6 +226,8 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
 int simhand_stem_geometry(int h, int w, int* hp, int* wp, int* ho, int* wo);
 int simhand_stem_pad_input(const float* x_nchw, void* xp, int n, int h, int w, int dtype, sh_stream_t stream);
 int simhand_stem_pack_weights(const float* w_oihw, void* wp, int dtype, sh_stream_t stream);
+/* rows of the bn_partial buffer simhand_stem_conv_fwd fills: [blocks][2][64] */
+int simhand_stem_conv_fwd_stat_blocks(int n, int h, int w, int dtype);
 int simhand_stem_conv_fwd(const void* xp, const void* wp, void* y, float* bn_partial, int n, int h, int w, int dtype, sh_stream_t stream);
 /* bf16 route of simhand_stem_conv_fwd: 1 (default) = activation-stationary kernel, 0 = 128 x 64 tile kernel (same k order,
  * bit-identical results; tuning / test hook) */

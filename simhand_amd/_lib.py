@@ -115,6 +115,7 @@ SIGNATURES = {
     "simhand_stem_geometry": (_I, [_I, _I, _P, _P, _P, _P]),
     "simhand_stem_pad_input": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "simhand_stem_pack_weights": (_I, [_P, _P, _I, _P]),
+    "simhand_stem_conv_fwd_stat_blocks": (_I, [_I, _I, _I, _I]),
     "simhand_stem_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "simhand_stem_conv_wgrad_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "simhand_stem_conv_wgrad": (_I, [_P, _P, _P, _P, _S, _I, _I, _I, _I, _P]),

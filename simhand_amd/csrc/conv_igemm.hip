@@ -1403,6 +1403,13 @@ int simhand_stem_geometry(int h, int w, int* hp, int* wp, int* ho, int* wo) {
   return 0;
 }
 
+int simhand_stem_conv_fwd_stat_blocks(int n, int h, int w, int dtype) {
+  int hp, wp, ho, wo;
+  if (n < 1 || simhand_stem_geometry(h, w, &hp, &wp, &ho, &wo)) return 0;
+  const long long m = (long long)n * ho * wo;
+  return ceil_div(m, dtype == SH_BF16 && g_stem_1x1 ? 256 : 128);  // rows per block of the kernel the same arguments select
+}
+
 int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_partial, int n, int h, int w, int dtype,
                           sh_stream_t stream) {
   SH_REQUIRE(xp && wp_ && y, "stem_conv_fwd: NULL pointer");

@@ -497,7 +497,8 @@ def stem_conv_fwd(xp: torch.Tensor, wp: torch.Tensor, h: int, w: int, want_stats
     n = xp.shape[0]
     _, _, ho, wo = stem_geometry(h, w)
     y = torch.empty(n, ho, wo, 64, dtype=xp.dtype, device=xp.device)
-    part = torch.empty((n * ho * wo + 127) // 128, 2, 64, dtype=torch.float32, device=xp.device) if want_stats else None
+    nblk = lib.simhand_stem_conv_fwd_stat_blocks(n, h, w, dt(xp.dtype))
+    part = torch.empty(nblk, 2, 64, dtype=torch.float32, device=xp.device) if want_stats else None
     check(lib.simhand_stem_conv_fwd(_ptr(xp), _ptr(wp), _ptr(y), _ptr(part), n, h, w, dt(xp.dtype), _stream()), "stem_conv_fwd")
     return y, part
 
