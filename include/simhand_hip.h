@@ -359,6 +359,9 @@ int simhand_igemm256_enable(int on);
 /* 1 (default): a 256 x 256 launch whose last round of tiles would leave more than two thirds of the CUs idle hands those
  * m-tiles to a second launch of the 128-row kernel (same results bit for bit); 0 = single launch (tuning / test hook) */
 int simhand_igemm256_split_tail(int on);
+/* 224-row tiles of the 256 x 256 kernel (7 x 32 rows: 401 408 pixels = exactly 7 rounds of 256 CUs instead of 6.125): 0 off, 1 auto
+ * (default: when they fill whole rounds and the 256-row plan does not), 2 forced whenever the pixel count is a multiple of 224 */
+int simhand_igemm256_tile224(int mode);
 
 /* tuning hook: non-temporal (streaming) loads / stores in the BatchNorm passes (1 = on [default]) */
 int simhand_bn_set_nt(int on);

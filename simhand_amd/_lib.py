@@ -158,6 +158,7 @@ SIGNATURES = {
     "simhand_conv3x3_c64_enable": (_I, [_I]),
     "simhand_stem_conv_route": (_I, [_I]),
     "simhand_igemm256_split_tail": (_I, [_I]),
+    "simhand_igemm256_tile224": (_I, [_I]),
     "simhand_conv2d_dgrad_dysrc_ok": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_dgrad_concat_ok": (_I, [C.POINTER(ConvDesc), _I]),
     "simhand_conv2d_fwd_bnact": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P]),

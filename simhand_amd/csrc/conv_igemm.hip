@@ -681,11 +681,14 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
 //   * per k-step: issue the next step's 8 DMA instructions, s_waitcnt vmcnt(8) (this step has landed), barrier,
 //     64 MFMAs per wave from the current stage, barrier.  No ordinary global loads in the loop.
 // Fragment layout, weight-row permutation and the epilogues are those of igemm_kernel (MI = 8 row tiles per wave).
-template <bool DGRAD>
+// MI = 7: 224-row tiles (each wave 112 x 64).  401 408 pixels (256 channels @ 14^2 at 2048 images) are 1568 tiles of 256 rows =
+// 6.125 rounds of the 256 CUs, but exactly 7 rounds of 224-row tiles: no ragged round, no second launch (launch_igemm256).  The
+// A region of a stage keeps 256 rows; rows 224.. fetch the zero page (waves 4-7 skip that DMA altogether).
+template <bool DGRAD, int MI = 8>
 __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   typedef bf16_t T;
-  constexpr int KE = 64, VE = 8, BM = 256, BN = 256, MI = 8, NI = 4;
-  constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BN * 128;
+  constexpr int KE = 64, VE = 8, BM = MI * 32, BN = 256, NI = 4, WR = MI * 16;  // WR: rows per wave
+  constexpr int A_BYTES = 256 * 128, STAGE = A_BYTES + BN * 128;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   // LDS-DMA as inline asm: hipcc's waitcnt pass makes every ds_read wait for ALL outstanding builtin LDS-DMAs
   // (s_waitcnt vmcnt(0) right after the barrier), which would drain the prefetch; the asm form is invisible to it and
@@ -753,7 +756,8 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   const T* pa0; const T* pa1; const T* pa2; const T* pa3;
   int h00, h01, h02, h03, w00, w01, w02, w03;
   auto init_row = [&](int i, const T*& pa, int& h0, int& w0) __attribute__((always_inline)) {
-    const Pixel px = decode(m0 + lrow + 64 * i);
+    const bool in_tile = lrow + 64 * i < BM;  // MI = 7: rows 224.. of the A region belong to no wave
+    const Pixel px = decode(in_tile ? m0 + lrow + 64 * i : 0xffffffffu);
     if (DGRAD) {
       h0 = par ? (px.hd + p.pad - r0) >> 1 : px.hd + p.pad;
       w0 = par ? (px.wd + p.pad - s0) >> 1 : px.wd + p.pad;
@@ -828,7 +832,9 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     if (q == 0) dma_a(pa0, h00, w00, 0);
     else if (q == 1) dma_a(pa1, h01, w01, 1);
     else if (q == 2) dma_a(pa2, h02, w02, 2);
-    else if (q == 3) dma_a(pa3, h03, w03, 3);
+    else if (q == 3) {
+      if (MI == 8 || wave < 4) dma_a(pa3, h03, w03, 3);  // wave-uniform: rows 192 + 8 wave .. of a 224-row tile exist for waves 0-3 only
+    }
     else dma16(n_live ? reinterpret_cast<const char*>(pb0 + (q - 4) * wrow64 + n_boff) : zsrc, n_dA + A_BYTES + (q - 4) * 64 * 128);
   };
 
@@ -840,7 +846,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
 
   const int fkey = (li >> 1) & 7;
   const int fo0 = (g ^ fkey) * 16;
-  const int fa_base = (wm * 128 + li) * 128;
+  const int fa_base = (wm * WR + li) * 128;
   const int rowb0 = wn * 64 + chan_of(0, li);
   const int fbo = A_BYTES + rowb0 * 128 + ((g ^ key_b(rowb0)) * 16);
 
@@ -876,37 +882,20 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
             fb[1][ni] = *reinterpret_cast<const uint4*>(st + (fbo ^ 64) + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
         }
         fa[(grp + 1) & 1][0] = *reinterpret_cast<const uint4*>(st + fa_base + (2 * nq) * 16 * 128 + fo);
-        fa[(grp + 1) & 1][1] = *reinterpret_cast<const uint4*>(st + fa_base + (2 * nq + 1) * 16 * 128 + fo);
+        if (2 * nq + 1 < MI) fa[(grp + 1) & 1][1] = *reinterpret_cast<const uint4*>(st + fa_base + (2 * nq + 1) * 16 * 128 + fo);
       }
-#ifndef SH_DMA_SCHED
-#define SH_DMA_SCHED 1
-#endif
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[2 * q][ni] = Mma<T>::run(fb[kk][ni], fa[grp & 1][0], acc[2 * q][ni]);
-#if SH_DMA_SCHED == 4  // between the two MFMA quads of the group, first half of the step
-      if (grp < 4) { dma_part(2 * grp); dma_part(2 * grp + 1); }
-#elif SH_DMA_SCHED == 5  // one between the quads, one after
-      if (grp < 4) dma_part(2 * grp);
-#elif SH_DMA_SCHED == 6  // 3,3,2
-      if (grp < 2) { dma_part(3 * grp); dma_part(3 * grp + 1); dma_part(3 * grp + 2); } else if (grp == 2) { dma_part(6); dma_part(7); }
-#endif
+      if (2 * q + 1 < MI) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[2 * q + 1][ni] = Mma<T>::run(fb[kk][ni], fa[grp & 1][1], acc[2 * q + 1][ni]);
-#if SH_DMA_SCHED == 5
-      if (grp < 4) dma_part(2 * grp + 1);
-#endif
-#ifndef SH_DMA_SCHED
-#define SH_DMA_SCHED 1
-#endif
-#if SH_DMA_SCHED == 0
-      dma_part(grp);
-#elif SH_DMA_SCHED == 1  // two per group in the first half of the step: the last DMA has half a step to land
-      if (grp < 4) { dma_part(2 * grp); dma_part(2 * grp + 1); }
-#elif SH_DMA_SCHED == 2
-      if (grp < 2) { dma_part(4 * grp); dma_part(4 * grp + 1); dma_part(4 * grp + 2); dma_part(4 * grp + 3); }
-#elif SH_DMA_SCHED == 3  // 2,2,1,1,1,1
-      if (grp < 2) { dma_part(2 * grp); dma_part(2 * grp + 1); } else if (grp < 6) dma_part(grp + 2);
-#endif
+        for (int ni = 0; ni < NI; ++ni) acc[2 * q + 1][ni] = Mma<T>::run(fb[kk][ni], fa[grp & 1][1], acc[2 * q + 1][ni]);
+      }
+      // next step's DMAs: two per group in the FIRST half of the step, so that the last one has half a step to land before the
+      // vmcnt(0) at the top of the loop (one per group over the whole step measured 3-7 % slower on the 3x3 layers)
+      if (grp < 4) {
+        dma_part(2 * grp);
+        dma_part(2 * grp + 1);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS is reused by the epilogues
@@ -948,7 +937,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     T* __restrict__ out = reinterpret_cast<T*>(p.out);
     const int ch0 = n0 + wn * 64 + g * VE;
     auto pixel_of = [&](int mi) __attribute__((always_inline)) -> long long {
-      const unsigned mrow = m0 + wm * 128 + mi * 16 + li;
+      const unsigned mrow = m0 + wm * WR + mi * 16 + li;
       long long pix = (long long)mrow;
       bool ok = pix < p.Mg;
       if (par) {
@@ -1175,7 +1164,8 @@ static int launch_igemm(const IgemmArgs& a0, hipStream_t s) {
 // launch of the 128-row kernel instead (bit-identical results: same k order, same fp32 MFMA chain), which takes a
 // fraction of a round.  main_m = m-tiles of the 256-row launch, tail128 = 128-row m-tiles of the second one.
 static hook_t g_split256{1};
-static void split256(long long Mg, int Ng, int classes, int* main_m, int* tail128) {
+static hook_t g_tile224{1};
+static void split256(long long Mg, int Ng, int classes, int* main_m, int* tail128, int* bm = nullptr) {
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;
@@ -1186,8 +1176,19 @@ static void split256(long long Mg, int Ng, int classes, int* main_m, int* tail12
   const int tiles_m = ceil_div(Mg, 256), n_tiles = Ng / 256;
   *main_m = tiles_m;
   *tail128 = 0;
+  if (bm) *bm = 256;
   const long long total = (long long)tiles_m * n_tiles;
   const int rem = (int)(total % cus);
+  // 224-row tiles when they fill whole rounds and the 256-row plan does not: 7 rounds of 7/8-size tiles beat 6 rounds + a ragged one
+  if (g_tile224 && bm && classes == 1 && (rem != 0 || g_tile224 == 2) && Mg % 224 == 0) {
+    const long long t224 = Mg / 224 * n_tiles;
+    const double cost256 = (double)(total / cus) + 0.75, cost224 = (double)(t224 / cus) * 0.9;
+    if (g_tile224 == 2 || (t224 % cus == 0 && cost224 < cost256)) {  // 2 = forced (tests)
+      *bm = 224;
+      *main_m = (int)(Mg / 224);
+      return;
+    }
+  }
   if (!g_split256 || classes != 1 || total <= cus || rem == 0 || 3 * rem > cus) return;
   const int tail_m = ceil_div(rem, n_tiles);
   *main_m = tiles_m - tail_m;
@@ -1197,13 +1198,14 @@ static void split256(long long Mg, int Ng, int classes, int* main_m, int* tail12
 template <bool DGRAD>
 static int launch_igemm256(IgemmArgs a, hipStream_t s) {
   if (a.lda == 0) a.lda = a.Ca;
-  int main_m, tail128;
-  split256(a.Mg, a.Ng, a.classes, &main_m, &tail128);
+  int main_m, tail128, bm;
+  split256(a.Mg, a.Ng, a.classes, &main_m, &tail128, &bm);
   a.m_tiles = main_m;
   a.n_tiles = a.Ng / 256;
   const int nblk = a.classes * a.m_tiles * a.n_tiles;
   route_hit(DGRAD ? SH_ROUTE_IGEMM256_DGRAD : SH_ROUTE_IGEMM256_FWD);
-  igemm256_kernel<DGRAD><<<nblk, 512, 0, s>>>(a);
+  if (bm == 224) igemm256_kernel<DGRAD, 7><<<nblk, 512, 0, s>>>(a);
+  else igemm256_kernel<DGRAD, 8><<<nblk, 512, 0, s>>>(a);
   if (tail128 > 0) {
     route_hit(SH_ROUTE_IGEMM256_TAIL);
     IgemmArgs t = a;
@@ -1218,8 +1220,8 @@ static int launch_igemm256(IgemmArgs a, hipStream_t s) {
 
 // rows of the partial-sum buffers a 256 x 256 launch writes
 static int stat_rows256(long long Mg, int Ng, int classes) {
-  int main_m, tail128;
-  split256(Mg, Ng, classes, &main_m, &tail128);
+  int main_m, tail128, bm;
+  split256(Mg, Ng, classes, &main_m, &tail128, &bm);
   return classes * (main_m + tail128);
 }
 
@@ -1244,6 +1246,7 @@ static bool use_1x1(const sh_conv_desc* d, int k, int n) {
 void hooks_reset_igemm() {
   g_use_256 = 1;
   g_split256 = 1;
+  g_tile224 = 1;
   g_stem_1x1 = 1;
   g_fuse_1x1 = 0;
 }
@@ -1264,6 +1267,11 @@ int simhand_conv1x1_set_rows(int k, int mf) {
 // tuning hook: route eligible layers to the 256 x 256 LDS-DMA kernel (0 = never, 1 = default heuristic, 2 = whenever legal)
 int simhand_igemm256_split_tail(int on) {
   g_split256 = on ? 1 : 0;
+  return 0;
+}
+
+int simhand_igemm256_tile224(int mode) {
+  g_tile224 = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
   return 0;
 }
 

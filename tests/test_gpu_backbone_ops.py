@@ -945,3 +945,51 @@ def test_bn_backward_apply_fused_into_the_1x1_data_gradient(n, h, cin, cout, rel
     ref_dx, _ = ops.conv2d_dgrad_ex(d, dy, wt, **kw)
     assert torch.equal(dx, ref_dx)
     _check(dx.float().cpu(), want_dx.float().cpu(), 2e-2, "dx")
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_big_tile_224_row_tiles_equal_256_row_tiles(k, force_big_tile):
+    """The 7 x 32-row variant of the 256 x 256 kernel (whole rounds at 2048 x 14^2): forced on a small shape whose pixel count is a
+    multiple of 224 but not of 256 -- outputs bit-identical to the 256-row tiles (+ 128-row tail), partial sums with the same totals;
+    forward (+ BatchNorm partials), data gradient, data gradient with fused BatchNorm-backward sums and second reduction segment."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    lib = ops._lib_dev()
+    h, c = 14, 256
+    n = 8  # 1568 pixels = 7 x 224 = 6.125 x 256
+    m = n * h * h
+    assert m % 224 == 0 and m % 256 != 0
+    g = torch.Generator().manual_seed(5 + k)
+    cin = 256 if k == 3 else 1024
+    d = ops.conv_desc(n, h, h, cin, c, k, k, 1, k // 2, dtype)
+    x = torch.randn(n, h, h, cin, generator=g).to(DEV).to(dtype)
+    w = (torch.randn(c, cin, k, k, generator=g) / math.sqrt(cin * k * k)).to(DEV)
+    wk = ops.pack_krsc(w, dtype)
+    dd = ops.conv_desc(n, h, h, c, cin, k, k, 1, k // 2, dtype)  # its data gradient has 256 destination channels
+    wt = ops.pack_crsk((torch.randn(cin, c, k, k, generator=g) / math.sqrt(cin * k * k)).to(DEV), dtype)
+    dy = torch.randn(n, h, h, cin, generator=g).to(DEV).to(dtype)
+    y_prev = torch.randn(n, h, h, c, generator=g).to(DEV).to(dtype)
+    st = ops.BNState(c, DEV)
+    st.scale.copy_(torch.randn(c, generator=g).to(DEV))
+    st.shift.copy_(torch.randn(c, generator=g).to(DEV) * 0.3)
+
+    def run():
+        y, part = ops.conv2d_fwd(d, x, wk, want_stats=True)
+        dx = ops.conv2d_dgrad(dd, dy, wt)
+        dxf, fpart = ops.conv2d_dgrad_fused(dd, dy, wt, y_prev, st, None)
+        return y, part, dx, dxf, fpart
+
+    lib.simhand_igemm256_tile224(0)
+    try:
+        ops.route_reset()
+        y0, p0, dx0, dxf0, f0 = run()
+        assert ops.route_counts()["igemm256_fwd"] == 1 and ops.route_counts()["igemm256_dgrad"] == 2
+        lib.simhand_igemm256_tile224(2)
+        y1, p1, dx1, dxf1, f1 = run()
+    finally:
+        lib.simhand_igemm256_tile224(1)
+    assert p1.shape[0] == m // 224 and f1.shape[0] == m // 224
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0) and torch.equal(dxf1, dxf0)
+    _check(p1.sum(0).cpu(), p0.sum(0).cpu(), 1e-5, "forward statistics")
+    _check(f1.sum(0).cpu(), f0.sum(0).cpu(), 1e-5, "fused BN-backward sums")
