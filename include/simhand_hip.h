@@ -78,7 +78,8 @@ enum sh_route {
   SH_ROUTE_WGRAD_BNBWD = 30,                                /* BN-backward apply fused into the 1x1 weight gradient's dy loader */
   SH_ROUTE_NTXENT_FUSED_DIST = 31,                          /* loss tile kernel computing the joint distances in-tile (no D block) */
   SH_ROUTE_DGRAD_DYSRC = 32,                                /* BN-backward apply fused into the 1x1 data gradient's dy loader */
-  SH_ROUTE_COUNT = 33
+  SH_ROUTE_FWD_CHAIN = 33,                                  /* conv3 + BN + residual + ReLU with the next block's conv1 chained on */
+  SH_ROUTE_COUNT = 34
 };
 int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
 int simhand_route_reset(void);
@@ -317,6 +318,19 @@ typedef struct sh_dgrad_opts {
 int simhand_conv2d_dgrad_concat_ok(const sh_conv_desc* d, int c2);
 int simhand_conv2d_dgrad_dysrc_ok(const sh_conv_desc* d);
 int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, const sh_dgrad_opts* opts, sh_stream_t stream);
+
+/* simhand_conv2d_fwd_bnact with the NEXT 1x1 convolution chained on (a Bottleneck's conv3 -> bn3 -> + identity -> ReLU followed by
+ * the next block's conv1): chain_y [pixels][cin] = out * chain_w^T (chain_w: KRSC [cin][cout] bf16 of that conv1, which maps
+ * d->cout channels back to d->cin) is computed from the bf16 output chunks while they are still in registers -- the block output is
+ * written (the residual path and the backward pass need it) but not read back -- together with its BatchNorm partial sums
+ * chain_partial [simhand_conv2d_fwd_chain_stat_blocks(d)][2][cin].  Results are bit-identical to simhand_conv2d_fwd_bnact followed by
+ * simhand_conv2d_fwd.  residual, relu_mask are required (ReLU is implied).  Only where simhand_conv2d_fwd_chain_ok(d) says so.
+ * Replaces (reference): the bn3 / add / relu tail of one torchvision Bottleneck and conv1 of the next (src/models/resnet_model.py:13-58). */
+int simhand_conv2d_fwd_chain_ok(const sh_conv_desc* d);
+int simhand_conv2d_fwd_chain_stat_blocks(const sh_conv_desc* d);
+int simhand_conv2d_fwd_bnact_chain(const sh_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
+                                   const void* residual, void* out, uint8_t* relu_mask, const void* chain_w, void* chain_y,
+                                   float* chain_partial, sh_stream_t stream);
 
 /* dw (fp32, KRSC) = sum over output pixels of dy (x) patches(x); deterministic two-stage split-K */
 size_t simhand_conv2d_wgrad_workspace_bytes(const sh_conv_desc* d);

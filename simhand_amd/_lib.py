@@ -32,8 +32,8 @@ ROUTES = ("igemm128_fwd", "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "i
           "gemm1x1_dgrad", "c64_fwd", "c64_dgrad", "stem_fwd", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
           "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
           "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram", "wgrad_bnbwd", "ntxent_fused_dist",
-          "dgrad_dysrc")
-ROUTE_COUNT = 33
+          "dgrad_dysrc", "fwd_chain")
+ROUTE_COUNT = 34
 
 
 class SimhandHipError(RuntimeError):
@@ -160,6 +160,9 @@ SIGNATURES = {
     "simhand_igemm256_split_tail": (_I, [_I]),
     "simhand_igemm256_tile224": (_I, [_I]),
     "simhand_conv2d_dgrad_dysrc_ok": (_I, [C.POINTER(ConvDesc)]),
+    "simhand_conv2d_fwd_chain_ok": (_I, [C.POINTER(ConvDesc)]),
+    "simhand_conv2d_fwd_chain_stat_blocks": (_I, [C.POINTER(ConvDesc)]),
+    "simhand_conv2d_fwd_bnact_chain": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "simhand_conv2d_dgrad_concat_ok": (_I, [C.POINTER(ConvDesc), _I]),
     "simhand_conv2d_fwd_bnact": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "simhand_conv2d_dgrad_ex": (_I, [C.POINTER(ConvDesc), _P, _P, _P, C.POINTER(DgradOpts), _P]),

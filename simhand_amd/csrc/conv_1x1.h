@@ -42,11 +42,19 @@ struct Gemm1x1Args {
   const float* xf_c = nullptr;
   bf16_t* xf_out = nullptr;
   int xf_relu = 0;
+  // forward, EP == 2 fast variant with K == 64 and N <= 256 only: CHAINED second 1x1 convolution (the next Bottleneck's conv1, N -> K
+  // channels): chain_y = out * chain_w^T computed from the bf16 output chunks while they are still in registers (a chunk's packed
+  // output IS the next MFMA's A operand) -- the block output is written but not read back.  chain_w: [K][N] bf16 (KRSC of the next
+  // conv1), chain_y: [M][K] bf16 raw conv output, chain_partial: [blocks][2][K] BatchNorm partial sums of it.  chain_w null = off
+  const bf16_t* chain_w = nullptr;
+  bf16_t* chain_y = nullptr;
+  float* chain_partial = nullptr;
   int stem_hp = 0, stem_wp = 0;
   FastDiv div_hw = {1, 0, 0}, div_w = {1, 0, 0};  // ho * wo, wo
 };
 
 bool gemm1x1_supported(int k, int n);
+bool gemm1x1_chain_ok(int k, int n, long long m);  // chained next conv1 available (K = 64 fast forward variant, 128-row blocks)
 int gemm1x1_rows_per_block(int k);
 void gemm1x1_set_mf(int k, int mf);
 int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s);

@@ -59,7 +59,9 @@ __device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
 // the prefetched rows is exposed instead of hidden under the MFMAs -- these kernels' MFMA time and HBM time ADDED UP.  The fast
 // variants (EP == 2, PF) keep the body branch-free, request the epilogue's rows right AFTER the chunk's first weight-tile fetch
 // (so that waiting for the tile does not wait for them), and the last step re-fetches tile 0 instead of skipping the fetch.
-template <int K, int MF, bool DGRAD, bool FUSE = false, int EP = 0, bool PF = false>
+// CH (EP == 2, K == 64, N <= 256): the chained next conv1 (Gemm1x1Args::chain_*): its [64][N] weights stay in LDS for the block's
+// life as N / 64 panels in the weight-tile format, every finished output chunk feeds 2 x 4 extra MFMAs per 16-row group.
+template <int K, int MF, bool DGRAD, bool FUSE = false, int EP = 0, bool PF = false, bool CH = false>
 #ifndef SH_G1_FUSE_MINB
 #define SH_G1_FUSE_MINB 3
 #endif
@@ -73,6 +75,8 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
   constexpr int ROWB = KC * 2;            // bytes per weight-tile row
   constexpr int BT = 64 * ROWB;           // bytes per weight tile
   constexpr bool FAST = EP == 2 || PF;
+  static_assert(!CH || (EP == 2 && K == 64), "the chained conv1 exists for the K = 64 fast forward variant only");
+  __shared__ __attribute__((aligned(16))) char sC[CH ? 4 * BT : 16];  // chain weights: panel pn = columns 64 pn .. +64 of chain_w
   __shared__ __attribute__((aligned(16))) char sB[2 * BT];
   __shared__ float red[2][4][2][64];
   __shared__ __attribute__((aligned(16))) float s_ep[EP ? 2 * 2048 : 4];  // [2][N <= 2048]: scale, shift
@@ -240,7 +244,22 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
   for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 vout[CH ? MF : 1][2];  // CH: the chunk's packed bf16 output
 
+  f32x4 cacc[CH ? MF : 1][4];
+  if constexpr (CH) {
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) cacc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // chunks tid + 256 i of each [64][8] panel (rows row0 + i * RSTEP), same swizzled offsets as the weight tiles
+    for (int pn = 0; pn < nch; ++pn) {
+      const bf16_t* src = p.chain_w + (long long)row0 * p.N + pn * 64 + ch0 * 8;
+      const uint4 c0 = *reinterpret_cast<const uint4*>(src), c1 = *reinterpret_cast<const uint4*>(src + (long long)RSTEP * p.N);
+      *reinterpret_cast<uint4*>(sC + pn * BT + st0) = c0;
+      *reinterpret_cast<uint4*>(sC + pn * BT + st1) = c1;
+    }
+  }
   SH_G1_STORE(sB);
   // everything the prologue requested (A rows, coefficients) is waited for HERE, explicitly: a load still pending on the loop's
   // entry path would make every iteration drain the queue down to that path's count (see the note on vmcnt above)
@@ -335,8 +354,9 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
               }
               if (EP == 2 || p.ep_mask != nullptr) p.ep_mask[row * (p.N >> 3) + (ch >> 3)] = (unsigned char)bits;
             }
-            Vec16<bf16_t>::store(dst, o);
-            return make_uint4(0, 0, 0, 0);
+            const uint4 pv = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+            *reinterpret_cast<uint4*>(dst) = pv;
+            return pv;
           }
           uint4 v;
           v.x = pack_bf16x2(lo[0], lo[1]);
@@ -438,8 +458,24 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
                 unsigned keep = 0xffu;
                 if constexpr (PF) keep = ((j == 0 ? pk[mi].x : pk[mi].y) >> (8 * g)) & 0xffu;
                 else if (DGRAD && p.fmode == 4) keep = p.fmask[row * (p.N >> 3) + ((n0 + j * 32 + g * 8) >> 3)];  // masked store, no sums
-                store_chunk(mi, j, row, keep);
+                const uint4 pv = store_chunk(mi, j, row, keep);
+                if constexpr (CH) vout[mi][j] = pv;
               }
+            }
+          }
+          if constexpr (CH) {
+            // chained conv1: k-slice j of panel nc x the chunk's packed output (lane = pixel li, channels n0 + 32 j + 8 g .. +8: exactly
+            // the A-operand layout) -> the same k order as the stand-alone conv1, so bit-identical accumulators
+            const char* cP = sC + nc * BT;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+              uint4 fc[4];
+#pragma unroll
+              for (int ni = 0; ni < 4; ++ni) fc[ni] = *reinterpret_cast<const uint4*>(cP + frow[ni] + fo[kk]);
+#pragma unroll
+              for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) cacc[mi][ni] = mma_bf16(fc[ni], vout[mi][kk], cacc[mi][ni]);
             }
           }
           if constexpr (EP == 1) {
@@ -464,6 +500,45 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
       }
     }
   }
+  if constexpr (CH) {
+    // the chained conv1's raw output: BatchNorm partial sums of the fp32 accumulators (layout of the stand-alone forward: one row
+    // pair per block) and the bf16 store, 8 consecutive channels per lane
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MF; ++mi) {
+          const float v = cacc[mi][ni][r];
+          s1 += v;
+          s2 += v * v;
+        }
+        s1 = row16_sum_g1(s1);
+        s2 = row16_sum_g1(s2);
+        if (li == 0) {
+          const int c = (ni >> 1) * 32 + g * 8 + (ni & 1) * 4 + r;
+          red[0][wave][0][c] = s1;
+          red[0][wave][1][c] = s2;
+        }
+      }
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi) {
+      const long long row = mbase + mi * 16 + li;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f32x4 lo = cacc[mi][2 * j], hi = cacc[mi][2 * j + 1];
+        *reinterpret_cast<uint4*>(p.chain_y + row * 64 + j * 32 + g * 8) =
+            make_uint4(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]));
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      const float v = (red[0][0][which][c] + red[0][1][which][c]) + (red[0][2][which][c] + red[0][3][which][c]);
+      p.chain_partial[((long long)blockIdx.x * 2 + which) * 64 + c] = v;
+    }
+  }
 }
 
 #undef SH_G1_LOAD
@@ -485,7 +560,15 @@ static int pf_of(int k) {
 
 int gemm1x1_rows_per_block(int k) { return 64 * mf_of(k); }
 
+bool gemm1x1_chain_ok(int k, int n, long long m) { return k == 64 && n % 64 == 0 && n <= 256 && m % 128 == 0 && pf_of(64); }
+
 int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
+  if (a.chain_w != nullptr) {  // the caller checked gemm1x1_chain_ok and passes residual + ReLU + mask
+    route_hit(SH_ROUTE_GEMM1X1_FWD_BNACT);
+    route_hit(SH_ROUTE_FWD_CHAIN);
+    gemm1x1_kernel<64, 2, false, false, 2, false, true><<<ceil_div(a.M, 128), 256, 0, s>>>(a);
+    return 0;
+  }
   int mf = mf_of(k);
   // the branch-free BN + residual + ReLU epilogue at K = 64 wants 128-row blocks (its rows are requested one short chunk ahead:
   // more resident blocks hide what the 32 MFMAs of a chunk cannot; measured 1.53 ms against 2.05 with 256 rows, 1.64 generic)

@@ -1397,6 +1397,34 @@ int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w
   return launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 
+int simhand_conv2d_fwd_chain_ok(const sh_conv_desc* d) {
+  return d != nullptr && use_1x1(d, d->cin, d->cout) && gemm1x1_chain_ok(d->cin, d->cout, (long long)d->n * d->ho * d->wo) ? 1 : 0;
+}
+
+int simhand_conv2d_fwd_chain_stat_blocks(const sh_conv_desc* d) { return d ? ceil_div((long long)d->n * d->ho * d->wo, 128) : 0; }
+
+int simhand_conv2d_fwd_bnact_chain(const sh_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
+                                   const void* residual, void* out, uint8_t* relu_mask, const void* chain_w, void* chain_y,
+                                   float* chain_partial, sh_stream_t stream) {
+  if (check_desc(d, "conv2d_fwd_bnact_chain")) return 1;
+  SH_REQUIRE(x && w && out && scale && shift && residual && relu_mask && chain_w && chain_y && chain_partial,
+             "conv2d_fwd_bnact_chain: NULL pointer");
+  SH_REQUIRE(simhand_conv2d_fwd_chain_ok(d), "conv2d_fwd_bnact_chain: layer not supported (see simhand_conv2d_fwd_chain_ok)");
+  const long long m = (long long)d->n * d->ho * d->wo;
+  // the chained conv1's FLOPs are algorithmic work of the forward class too
+  ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, 2.0 * 2.0 * (double)m * d->cout * d->cin,
+               2.0 * ((double)m * d->cin * 2 + (double)m * d->cout * 2));
+  route_hit(SH_ROUTE_FWD_BNACT);
+  Gemm1x1Args g;
+  g.a = (const bf16_t*)x; g.w = (const bf16_t*)w; g.out = (bf16_t*)out; g.bn_partial = nullptr;
+  g.M = m; g.N = d->cout; g.accumulate = 0; g.res_grad = nullptr; g.res_mask = nullptr;
+  g.fy = nullptr; g.fscale = g.fshift = nullptr; g.fmask = nullptr; g.fmode = 0; g.fpartial = nullptr; g.bias = nullptr;
+  g.ep_scale = scale; g.ep_shift = shift; g.ep_res = (const bf16_t*)residual; g.ep_mask = relu_mask; g.ep_relu = 1;
+  g.chain_w = (const bf16_t*)chain_w; g.chain_y = (bf16_t*)chain_y; g.chain_partial = chain_partial;
+  launch_gemm1x1(g, d->cin, false, (hipStream_t)stream);
+  return check_launch("conv2d_fwd_bnact_chain");
+}
+
 // ---- direct 7x7 / stride 2 / pad 3 / 3 -> 64 stem --------------------------------------------------------------------
 // torchvision ResNet conv1 (reference: src/models/resnet_model.py:13-26).  Cin = 3 cannot form a k-contiguous MFMA
 // operand, so the input is first repacked (simhand_stem_pad_input) to zero-padded NHWC4 [N][h+8][wp][4]; then filter

@@ -158,6 +158,10 @@ class ResNetEngine:
         # reads the dy it wrote (env: A/B timing only)
         self.fuse_bwd_apply_dgrad = os.environ.get("SIMHAND_FUSE_BWDD", "1") == "1"
         self._gram = None  # (activation tensor, a^T a, sum a) of the unit just applied that way
+        # the next block's conv1 chained onto this block's conv3 + bn3 + add + ReLU launch (ops.conv2d_fwd_bnact_chain): the block
+        # output is written but not read back by that conv1 (env: A/B timing only)
+        self.chain_conv1 = os.environ.get("SIMHAND_CHAIN", "1") == "1"
+        self._chain = None  # (block output tensor, the chained conv module, its raw output, its BatchNorm partial sums)
         # multi-GPU: host.dist.OverlappedGradReducer -- finished parameter gradients go out block by block during backward
         self.grad_reducer = None
 
@@ -208,7 +212,7 @@ class ResNetEngine:
                 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and conv.out_channels >= 2 * conv.in_channels
                 and (residual is not None or not relu))
 
-    def _conv_bn_folded(self, conv, bn, x, relu, residual, training, save: Optional[list]):
+    def _conv_bn_folded(self, conv, bn, x, relu, residual, training, save: Optional[list], chain_conv=None):
         """y = conv1x1(x), out = act(bn(y) (+ residual)) in ONE pass over the wide tensor: train-mode batch statistics of y
         come from the Gram matrix of the (narrow) input -- mean_c = W_c . sum(x) / M, E[y^2]_c = W_c^T (x^T x) W_c / M --
         so they are known before the convolution runs and BN + residual + ReLU live in its epilogue; y itself is never
@@ -234,8 +238,15 @@ class ResNetEngine:
         else:
             st = ops.bn_eval_state(cout, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
         want_mask = save is not None and relu and residual is not None
-        res = ops.conv2d_fwd_bnact(d, x, pk.krsc, st, relu, residual, want_mask=want_mask)
-        a, mask = res if want_mask else (res, None)
+        chain = (self.chain_conv1 and chain_conv is not None and want_mask and training and s == 1 and chain_conv.kernel_size == (1, 1)
+                 and chain_conv.stride == (1, 1) and chain_conv.padding == (0, 0) and chain_conv.in_channels == cout
+                 and chain_conv.out_channels == cin and ops.conv2d_fwd_chain_ok(d))
+        if chain:
+            a, mask, cy, cpart = ops.conv2d_fwd_bnact_chain(d, x, pk.krsc, st, residual, self._pack(chain_conv, need_t=True).krsc)
+            self._chain = (a, chain_conv, cy, cpart)
+        else:
+            res = ops.conv2d_fwd_bnact(d, x, pk.krsc, st, relu, residual, want_mask=want_mask)
+            a, mask = res if want_mask else (res, None)
         if save is not None:
             u = _Unit()
             u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv, bn, d, x, None, a, st, relu, False
@@ -262,16 +273,19 @@ class ResNetEngine:
         xq = site[0].quantize(x)
         return ops.conv2d_fwd_fp8(d, xq, site[2], site[0], site[1], want_stats=training)
 
-    def _conv_bn(self, conv, bn, x, relu, residual, training, save: Optional[list], need_dgrad=True, gram_next=False):
+    def _conv_bn(self, conv, bn, x, relu, residual, training, save: Optional[list], need_dgrad=True, gram_next=False, chain_conv=None):
         """gram_next: the activation feeds a folded 1x1 convolution (which needs a^T a and sum a): BatchNorm-apply + ReLU then
         run inside that Gram launch (ops.bn_apply_gram) instead of as a pass of their own."""
         if self._fold_fwd_ok(conv, relu, residual):
-            return self._conv_bn_folded(conv, bn, x, relu, residual, training, save)
+            return self._conv_bn_folded(conv, bn, x, relu, residual, training, save, chain_conv=chain_conv)
         n, h, w, cin = x.shape
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         d = ops.conv_desc(n, h, w, cin, conv.out_channels, k, k, s, p, self.dtype)
         pk = self._pack(conv, need_t=save is not None and need_dgrad)
-        if self._fp8_ok(conv, d):
+        chained, self._chain = self._chain, None
+        if chained is not None and chained[0] is x and chained[1] is conv:
+            y, part = chained[2], chained[3]  # computed by the previous block's conv3 launch from its output chunks
+        elif self._fp8_ok(conv, d):
             y, part = self._conv_fwd_fp8(conv, d, x, training)
         else:
             y, part = ops.conv2d_fwd(d, x, pk.krsc, want_stats=training)
@@ -327,8 +341,11 @@ class ResNetEngine:
             ctx["stem"] = u
             ctx["pool_idx"] = idx
             ctx["pool_ywin"] = ywin
+        self._chain = None
         for li in (4, 5, 6, 7):
-            for blk in f[li]:
+            stage = list(f[li])
+            for bi, blk in enumerate(stage):
+                nxt = stage[bi + 1] if bi + 1 < len(stage) else None
                 saved: Optional[list] = [] if want_ctx else None
                 inp = x
                 units = blk.units()
@@ -343,7 +360,8 @@ class ResNetEngine:
                 if blk.downsample is not None:
                     idn = self._conv_bn(blk.downsample[0], blk.downsample[1], inp, False, None, training, dsaved)
                 conv, bn = units[-1]
-                x = self._conv_bn(conv, bn, t, True, idn, training, saved)
+                chain_conv = nxt.units()[0][0] if (nxt is not None and nxt.downsample is None and not self.fp8) else None
+                x = self._conv_bn(conv, bn, t, True, idn, training, saved, chain_conv=chain_conv)
                 if want_ctx:
                     ctx["blocks"].append((saved, dsaved[0] if dsaved else None))
         enc = ops.avgpool_fwd(x)

@@ -208,6 +208,25 @@ def conv2d_fwd_bnact(d: ConvDesc, x, w, st: "BNState", relu: bool, residual=None
     return (out, mask) if want_mask else out
 
 
+def conv2d_fwd_chain_ok(d: ConvDesc) -> bool:
+    return bool(_lib_dev().simhand_conv2d_fwd_chain_ok(C.byref(d)))
+
+
+def conv2d_fwd_bnact_chain(d: ConvDesc, x, w, st: "BNState", residual, chain_w):
+    """conv2d_fwd_bnact (residual + ReLU + bit mask) with the next block's conv1 chained on (simhand_conv2d_fwd_bnact_chain):
+    returns (out, mask, chain_y [n][ho][wo][cin] raw conv output of that conv1, its BatchNorm partial sums)."""
+    lib = _lib_dev()
+    m = d.n * d.ho * d.wo
+    out = torch.empty(d.n, d.ho, d.wo, d.cout, dtype=x.dtype, device=x.device)
+    mask = torch.empty(m, d.cout // 8, dtype=torch.uint8, device=x.device)
+    cy = torch.empty(d.n, d.ho, d.wo, d.cin, dtype=x.dtype, device=x.device)
+    part = torch.empty(lib.simhand_conv2d_fwd_chain_stat_blocks(C.byref(d)), 2, d.cin, dtype=torch.float32, device=x.device)
+    check(lib.simhand_conv2d_fwd_bnact_chain(C.byref(d), _ptr(x, torch.bfloat16), _ptr(w, torch.bfloat16), _ptr(st.scale), _ptr(st.shift),
+                                             _ptr(residual, torch.bfloat16), _ptr(out), _ptr(mask), _ptr(chain_w, torch.bfloat16), _ptr(cy),
+                                             _ptr(part), _stream()), "conv2d_fwd_bnact_chain")
+    return out, mask, cy, part
+
+
 def conv2d_dgrad(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accumulate: bool = False):
     lib = _lib_dev()
     if dx is None:

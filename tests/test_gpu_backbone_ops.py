@@ -993,3 +993,65 @@ def test_big_tile_224_row_tiles_equal_256_row_tiles(k, force_big_tile):
     assert torch.equal(y1, y0) and torch.equal(dx1, dx0) and torch.equal(dxf1, dxf0)
     _check(p1.sum(0).cpu(), p0.sum(0).cpu(), 1e-5, "forward statistics")
     _check(f1.sum(0).cpu(), f0.sum(0).cpu(), 1e-5, "fused BN-backward sums")
+
+
+@pytest.mark.parametrize("n,h,cout", [(4, 16, 256), (2, 24, 128), (3, 16, 64)])
+def test_conv_fwd_bnact_with_the_next_conv1_chained_on(n, h, cout):
+    """simhand_conv2d_fwd_bnact_chain (conv3 + BN + residual + ReLU of one Bottleneck, conv1 of the next computed from the output
+    chunks in registers) == simhand_conv2d_fwd_bnact followed by simhand_conv2d_fwd, bit for bit: block output, ReLU mask, the chained
+    raw conv output and its BatchNorm partial sums."""
+    from simhand_amd import ops
+
+    dt = torch.bfloat16
+    cin = 64
+    g = torch.Generator().manual_seed(n + h + cout)
+    d = ops.conv_desc(n, h, h, cin, cout, 1, 1, 1, 0, dt)
+    assert ops.conv2d_fwd_chain_ok(d)
+    a2 = torch.randn(n, h, h, cin, generator=g).to(DEV).to(dt)
+    res = torch.randn(n, h, h, cout, generator=g).to(DEV).to(dt)
+    w3 = ops.pack_krsc((torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)).to(DEV), dt)
+    w1n = ops.pack_krsc((torch.randn(cin, cout, 1, 1, generator=g) / math.sqrt(cout)).to(DEV), dt)
+    st = ops.BNState(cout, DEV)
+    st.scale.copy_((torch.rand(cout, generator=g) + 0.5).to(DEV))
+    st.shift.copy_((torch.randn(cout, generator=g) * 0.3).to(DEV))
+    want_out, want_mask = ops.conv2d_fwd_bnact(d, a2, w3, st, True, res, want_mask=True)
+    d1 = ops.conv_desc(n, h, h, cout, cin, 1, 1, 1, 0, dt)
+    want_y, want_part = ops.conv2d_fwd(d1, want_out, w1n, want_stats=True)
+    ops.route_reset()
+    out, mask, cy, part = ops.conv2d_fwd_bnact_chain(d, a2, w3, st, res, w1n)
+    assert ops.route_counts()["fwd_chain"] == 1
+    assert torch.equal(out, want_out) and torch.equal(mask, want_mask)
+    assert torch.equal(cy, want_y)
+    _check(part.sum(0).cpu(), want_part.sum(0).cpu(), 1e-6, "chained BatchNorm partial sums")
+    # and against torch in fp32
+    ref = F.conv2d(out.float().cpu().permute(0, 3, 1, 2), w1n.float().cpu().view(cin, cout, 1, 1))
+    _check(cy.float().cpu().permute(0, 3, 1, 2), ref, 1e-2, "chained conv1 vs torch")
+
+
+def test_engine_chained_conv1_equals_separate_launches():
+    """ResNetEngine.chain_conv1: the stage-1 identity blocks' conv1 computed inside the previous block's conv3 launch -- the encoder
+    output and every parameter gradient are bit-identical to the run with separate launches."""
+    from types import SimpleNamespace
+
+    from simhand_amd import ops
+    from simhand_amd.host.resnet_model import ResNetModel
+
+    torch.manual_seed(4)
+    cfg = SimpleNamespace(model=SimpleNamespace(backend_model="resnet50", pretrained=False))
+    m = ResNetModel(cfg, "pretraining", torch.bfloat16).to(DEV).train()
+    x = torch.randn(8, 3, 64, 64, device=DEV)   # stage 1 at 16 x 16: 2048 pixels, a multiple of the 128-row blocks
+    outs = []
+    for on in (False, True):
+        m.engine.chain_conv1 = on
+        m.zero_grad()
+        for mod in m.modules():  # same running statistics going in
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.reset_running_stats()
+        ops.route_reset()
+        y = m(x)
+        y.square().sum().backward()
+        assert (ops.route_counts()["fwd_chain"] == 2) == on
+        outs.append((y.detach().clone(), [p.grad.clone() for p in m.features.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for g0, g1 in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(g0, g1)
