@@ -327,6 +327,8 @@ int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* w
  * simhand_conv2d_fwd.  residual, relu_mask are required (ReLU is implied).  Only where simhand_conv2d_fwd_chain_ok(d) says so.
  * Replaces (reference): the bn3 / add / relu tail of one torchvision Bottleneck and conv1 of the next (src/models/resnet_model.py:13-58). */
 int simhand_conv2d_fwd_chain_ok(const sh_conv_desc* d);
+/* test / tuning hook: which input widths chain (bit 0: 64, bit 1: 128; -1 = default = 64 only: the 128-wide form measured no faster) */
+int simhand_conv1x1_chain_mask(int mask);
 int simhand_conv2d_fwd_chain_stat_blocks(const sh_conv_desc* d);
 int simhand_conv2d_fwd_bnact_chain(const sh_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                                    const void* residual, void* out, uint8_t* relu_mask, const void* chain_w, void* chain_y,

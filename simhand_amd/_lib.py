@@ -161,6 +161,7 @@ SIGNATURES = {
     "simhand_igemm256_tile224": (_I, [_I]),
     "simhand_conv2d_dgrad_dysrc_ok": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_fwd_chain_ok": (_I, [C.POINTER(ConvDesc)]),
+    "simhand_conv1x1_chain_mask": (_I, [_I]),
     "simhand_conv2d_fwd_chain_stat_blocks": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_fwd_bnact_chain": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "simhand_conv2d_dgrad_concat_ok": (_I, [C.POINTER(ConvDesc), _I]),

@@ -54,7 +54,9 @@ struct Gemm1x1Args {
 };
 
 bool gemm1x1_supported(int k, int n);
-bool gemm1x1_chain_ok(int k, int n, long long m);  // chained next conv1 available (K = 64 fast forward variant, 128-row blocks)
+bool gemm1x1_chain_ok(int k, int n, long long m);  // chained next conv1 available (the K = 64 / 128 fast forward variants)
+void gemm1x1_set_chain(int mask);                   // bit 0: K = 64, bit 1: K = 128, -1: default
+int gemm1x1_chain_rows(int k);                      // rows per block of that launch (= rows per BatchNorm partial-sum pair)
 int gemm1x1_rows_per_block(int k);
 void gemm1x1_set_mf(int k, int mf);
 int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s);

@@ -59,8 +59,10 @@ __device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
 // the prefetched rows is exposed instead of hidden under the MFMAs -- these kernels' MFMA time and HBM time ADDED UP.  The fast
 // variants (EP == 2, PF) keep the body branch-free, request the epilogue's rows right AFTER the chunk's first weight-tile fetch
 // (so that waiting for the tile does not wait for them), and the last step re-fetches tile 0 instead of skipping the fetch.
-// CH (EP == 2, K == 64, N <= 256): the chained next conv1 (Gemm1x1Args::chain_*): its [64][N] weights stay in LDS for the block's
-// life as N / 64 panels in the weight-tile format, every finished output chunk feeds 2 x 4 extra MFMAs per 16-row group.
+// CH (EP == 2): the chained next conv1 (Gemm1x1Args::chain_*, N -> K channels), fed by every finished output chunk (2 k-slices x
+// K / 16 extra MFMAs per 16-row group).  Its weights are used as panels [K rows][64 k] (columns 64 nc .. of chain_w) in the
+// 128-B-row tile format: K == 64 (N <= 256) keeps all N / 64 panels in LDS for the block's life; K == 128 (N <= 512, MF == 1)
+// streams panel nc + 1 through registers into a second LDS buffer while chunk nc runs.
 template <int K, int MF, bool DGRAD, bool FUSE = false, int EP = 0, bool PF = false, bool CH = false>
 #ifndef SH_G1_FUSE_MINB
 #define SH_G1_FUSE_MINB 3
@@ -75,11 +77,14 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
   constexpr int ROWB = KC * 2;            // bytes per weight-tile row
   constexpr int BT = 64 * ROWB;           // bytes per weight tile
   constexpr bool FAST = EP == 2 || PF;
-  static_assert(!CH || (EP == 2 && K == 64), "the chained conv1 exists for the K = 64 fast forward variant only");
-  __shared__ __attribute__((aligned(16))) char sC[CH ? 4 * BT : 16];  // chain weights: panel pn = columns 64 pn .. +64 of chain_w
+  static_assert(!CH || (EP == 2 && (K == 64 || (K == 128 && MF == 1))), "the chained conv1 exists for the K = 64 / 128 fast forward variants");
+  constexpr int CT = K / 16;              // chained conv1: 16-channel output tiles
+  constexpr int PB = K * 128;             // bytes of one chain panel [K][64]
+  constexpr int EPN = CH ? 512 : 2048;    // channels the epilogue coefficient cache holds
+  __shared__ __attribute__((aligned(16))) char sC[CH ? (K == 64 ? 4 * PB : 2 * PB) : 16];  // K == 64: all panels; K == 128: two buffers
   __shared__ __attribute__((aligned(16))) char sB[2 * BT];
   __shared__ float red[2][4][2][64];
-  __shared__ __attribute__((aligned(16))) float s_ep[EP ? 2 * 2048 : 4];  // [2][N <= 2048]: scale, shift
+  __shared__ __attribute__((aligned(16))) float s_ep[EP ? 2 * EPN : 4];  // [2][N]: scale, shift
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
   if constexpr (EP) {
     for (int i = tid; i < p.N; i += 256) {
       s_ep[i] = p.ep_scale[i];
-      s_ep[2048 + i] = p.ep_shift[i];
+      s_ep[EPN + i] = p.ep_shift[i];
     }
     if (EP == 1 && p.ep_res != nullptr) load_res(0);
   }
@@ -246,18 +251,45 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
   uint4 vout[CH ? MF : 1][2];  // CH: the chunk's packed bf16 output
 
-  f32x4 cacc[CH ? MF : 1][4];
+  f32x4 cacc[CH ? MF : 1][CH ? CT : 1];
+  // chain panel staging map (128-B rows: 8 chunks per row): chunks tid + 256 i = rows tid / 8 + 32 i, chunk tid % 8; key from row bits 1, 3, 4
+  const int prow = tid >> 3, pch = tid & 7;
+  const int pst = prow * 128 + ((pch ^ (((prow >> 1) & 1) | (((prow >> 3) & 3) << 1))) * 16);  // + i * 32 * 128 (the key ignores bits 5, 6)
+  // fragment offsets in a panel: tile ct = channels (ct >> 2) * 64 + chan_of(ct & 3, li); k-slice kk = chunk 4 kk + g
+  const int pkey = ((li & 3) >> 1) | ((li >> 2) << 1);
+  const int pfo0 = (g ^ pkey) * 16, pfo1 = ((4 + g) ^ pkey) * 16;
+  const int pfr0 = ((li >> 2) * 8 + (li & 3)) * 128;  // chan_of(0, li) rows; tile ct adds ((ct >> 2) * 64 + ((ct >> 1) & 1) * 32 + (ct & 1) * 4) * 128
+  uint4 pr0, pr1, pr2, pr3;  // K == 128: the next panel on its way to LDS
+  auto panel_load = [&](int pn) __attribute__((always_inline)) {
+    const bf16_t* src = p.chain_w + (long long)prow * p.N + pn * 64 + pch * 8;
+    pr0 = *reinterpret_cast<const uint4*>(src);
+    pr1 = *reinterpret_cast<const uint4*>(src + 32ll * p.N);
+    if constexpr (K == 128) {
+      pr2 = *reinterpret_cast<const uint4*>(src + 64ll * p.N);
+      pr3 = *reinterpret_cast<const uint4*>(src + 96ll * p.N);
+    }
+  };
+  auto panel_store = [&](char* dst) __attribute__((always_inline)) {
+    *reinterpret_cast<uint4*>(dst + pst) = pr0;
+    *reinterpret_cast<uint4*>(dst + pst + 32 * 128) = pr1;
+    if constexpr (K == 128) {
+      *reinterpret_cast<uint4*>(dst + pst + 64 * 128) = pr2;
+      *reinterpret_cast<uint4*>(dst + pst + 96 * 128) = pr3;
+    }
+  };
   if constexpr (CH) {
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) cacc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // chunks tid + 256 i of each [64][8] panel (rows row0 + i * RSTEP), same swizzled offsets as the weight tiles
-    for (int pn = 0; pn < nch; ++pn) {
-      const bf16_t* src = p.chain_w + (long long)row0 * p.N + pn * 64 + ch0 * 8;
-      const uint4 c0 = *reinterpret_cast<const uint4*>(src), c1 = *reinterpret_cast<const uint4*>(src + (long long)RSTEP * p.N);
-      *reinterpret_cast<uint4*>(sC + pn * BT + st0) = c0;
-      *reinterpret_cast<uint4*>(sC + pn * BT + st1) = c1;
+      for (int ct = 0; ct < CT; ++ct) cacc[mi][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (K == 64) {
+      for (int pn = 0; pn < nch; ++pn) {
+        panel_load(pn);
+        panel_store(sC + pn * PB);
+      }
+    } else {
+      panel_load(0);
+      panel_store(sC);
     }
   }
   SH_G1_STORE(sB);
@@ -282,6 +314,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
           if constexpr (EP == 2) load_res(nc);
           else load_pf(nc);
         }
+        if constexpr (CH && K == 128) panel_load(nc + 1 < nch ? nc + 1 : 0);  // lands under this chunk's MFMAs (last: panel 0 again, unused)
         __builtin_amdgcn_sched_barrier(0);
       }
       const char* cB = sB + buf * BT;
@@ -334,7 +367,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
           if constexpr (EP) {
             // BatchNorm (statistics known up front) + residual + ReLU on the fp32 accumulators; ReLU bit mask out
             const float4 s0 = *reinterpret_cast<const float4*>(s_ep + ch), s1 = *reinterpret_cast<const float4*>(s_ep + ch + 4);
-            const float4 h0 = *reinterpret_cast<const float4*>(s_ep + 2048 + ch), h1 = *reinterpret_cast<const float4*>(s_ep + 2048 + ch + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(s_ep + EPN + ch), h1 = *reinterpret_cast<const float4*>(s_ep + EPN + ch + 4);
             float o[8] = {lo[0] * s0.x + h0.x, lo[1] * s0.y + h0.y, lo[2] * s0.z + h0.z, lo[3] * s0.w + h0.w,
                           hi[0] * s1.x + h1.x, hi[1] * s1.y + h1.y, hi[2] * s1.z + h1.z, hi[3] * s1.w + h1.w};
             if (EP == 2 || p.ep_res != nullptr) {
@@ -466,17 +499,19 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
           if constexpr (CH) {
             // chained conv1: k-slice j of panel nc x the chunk's packed output (lane = pixel li, channels n0 + 32 j + 8 g .. +8: exactly
             // the A-operand layout) -> the same k order as the stand-alone conv1, so bit-identical accumulators
-            const char* cP = sC + nc * BT;
+            const char* cP = sC + (K == 64 ? nc : (nc & 1)) * PB + pfr0;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-              uint4 fc[4];
+              uint4 fc[CT];
 #pragma unroll
-              for (int ni = 0; ni < 4; ++ni) fc[ni] = *reinterpret_cast<const uint4*>(cP + frow[ni] + fo[kk]);
+              for (int ct = 0; ct < CT; ++ct)
+                fc[ct] = *reinterpret_cast<const uint4*>(cP + ((ct >> 2) * 64 + ((ct >> 1) & 1) * 32 + (ct & 1) * 4) * 128 + (kk == 0 ? pfo0 : pfo1));
 #pragma unroll
               for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) cacc[mi][ni] = mma_bf16(fc[ni], vout[mi][kk], cacc[mi][ni]);
+                for (int ct = 0; ct < CT; ++ct) cacc[mi][ct] = mma_bf16(fc[ct], vout[mi][kk], cacc[mi][ct]);
             }
+            if constexpr (K == 128) panel_store(sC + ((nc + 1) & 1) * PB);  // visible after the barrier that ends this step
           }
           if constexpr (EP == 1) {
             if (p.ep_res != nullptr && nc + 1 < nch) load_res(nc + 1);  // lands under the next chunk's MFMAs
@@ -501,42 +536,46 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
     }
   }
   if constexpr (CH) {
-    // the chained conv1's raw output: BatchNorm partial sums of the fp32 accumulators (layout of the stand-alone forward: one row
-    // pair per block) and the bf16 store, 8 consecutive channels per lane
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int mi = 0; mi < MF; ++mi) {
-          const float v = cacc[mi][ni][r];
-          s1 += v;
-          s2 += v * v;
-        }
-        s1 = row16_sum_g1(s1);
-        s2 = row16_sum_g1(s2);
-        if (li == 0) {
-          const int c = (ni >> 1) * 32 + g * 8 + (ni & 1) * 4 + r;
-          red[0][wave][0][c] = s1;
-          red[0][wave][1][c] = s2;
-        }
-      }
+    // the chained conv1's raw output: bf16 store (8 consecutive channels per lane) and the BatchNorm partial sums of the fp32
+    // accumulators in the layout of the stand-alone forward (one row pair per block), 64 channels (= 4 tiles) at a time
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi) {
       const long long row = mbase + mi * 16 + li;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const f32x4 lo = cacc[mi][2 * j], hi = cacc[mi][2 * j + 1];
-        *reinterpret_cast<uint4*>(p.chain_y + row * 64 + j * 32 + g * 8) =
+      for (int jj = 0; jj < CT / 2; ++jj) {
+        const f32x4 lo = cacc[mi][2 * jj], hi = cacc[mi][2 * jj + 1];
+        *reinterpret_cast<uint4*>(p.chain_y + row * K + jj * 32 + g * 8) =
             make_uint4(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]));
       }
     }
-    __syncthreads();
-    if (tid < 128) {
-      const int which = tid >> 6, c = tid & 63;
-      const float v = (red[0][0][which][c] + red[0][1][which][c]) + (red[0][2][which][c] + red[0][3][which][c]);
-      p.chain_partial[((long long)blockIdx.x * 2 + which) * 64 + c] = v;
+#pragma unroll
+    for (int hf = 0; hf < CT / 4; ++hf) {
+      __syncthreads();  // red[0] is free (the loop ended with a barrier / the previous half was read)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int mi = 0; mi < MF; ++mi) {
+            const float v = cacc[mi][hf * 4 + ni][r];
+            s1 += v;
+            s2 += v * v;
+          }
+          s1 = row16_sum_g1(s1);
+          s2 = row16_sum_g1(s2);
+          if (li == 0) {
+            const int c = (ni >> 1) * 32 + g * 8 + (ni & 1) * 4 + r;
+            red[0][wave][0][c] = s1;
+            red[0][wave][1][c] = s2;
+          }
+        }
+      __syncthreads();
+      if (tid < 128) {
+        const int which = tid >> 6, c = tid & 63;
+        const float v = (red[0][0][which][c] + red[0][1][which][c]) + (red[0][2][which][c] + red[0][3][which][c]);
+        p.chain_partial[((long long)blockIdx.x * 2 + which) * K + hf * 64 + c] = v;
+      }
     }
   }
 }
@@ -548,7 +587,7 @@ bool gemm1x1_supported(int k, int n) { return (k == 64 || k == 128 || k == 256) 
 
 // rows per block = 64 * MF; tuned per K on MI355X (scripts/conv_bench.py), overridable for experiments
 static hook_t g_mf[3] = {{4}, {2}, {2}};  // K = 64, 128, 256
-void hooks_reset_1x1() { g_mf[0] = 4; g_mf[1] = 2; g_mf[2] = 2; }
+void hooks_reset_1x1() { g_mf[0] = 4; g_mf[1] = 2; g_mf[2] = 2; gemm1x1_set_chain(-1); }
 static int mf_of(int k) { return g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)]; }
 void gemm1x1_set_mf(int k, int mf) { g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)] = mf; }
 
@@ -560,13 +599,30 @@ static int pf_of(int k) {
 
 int gemm1x1_rows_per_block(int k) { return 64 * mf_of(k); }
 
-bool gemm1x1_chain_ok(int k, int n, long long m) { return k == 64 && n % 64 == 0 && n <= 256 && m % 128 == 0 && pf_of(64); }
+// chained next conv1: K = 64 (128-row blocks, all panels resident: N <= 256) and K = 128 (64-row blocks, streamed panels: N <= 512)
+// bit 0: K = 64, bit 1: K = 128; -1 = SIMHAND_G1_CHAIN or 1 (test / tuning hook, env for A/B timing).  K = 128 is OFF by default:
+// measured at 2048 x 28^2 the chained launch takes 1353 us against 908 + 434 for the two separate ones (its 64-row blocks and the
+// streamed panels cost what the saved read of the block output gains); K = 64 @ 56^2: 1816 against 1590 + 750.
+static hook_t g_chain{-1};
+static int chain_env() {
+  static const int env = getenv("SIMHAND_G1_CHAIN") ? atoi(getenv("SIMHAND_G1_CHAIN")) : 1;
+  const int h = g_chain;
+  return h >= 0 ? h : env;
+}
+void gemm1x1_set_chain(int mask) { g_chain = mask; }
+bool gemm1x1_chain_ok(int k, int n, long long m) {
+  if (k == 64) return (chain_env() & 1) && n % 64 == 0 && n <= 256 && m % 128 == 0 && pf_of(64);
+  if (k == 128) return (chain_env() & 2) && n % 64 == 0 && n <= 512 && m % 64 == 0 && pf_of(128);
+  return false;
+}
+int gemm1x1_chain_rows(int k) { return k == 64 ? 128 : 64; }
 
 int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
   if (a.chain_w != nullptr) {  // the caller checked gemm1x1_chain_ok and passes residual + ReLU + mask
     route_hit(SH_ROUTE_GEMM1X1_FWD_BNACT);
     route_hit(SH_ROUTE_FWD_CHAIN);
-    gemm1x1_kernel<64, 2, false, false, 2, false, true><<<ceil_div(a.M, 128), 256, 0, s>>>(a);
+    if (k == 64) gemm1x1_kernel<64, 2, false, false, 2, false, true><<<ceil_div(a.M, 128), 256, 0, s>>>(a);
+    else gemm1x1_kernel<128, 1, false, false, 2, false, true><<<ceil_div(a.M, 64), 256, 0, s>>>(a);
     return 0;
   }
   int mf = mf_of(k);

@@ -1397,11 +1397,18 @@ int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w
   return launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 
+int simhand_conv1x1_chain_mask(int mask) {
+  gemm1x1_set_chain(mask);
+  return 0;
+}
+
 int simhand_conv2d_fwd_chain_ok(const sh_conv_desc* d) {
   return d != nullptr && use_1x1(d, d->cin, d->cout) && gemm1x1_chain_ok(d->cin, d->cout, (long long)d->n * d->ho * d->wo) ? 1 : 0;
 }
 
-int simhand_conv2d_fwd_chain_stat_blocks(const sh_conv_desc* d) { return d ? ceil_div((long long)d->n * d->ho * d->wo, 128) : 0; }
+int simhand_conv2d_fwd_chain_stat_blocks(const sh_conv_desc* d) {
+  return d ? ceil_div((long long)d->n * d->ho * d->wo, gemm1x1_chain_rows(d->cin)) : 0;
+}
 
 int simhand_conv2d_fwd_bnact_chain(const sh_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                                    const void* residual, void* out, uint8_t* relu_mask, const void* chain_w, void* chain_y,

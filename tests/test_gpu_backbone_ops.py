@@ -995,17 +995,17 @@ def test_big_tile_224_row_tiles_equal_256_row_tiles(k, force_big_tile):
     _check(f1.sum(0).cpu(), f0.sum(0).cpu(), 1e-5, "fused BN-backward sums")
 
 
-@pytest.mark.parametrize("n,h,cout", [(4, 16, 256), (2, 24, 128), (3, 16, 64)])
-def test_conv_fwd_bnact_with_the_next_conv1_chained_on(n, h, cout):
+@pytest.mark.parametrize("n,h,cin,cout", [(4, 16, 64, 256), (2, 24, 64, 128), (3, 16, 64, 64), (4, 16, 128, 512), (3, 8, 128, 256)])
+def test_conv_fwd_bnact_with_the_next_conv1_chained_on(n, h, cin, cout):
     """simhand_conv2d_fwd_bnact_chain (conv3 + BN + residual + ReLU of one Bottleneck, conv1 of the next computed from the output
     chunks in registers) == simhand_conv2d_fwd_bnact followed by simhand_conv2d_fwd, bit for bit: block output, ReLU mask, the chained
     raw conv output and its BatchNorm partial sums."""
     from simhand_amd import ops
 
     dt = torch.bfloat16
-    cin = 64
     g = torch.Generator().manual_seed(n + h + cout)
     d = ops.conv_desc(n, h, h, cin, cout, 1, 1, 1, 0, dt)
+    ops._lib_dev().simhand_conv1x1_chain_mask(3)  # the 128-wide form is off by default (no faster), but kept correct
     assert ops.conv2d_fwd_chain_ok(d)
     a2 = torch.randn(n, h, h, cin, generator=g).to(DEV).to(dt)
     res = torch.randn(n, h, h, cout, generator=g).to(DEV).to(dt)
@@ -1022,7 +1022,7 @@ def test_conv_fwd_bnact_with_the_next_conv1_chained_on(n, h, cout):
     assert ops.route_counts()["fwd_chain"] == 1
     assert torch.equal(out, want_out) and torch.equal(mask, want_mask)
     assert torch.equal(cy, want_y)
-    _check(part.sum(0).cpu(), want_part.sum(0).cpu(), 1e-6, "chained BatchNorm partial sums")
+    _check(part.sum(0).cpu(), want_part.sum(0).cpu(), 1e-5, "chained BatchNorm partial sums")
     # and against torch in fp32
     ref = F.conv2d(out.float().cpu().permute(0, 3, 1, 2), w1n.float().cpu().view(cin, cout, 1, 1))
     _check(cy.float().cpu().permute(0, 3, 1, 2), ref, 1e-2, "chained conv1 vs torch")
@@ -1041,6 +1041,8 @@ def test_engine_chained_conv1_equals_separate_launches():
     m = ResNetModel(cfg, "pretraining", torch.bfloat16).to(DEV).train()
     x = torch.randn(8, 3, 64, 64, device=DEV)   # stage 1 at 16 x 16: 2048 pixels, a multiple of the 128-row blocks
     outs = []
+    ops._lib_dev().simhand_conv1x1_chain_mask(1)  # stage 1 only: its launches are bit-identical to the separate ones (the 128-channel
+    # chain of stage 2 sums its BatchNorm partials over 64-row blocks instead of 128-row tiles: same values to fp32 round-off)
     for on in (False, True):
         m.engine.chain_conv1 = on
         m.zero_grad()
