@@ -24,5 +24,6 @@ for w, h in ((64, 56), (128, 28), (256, 14), (512, 7)):
     _, mask2 = ops.bn_apply(torch.randn(m, cin, device="cuda").to(dt), one, m, cin, True, None, want_mask=True)
     t = timeit(lambda: ops.conv2d_dgrad_ex(d, dy, wt, res_grad=g, res_mask=mask, fuse_mode=4, prev_mask=mask2, want_sums=False))
     gb = (m * w * 2 + 2 * m * cin * 2 + 2 * m * cin / 8) / 1e9
-    print(f"w={w:4d} @{h:3d}: {t:.3f} ms  {gb / t:.2f} TB/s")
+    t2 = timeit(lambda: ops.conv2d_dgrad_ex(d, dy, wt, fuse_mode=4, prev_mask=mask2, want_sums=False))  # first block of a stage: no residual
+    print(f"w={w:4d} @{h:3d}: {t:.3f} ms  {gb / t:.2f} TB/s   | masked store only: {t2:.3f} ms")
     del dy, g, mask, mask2

@@ -50,7 +50,8 @@ __device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
 // every chunk would expose a global-load latency (measured 1.6x the HBM-bound time).
 // EP == 2: the same with residual, ReLU and bit mask all present and M a multiple of the block's rows (the conv3 of every
 // identity block): no conditional anywhere near a global load or store, see the note on vmcnt below.
-// PF (data gradient; accumulate 2, masked store, full blocks): residual-gradient rows and both bit masks of the chunk are
+// PF == 2: the same without a residual gradient (first block of a stage: masked store only, accumulate 0).
+// PF == 1 (data gradient; accumulate 2, masked store, full blocks): residual-gradient rows and both bit masks of the chunk are
 // requested when the chunk's MFMAs start (masks as one 8-byte load per pixel row instead of two byte loads per mask).
 //
 // vmcnt: vector-memory operations retire IN ORDER, and hipcc's waitcnt pass takes the most conservative pending state over all
@@ -63,7 +64,7 @@ __device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
 // K / 16 extra MFMAs per 16-row group).  Its weights are used as panels [K rows][64 k] (columns 64 nc .. of chain_w) in the
 // 128-B-row tile format: K == 64 (N <= 256) keeps all N / 64 panels in LDS for the block's life; K == 128 (N <= 512, MF == 1)
 // streams panel nc + 1 through registers into a second LDS buffer while chunk nc runs.
-template <int K, int MF, bool DGRAD, bool FUSE = false, int EP = 0, bool PF = false, bool CH = false>
+template <int K, int MF, bool DGRAD, bool FUSE = false, int EP = 0, int PF = 0, bool CH = false>
 #ifndef SH_G1_FUSE_MINB
 #define SH_G1_FUSE_MINB 3
 #endif
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
   constexpr int NBL = 64 * CPR / 256;     // staged chunks per thread and step
   constexpr int ROWB = KC * 2;            // bytes per weight-tile row
   constexpr int BT = 64 * ROWB;           // bytes per weight tile
-  constexpr bool FAST = EP == 2 || PF;
+  constexpr bool FAST = EP == 2 || PF != 0;
   static_assert(!CH || (EP == 2 && (K == 64 || (K == 128 && MF == 1))), "the chained conv1 exists for the K = 64 / 128 fast forward variants");
   constexpr int CT = K / 16;              // chained conv1: 16-channel output tiles
   constexpr int PB = K * 128;             // bytes of one chain panel [K][64]
@@ -228,9 +229,11 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
 #pragma unroll
     for (int mi = 0; mi < (PF ? MF : 1); ++mi) {
       const long long r = mbase + mi * 16 + li;
+      if constexpr (PF == 1) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) pg[mi][j] = *reinterpret_cast<const uint4*>(p.res_grad + r * p.N + nc2 * 64 + j * 32 + g * 8);
-      pm[mi] = *reinterpret_cast<const uint2*>(p.res_mask + r * (p.N >> 3) + nc2 * 8);
+        for (int j = 0; j < 2; ++j) pg[mi][j] = *reinterpret_cast<const uint4*>(p.res_grad + r * p.N + nc2 * 64 + j * 32 + g * 8);
+        pm[mi] = *reinterpret_cast<const uint2*>(p.res_mask + r * (p.N >> 3) + nc2 * 8);
+      }
       pk[mi] = *reinterpret_cast<const uint2*>(p.fmask + r * (p.N >> 3) + nc2 * 8);
     }
   };
@@ -396,10 +399,10 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
           v.y = pack_bf16x2(lo[2], lo[3]);
           v.z = pack_bf16x2(hi[0], hi[1]);
           v.w = pack_bf16x2(hi[2], hi[3]);
-          if (DGRAD && (PF || p.accumulate == 2)) {
+          if (DGRAD && (PF == 1 || (PF == 0 && p.accumulate == 2))) {
             uint4 o;
             unsigned bits;
-            if constexpr (PF) {
+            if constexpr (PF == 1) {
               o = pg[mi][j];
               bits = ((j == 0 ? pm[mi].x : pm[mi].y) >> (8 * g)) & 0xffu;
             } else {
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
             v.y = add_bf16x2_g1(v.y, o.y & m1w);
             v.z = add_bf16x2_g1(v.z, o.z & m2w);
             v.w = add_bf16x2_g1(v.w, o.w & m3w);
-          } else if (DGRAD && p.accumulate) {
+          } else if (DGRAD && PF == 0 && p.accumulate) {
             const uint4 o = *reinterpret_cast<const uint4*>(dst);
             v.x = add_bf16x2_g1(v.x, o.x);
             v.y = add_bf16x2_g1(v.y, o.y);
@@ -637,7 +640,9 @@ int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
   do {                                                                                          \
     if (dgrad && a.fpartial != nullptr) gemm1x1_kernel<KV, MFV, true, true><<<nblk, 256, 0, s>>>(a);  \
     else if (dgrad && a.accumulate == 2 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && full && pf_of(KV))  \
-      gemm1x1_kernel<KV, MFV, true, false, 0, true><<<nblk, 256, 0, s>>>(a);                    \
+      gemm1x1_kernel<KV, MFV, true, false, 0, 1><<<nblk, 256, 0, s>>>(a);                       \
+    else if (dgrad && a.accumulate == 0 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && full && pf_of(KV))  \
+      gemm1x1_kernel<KV, MFV, true, false, 0, 2><<<nblk, 256, 0, s>>>(a);                       \
     else if (dgrad) gemm1x1_kernel<KV, MFV, true><<<nblk, 256, 0, s>>>(a);                      \
     else if (a.ep_scale != nullptr && a.ep_res != nullptr && a.ep_relu && a.ep_mask != nullptr && full && pf_of(KV))  \
       gemm1x1_kernel<KV, MFV, false, false, 2><<<nblk, 256, 0, s>>>(a);                         \
