@@ -1,0 +1,130 @@
+"""Multi-step stability evidence for the mixed-precision policy: the SAME contrastive training run -- ResNet-50 handclr_w,
+LARS + Adam with the reference's warm-up / cosine schedule, a fixed synthetic data set revisited every epoch, view 2 = view 1 + noise so
+that there is something to learn -- in bf16 (storage bf16 / fp32 accumulate, no loss scaling) and in the fp32 parity mode, from the same
+initial weights.  Logs both loss curves; exits non-zero unless every loss is finite, the bf16 loss falls, and bf16 tracks fp32.
+usage: python scripts/stability_run.py [steps] [out.md]      (on the GPU box)"""
+import argparse
+import math
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+sys.path.insert(0, ".")
+import bench  # noqa: E402  (model construction shared with the benchmark)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("steps", nargs="?", type=int, default=160)
+ap.add_argument("out", nargs="?", default=None)
+ap.add_argument("--pairs", type=int, default=64)
+ap.add_argument("--size", type=int, default=112)
+ap.add_argument("--batches", type=int, default=8)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+
+
+def dataset():
+    g = torch.Generator(device=dev).manual_seed(11)
+    out = []
+    for _ in range(a.batches):
+        b = bench.device_batch(a.pairs, a.size, int(torch.randint(0, 1 << 30, (1,), generator=g, device=dev)), dev)
+        b["transformed_image2"] = b["transformed_image1"] + 0.5 * torch.randn(b["transformed_image1"].shape, generator=g, device=dev)
+        out.append(b)
+    return out
+
+
+def run(precision):
+    args = SimpleNamespace(experiment="handclr_w", resnet="50", per_gpu_batch=a.pairs, precision=precision)
+    model = bench.make_model(args, 1).to(dev).train()
+    for kv in filter(None, os.environ.get("SIMHAND_ENGINE", "").split(",")):  # e.g. SIMHAND_ENGINE=fold_bn3=0,chain_conv1=0 (diagnostics)
+        k, v = kv.split("=")
+        setattr(model.encoder.engine, k, bool(int(v)))
+
+    class _T:
+        max_epochs, world_size = math.ceil(a.steps / a.batches), 1
+
+    model.trainer = _T()
+    model.setup("fit")
+    (opt,), (sched,) = model.configure_optimizers()
+    data = dataset()
+    losses = []
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(data[i % a.batches], i)["loss"]
+        loss.backward()
+        opt.step()
+        sched["scheduler"].step()
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    pmax = max(float(p.detach().abs().max()) for p in model.parameters())
+    return losses, pmax, time.perf_counter() - t0
+
+
+def run_oracle(bf16_storage):
+    """The CHECKER's curve: oracle.StepOracle (plain torch ops) on the same device, same initial weights / data / optimizer / schedule;
+    bf16_storage: its convolutions see bf16-rounded weights, inputs and outputs (differentiable casts: the gradients crossing them are
+    rounded too) -- the numerics model of the HIP bf16 path, independent of any of its kernels."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from oracle import step as orc
+
+    torch.backends.cudnn.allow_tf32 = False
+    args = SimpleNamespace(experiment="handclr_w", resnet="50", per_gpu_batch=a.pairs, precision="32")
+    prod = bench.make_model(args, 1)
+    om = orc.StepOracle("simhand_w", "50", bench.AUG, weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg")
+    om.load_state_dict(prod.state_dict(), strict=True)
+    om = om.to(dev).train()
+    if bf16_storage:
+        rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+        for m in om.encoder.modules():
+            if isinstance(m, nn.Conv2d):
+                m.forward = (lambda x, m=m: rnd(F.conv2d(rnd(x), rnd(m.weight), None, m.stride, m.padding)))
+
+    class _T:
+        max_epochs, world_size = math.ceil(a.steps / a.batches), 1
+
+    prod.trainer = _T()
+    prod.setup("fit")
+    # the product's own optimizer / schedule construction, on the oracle's parameters (same names -> same groups)
+    named = dict(om.named_parameters())
+    prod.named_parameters = lambda *aa, **kk: iter(named.items())
+    (opt,), (sched,) = prod.configure_optimizers()
+    data = dataset()
+    losses = []
+    for i in range(a.steps):
+        opt.zero_grad(set_to_none=True)
+        loss = om.contrastive_step(data[i % a.batches])
+        loss.backward()
+        opt.step()
+        sched["scheduler"].step()
+        losses.append(float(loss.detach()))
+    return losses
+
+
+bf, bf_pmax, bf_s = run("bf16")
+fp, fp_pmax, fp_s = run("32")
+ora = ora_bf = None
+if os.environ.get("SIMHAND_STABILITY_ORACLE", "0") == "1":
+    ora, ora_bf = run_oracle(False), run_oracle(True)
+lines = [f"# {a.steps} training steps, ResNet-50 handclr_w, {a.batches} fixed batches of {a.pairs} pairs @ {a.size}^2 revisited every epoch, LARS + Adam, "
+         "linear warm-up + cosine schedule; same initial weights", "",
+         "| step | loss bf16 (bf16 storage, fp32 accumulate / statistics / loss / optimizer, no loss scaling) | loss fp32 parity mode | bf16 / fp32 |"
+         + (" oracle fp32 (torch ops) | oracle with bf16-rounded conv weights / inputs / outputs |" if ora else ""), "|---|---|---|---|" + ("---|---|" if ora else "")]
+for i in list(range(0, a.steps, max(1, a.steps // 16))) + [a.steps - 1]:
+    lines.append(f"| {i} | {bf[i]:.4f} | {fp[i]:.4f} | {bf[i] / fp[i]:.4f} |" + (f" {ora[i]:.4f} | {ora_bf[i]:.4f} |" if ora else ""))
+k = max(1, a.steps // 10)
+head_b, tail_b, tail_f = sum(bf[:k]) / k, sum(bf[-k:]) / k, sum(fp[-k:]) / k
+lines += ["", f"mean of the first {k} losses (bf16) {head_b:.4f}; mean of the last {k}: bf16 {tail_b:.4f}, fp32 {tail_f:.4f}; "
+          f"max |parameter| bf16 {bf_pmax:.3f} / fp32 {fp_pmax:.3f}; wall {bf_s:.1f} s / {fp_s:.1f} s"]
+if ora:
+    lines.append(f"oracle, mean of the last {k}: fp32 {sum(ora[-k:]) / k:.4f}, bf16-storage twin {sum(ora_bf[-k:]) / k:.4f}")
+text = "\n".join(lines)
+print(text)
+if a.out:
+    open(a.out, "w").write(text + "\n")
+ok = all(math.isfinite(v) for v in bf + fp) and tail_b < head_b - 0.05 and abs(tail_b - tail_f) <= 0.1 * abs(tail_f) + 0.05
+sys.exit(0 if ok else 1)

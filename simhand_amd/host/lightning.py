@@ -94,7 +94,8 @@ class Trainer:
                              GradScaler guards against cannot occur;
       precision "fp8"     -> as bf16, plus e4m3 forward operands (per-tensor scales: weights current, activations delayed
                              with a 16-entry amax ring and 1 bit of margin, ops.FP8Scaler) for the matrix-core-bound layers.
-    tests/test_gpu_fp8.py / test_gpu_main.py hold the multi-step stability evidence."""
+    tests/test_gpu_fp8.py / test_gpu_main.py and profiles/r02_stability_160steps.md (scripts/stability_run.py: 160 steps, fp32 mode ==
+    the oracle's curve, bf16 mode == the oracle's bf16-storage twin) hold the multi-step stability evidence."""
 
     def __init__(self, max_epochs: int = 1, precision=32, callbacks: Optional[list] = None, log_every_n_steps: int = 5,
                  default_root_dir: str = ".", max_steps: int = -1, logger=None, **_ignored):
