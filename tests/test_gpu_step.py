@@ -372,3 +372,56 @@ def test_folded_forward_tracks_the_two_pass_forward():
     c_f, c_t = cos(folded, ref), cos(two_pass, ref)
     assert c_t > 0.97 and c_f >= c_t - 5e-3, (c_f, c_t)
     assert cos(folded, two_pass) > 0.98
+
+
+def test_training_run_fp32_mode_reproduces_the_oracles_loss_curve():
+    """A whole (short) training run instead of one step: 12 steps of ResNet-50 HandCLR_W -- forward, backward, LARS + Adam (multi-tensor
+    HIP kernels) and the warm-up / cosine schedule -- against the oracle trained by the SAME optimizer construction on its own
+    parameters (plain torch ops on the CPU).  fp32 mode: every loss of the run within 1e-3 relative (north-star bar); the longer
+    160-step run with the bf16-storage twin is scripts/stability_run.py -> profiles/r02_stability_160steps.md."""
+    import math
+
+    exp, wcfg = CASES["HandCLR_W"]
+    torch.manual_seed(21)
+    om = orc.StepOracle(exp, "50", AUG, **wcfg).train()
+    model = _product("HandCLR_W", "50", wcfg, om)
+    batches = [orc.synthetic_batch(32, size=96, seed=40 + i) for i in range(3)]  # (tiny batches make BatchNorm nets chaotic: see the module docstring)
+    for b in batches:  # something to learn: view 2 = view 1 + noise
+        b["transformed_image2"] = b["transformed_image1"] + 0.5 * torch.randn(b["transformed_image1"].shape, generator=torch.Generator().manual_seed(7))
+    steps = 12
+
+    class _T:
+        max_epochs, world_size = math.ceil(steps / len(batches)), 1
+
+    def train(mod, step_fn, dev):
+        owner = model if mod is om else mod  # the product's optimizer / schedule construction, on this module's parameters
+        owner.trainer = _T()
+        # the benchmark's schedule regime (10 warm-up EPOCHS of a 10^6-sample set): the learning rate stays small, so the two
+        # trajectories remain comparable step by step -- at a large rate the 1e-4 gradient differences that ReLU kinks cause
+        # (module docstring) send any two fp32 implementations down visibly different paths within a few steps
+        owner.config.num_samples = 1_000_000
+        owner.setup("fit")
+        named = dict(mod.named_parameters())
+        saved = owner.named_parameters
+        owner.named_parameters = lambda *a, **k: iter(named.items())
+        try:
+            (opt,), (sched,) = owner.configure_optimizers()
+        finally:
+            owner.named_parameters = saved
+        out = []
+        for i in range(steps):
+            opt.zero_grad(set_to_none=True)
+            loss = step_fn({k: v.to(dev) for k, v in batches[i % len(batches)].items()}, i)
+            loss.backward()
+            opt.step()
+            sched["scheduler"].step()
+            out.append(float(loss.detach()))
+        return out
+
+    got = train(model, lambda b, i: model.training_step(b, i)["loss"], DEV)
+    om_dev = om.to(DEV)  # its parameters live on the device so that the same multi-tensor optimizer kernels update them; ops are torch's
+    want = train(om_dev, lambda b, i: om_dev.contrastive_step(b), DEV)
+    assert all(math.isfinite(v) for v in got + want)
+    dev_max = max(abs(g_ - w_) / abs(w_) for g_, w_ in zip(got, want))
+    print(f"training run: max relative loss deviation over {steps} steps {dev_max:.2e}; losses {got[0]:.4f} -> {got[-1]:.4f}")
+    assert dev_max <= 1e-3, (got, want)
