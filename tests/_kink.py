@@ -39,6 +39,13 @@ def record_hip_relu_masks(store: list):
             store.append(((res[0] if want_mask else res) > 0).cpu())
         return res
 
+    orig_chain = ops.conv2d_fwd_bnact_chain
+
+    def conv2d_fwd_bnact_chain(d, x, w, st, residual, chain_w):
+        res = orig_chain(d, x, w, st, residual, chain_w)  # (out, mask, chained raw conv output, its partial sums): ReLU is implied
+        store.append((res[0] > 0).cpu())
+        return res
+
     orig_gram = ops.bn_apply_gram
 
     def bn_apply_gram(y, st, relu=True):
@@ -51,12 +58,14 @@ def record_hip_relu_masks(store: list):
     ops.bn_apply = bn_apply
     ops.bn_relu_maxpool_fwd = bn_relu_maxpool_fwd
     ops.conv2d_fwd_bnact = conv2d_fwd_bnact
+    ops.conv2d_fwd_bnact_chain = conv2d_fwd_bnact_chain
     try:
         yield store
     finally:
         ops.bn_apply = orig
         ops.bn_relu_maxpool_fwd = orig_stem
         ops.conv2d_fwd_bnact = orig_fused
+        ops.conv2d_fwd_bnact_chain = orig_chain
         ops.bn_apply_gram = orig_gram
 
 
