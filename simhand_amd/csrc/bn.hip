@@ -436,24 +436,44 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
       braw[e] = 0.f;
       bi[e] = 0;
     }
-    // scan order kh then kw, strict '>' (first maximum wins) like ATen's max_pool2d
+    // scan order kh then kw, strict '>' (first maximum wins) like ATen's max_pool2d.  All nine taps are requested before the
+    // first one is used, branch-free (taps outside the image read a clamped address and are skipped by predicate): conditional
+    // loads would make the compiler wait for each tap in turn (nine exposed round trips per thread)
+    uint4 tv[9];
+    bool tok[9];
+#pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int ih = oh * 2 - 1 + kh;
-      if ((unsigned)ih >= (unsigned)h) continue;
+      const int ihc = min(max(ih, 0), h - 1);
+#pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int iw = ow * 2 - 1 + kw;
-        if ((unsigned)iw >= (unsigned)w) continue;
-        float v[VE];
-        Vec16<T>::load(y + (((int64_t)img * h + ih) * w + iw) * c + cv * VE, v);
+        const int iwc = min(max(iw, 0), w - 1);
+        tok[kh * 3 + kw] = (unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w;
+        tv[kh * 3 + kw] = ld16<false>(y + (((int64_t)img * h + ihc) * w + iwc) * c + cv * VE);
+      }
+    }
 #pragma unroll
-        for (int e = 0; e < VE; ++e) {
-          float a = v[e] * sc[e] + sh[e];
-          a = round_as<T>(a > 0.f ? a : 0.f);  // the activation as bn_apply would have stored it
-          if (a > best[e] || a != a) {
-            best[e] = a;
-            braw[e] = v[e];
-            bi[e] = kh * 3 + kw;
-          }
+    for (int t9 = 0; t9 < 9; ++t9) {
+      float v[VE];
+      if constexpr (VE == 8) {
+        const unsigned w4[4] = {tv[t9].x, tv[t9].y, tv[t9].z, tv[t9].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[2 * q] = __uint_as_float(w4[q] << 16);
+          v[2 * q + 1] = __uint_as_float(w4[q] & 0xffff0000u);
+        }
+      } else {
+        v[0] = __uint_as_float(tv[t9].x); v[1] = __uint_as_float(tv[t9].y); v[2] = __uint_as_float(tv[t9].z); v[3] = __uint_as_float(tv[t9].w);
+      }
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        float a = v[e] * sc[e] + sh[e];
+        a = round_as<T>(a > 0.f ? a : 0.f);  // the activation as bn_apply would have stored it
+        if (tok[t9] && (a > best[e] || a != a)) {
+          best[e] = a;
+          braw[e] = v[e];
+          bi[e] = t9;
         }
       }
     }
