@@ -673,21 +673,20 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_blk_kernel(const T* __restric
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        // branch-free: a window past the edge reads the clamped one and is voided by predicate (conditional loads would make the
+        // compiler's merged vmcnt state wait for each of them in turn)
         const bool ok = a + i < ho && b + j < wo;
-        const int64_t o = ((((int64_t)img * ho + (a + i)) * wo + (b + j)) * cvecs + cv) * VE;
-        wlo[i][j] = whi[i][j] = 0xffffffffu;
-        if (ok) {
-          Vec16<T>::load(dz + o, d[i][j]);
-          if (VE == 8) {
-            const uint2 u = *reinterpret_cast<const uint2*>(idx + o);
-            wlo[i][j] = u.x;
-            whi[i][j] = u.y;
-          } else {
-            wlo[i][j] = *reinterpret_cast<const unsigned*>(idx + o);
-          }
+        const int ai = a + i < ho ? a + i : ho - 1, bj = b + j < wo ? b + j : wo - 1;
+        const int64_t o = ((((int64_t)img * ho + ai) * wo + bj) * cvecs + cv) * VE;
+        Vec16<T>::load(dz + o, d[i][j]);
+        if (VE == 8) {
+          const uint2 u = *reinterpret_cast<const uint2*>(idx + o);
+          wlo[i][j] = ok ? u.x : 0xffffffffu;
+          whi[i][j] = ok ? u.y : 0xffffffffu;
         } else {
-#pragma unroll
-          for (int e = 0; e < VE; ++e) d[i][j][e] = 0.f;
+          const unsigned u = *reinterpret_cast<const unsigned*>(idx + o);
+          wlo[i][j] = ok ? u : 0xffffffffu;
+          whi[i][j] = 0xffffffffu;
         }
       }
     // all four y rows are requested before any of the gather arithmetic (12 loads in flight per thread)
