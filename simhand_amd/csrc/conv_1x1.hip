@@ -161,15 +161,26 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
 #pragma unroll
         for (int j = 0; j < KF; ++j) yfr[mi][j] = *reinterpret_cast<const uint4*>(py + j * 32);
       }
+      // the five coefficient vectors through LDS (the weight-tile buffers are idle until the first SH_G1_STORE): one global load per
+      // thread and vector instead of ten float4 loads per lane and k-slice
+      float* s_xf = reinterpret_cast<float*>(sB);  // [5][K]: 5 KB at K = 256 <= 2 * BT
+      for (int i = tid; i < K; i += 256) {
+        s_xf[i] = p.xf_s[i];
+        s_xf[K + i] = p.xf_h[i];
+        s_xf[2 * K + i] = p.xf_a[i];
+        s_xf[3 * K + i] = p.xf_b[i];
+        s_xf[4 * K + i] = p.xf_c[i];
+      }
+      __syncthreads();
 #pragma unroll
       for (int j = 0; j < KF; ++j) {
         const int kc = j * 32 + g * 8;
         float cs[8], ch[8], ca[8], cb[8], cc[8];
 #pragma unroll
         for (int e = 0; e < 8; e += 4) {
-          const float4 t0 = *reinterpret_cast<const float4*>(p.xf_s + kc + e), t1 = *reinterpret_cast<const float4*>(p.xf_h + kc + e);
-          const float4 t2 = *reinterpret_cast<const float4*>(p.xf_a + kc + e), t3 = *reinterpret_cast<const float4*>(p.xf_b + kc + e);
-          const float4 t4 = *reinterpret_cast<const float4*>(p.xf_c + kc + e);
+          const float4 t0 = *reinterpret_cast<const float4*>(s_xf + kc + e), t1 = *reinterpret_cast<const float4*>(s_xf + K + kc + e);
+          const float4 t2 = *reinterpret_cast<const float4*>(s_xf + 2 * K + kc + e), t3 = *reinterpret_cast<const float4*>(s_xf + 3 * K + kc + e);
+          const float4 t4 = *reinterpret_cast<const float4*>(s_xf + 4 * K + kc + e);
           cs[e] = t0.x; cs[e + 1] = t0.y; cs[e + 2] = t0.z; cs[e + 3] = t0.w;
           ch[e] = t1.x; ch[e + 1] = t1.y; ch[e + 2] = t1.z; ch[e + 3] = t1.w;
           ca[e] = t2.x; ca[e + 1] = t2.y; ca[e + 2] = t2.z; ca[e + 3] = t2.w;
@@ -200,6 +211,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
           if (ok) *reinterpret_cast<uint4*>(p.xf_out + row * K + g * 8 + j * 32) = afr[mi][j];
         }
       }
+      __syncthreads();  // every wave is done with the coefficients before the first weight tile overwrites them
     }
   }
 
