@@ -597,10 +597,14 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
         const int ch = ch0 + j * 4 * VE;
         float sc[VE], sh[VE], s1[VE], s2[VE];
 #pragma unroll
-        for (int e = 0; e < VE; ++e) {
-          sc[e] = p.fmode == 2 ? p.fscale[ch + e] : 0.f;
-          sh[e] = p.fmode == 2 ? p.fshift[ch + e] : 0.f;
-          s1[e] = s2[e] = 0.f;
+        for (int e = 0; e < VE; ++e) sc[e] = sh[e] = s1[e] = s2[e] = 0.f;
+        if (p.fmode == 2) {  // 16-B loads (the per-element conditional form compiles to one dword load per coefficient)
+#pragma unroll
+          for (int e = 0; e < VE; e += 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(p.fscale + ch + e), b4 = *reinterpret_cast<const float4*>(p.fshift + ch + e);
+            sc[e] = a4.x; sc[e + 1] = a4.y; sc[e + 2] = a4.z; sc[e + 3] = a4.w;
+            sh[e] = b4.x; sh[e + 1] = b4.y; sh[e + 2] = b4.z; sh[e + 3] = b4.w;
+          }
         }
         // the four y rows / mask bytes of this channel group are requested together, branch-free (rows past the range read row 0)
         uint4 yq[4];
@@ -1068,10 +1072,14 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         const int ch = ch0 + j * 32;
         float sc[VE], sh[VE], s1[VE], s2[VE];
 #pragma unroll
-        for (int e = 0; e < VE; ++e) {
-          sc[e] = p.fmode == 2 ? p.fscale[ch + e] : 0.f;
-          sh[e] = p.fmode == 2 ? p.fshift[ch + e] : 0.f;
-          s1[e] = s2[e] = 0.f;
+        for (int e = 0; e < VE; ++e) sc[e] = sh[e] = s1[e] = s2[e] = 0.f;
+        if (p.fmode == 2) {  // 16-B loads (the per-element conditional form compiles to one dword load per coefficient)
+#pragma unroll
+          for (int e = 0; e < VE; e += 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(p.fscale + ch + e), b4 = *reinterpret_cast<const float4*>(p.fshift + ch + e);
+            sc[e] = a4.x; sc[e + 1] = a4.y; sc[e + 2] = a4.z; sc[e + 3] = a4.w;
+            sh[e] = b4.x; sh[e + 1] = b4.y; sh[e + 2] = b4.z; sh[e + 3] = b4.w;
+          }
         }
         // all y rows / mask bytes of this 32-channel group are requested before the first one is used (rows past the range read row
         // 0, branch-free): one exposed round trip per group instead of one per 16-pixel row -- the block is alone on its CU
