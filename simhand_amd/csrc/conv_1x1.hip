@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
 #pragma unroll
   for (int mi = 0; mi < MF; ++mi) {
     const long long row = mbase + mi * 16 + li;
-    const bool ok = row < p.M;
+    const bool ok = FAST || row < p.M;  // the fast variants only run on whole blocks: no branch per row
     const bf16_t* pr = p.a + (ok ? row : 0) * K + g * 8;
     int jstride = 32;
     if constexpr (K == 256 && !DGRAD && !FUSE && !EP) {
