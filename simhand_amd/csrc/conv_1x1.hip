@@ -126,6 +126,30 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
     }                                                     \
   } while (0)
   SH_G1_LOAD(0);
+  // W2 (fast variants, K = 256: two weight tiles per chunk): a SECOND staging set, so that every tile is fetched TWO k-steps before
+  // its use -- the counted wait at the end of a k-step then finds its tile landed long ago instead of exposing an L2 round trip per
+  // step (with one set the fetch is issued at the start of the step that ends by waiting for it).  Even tiles travel in rb, odd in rc.
+  constexpr bool W2 = FAST && KSTEPS == 2;
+  uint4 rc0 = make_uint4(0, 0, 0, 0), rc1 = rc0, rc2 = rc0, rc3 = rc0;
+#define SH_G1_LOAD2(OFF)                                                                        \
+  do {                                                                                          \
+    rc0 = *reinterpret_cast<const uint4*>(wsrc0 + (OFF));                                       \
+    rc1 = *reinterpret_cast<const uint4*>(wsrc0 + (OFF) + 1 * RSTEP * K);                       \
+    if (NBL == 4) {                                                                             \
+      rc2 = *reinterpret_cast<const uint4*>(wsrc0 + (OFF) + 2 * RSTEP * K);                     \
+      rc3 = *reinterpret_cast<const uint4*>(wsrc0 + (OFF) + 3 * RSTEP * K);                     \
+    }                                                                                           \
+  } while (0)
+#define SH_G1_STORE2(DST)                                 \
+  do {                                                    \
+    *reinterpret_cast<uint4*>((DST) + st0) = rc0;         \
+    *reinterpret_cast<uint4*>((DST) + st1) = rc1;         \
+    if (NBL == 4) {                                       \
+      *reinterpret_cast<uint4*>((DST) + st2) = rc2;       \
+      *reinterpret_cast<uint4*>((DST) + st3) = rc3;       \
+    }                                                     \
+  } while (0)
+  if constexpr (W2) SH_G1_LOAD2(KC);  // tile 1 = (chunk 0, second k-step)
 
   // ---- A: this wave's 16*MF rows, whole K, straight into MFMA operand registers ----------------------------------------
   uint4 afr[MF][KF];
@@ -319,15 +343,23 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
     for (int ks = 0; ks < KSTEPS; ++ks, ++s) {
       const int buf = s & 1;
       const bool more = s + 1 < total;
-      {  // next weight tile: (nc, ks + 1) or (nc + 1, 0); after the last one tile 0 again (unused)
+      if constexpr (W2) {  // tile s + 2 = (nc + 1, ks); past the end tile 0 again (unused)
+        const long long off2 = nc + 1 < nch ? (long long)(nc + 1) * 64 * K + ks * KC : 0ll;
+        if (ks == 0) SH_G1_LOAD(off2);
+        else SH_G1_LOAD2(off2);
+      } else {  // next weight tile: (nc, ks + 1) or (nc + 1, 0); after the last one tile 0 again (unused)
         const long long off = !more ? 0ll : (ks + 1 < KSTEPS ? (long long)nc * 64 * K + (ks + 1) * KC : (long long)(nc + 1) * 64 * K);
         SH_G1_LOAD(off);
       }
       if constexpr (FAST) {  // this chunk's epilogue rows: younger than the tile fetch above, a whole chunk of MFMAs to land
         __builtin_amdgcn_sched_barrier(0);  // the machine scheduler would hoist them above the tile fetch
         if (ks == 0) {
+#ifndef SH_ABL_R
           if constexpr (EP == 2) load_res(nc);
           else load_pf(nc);
+#else   // ablation (garbage results): the epilogue rows are fetched once, by chunk 0 only
+          if (nc == 0) { if constexpr (EP == 2) load_res(0); else load_pf(0); }
+#endif
         }
         if constexpr (CH && K == 128) panel_load(nc + 1 < nch ? nc + 1 : 0);  // lands under this chunk's MFMAs (last: panel 0 again, unused)
         __builtin_amdgcn_sched_barrier(0);
@@ -403,7 +435,11 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
               if (EP == 2 || p.ep_mask != nullptr) p.ep_mask[row * (p.N >> 3) + (ch >> 3)] = (unsigned char)bits;
             }
             const uint4 pv = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+#if !defined(SH_ABL_S)
             *reinterpret_cast<uint4*>(dst) = pv;
+#else   // ablation: no output stores
+            if (pv.x == 0x12345678u) *reinterpret_cast<uint4*>(dst) = pv;
+#endif
             return pv;
           }
           uint4 v;
@@ -539,7 +575,12 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
       }
       {
         char* dB = sB + (buf ^ 1) * BT;
-        SH_G1_STORE(dB);
+        if constexpr (W2) {  // tile s + 1, fetched a whole k-step ago: rc after an even step, rb after an odd one
+          if (ks == 0) SH_G1_STORE2(dB);
+          else SH_G1_STORE(dB);
+        } else {
+          SH_G1_STORE(dB);
+        }
       }
       __syncthreads();
       float* stat_out = DGRAD ? (FUSE ? p.fpartial : nullptr) : p.bn_partial;
@@ -597,6 +638,8 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
 
 #undef SH_G1_LOAD
 #undef SH_G1_STORE
+#undef SH_G1_LOAD2
+#undef SH_G1_STORE2
 
 bool gemm1x1_supported(int k, int n) { return (k == 64 || k == 128 || k == 256) && n % 64 == 0 && n >= 64; }
 
