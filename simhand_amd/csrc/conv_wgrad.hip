@@ -20,6 +20,8 @@
 // in the logical block order and mapped to one XCD so dy / x tiles are shared in its L2.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace sh {
 
 struct WgradArgs {
@@ -766,10 +768,23 @@ static hook_t g_plain_kpm{2};  // k-step multiplier of the 1x1 pointer-walking k
 static bool is_plain(const sh_conv_desc* d) {
   return d->dtype == SH_BF16 && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0;
 }
-static void plan(const sh_conv_desc* d, int* bm, int* bn, int* splitk, int* pps) {
-  const int kp = d->dtype == SH_F32 ? 16 : (is_plain(d) && g_use_tr ? 32 * g_plain_kpm : 32);
+// 256 x 128 tiles (32-pixel k-steps, 8 x 4 MFMA tiles per wave) for the plain 1x1 kernel where cout % 256 == 0: a quarter less operand
+// traffic per MFMA than 128 x 128 -- (1024, 256) @ 14^2 293 -> 264 us, (2048, 512) @ 7^2 268 -> 251 (env SIMHAND_WG_BIG=0: A/B timing)
+static hook_t g_wg_big{-1};
+static bool wg_big(const sh_conv_desc* d) {
+  static const int env = getenv("SIMHAND_WG_BIG") ? atoi(getenv("SIMHAND_WG_BIG")) : 1;
+  const int h = g_wg_big;
+  // cout != cin: never the Gram launches of the BatchNorm fold (x = dy = a: their operand transforms live in the 128-row tiles)
+  return (h >= 0 ? h : env) && is_plain(d) && g_use_tr && d->cout % 256 == 0 && d->cin % 128 == 0 && d->cout != d->cin;
+}
+static void plan(const sh_conv_desc* d, int* bm, int* bn, int* splitk, int* pps, bool allow_big = true) {
+  int kp = d->dtype == SH_F32 ? 16 : (is_plain(d) && g_use_tr ? 32 * g_plain_kpm : 32);
   *bm = d->cout % 128 == 0 ? 128 : 64;
   *bn = d->cin % 128 == 0 ? 128 : 64;
+  if (allow_big && wg_big(d)) {  // (launches with an operand transform keep the 128-row tiles)
+    *bm = 256;
+    kp = 32;
+  }
   const long long mo = (long long)d->n * d->ho * d->wo;
   const long long tiles = (long long)(d->cout / *bm) * (d->cin / *bn) * d->r * d->s;
   const long long ksteps = (mo + kp - 1) / kp;
@@ -828,7 +843,12 @@ size_t simhand_conv2d_wgrad_workspace_bytes(const sh_conv_desc* d) {
   if (!d) return 0;
   int bm, bn, sk, pps;
   if (use_wgrad3(d)) plan3(d, &sk, &pps);
-  else plan(d, &bm, &bn, &sk, &pps);
+  else {
+    int sk2;
+    plan(d, &bm, &bn, &sk, &pps);
+    plan(d, &bm, &bn, &sk2, &pps, false);  // either tile plan may run (operand-transform launches take the 128-row one)
+    if (sk2 > sk) sk = sk2;
+  }
   return (size_t)sk * d->cout * d->cin * d->r * d->s * sizeof(float);
 }
 
@@ -878,7 +898,7 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
   }
   WgradArgs a;
   int bm, bn;
-  plan(d, &bm, &bn, &a.splitk, &a.pix_per_split);
+  plan(d, &bm, &bn, &a.splitk, &a.pix_per_split, xf == nullptr);
   a.x = x; a.dy = dy; a.part = (float*)workspace;
   a.Mo = mo; a.Cout = d->cout; a.Cin = d->cin;
   a.R = d->r; a.S = d->s; a.stride = d->stride; a.pad = d->pad;
@@ -938,7 +958,8 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
       else if (bm == 128) SH_WGX(128, 64, 2);
       else if (bn == 128) SH_WGX(64, 128, 2);
       else SH_WGX(64, 64, 2);
-    } else if (bm == 128 && bn == 128) SH_WGP(128, 128);
+    } else if (bm == 256) wgrad_kernel<bf16_t, 256, 128, false, true, 1><<<nblk, 256, 0, s>>>(a);
+    else if (bm == 128 && bn == 128) SH_WGP(128, 128);
     else if (bm == 128) SH_WGP(128, 64);
     else if (bn == 128) SH_WGP(64, 128);
     else SH_WGP(64, 64);

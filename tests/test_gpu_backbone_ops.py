@@ -33,6 +33,8 @@ CONV_SHAPES = [
     # n, h, w, cin, cout, k, stride, pad
     (2, 14, 14, 64, 64, 1, 1, 0),
     (2, 14, 14, 64, 256, 1, 1, 0),
+    (3, 14, 14, 128, 256, 1, 1, 0),  # cout % 256 == 0, cin % 128 == 0: the 256 x 128 weight-gradient tile
+    (2, 7, 7, 256, 512, 1, 1, 0),
     (3, 9, 9, 128, 128, 3, 1, 1),
     (2, 16, 16, 64, 64, 3, 1, 1),
     (2, 16, 16, 128, 128, 3, 2, 1),
