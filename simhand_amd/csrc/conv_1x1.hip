@@ -60,11 +60,12 @@ __device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
 // the prefetched rows is exposed instead of hidden under the MFMAs -- these kernels' MFMA time and HBM time ADDED UP.  The fast
 // variants (EP == 2, PF) keep the body branch-free, request the epilogue's rows right AFTER the chunk's first weight-tile fetch
 // (so that waiting for the tile does not wait for them), and the last step re-fetches tile 0 instead of skipping the fetch.
+// ST (K == 256 plain forward): the direct 7x7 stem -- its eighth k-slice (filter row 7) is all zero weights: neither loaded nor multiplied.
 // CH (EP == 2): the chained next conv1 (Gemm1x1Args::chain_*, N -> K channels), fed by every finished output chunk (2 k-slices x
 // K / 16 extra MFMAs per 16-row group).  Its weights are used as panels [K rows][64 k] (columns 64 nc .. of chain_w) in the
 // 128-B-row tile format: K == 64 (N <= 256) keeps all N / 64 panels in LDS for the block's life; K == 128 (N <= 512, MF == 1)
 // streams panel nc + 1 through registers into a second LDS buffer while chunk nc runs.
-template <int K, int MF, bool DGRAD, bool FUSE = false, int EP = 0, int PF = 0, bool CH = false>
+template <int K, int MF, bool DGRAD, bool FUSE = false, int EP = 0, int PF = 0, bool CH = false, bool ST = false>
 #ifndef SH_G1_FUSE_MINB
 #define SH_G1_FUSE_MINB 3
 #endif
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
       }
     }
 #pragma unroll
-    for (int j = 0; j < KF; ++j) afr[mi][j] = ok ? *reinterpret_cast<const uint4*>(pr + j * jstride) : make_uint4(0, 0, 0, 0);
+    for (int j = 0; j < (ST ? KF - 1 : KF); ++j) afr[mi][j] = ok ? *reinterpret_cast<const uint4*>(pr + j * jstride) : make_uint4(0, 0, 0, 0);
   }
   if constexpr (DGRAD) {
     if (p.xf_y != nullptr) {  // block-uniform, prologue only: BatchNorm-backward apply on the freshly loaded gradient rows
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
       const char* cB = sB + buf * BT;
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
+        if (ST && ks * KK + kk == KF - 1) continue;  // compile-time after unrolling: the stem's zero filter row
         uint4 fb[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) fb[ni] = *reinterpret_cast<const uint4*>(cB + frow[ni] + fo[kk]);
@@ -718,7 +720,7 @@ int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
 int launch_gemm1x1_stem(const Gemm1x1Args& a, hipStream_t s) {
   // 256 rows per block: with N = 64 a block has ONE output chunk, so its prologue (the A rows' first touch) is all the latency it
   // can hide; twice the rows per prologue measured 1.76 -> 1.62 ms at 2048 x 224^2 (250 VGPRs, still two blocks per CU)
-  gemm1x1_kernel<256, 4, false><<<ceil_div(a.M, 256), 256, 0, s>>>(a);
+  gemm1x1_kernel<256, 4, false, false, 0, 0, false, true><<<ceil_div(a.M, 256), 256, 0, s>>>(a);
   return 0;
 }
 
