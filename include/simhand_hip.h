@@ -230,9 +230,10 @@ int simhand_stem_pack_weights(const float* w_oihw, void* wp, int dtype, sh_strea
 /* rows of the bn_partial buffer simhand_stem_conv_fwd fills: [blocks][2][64] */
 int simhand_stem_conv_fwd_stat_blocks(int n, int h, int w, int dtype);
 int simhand_stem_conv_fwd(const void* xp, const void* wp, void* y, float* bn_partial, int n, int h, int w, int dtype, sh_stream_t stream);
-/* bf16 route of simhand_stem_conv_fwd: 1 (default) = activation-stationary kernel, 0 = 128 x 64 tile kernel (same k order,
- * bit-identical results; tuning / test hook) */
-int simhand_stem_conv_route(int activation_stationary);
+/* bf16 route of simhand_stem_conv_fwd: 1 (default) = persistent direct-stem kernel (weights resident in LDS, next tile's rows in
+ * flight under the current tile's MFMAs), 2 = activation-stationary kernel, one block per 256 rows, 0 = 128 x 64 tile kernel
+ * (same k order, bit-identical outputs; tuning / test hook) */
+int simhand_stem_conv_route(int mode);
 size_t simhand_stem_conv_wgrad_workspace_bytes(int n, int h, int w, int dtype);
 int simhand_stem_conv_wgrad(const void* xp, const void* dy, float* dw_oihw, void* workspace, size_t workspace_bytes, int n, int h, int w, int dtype, sh_stream_t stream);
 /* dx = conv_transpose(dy, w).  wt = weights permuted to [Cin][R][S][Cout] (simhand_oihw_f32_to_crsk).

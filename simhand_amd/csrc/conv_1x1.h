@@ -60,6 +60,8 @@ int gemm1x1_chain_rows(int k);                      // rows per block of that la
 int gemm1x1_rows_per_block(int k);
 void gemm1x1_set_mf(int k, int mf);
 int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s);
-int launch_gemm1x1_stem(const Gemm1x1Args& a, hipStream_t s);  // 128 rows per block
+int launch_gemm1x1_stem(const Gemm1x1Args& a, hipStream_t s);  // persistent direct-stem forward (or 256 rows per block)
+int gemm1x1_stem_stat_blocks(long long m);                      // rows of the BatchNorm partial-sum buffer that launch fills
+void gemm1x1_set_stem_persistent(int on);
 
 }  // namespace sh

@@ -647,7 +647,8 @@ bool gemm1x1_supported(int k, int n) { return (k == 64 || k == 128 || k == 256) 
 
 // rows per block = 64 * MF; tuned per K on MI355X (scripts/conv_bench.py), overridable for experiments
 static hook_t g_mf[3] = {{4}, {2}, {2}};  // K = 64, 128, 256
-void hooks_reset_1x1() { g_mf[0] = 4; g_mf[1] = 2; g_mf[2] = 2; gemm1x1_set_chain(-1); }
+void gemm1x1_set_stem_persistent(int on);
+void hooks_reset_1x1() { g_mf[0] = 4; g_mf[1] = 2; g_mf[2] = 2; gemm1x1_set_chain(-1); gemm1x1_set_stem_persistent(1); }
 static int mf_of(int k) { return g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)]; }
 void gemm1x1_set_mf(int k, int mf) { g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)] = mf; }
 
@@ -717,7 +718,144 @@ int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
   return 0;
 }
 
+// ---- persistent direct-stem forward ------------------------------------------------------------------------------------
+// The stem (N = 64) is ONE output chunk per row tile: in gemm1x1_kernel every block pays a prologue (its A rows' first touch, a
+// weight tile, a barrier) per 256 rows and nothing overlaps it.  Here the whole [64][256] weight matrix (32 KB) stays in LDS for the
+// life of a block, a block walks row tiles of 64 pixels (grid = a few blocks per CU), and the loop has no barrier and no weight
+// traffic at all: a wave requests the NEXT tile's seven k-slices (filter rows 0..6; row 7 is zero weights) before it multiplies
+// the current tile, then stores 64 channels per pixel and adds the tile into per-lane BatchNorm partial sums that leave the block
+// ONCE, at the end (partial rows = blocks, not tiles).  Same fragment layout, k order and rounding as gemm1x1_kernel<256, ., ST>.
+constexpr int STEM_PB = 512;  // persistent blocks: 2 per CU on 256 CUs (230 VGPRs; a 168-register build for 3 per CU spills: 4.0 ms)
+#ifndef SH_STEM_MF
+#define SH_STEM_MF 1
+#endif
+__global__ __launch_bounds__(256, 2) void stem_fwd_persistent_kernel(Gemm1x1Args p) {
+  constexpr int K = 256, KC = 128, MF = SH_STEM_MF, KF = 7, ROWB = 256, BT = 64 * ROWB, TR = 64 * MF;  // TR: rows per tile
+  __shared__ __attribute__((aligned(16))) char sW[2 * BT];
+  __shared__ float red[4][2][64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  // weights -> LDS once (two [64][128] tiles, 16-B chunks XOR-swizzled by (row & 3) | ((row >> 3) & 3) << 2 as in gemm1x1_kernel)
+  for (int id = tid; id < 2 * 64 * 16; id += 256) {
+    const int t = id >> 10, r = (id >> 4) & 63, c = id & 15;
+    const uint4 v = *reinterpret_cast<const uint4*>(p.w + (long long)r * K + t * KC + c * 8);
+    *reinterpret_cast<uint4*>(sW + t * BT + r * ROWB + ((c ^ ((r & 3) | (((r >> 3) & 3) << 2))) * 16)) = v;
+  }
+  int frow[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) frow[ni] = ((ni >> 1) * 32 + (li >> 2) * 8 + (ni & 1) * 4 + (li & 3)) * ROWB;
+  int fo[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) fo[kk] = ((kk * 4 + g) ^ li) * 16;
+  const long long ntiles = (p.M + TR - 1) / TR;
+  const int jstride = p.stem_wp * 4;
+  auto row_ptr = [&](long long row, bool& ok) __attribute__((always_inline)) -> const bf16_t* {
+    ok = row < p.M;
+    const unsigned m = ok ? (unsigned)row : 0u;
+    const unsigned img = fdiv(m, p.div_hw);
+    const unsigned rem = m - img * p.div_hw.d;
+    const unsigned ho = fdiv(rem, p.div_w);
+    const unsigned wo = rem - ho * p.div_w.d;
+    return p.a + (((long long)img * p.stem_hp + 2 * ho) * p.stem_wp + 2 * wo) * 4 + g * 8;
+  };
+  uint4 cur[MF][KF], nxt[MF][KF];
+  auto load_tile = [&](long long tile, uint4 (&dst)[MF][KF]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi) {
+      bool ok;
+      const bf16_t* pr = row_ptr(tile * TR + wave * (16 * MF) + mi * 16 + li, ok);
+#pragma unroll
+      for (int j = 0; j < KF; ++j) {
+        const uint4 v = *reinterpret_cast<const uint4*>(pr + j * jstride);  // rows past M read pixel 0 (branch-free) and are zeroed
+        dst[mi][j] = ok ? v : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  float s1[4][4], s2[4][4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[ni][r] = s2[ni][r] = 0.f;
+  long long tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile, cur);
+  __syncthreads();  // weights visible
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long long tn = tile + gridDim.x;
+    load_tile(tn < ntiles ? tn : tile, nxt);  // in flight under this tile's MFMAs (past the end: this tile again, unused)
+    f32x4 acc[MF][4];
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KF; ++j) {
+      const char* cB = sW + (j >> 2) * BT;
+      uint4 fb[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) fb[ni] = *reinterpret_cast<const uint4*>(cB + frow[ni] + fo[j & 3]);
+#pragma unroll
+      for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mma_bf16(fb[ni], cur[mi][j], acc[mi][ni]);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi) {
+      const long long row = tile * TR + wave * (16 * MF) + mi * 16 + li;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[mi][ni][r];  // rows past M are exact zeros (zeroed operands)
+          s1[ni][r] += v;
+          s2[ni][r] += v * v;
+        }
+      if (row < p.M) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
+          *reinterpret_cast<uint4*>(p.out + row * 64 + j * 32 + g * 8) =
+              make_uint4(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]));
+        }
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+      for (int j = 0; j < KF; ++j) cur[mi][j] = nxt[mi][j];
+  }
+  if (p.bn_partial != nullptr) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t1 = row16_sum_g1(s1[ni][r]), t2 = row16_sum_g1(s2[ni][r]);
+        if (li == 0) {
+          const int c = (ni >> 1) * 32 + g * 8 + (ni & 1) * 4 + r;
+          red[wave][0][c] = t1;
+          red[wave][1][c] = t2;
+        }
+      }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      p.bn_partial[((long long)blockIdx.x * 2 + which) * 64 + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+  }
+}
+
+static hook_t g_stem_persistent{1};
+void gemm1x1_set_stem_persistent(int on) { g_stem_persistent = on ? 1 : 0; }
+int gemm1x1_stem_stat_blocks(long long m) {
+  if (!g_stem_persistent) return ceil_div(m, 256);
+  const long long tiles = (m + 64 * SH_STEM_MF - 1) / (64 * SH_STEM_MF);
+  return (int)(tiles < STEM_PB ? tiles : STEM_PB);
+}
+
 int launch_gemm1x1_stem(const Gemm1x1Args& a, hipStream_t s) {
+  if (g_stem_persistent) {
+    stem_fwd_persistent_kernel<<<gemm1x1_stem_stat_blocks(a.M), 256, 0, s>>>(a);
+    return 0;
+  }
   // 256 rows per block: with N = 64 a block has ONE output chunk, so its prologue (the A rows' first touch) is all the latency it
   // can hide; twice the rows per prologue measured 1.76 -> 1.62 ms at 2048 x 224^2 (250 VGPRs, still two blocks per CU)
   gemm1x1_kernel<256, 4, false, false, 0, 0, false, true><<<ceil_div(a.M, 256), 256, 0, s>>>(a);

@@ -1458,7 +1458,7 @@ int simhand_stem_conv_fwd_stat_blocks(int n, int h, int w, int dtype) {
   int hp, wp, ho, wo;
   if (n < 1 || simhand_stem_geometry(h, w, &hp, &wp, &ho, &wo)) return 0;
   const long long m = (long long)n * ho * wo;
-  return ceil_div(m, dtype == SH_BF16 && g_stem_1x1 ? 256 : 128);  // rows per block of the kernel the same arguments select
+  return dtype == SH_BF16 && g_stem_1x1 ? gemm1x1_stem_stat_blocks(m) : ceil_div(m, 128);  // partial rows of the kernel the same arguments select
 }
 
 int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_partial, int n, int h, int w, int dtype,
@@ -1507,8 +1507,9 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
   return dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 
-int simhand_stem_conv_route(int activation_stationary) {
-  g_stem_1x1 = activation_stationary ? 1 : 0;
+int simhand_stem_conv_route(int mode) {
+  g_stem_1x1 = mode ? 1 : 0;
+  gemm1x1_set_stem_persistent(mode != 2);
   return 0;
 }
 

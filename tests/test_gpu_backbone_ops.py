@@ -174,13 +174,14 @@ def test_stem_direct_conv(dtype, n, h, w):
     _check(part[:, 1].sum(0).cpu() / m, (yf * yf).mean(0), 1e-2 if dtype == torch.bfloat16 else 1e-4, "stat sumsq")
     if dtype == torch.bfloat16:  # the default bf16 route is the activation-stationary kernel: same bits as the tile kernel
         lib = ops._lib_dev()
-        lib.simhand_stem_conv_route(0)
-        try:
-            y_tile, part_tile = ops.stem_conv_fwd(xp, wpk, h, w)
-        finally:
-            lib.simhand_stem_conv_route(1)
-        assert torch.equal(yd, y_tile)
-        _check(part.sum(0).cpu(), part_tile.sum(0).cpu(), 1e-5, "partials vs tile kernel")
+        for route in (0, 2):  # tile kernel, per-block activation-stationary kernel (default: the persistent kernel)
+            lib.simhand_stem_conv_route(route)
+            try:
+                y_tile, part_tile = ops.stem_conv_fwd(xp, wpk, h, w)
+            finally:
+                lib.simhand_stem_conv_route(1)
+            assert torch.equal(yd, y_tile)
+            _check(part.sum(0).cpu(), part_tile.sum(0).cpu(), 1e-5, f"partials vs route {route}")
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
     dw = ops.stem_conv_wgrad(xp, dyd, h, w).cpu()
     _check(dw, wr.grad, 2e-5 if dtype == torch.float32 else 2e-3, "stem wgrad")
