@@ -5,7 +5,7 @@
 // Replaces (reference): layer1.*.conv2 of torchvision's Bottleneck (src/models/resnet_model.py:13-58) and its
 // input-gradient (cuDNN there).
 //
-// Same idea as wgrad3x3_kernel (conv_wgrad.hip): work on the ZERO-PADDED pixel grid ((H+2) x (W+2) per image, images back to
+// Same idea as wgrad3x3_kernel (conv_wgrad.hip): work on the ZERO-PADDED pixel grid with shared padding ((H+1) x (W+1) per image, images back to
 // back), where tap (r, s) is the constant row shift (r-1)(W+2) + (s-1).  A persistent block walks a range of padded pixels
 // in steps of 64: the x rows go global -> LDS ring once (LDS-DMA, two steps ahead, zero page for pad positions), the nine
 // tap operands are read from the ring at nine row offsets -- and the WEIGHTS never move: with K = 64 the whole
@@ -13,7 +13,7 @@
 // the lifetime of the block.  Per step a wave issues 72 MFMAs against 36 ds_read_b128; nothing is staged per tap.
 //   block = 4 waves as 2 (pixels) x 2 (channels): a wave owns 32 of the step's 64 pixels x 32 channels;
 //   ring = 512 rows x 128 B, 16-B chunks XOR-swizzled by row/2 on the DMA source side (conflict-free fragment reads);
-//   outputs at pad positions are computed and dropped ((H+2)(W+2)/(HW) = 7 % extra MFMAs at 56 x 56);
+//   outputs at pad positions are computed and dropped ((H+1)(W+1)/(HW) = 3.6 % extra MFMAs at 56 x 56);
 //   forward: BN partial sums of the fp32 results ride in registers across the block's steps (one [2][64] row per block);
 //   data gradient: optionally the previous unit's BN-backward sums (sum g, sum g*y, ReLU mask recomputed from y).
 #include "conv3x3_c64.h"
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
   // 128-B half of the 256-B bank line, the row/2 key separates the 8 rows of one parity) for every offset.
   const int pl = (li & 4) == ((li & 8) >> 1) ? 2 * ((li & 3) + ((li >> 3) << 2)) : 2 * (li - 4) + 1;
   const int wm = wave >> 1, wn = wave & 1;
-  const int WP = p.W + 2;
+  const int WP = p.W + 1;  // SHARED padding as in wgrad3x3_kernel: one zero column between rows, one zero row between images
   const long long total_steps = (p.q_total + 63) / 64;
   const long long step0 = (long long)blockIdx.x * p.steps_per_block;
   long long step1 = step0 + p.steps_per_block;

@@ -1289,7 +1289,7 @@ int simhand_igemm256_enable(int on) {
 }
 
 // 64 -> 64 channel 3x3 / stride 1 on the padded pixel grid with register-resident weights (conv3x3_c64.hip)
-static long long c64_q_total(const sh_conv_desc* d) { return (long long)d->n * (d->h + 2) * (d->w + 2); }
+static long long c64_q_total(const sh_conv_desc* d) { return (long long)d->n * (d->h + 1) * (d->w + 1); }
 static bool use_c64(const sh_conv_desc* d) {
   return c64_supported(d->dtype, d->cin, d->cout, d->r, d->s, d->stride, d->pad, d->w, c64_q_total(d));
 }
@@ -1308,8 +1308,8 @@ static int launch_c64_conv(const sh_conv_desc* d, const void* x, const void* w, 
   c.N = d->n; c.H = d->h; c.W = d->w; c.dgrad = dgrad ? 1 : 0;
   c.q_total = c64_q_total(d);
   c.steps_per_block = 0;
-  c.div_pp = make_fastdiv((unsigned)((d->h + 2) * (d->w + 2)));
-  c.div_wp = make_fastdiv((unsigned)(d->w + 2));
+  c.div_pp = make_fastdiv((unsigned)((d->h + 1) * (d->w + 1)));
+  c.div_wp = make_fastdiv((unsigned)(d->w + 1));
   launch_c64(c, s);
   return check_launch(dgrad ? "conv2d_dgrad (3x3 c64)" : "conv2d_fwd (3x3 c64)");
 }

@@ -422,7 +422,7 @@ def test_big_tile_conv_fwd_dgrad(shape, force_big_tile):
 # ---------------------------------------------------------------------------------------------------------------------
 # 64 -> 64 channel 3x3 on the padded pixel grid, filter resident in registers (conv3x3_c64.hip)
 # ---------------------------------------------------------------------------------------------------------------------
-C64_SHAPES = [(8, 28, 28), (4, 56, 56), (16, 5, 61), (9, 23, 17)]  # n, h, w (w + 3 <= 64; >= 4096 padded pixels)
+C64_SHAPES = [(8, 28, 28), (4, 56, 56), (16, 5, 61), (10, 23, 17)]  # n, h, w (w + 3 <= 64; >= 4096 positions of the (h + 1) x (w + 1) padded grid)
 
 
 @pytest.mark.parametrize("shape", C64_SHAPES)
