@@ -26,6 +26,8 @@
 // Block ids are remapped so all n-tiles of an m-tile run on one XCD (shared L2 for A rows).
 #include "common.h"
 #include "conv_1x1.h"
+
+#include <stdlib.h>
 #include "conv3x3_c64.h"
 
 namespace sh {
@@ -1639,7 +1641,8 @@ int simhand_conv2d_dgrad_fuse_pays(const sh_conv_desc* d) {
   if (!d) return 0;
   // stride-2 3x3: each of the four parity-class launches pays the extra read of y against a quarter of the MFMA work; the
   // standalone pass is faster (same-box A/B of the whole step: 126.4 -> 125.9 ms)
-  if (d->stride == 2 && d->r == 3 && !g_fuse_1x1) return 0;
+  static const int fuse_s2 = getenv("SIMHAND_FUSE_S2") ? atoi(getenv("SIMHAND_FUSE_S2")) : 0;  // A/B timing
+  if (d->stride == 2 && d->r == 3 && !g_fuse_1x1 && !fuse_s2) return 0;
   return (!use_1x1(d, d->cout, d->cin) || g_fuse_1x1) ? 1 : 0;
 }
 
