@@ -124,39 +124,44 @@ __device__ __forceinline__ void canvas_pixel(const unsigned char* __restrict__ i
   }
 }
 
-// 1-D resampling footprint of destination index o: taps i0 .. i0 + cnt - 1 with weights (INTER_AREA for scale >= 1, else bilinear)
+// 1-D resampling footprint of destination index o: taps i0 .. i0 + cnt - 1 (INTER_AREA for scale >= 1, else bilinear).  The
+// area footprint is as long as the scale asks for (ceil(scale) + 1 taps at most): weights are evaluated on the fly by
+// foot_weight, nothing is capped (a 6-tap cap used to drop taps -- and darken the image -- for crops > 5x the output side).
 struct Foot {
   int i0, cnt;
-  double w[6];
+  double lo, hi, scale;  // area branch: covered interval [lo, hi) in source pixels; bilinear branch: scale < 0, lo = weight of tap 0
 };
 __device__ __forceinline__ Foot footprint(int o, int n_in, int n_out) {
   Foot f;
   const double scale = (double)n_in / (double)n_out;
   if (scale >= 1.0) {
-    const double lo = o * scale, hi = (o + 1) * scale;
-    f.i0 = (int)floor(lo);
-    const int i1 = min((int)ceil(hi), n_in);
-    f.cnt = min(i1 - f.i0, 6);
-    for (int k = 0; k < f.cnt; ++k) {
-      const int i = f.i0 + k;
-      f.w[k] = fmax(0.0, fmin(hi, (double)(i + 1)) - fmax(lo, (double)i)) / scale;
-    }
+    f.lo = o * scale;
+    f.hi = (o + 1) * scale;
+    f.scale = scale;
+    f.i0 = (int)floor(f.lo);
+    f.cnt = min((int)ceil(f.hi), n_in) - f.i0;
   } else {
     const double c = (o + 0.5) * scale - 0.5;
     const int i0 = (int)floor(c);
     const double fr = c - i0;
     const int a = min(max(i0, 0), n_in - 1), b = min(max(i0 + 1, 0), n_in - 1);
     f.i0 = a;
+    f.scale = -1.0;
+    f.hi = 0.0;
     if (a == b) {
       f.cnt = 1;
-      f.w[0] = 1.0;
+      f.lo = 1.0;
     } else {
       f.cnt = 2;
-      f.w[0] = 1.0 - fr;
-      f.w[1] = fr;
+      f.lo = 1.0 - fr;
     }
   }
   return f;
+}
+__device__ __forceinline__ double foot_weight(const Foot& f, int k) {
+  if (f.scale < 0.0) return k == 0 ? f.lo : 1.0 - f.lo;
+  const int i = f.i0 + k;
+  return fmax(0.0, fmin(f.hi, (double)(i + 1)) - fmax(f.lo, (double)i)) / f.scale;
 }
 
 __global__ __launch_bounds__(128) void augment_image_kernel(const unsigned char* __restrict__ images, const AugGeo* __restrict__ geo,
@@ -168,19 +173,23 @@ __global__ __launch_bounds__(128) void augment_image_kernel(const unsigned char*
   const long long plane = (long long)out_h * out_w;
   for (int u = threadIdx.x; u < out_w; u += blockDim.x) {
     float px[3] = {0.f, 0.f, 0.f};
-    if (g.wc > 0 && g.hc > 0) {
-      // resize scales above 6 (crop > 6x the output) would need a longer footprint: the recipes crop <= 224 -> 128
+    // an empty crop (box entirely off the canvas): cv2.resize raises in the reference; here the sample's image is NaN (loud
+    // downstream) and rec[4..5] = (0, 0) lets the host raise (GpuAugmenter(check=True))
+    const bool empty = g.wc <= 0 || g.hc <= 0;
+    if (!empty) {
       const Foot fy = footprint(v, g.hc, out_h), fx = footprint(u, g.wc, out_w);
       double acc[3] = {0.0, 0.0, 0.0};
-      for (int a = 0; a < fy.cnt; ++a)
+      for (int a = 0; a < fy.cnt; ++a) {
+        const double wy = foot_weight(fy, a);
         for (int b = 0; b < fx.cnt; ++b) {
           float c3[3];
           canvas_pixel(img, H, W, g, g.ox + fx.i0 + b, g.oy + fy.i0 + a, c3);
-          const double w = fy.w[a] * fx.w[b];
+          const double w = wy * foot_weight(fx, b);
           acc[0] += w * c3[0];
           acc[1] += w * c3[1];
           acc[2] += w * c3[2];
         }
+      }
 #pragma unroll
       for (int c = 0; c < 3; ++c) px[c] = round_u8((float)acc[c]);
     }
@@ -221,7 +230,8 @@ __global__ __launch_bounds__(128) void augment_image_kernel(const unsigned char*
     }
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[((long long)n * 3 + c) * plane + (long long)v * out_w + u] = (px[c] / 255.0f - mean[c]) / stdv[c];
+    for (int c = 0; c < 3; ++c)
+      out[((long long)n * 3 + c) * plane + (long long)v * out_w + u] = empty ? __builtin_nanf("") : (px[c] / 255.0f - mean[c]) / stdv[c];
   }
 }
 

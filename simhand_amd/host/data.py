@@ -23,8 +23,11 @@ from . import dist as shdist
 
 
 class GpuAugmenter:
-    def __init__(self, augmentation_flags, augmentation_params):
+    def __init__(self, augmentation_flags, augmentation_params, check: bool = False):
+        """check: read the crop records back after every batch (one host sync) and raise ValueError for an empty crop -- the
+        reference's cv2.resize raises there (sample_augmenter.py:197-224); without it such a sample's image is NaN."""
         f, p = augmentation_flags, augmentation_params
+        self.check = check
         self.rotate, self.crop, self.random_crop = bool(f["rotate"]), bool(f["crop"]), bool(f["random_crop"])
         self.resize, self.color_jitter = bool(f["resize"]), bool(f["color_jitter"])
         for name in ("cut_out", "gaussian_blur", "gaussian_noise", "sobel_filter", "color_drop", "flip"):
@@ -58,6 +61,8 @@ class GpuAugmenter:
         """One view of a batch: (images fp32 (n,3,H,W) normalised, joints_aug (n,21,3), per-sample entries as collated)."""
         img, ja, rec = ops.augment_batch(images_u8.contiguous(), joints.contiguous().float(), draws.get("angle"), draws["crop_margin"].float().contiguous(),
                                          draws["jitter"].contiguous(), draws.get("hsab"), out_hw=(self.resize_shape[1], self.resize_shape[0]))
+        if self.check and bool((rec[:, 4:6] <= 0).any()):
+            raise ValueError("augment_batch: empty crop (the crop box of a sample lies outside its frame)")
         ent = {"jitter_x": rec[:, 0].to(torch.int64), "jitter_y": rec[:, 1].to(torch.int64),
                "crop_margin_scale": draws["crop_margin"].to(torch.float64), "blur_flag": torch.zeros(img.shape[0], dtype=torch.bool, device=img.device)}
         if "angle" in draws:

@@ -28,7 +28,8 @@ def _raw(n, size, seed):
     return img, torch.from_numpy(j)
 
 
-@pytest.mark.parametrize("size,out,rotate,color", [(224, 128, True, True), (160, 128, True, False), (96, 128, False, True), (224, 64, True, True)])
+@pytest.mark.parametrize("size,out,rotate,color", [(224, 128, True, True), (160, 128, True, False), (96, 128, False, True), (224, 64, True, True),
+                                                    (720, 64, True, True), (512, 32, False, False)])  # last two: area footprints of 7-16 taps per axis
 def test_augment_batch_against_oracle(size, out, rotate, color):
     from simhand_amd import ops
 
@@ -51,6 +52,28 @@ def test_augment_batch_against_oracle(size, out, rotate, color):
         diff = np.abs(got_img[i] - want_img) / LEVEL
         assert (diff <= 1.01).mean() >= 0.995 and diff.max() <= 3.01, (i, float((diff > 1.01).mean()), float(diff.max()))
         assert (diff <= 0.01).mean() >= 0.97, float((diff <= 0.01).mean())  # and the vast majority bit-identical
+
+
+def test_augment_empty_crop_is_loud():
+    """A crop box entirely off the canvas: the reference's cv2.resize raises; the kernel emits a NaN image + a zero-size record and
+    GpuAugmenter(check=True) raises."""
+    from simhand_amd import ops
+    from simhand_amd.host import config as C
+    from simhand_amd.host.config import edict, read_json
+    from simhand_amd.host.data import GpuAugmenter
+
+    img, j = _raw(2, 96, 3)
+    j[1, :, :2] += 500.0  # joints (and so the crop box) far outside the 96 x 96 canvas
+    margin = torch.full((2,), 1.2)
+    jitter = torch.zeros(2, 2, dtype=torch.int32)
+    out, _, rec = ops.augment_batch(img.to(DEV), j.to(DEV), None, margin.to(DEV), jitter.to(DEV), None, out_hw=(32, 32))
+    assert torch.isfinite(out[0]).all() and torch.isnan(out[1]).all()
+    assert rec[1, 4].item() == 0 and rec[1, 5].item() == 0
+    tp = edict(read_json(C.TRAINING_CONFIG_PATH))
+    tp.augmentation_flags["resize"] = True
+    aug = GpuAugmenter(tp.augmentation_flags, tp.augmentation_params, check=True)
+    with pytest.raises(ValueError):
+        aug.transform(img.to(DEV), j.to(DEV), aug.draw(2, torch.device(DEV)))
 
 
 def test_augment_crop_box_against_reference_golden(golden_dir):
