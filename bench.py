@@ -41,6 +41,21 @@ AUG = ["color_jitter", "crop", "random_crop", "resize", "rotate"]
 TRAIN_GFLOP_PER_PAIR = {"18": 21.77, "50": 49.06, "152": 138.15}  # BASELINE.md section 3 (@224)
 
 
+def source_hash() -> str:
+    """sha1 over the sources that decide what the step launches (kernels, dispatch, engine): profiles/hbm_traffic.json records the
+    hash it was measured at, so a static PMC figure can never be quoted against a different build without saying so."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, "simhand_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "simhand_amd", "csrc", "*.h"))
+                   + [os.path.join(ROOT, "simhand_amd", "ops.py"), os.path.join(ROOT, "simhand_amd", "host", "resnet_model.py")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,10 +68,10 @@ def parse():
                     help="fp8 = BASELINE configs[4] slice: bf16 storage, e4m3 forward operands on the MFMA-bound layers (parity n/a)")
     ap.add_argument("--experiment", default="handclr_w", choices=["handclr_w", "peclr_w", "simclr"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=16,
-                    help="pairs in the default CPU-baseline sample (bounded to ~20-30 s; --cpu-full times the SURVEY 8d points 32 / 128)")
+    ap.add_argument("--cpu-pairs", type=int, default=32,
+                    help="pairs in the CPU-baseline sample (default = the SURVEY 8d point B = 32; ~40 s on the box's host for ResNet-50)")
     ap.add_argument("--cpu-full", action="store_true",
-                    help="also time the other SURVEY 8d CPU points (ResNet-18 B=32 = BASELINE configs[0], ResNet-50 B=128): minutes of CPU time")
+                    help="also time the third SURVEY 8d CPU point (ResNet-50 B=128): minutes of CPU time")
     return ap.parse_args()
 
 
@@ -76,9 +91,29 @@ def self_launch(args) -> int:
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # poll all ranks: the first failure ends the siblings (they would otherwise sit in a collective until the backend's watchdog
+    # fires); an overall limit bounds the whole run
+    deadline = time.monotonic() + float(os.environ.get("SIMHAND_BENCH_TIMEOUT_S", "3600"))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = abs(code)
+        if rc != 0 or time.monotonic() > deadline:
+            for p in live:  # exact PIDs this process started, nothing else
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            return rc or 124
+        time.sleep(0.05)
     return rc
 
 
@@ -129,7 +164,7 @@ def host_cpu():
     return info
 
 
-def _cpu_point(exp, resnet, pairs, size, wcfg, budget_s, warm=2):
+def _cpu_point(exp, resnet, pairs, size, wcfg, budget_s, warm=2, max_timed=5):
     """One CPU reference point: the oracle step (fwd + bwd, then LARS/Adam timed separately) -- median of up to 5 timed
     steps after `warm` warm-ups; the timed steps stop early once `budget_s` of wall time is spent (never fewer than 1)."""
     from oracle import step as orc
@@ -142,7 +177,7 @@ def _cpu_point(exp, resnet, pairs, size, wcfg, budget_s, warm=2):
     batch = orc.synthetic_batch(pairs, size=size, seed=5)
     fb, op = [], []
     t_start = time.perf_counter()
-    for i in range(warm + 5):
+    for i in range(warm + max_timed):
         t0 = time.perf_counter()
         adam.zero_grad(set_to_none=True)
         loss = model.contrastive_step(batch)
@@ -170,19 +205,20 @@ def cpu_baseline(args):
     exp = {"handclr_w": "simhand_w", "peclr_w": "peclr_w", "simclr": "simclr"}[args.experiment]
     cpu = host_cpu()
     threads = torch.get_num_threads()
-    pt = _cpu_point(exp, args.resnet, args.cpu_pairs, args.image_size, wcfg, budget_s=20.0, warm=1)
+    # bounded sample: 1 warm-up + 2 timed steps of the benchmarked network at the SURVEY 8d batch (B = 32), and BASELINE configs[0]
+    # (ResNet-18 handclr_w, B = 32 -- the reference's own CPU-runnable case) next to it: ~50 s of host time in the default run
+    pt = _cpu_point(exp, args.resnet, args.cpu_pairs, args.image_size, wcfg, budget_s=25.0, warm=1, max_timed=2)
     res = {"value": pt["pairs_per_s"], "unit": "pairs/s", "cores": threads, "kind": "port",
            "cpu_model": cpu["model"], "physical_cores": cpu["physical_cores"], "hardware_threads": cpu["threads"],
            "optimizer_ms": pt["optimizer_ms"], "fwd_bwd_ms": pt["fwd_bwd_ms"],
            "sample": f"oracle.StepOracle ResNet-{args.resnet} {args.experiment} fp32, {pt['pairs']} pairs of {args.image_size}x{args.image_size}, "
                      f"fwd+bwd (optimizer timed separately: {pt['optimizer_ms']:.0f} ms), median of {pt['timed_steps']} steps after {pt['warmups']} warm-up "
                      f"({pt['fwd_bwd_ms']:.0f} ms/step), {threads} torch threads on {cpu['model']} ({cpu['physical_cores']} physical cores)"}
+    res["points"] = {f"ResNet-{args.resnet} B={args.cpu_pairs}": pt}
+    if args.experiment == "handclr_w":
+        res["points"]["configs[0] ResNet-18 B=32"] = _cpu_point(exp, "18", 32, args.image_size, wcfg, budget_s=15.0, warm=1, max_timed=3)
     if args.cpu_full:
-        res["points"] = {
-            "configs[0] ResNet-18 B=32": _cpu_point(exp, "18", 32, args.image_size, wcfg, budget_s=60.0),
-            f"ResNet-{args.resnet} B=32": _cpu_point(exp, args.resnet, 32, args.image_size, wcfg, budget_s=120.0),
-            f"ResNet-{args.resnet} B=128": _cpu_point(exp, args.resnet, 128, args.image_size, wcfg, budget_s=400.0),
-        }
+        res["points"][f"ResNet-{args.resnet} B=128"] = _cpu_point(exp, args.resnet, 128, args.image_size, wcfg, budget_s=400.0)
     return res
 
 
@@ -275,10 +311,25 @@ def main():
         breakdown, bsteps = (warm_prof, 1) if warm_prof is not None else (prof, args.steps)
         all_conv_flops = sum(breakdown[k]["flops"] for k in conv_classes)
         all_conv_ms = sum(breakdown[k]["ms"] for k in conv_classes)
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived, filled from rocprofv3 --pmc passes
-        if os.path.exists(tf):  # bytes per launch of that kernel class from the committed rocprofv3 --pmc passes
-            traffic = (json.load(open(tf)).get(dom) or {}).get("bytes_per_launch")
+        # HBM view of the step.  The PMC counters (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) need rocprofv3's
+        # own passes (scripts/refresh_profiles.sh), so the byte counts are STATIC: profiles/hbm_traffic.json records the source hash
+        # they were taken at; against a different build they are reported as stale (null), never silently.
+        traffic, hbm = None, None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf) and args.per_gpu_batch == 1024 and args.resnet == "50" and args.precision == "bf16" and args.image_size == 224:
+            tj = json.load(open(tf))
+            stale = tj.get("source_hash") != source_hash()
+            src = f"profiles/hbm_traffic.json (static: rocprofv3 --pmc passes of this command at source hash {tj.get('source_hash')}, commit {tj.get('commit')})"
+            if stale:
+                print(f"bench.py: profiles/hbm_traffic.json was measured at source hash {tj.get('source_hash')}, this build is {source_hash()}: "
+                      f"HBM traffic figures withheld (re-run scripts/refresh_profiles.sh)", file=sys.stderr, flush=True)
+                hbm = {"bytes_per_step": None, "gbps": None, "peak": 8000.0, "frac": None, "stale": True, "source": src}
+            else:
+                traffic = (tj.get(dom) or {}).get("bytes_per_launch")
+                bps = (tj.get("step") or {}).get("bytes_per_step")
+                if bps:
+                    gbps = bps / (elapsed / args.steps) / 1e9
+                    hbm = {"bytes_per_step": bps, "gbps": gbps, "peak": 8000.0, "frac": gbps / 8000.0, "stale": False, "source": src}
         res = {
             "metric": "hand-image-pairs/sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -291,7 +342,7 @@ def main():
                        "world_size_backend": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "launches": d["count"], "avg_launch_ms": d["ms"] / max(1, d["count"]),
+                         "traffic": traffic, "hbm": hbm, "launches": d["count"], "avg_launch_ms": d["ms"] / max(1, d["count"]),
                          "all_conv_tflops": all_conv_flops / (all_conv_ms * 1e-3) / 1e12 if all_conv_ms > 0 else 0.0,
                          "step_tflops_per_gpu": TRAIN_GFLOP_PER_PAIR.get(args.resnet, 0.0) * (args.image_size / 224.0) ** 2
                                                 * args.per_gpu_batch * args.steps / elapsed / 1e3},

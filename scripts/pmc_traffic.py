@@ -33,4 +33,20 @@ for c, pats in cls.items():
     n = sum(r[2] for r in sel)
     out[c] = {"bytes_per_launch": sum(r[0] for r in sel) / max(1, n), "launches_profiled": n,
               "read_bytes": sum(r[3] for r in sel), "write_bytes": sum(r[4] for r in sel)}
+# whole-step view + provenance (bench.py quotes these only against the build they were measured on)
+import os, subprocess
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else 2  # bench.py --steps 1 --warmup 1
+rd_all, wr_all = sum(r[3] for r in rows), sum(r[4] for r in rows)
+out["step"] = {"bytes_per_step": (rd_all + wr_all) / steps, "read_bytes_per_step": rd_all / steps, "write_bytes_per_step": wr_all / steps,
+               "steps_profiled": steps}
+try:
+    from bench import source_hash
+    out["source_hash"] = source_hash()
+except Exception as e:  # noqa: BLE001
+    out["source_hash"] = None
+try:
+    out["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or os.environ.get("SIMHAND_COMMIT")
+except Exception:  # noqa: BLE001 -- no git on the GPU box snapshot
+    out["commit"] = os.environ.get("SIMHAND_COMMIT")
 json.dump(out, open(sys.argv[4], "w"), indent=1)

@@ -9,9 +9,11 @@ per GPU (RCCL) instead of the reference's ``strategy="dp"``.
 """
 from __future__ import annotations
 
+import collections
 import os
 import random
-from typing import Any, Dict, List, Optional
+import re
+from typing import Any, Deque, Dict, List, Optional
 
 import numpy as np
 import torch
@@ -84,6 +86,24 @@ class ModelCheckpoint:
                 os.remove(drop)
         self.best_model_path = self.kept[0][1]
 
+    def rescan(self) -> None:
+        """Rebuild `kept` from the checkpoint files already in dirpath (a resumed run must keep pruning to save_top_k across the
+        restart): the monitored score is parsed back out of the reference's filename template ({monitor}=%.6f)."""
+        if not self.dirpath or not os.path.isdir(self.dirpath):
+            return
+        pat = re.compile(re.escape(self.monitor) + r"=(-?\d+\.\d+)")
+        known = {p for _, p in self.kept}
+        for fn in sorted(os.listdir(self.dirpath)):
+            m = pat.search(fn)
+            path = os.path.join(self.dirpath, fn)
+            if m is None or not fn.endswith(".ckpt") or path in known:
+                continue
+            score = float(m.group(1))
+            self.kept.append((score if self.mode == "min" else -score, path))
+        self.kept.sort(key=lambda t: t[0])
+        if self.kept:
+            self.best_model_path = self.kept[0][1]
+
 
 class Trainer:
     """fit loop for the contrastive step classes.  Mixed-precision policy (the reference runs fp16 autocast +
@@ -95,16 +115,20 @@ class Trainer:
       precision "fp8"     -> as bf16, plus e4m3 forward operands (per-tensor scales: weights current, activations delayed
                              with a 16-entry amax ring and 1 bit of margin, ops.FP8Scaler) for the matrix-core-bound layers.
     tests/test_gpu_fp8.py / test_gpu_main.py and profiles/r02_stability_160steps.md (scripts/stability_run.py: 160 steps, fp32 mode ==
-    the oracle's curve, bf16 mode == the oracle's bf16-storage twin) hold the multi-step stability evidence."""
+    the oracle's curve, bf16 mode == the oracle's bf16-storage twin) hold the multi-step stability evidence.
+    Resume: bf16 / fp32 runs continue bit for bit (tests/test_gpu_main.py); the fp8 delayed-scaling amax rings are NOT part of the
+    checkpoint -- a resumed fp8 run re-seeds them with a current-scaling first step (documented limitation)."""
 
     def __init__(self, max_epochs: int = 1, precision=32, callbacks: Optional[list] = None, log_every_n_steps: int = 5,
-                 default_root_dir: str = ".", max_steps: int = -1, logger=None, **_ignored):
+                 default_root_dir: str = ".", max_steps: int = -1, logger=None, keep_step_losses: int = 4096, **_ignored):
         self.max_epochs, self.precision, self.callbacks = max_epochs, precision, callbacks or []
         self.log_every_n_steps, self.default_root_dir, self.max_steps = log_every_n_steps, default_root_dir, max_steps
         self.global_step = 0
         self.current_epoch = 0
         self._epoch_complete, self._batches_seen = True, 0
-        self.step_losses: List[torch.Tensor] = []  # detached per-step loss scalars (device tensors: no host sync per step)
+        # detached per-step loss scalars (device tensors: no host sync per step); bounded -- a full run is 1e5..1e6 steps and every
+        # entry pins an allocator block
+        self.step_losses: Deque[torch.Tensor] = collections.deque(maxlen=max(1, keep_step_losses))
         self.history: List[Dict[str, float]] = []
         self.optimizers: list = []
         self.schedulers: list = []
@@ -165,6 +189,8 @@ class Trainer:
         for cb in self.callbacks:
             if isinstance(cb, ModelCheckpoint) and cb.dirpath is None:
                 cb.dirpath = os.path.join(self.default_root_dir, "checkpoints")
+            if isinstance(cb, ModelCheckpoint) and ckpt_path:
+                cb.rescan()  # earlier top-k files of the run being resumed stay subject to pruning
         reducer = None
         if self.world_size > 1 and hasattr(getattr(model, "encoder", None), "engine"):
             reducer = OverlappedGradReducer(getattr(model, "process_group", None))

@@ -228,10 +228,10 @@ class ResNetEngine:
         if training:
             if self._gram is not None and self._gram[0] is x_in:            # came out of the producer's fused BN-apply + Gram launch
                 s2, t2 = self._gram[1], self._gram[2]
-            else:
+                self._gram = None                                            # consumed (a stage-entry block's shortcut conv, which runs
+            else:                                                            # between conv2 and conv3, must not throw conv3's Gram away)
                 dww = ops.conv_desc(n, d.ho, d.wo, cin, cin, 1, 1, 1, 0, self.dtype)
                 s2, t2 = ops.conv2d_wgrad_colsum(dww, x_in, x_in)            # x^T x (fp32) and sum x ride on one kernel
-            self._gram = None
             # sum y = W . sum x, sum y^2 = rowdot(W S2, W) with the weights the MFMAs see -> statistics, running stats, W S2
             st, ws2 = ops.bn_fold_fwd(conv.weight.detach().view(cout, cin), True, s2, t2, m, bn.weight.detach(), bn.bias.detach(),
                                       bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum)
@@ -342,6 +342,7 @@ class ResNetEngine:
             ctx["pool_idx"] = idx
             ctx["pool_ywin"] = ywin
         self._chain = None
+        self._gram = None
         for li in (4, 5, 6, 7):
             stage = list(f[li])
             for bi, blk in enumerate(stage):
