@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "32", "fp8"],
                     help="fp8 = BASELINE configs[4] slice: bf16 storage, e4m3 forward operands on the MFMA-bound layers (parity n/a)")
     ap.add_argument("--experiment", default="handclr_w", choices=["handclr_w", "peclr_w", "simclr"])
+    ap.add_argument("--comm", default="torch", choices=["torch", "abi"],
+                    help="N > 1: collectives through torch.distributed (nccl = RCCL) or through the C ABI's own RCCL wrappers (simhand_comm_*)")
+    ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="N > 1: wire format of the gradient all-reduce buckets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=32,
                     help="pairs in the CPU-baseline sample (default = the SURVEY 8d point B = 32; ~40 s on the box's host for ResNet-50)")
@@ -245,16 +248,19 @@ def main():
     (opt,), (sched,) = model.configure_optimizers()
     batch = device_batch(args.per_gpu_batch, args.image_size, 5 + rank, device)
     params = [p for p in model.parameters()]
-    reducer = None
+    reducer, group = None, None
     if world > 1:  # backbone gradients go out block by block during the backward pass; the head's follow in allreduce_gradients
-        reducer = shdist.OverlappedGradReducer()
+        if args.comm == "abi" and dist.get_backend() == "nccl":  # bootstrap over torch.distributed, data path on the ABI communicator
+            group = shdist.RcclComm.from_torch_distributed()
+            model.process_group = group
+        reducer = shdist.OverlappedGradReducer(group, wire=args.grad_wire)
         model.encoder.engine.grad_reducer = reducer
 
     def step(i):
         opt.zero_grad(set_to_none=True)
         out = model.training_step(batch, i)
         out["loss"].backward()
-        shdist.allreduce_gradients(params, skip=reducer.reduced if reducer is not None else None)
+        shdist.allreduce_gradients(params, group=group, skip=reducer.reduced if reducer is not None else None, wire=args.grad_wire)
         opt.step()
         sched["scheduler"].step()
         return out["loss"]
@@ -298,6 +304,14 @@ def main():
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # every rank must have timed the same number of steps on the same per-rank batch: a rank that fell out of step would
+        # otherwise inflate the aggregate silently
+        did = torch.tensor([args.steps, args.warmup, args.per_gpu_batch], dtype=torch.int64, device=device)
+        lo, hi = did.clone(), did.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit(f"bench.py: ranks disagree on (steps, warmup, per-gpu batch): min {lo.tolist()} max {hi.tolist()}")
     elapsed = float(t)
 
     if rank == 0:
@@ -340,7 +354,9 @@ def main():
                        "global_batch": global_pairs, "per_gpu_batch": args.per_gpu_batch, "image_size": args.image_size,
                        "parallelism": f"dp{world}", "loss": final_loss, "parity": "n/a (the reference has no fp8 path)" if args.precision == "fp8" else "oracle",
                        "world_size_backend": dist.get_world_size() if world > 1 else 1,
-                       "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none"},
+                       "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none",
+                       "comm": ("abi (simhand_comm_*)" if group is not None else "torch.distributed") if world > 1 else "none",
+                       "grad_wire": args.grad_wire if world > 1 else "n/a"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "hbm": hbm, "launches": d["count"], "avg_launch_ms": d["ms"] / max(1, d["count"]),
                          "all_conv_tflops": all_conv_flops / (all_conv_ms * 1e-3) / 1e12 if all_conv_ms > 0 else 0.0,

@@ -84,7 +84,13 @@ class RcclComm:
         return cls(box[0], dist.get_world_size(group), dist.get_rank(group))
 
     def _stream(self):
-        return self._C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return self._C.c_void_p(torch.cuda.current_stream().cuda_stream)  # inside `with torch.cuda.stream(s)`: s
+
+    def side_stream(self) -> "torch.cuda.Stream":
+        """The communicator's own HIP stream for collectives that overlap the compute stream (OverlappedGradReducer)."""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     def all_gather_into(self, out: torch.Tensor, x: torch.Tensor) -> None:
         from .. import _lib
@@ -116,20 +122,43 @@ def shard_pairs(global_pairs: int, rank: int, world: int) -> Tuple[int, int]:
     return rank * b, b
 
 
+_WIRE = {None: None, "fp32": None, "bf16": torch.bfloat16}
+
+
+def _bucket_flat(tensors: List[torch.Tensor], wire) -> torch.Tensor:
+    """One flat buffer holding `tensors` back to back (optionally in the reduced-precision wire format)."""
+    flat = torch.cat([g.reshape(-1) for g in tensors])
+    return flat if wire is None else flat.to(wire)
+
+
+def _bucket_views(flat: torch.Tensor, tensors: List[torch.Tensor]) -> List[torch.Tensor]:
+    """Views of the reduced bucket shaped like the tensors that went in: they BECOME the gradients (no copy back)."""
+    if flat.dtype != tensors[0].dtype:
+        flat = flat.to(tensors[0].dtype)
+    out, off = [], 0
+    for g in tensors:
+        n = g.numel()
+        out.append(flat[off:off + n].view_as(g))
+        off += n
+    return out
+
+
 class OverlappedGradReducer:
     """Gradient all-reduce OVERLAPPED with the backward pass (north star: "all-reduce of gradients ... overlapped with
     backward").  The backbone is one hand-written backward (`ResNetEngine.backward`) that finishes its parameter gradients
-    block by block, last stage first; each finished group is handed to ``submit``: full buckets are flattened and go out as
-    asynchronous SUM all-reduces (RCCL runs them on its own stream, behind an event on the launch stream) while the earlier
-    blocks' kernels keep the compute stream busy.  ``finish`` (end of the backbone's backward) waits and scatters the sums
-    back into the gradient tensors, so what autograd hands to ``p.grad`` is already reduced; ``reduced`` tells
-    ``allreduce_gradients`` which parameters are done.  xGMI is point to point (7 links x ~153 GB/s per GPU): a ResNet-50's
+    block by block, last stage first; each finished group is handed to ``submit``: full buckets are flattened once and go out
+    as asynchronous SUM all-reduces while the earlier blocks' kernels keep the compute stream busy -- torch.distributed runs
+    them on RCCL's own stream; with an ``RcclComm`` group they are issued on the communicator's side stream behind an event
+    on the launch stream.  ``finish`` (end of the backbone's backward) waits and returns ``{parameter: reduced gradient}``
+    whose tensors are VIEWS of the reduced buckets (nothing is copied back; the engine hands them to autograd as the
+    gradients); ``reduced`` tells ``allreduce_gradients`` which parameters are done.  wire="bf16": buckets travel as bf16
+    (half the ring time; the sum is then a bf16 sum).  xGMI is point to point (7 links x ~153 GB/s per GPU): a ResNet-50's
     98.5 MB of fp32 gradients are ~1-3 ms of ring time per step -- hidden behind ~80 ms of backward instead of appended."""
 
-    def __init__(self, group=None, bucket_bytes: int = 32 << 20):
-        self.group, self.bucket_bytes = group, bucket_bytes
+    def __init__(self, group=None, bucket_bytes: int = 32 << 20, wire: str = None):
+        self.group, self.bucket_bytes, self.wire = group, bucket_bytes, _WIRE[wire]
         self.reduced = set()
-        self._bucket: List[torch.Tensor] = []
+        self._bucket: List[Tuple[object, torch.Tensor]] = []
         self._size = 0
         self._pending = []
 
@@ -141,10 +170,17 @@ class OverlappedGradReducer:
     def _flush(self) -> None:
         if not self._bucket:
             return
-        flat = torch.cat([g.reshape(-1) for g in self._bucket])
+        flat = _bucket_flat([g for _, g in self._bucket], self.wire)
         if isinstance(self.group, RcclComm):
-            self.group.all_reduce_(flat, "sum")  # stream-ordered
-            work = None
+            side = self.group.side_stream()
+            ready = torch.cuda.Event()
+            ready.record()                     # the flatten above, on the launch stream
+            flat.record_stream(side)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                self.group.all_reduce_(flat, "sum")
+            work = torch.cuda.Event()
+            work.record(side)
         else:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((work, flat, self._bucket))
@@ -156,22 +192,23 @@ class OverlappedGradReducer:
             if g is None:
                 continue
             self.reduced.add(id(p))
-            self._bucket.append(g)
-            self._size += g.numel() * g.element_size()
+            self._bucket.append((p, g))
+            self._size += g.numel() * (g.element_size() if self.wire is None else 2)
             if self._size >= self.bucket_bytes:
                 self._flush()
 
-    def finish(self) -> None:
+    def finish(self) -> dict:
         self._flush()
+        out = {}
         for work, flat, bucket in self._pending:
-            if work is not None:
+            if isinstance(work, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(work)
+            elif work is not None:
                 work.wait()
-            off = 0
-            for g in bucket:
-                n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
-                off += n
+            for (p, _), v in zip(bucket, _bucket_views(flat, [g for _, g in bucket])):
+                out[p] = v
         self._pending = []
+        return out
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) -> None:
@@ -183,11 +220,23 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) ->
             dist.broadcast(t.data, src=src, group=group)
 
 
-def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20, skip=None) -> None:
+_GRAD_PLANS: dict = {}
+
+
+def reset_gradient_plans() -> None:
+    """Forget the cached gradient patterns of ``allreduce_gradients`` (a model whose set of trained parameters changed)."""
+    _GRAD_PLANS.clear()
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20, skip=None, wire: str = None) -> None:
     """SUM all-reduce over a FIXED parameter list: every rank buckets the same tensors in the same order, whatever
     received a gradient locally.  A trainable parameter without a gradient on this rank contributes zeros (and receives
     the other ranks' sum); parameters with requires_grad=False are skipped on every rank alike.  skip: ids of parameters an
-    OverlappedGradReducer already reduced during this step's backward (the set is emptied)."""
+    OverlappedGradReducer already reduced during this step's backward (the set is emptied).
+    The pattern "which parameters have a gradient on ANY rank" is agreed once per parameter list (one small MAX all-reduce +
+    one host read) and cached: later steps issue no host synchronisation at all.  A gradient that shows up outside the cached
+    pattern raises (call reset_gradient_plans() after changing what is trained).  The reduced buckets BECOME the gradients
+    (`p.grad` is re-pointed at views of them: no copy back); wire="bf16" sends them as bf16."""
     abi = isinstance(group, RcclComm)
     if abi:
         if group.world == 1:
@@ -197,49 +246,47 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
     plist = [p for p in params if p.requires_grad and not (skip and id(p) in skip)]  # skip: already reduced during backward
     if skip:
         skip.clear()
-    # which parameters have a gradient anywhere: one small MAX all-reduce keeps the bucket layout identical on all ranks
-    has = torch.tensor([1 if p.grad is not None else 0 for p in plist], dtype=torch.int64, device=plist[0].device if plist else "cpu")
-    if has.numel():
+    if not plist:
+        return
+    key = (tuple(id(p) for p in plist), id(group))
+    keep = _GRAD_PLANS.get(key)
+    if keep is None:
+        has = torch.tensor([1 if p.grad is not None else 0 for p in plist], dtype=torch.int64, device=plist[0].device)
         if abi:
             group.all_reduce_(has, "max")
         else:
             dist.all_reduce(has, op=dist.ReduceOp.MAX, group=group)
-    keep = has.tolist()
+        keep = _GRAD_PLANS[key] = [bool(k) for k in has.tolist()]  # the only host read, first step only
     grads: List[torch.Tensor] = []
+    owners: List[torch.nn.Parameter] = []
     for p, k in zip(plist, keep):
         if not k:
+            if p.grad is not None:
+                raise RuntimeError("allreduce_gradients: a parameter outside the agreed gradient pattern received a gradient "
+                                   "(reset_gradient_plans() after changing the trained set)")
             continue
         if p.grad is None:
             p.grad = torch.zeros_like(p)
         grads.append(p.grad)
-    bucket: List[torch.Tensor] = []
-    size = 0
+        owners.append(p)
+    wdt = _WIRE[wire]
     pending = []
-
-    def flush():
-        nonlocal bucket, size
-        if not bucket:
-            return
-        flat = torch.cat([g.reshape(-1) for g in bucket])
-        if abi:  # stream-ordered on the current stream: nothing to wait for on the host
-            group.all_reduce_(flat, "sum")
-            work = None
-        else:
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        pending.append((work, flat, bucket))
-        bucket, size = [], 0
-
-    for g in reversed(grads):  # reverse registration order ~ order of production in backward
-        bucket.append(g)
-        size += g.numel() * g.element_size()
-        if size >= bucket_bytes:
-            flush()
-    flush()
-    for work, flat, bucket_ in pending:
+    lo = len(grads)
+    size = 0
+    for i in range(len(grads) - 1, -1, -1):  # reverse registration order ~ order of production in backward
+        size += grads[i].numel() * (grads[i].element_size() if wdt is None else 2)
+        if size >= bucket_bytes or i == 0:
+            tensors = grads[i:lo]
+            flat = _bucket_flat(tensors, wdt)
+            if abi:  # stream-ordered on the current stream: nothing to wait for on the host
+                group.all_reduce_(flat, "sum")
+                work = None
+            else:
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            pending.append((work, flat, i, lo))
+            lo, size = i, 0
+    for work, flat, i, hi in pending:
         if work is not None:
             work.wait()
-        off = 0
-        for g in bucket_:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
+        for p, v in zip(owners[i:hi], _bucket_views(flat, grads[i:hi])):
+            p.grad = v

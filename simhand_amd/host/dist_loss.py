@@ -5,13 +5,13 @@ SURVEY 8(e): the reference computes per-replica losses under nn.DataParallel
 which equals the reference's single-device loss at the global batch.  Each
 rank owns b_loc contiguous pairs (both views of a pair on the same rank):
 
-  1. all-gather Z (2 b_loc x 128) and J (2 b_loc x F) into the reference's
-     row order cat(all view-1, all view-2)           [RCCL, 4 small messages]
+  1. ONE all-gather of the packed [Z (2 b_loc x 128) | J (2 b_loc x F)] rows,
+     re-ordered into the reference's row order cat(all view-1, all view-2)   [RCCL]
   2. d+ for all B pairs (redundant, tiny) ; D row block (2 b_loc x N) + its
      max / min / sum                                  [HIP]
-  3. all-reduce(MAX) of (max, -min), all-reduce(SUM) of the sum  [RCCL, scalars]
+  3. ONE all-gather of the local (max, min, sum), folded identically on every rank  [RCCL, 3 doubles]
   4. fused tile loop -> neg_i for local rows, loss partial       [HIP, MFMA f32]
-  5. all-gather neg (N floats), all-reduce(SUM) loss             [RCCL]
+  5. ONE all-gather of [neg (2 b_loc floats) | loss partial]      [RCCL]
   backward: dZ for the local rows only from Z_all, D_loc, neg_all (closed form,
   no reduce-scatter needed)                                      [HIP, MFMA f32]
 
@@ -72,27 +72,43 @@ def _world(group):
     return 1, 0
 
 
-def _gather_rows(x_loc: Tensor, b_loc: int, world: int, group) -> Tensor:
-    """(2*b_loc, w) local rows -> (2*B, w) in the reference order: the two halves are
-    gathered separately straight into their slices (no permute copy)."""
-    if world == 1:
-        return x_loc
-    B = b_loc * world
-    out = torch.empty(2 * B, x_loc.shape[1], dtype=x_loc.dtype, device=x_loc.device)
+def _all_gather(out: Tensor, x: Tensor, group) -> Tensor:
+    """out [world * x.numel()] <- every rank's contiguous x, rank order."""
     if _is_abi(group):
-        group.all_gather_into(out[:B], x_loc[:b_loc].contiguous())
-        group.all_gather_into(out[B:], x_loc[b_loc:].contiguous())
+        group.all_gather_into(out, x)
     else:
-        dist.all_gather_into_tensor(out[:B], x_loc[:b_loc].contiguous(), group=group)
-        dist.all_gather_into_tensor(out[B:], x_loc[b_loc:].contiguous(), group=group)
+        dist.all_gather_into_tensor(out, x, group=group)
     return out
 
 
-def _all_reduce(t: Tensor, op: str, group) -> Tensor:
-    if _is_abi(group):
-        return group.all_reduce_(t, op)
-    dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op], group=group)
-    return t
+def _reference_order(buf: Tensor, b_loc: int, world: int) -> Tensor:
+    """[world][2 b_loc][w] rank-major gather -> [2 B][w] in the reference's row order cat(all view-1 rows, all view-2 rows)."""
+    w = buf.shape[-1]
+    return buf.view(world, 2, b_loc, w).transpose(0, 1).reshape(2 * b_loc * world, w)
+
+
+def _gather_packed(z_loc: Tensor, j_loc: Optional[Tensor], b_loc: int, world: int, group):
+    """ONE all-gather per step for the embeddings and the joints ("one fused all-gather of a packed [Z | J]
+    buffer" -- the messages are <= 1.4 MB per rank, i.e. latency-bound): local rows packed as [2 b_loc][128 + F] fp32,
+    gathered rank-major, re-ordered into the reference's row order and split.  Returns (Z_all, J_all or None)."""
+    if world == 1:
+        return z_loc, j_loc
+    packed = z_loc if j_loc is None else torch.cat((z_loc, j_loc), dim=1)
+    packed = packed.contiguous()
+    buf = torch.empty(world * packed.shape[0], packed.shape[1], dtype=packed.dtype, device=packed.device)  # rank-major concatenation
+    _all_gather(buf, packed, group)
+    allr = _reference_order(buf, b_loc, world)
+    dz = z_loc.shape[1]
+    if j_loc is None:
+        return allr.contiguous(), None
+    return allr[:, :dz].contiguous(), allr[:, dz:].contiguous()
+
+
+def _gather_scalars(loc: Tensor, world: int, group) -> Tensor:
+    """[k] local scalars -> [world][k] (rank order): ONE small all-gather; every rank folds the same table in the same order,
+    so max / min / sum come out bit-identical everywhere (an all-reduce(SUM) leaves the summation order to the backend)."""
+    buf = torch.empty(world * loc.numel(), dtype=loc.dtype, device=loc.device)
+    return _all_gather(buf, loc.contiguous().reshape(-1), group).view(world, loc.numel())
 
 
 class ShardedNtxent(torch.autograd.Function):
@@ -113,7 +129,8 @@ class ShardedNtxent(torch.autograd.Function):
         weighted = cfg.weight_type is not None and (cfg.use_wpos or cfg.use_wneg)
         if explicit and world != 1:
             raise ValueError("explicit weight tensors are a single-process convenience (functional surface)")
-        Z = _gather_rows(z_loc, b_loc, world, group)
+        need_j = weighted and not explicit
+        Z, J = _gather_packed(z_loc, j_loc.contiguous().float() if need_j else None, b_loc, world, group)
         stats = torch.zeros(8, dtype=torch.float64, device=z_loc.device)
         D = dpos = None
         fused_dist = False
@@ -121,7 +138,6 @@ class ShardedNtxent(torch.autograd.Function):
             dpos = None if pos_w is None else pos_w.contiguous().float()
             D = None if neg_w is None else neg_w.contiguous().float()
         elif weighted:
-            J = _gather_rows(j_loc.contiguous().float(), b_loc, world, group)
             mode = cfg.diff_type
             if cfg.use_wpos:
                 dpos = K.pos_dist(J, B, mode, stats)
@@ -132,10 +148,9 @@ class ShardedNtxent(torch.autograd.Function):
                     K.neg_dist(J, B, mode, b_loc, rank * b_loc, stats, stats_only=True)
                 else:
                     D = K.neg_dist(J, B, mode, b_loc, rank * b_loc, stats)
-                if world > 1:
-                    mm = _all_reduce(torch.stack((stats[0], -stats[1])), "max", group)
-                    sm = _all_reduce(stats[2:3].clone(), "sum", group)
-                    stats[0], stats[1], stats[2] = mm[0], -mm[1], sm[0]
+                if world > 1:  # one packed exchange of (max, min, sum) of the local distance row blocks
+                    tab = _gather_scalars(stats[0:3], world, group)
+                    stats[0], stats[1], stats[2] = tab[:, 0].max(), tab[:, 1].min(), tab[:, 2].sum()
         plan = K.NtxentPlan(B, b_loc, rank * b_loc, cfg.weight_type if weighted or explicit else None,
                             cfg.use_wpos and dpos is not None, cfg.use_wneg and (D is not None or fused_dist), cfg.temperature,
                             cfg.lambda_pos, cfg.lambda_neg, dim=Z.shape[1])
@@ -144,9 +159,10 @@ class ShardedNtxent(torch.autograd.Function):
             neg_loc, loss = K.ntxent_fwd_fused(plan, Z, fused_j, cfg.diff_type, dpos, stats)
         else:
             neg_loc, loss = K.ntxent_fwd(plan, Z, D, dpos, stats)
-        if world > 1:
-            neg_all = _gather_rows(neg_loc.view(rows, 1), b_loc, world, group).view(-1)
-            _all_reduce(loss, "sum", group)
+        if world > 1:  # one packed exchange: the local rows' negative sums + this rank's loss partial
+            tab = _gather_scalars(torch.cat((neg_loc.reshape(-1), loss.reshape(-1))), world, group)
+            neg_all = _reference_order(tab[:, :rows].reshape(world, rows, 1), b_loc, world).reshape(-1).contiguous()
+            loss = tab[:, rows].double().sum().float().reshape(1)
         else:
             neg_all = neg_loc
         ctx.k, ctx.plan, ctx.fused_mode = K, plan, (cfg.diff_type if fused_j is not None else None)

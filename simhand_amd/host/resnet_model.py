@@ -599,7 +599,7 @@ class ResNetEngine:
         grads[u.conv.weight] = ops.stem_conv_wgrad(u.x, dy, u.desc.h, u.desc.w)
         if red is not None:
             red.submit(list(grads.items())[sent:])
-            red.finish()  # waits for the buckets still in flight and scatters the sums back: what autograd receives is reduced
+            grads.update(red.finish())  # waits for the buckets in flight; the reduced buckets' views ARE the gradients autograd receives
         return grads
 
 

@@ -49,6 +49,7 @@ if BACKEND == "nccl" and world > 1:
     # the same step with every exchange routed through the C ABI's RCCL wrappers (simhand_comm_*) instead of torch.distributed
     comm = shdist.RcclComm.from_torch_distributed()
     assert (comm.world, comm.rank) == (world, rank)
+    torch_grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
     model.zero_grad()
     model.process_group = comm
     model.encoder.engine.grad_reducer = shdist.OverlappedGradReducer(comm, bucket_bytes=1 << 20)
@@ -57,6 +58,11 @@ if BACKEND == "nccl" and world > 1:
     shdist.allreduce_gradients(model.parameters(), group=comm, bucket_bytes=1 << 20, skip=model.encoder.engine.grad_reducer.reduced)
     torch.cuda.synchronize()
     assert abs(loss_abi.item() - loss.item()) <= 1e-6 * abs(loss.item()), (loss_abi.item(), loss.item())
+    # the ABI path's reduced gradients (side-stream buckets) against the torch.distributed path's, tensor by tensor
+    for k, p in model.named_parameters():
+        if k in torch_grads:
+            ref = torch_grads[k]
+            assert (p.grad - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-8, k
     comm.close()
 
 if rank == 0:

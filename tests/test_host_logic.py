@@ -201,33 +201,65 @@ p[0].grad = torch.full((5,), float(rank + 1)); p[1].grad = torch.full((3, 2), 10
 shdist.allreduce_gradients(p, bucket_bytes=16)
 tot = sum(range(1, world + 1))
 assert torch.equal(p[0].grad, torch.full((5,), float(tot))) and torch.equal(p[1].grad, torch.full((3, 2), 10.0 * tot))
-# overlapped reducer: groups handed over "block by block" go out as asynchronous buckets, finish() scatters the sums back into
-# the very tensors that were submitted; what it reduced is skipped (once) by allreduce_gradients
+# the agreed gradient pattern is cached: the second call issues no MAX all-reduce / host read, and re-points p.grad at bucket views
+p[0].grad = torch.full((5,), float(rank + 1)); p[1].grad = None     # a rank-local missing gradient is zero-filled from the cached plan
+calls = []
+orig = dist.all_reduce
+dist.all_reduce = lambda t, *a, **k: (calls.append(k.get("op", a[0] if a else None)), orig(t, *a, **k))[1]
+shdist.allreduce_gradients(p, bucket_bytes=16)
+dist.all_reduce = orig
+assert dist.ReduceOp.MAX not in calls, calls
+assert torch.equal(p[0].grad, torch.full((5,), float(tot))) and torch.equal(p[1].grad, torch.zeros(3, 2))
+r = torch.nn.Parameter(torch.zeros(4)); r.requires_grad_(True)
+# overlapped reducer: groups handed over "block by block" go out as asynchronous buckets; finish() returns the reduced gradients as
+# views of the buckets (no copy back); what it reduced is skipped (once) by allreduce_gradients
 q = [torch.nn.Parameter(torch.zeros(n)) for n in (7, 3, 11, 2)]
 gr = [torch.full((p_.numel(),), float((rank + 1) * (i + 1))) for i, p_ in enumerate(q)]
 red = shdist.OverlappedGradReducer(bucket_bytes=32)
 assert red.active()
-red.submit([(q[0], gr[0]), (q[1], gr[1])]); red.submit([(q[2], gr[2])]); red.finish()
+red.submit([(q[0], gr[0]), (q[1], gr[1])]); red.submit([(q[2], gr[2])]); out = red.finish()
+assert set(out) == {q[0], q[1], q[2]}
 for i in range(3):
-    assert torch.equal(gr[i], torch.full_like(gr[i], float(tot * (i + 1)))), (rank, i, gr[i])
-    q[i].grad = gr[i]
+    assert torch.equal(out[q[i]], torch.full_like(gr[i], float(tot * (i + 1)))), (rank, i, out[q[i]])
+    q[i].grad = out[q[i]]
+assert out[q[0]].untyped_storage().data_ptr() == out[q[1]].untyped_storage().data_ptr()   # one bucket, two views
 q[3].grad = gr[3]
 assert red.reduced == {id(q[0]), id(q[1]), id(q[2])}
 shdist.allreduce_gradients(q, bucket_bytes=16, skip=red.reduced)
 assert not red.reduced
 assert torch.equal(q[0].grad, torch.full((7,), float(tot))) and torch.equal(q[3].grad, torch.full((2,), 4.0 * tot))
+# bf16 wire format: same sums where they are exactly representable
+w = [torch.nn.Parameter(torch.zeros(6))]
+w[0].grad = torch.full((6,), 0.5 * (rank + 1))
+shdist.allreduce_gradients(w, wire="bf16")
+assert w[0].grad.dtype == torch.float32 and torch.equal(w[0].grad, torch.full((6,), 0.5 * tot))
+red2 = shdist.OverlappedGradReducer(bucket_bytes=8, wire="bf16")
+g2 = torch.full((5,), 0.25 * (rank + 1)); red2.submit([(w[0], g2)]); o2 = red2.finish()
+assert o2[w[0]].dtype == torch.float32 and torch.equal(o2[w[0]], torch.full((5,), 0.25 * tot))
+# a gradient outside the agreed pattern is an error, not a silent desynchronisation
+s2 = [torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(2))]
+s2[0].grad = torch.ones(2)
+shdist.allreduce_gradients(s2)
+s2[1].grad = torch.ones(2)
+try:
+    shdist.allreduce_gradients(s2)
+    raise SystemExit("expected a RuntimeError")
+except RuntimeError:
+    pass
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
 
 
-def test_sharded_loss_and_grad_allreduce_gloo_world2(tmp_path):
-    """world_size 2 over gloo on CPU: sharded loss (+ its backward) == single-process oracle on the global batch."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_loss_and_grad_allreduce_gloo(tmp_path, world):
+    """world_size 2 / 4 over gloo on CPU: sharded loss (packed [Z | J] all-gather, packed scalar exchanges; + its backward) ==
+    single-process oracle on the global batch; gradient reducers (cached pattern, bucket views, bf16 wire)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29609 + world), WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
