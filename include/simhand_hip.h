@@ -12,12 +12,19 @@
  *     tensor); no ownership transfer, no allocation inside the library;
  *   - workspaces are caller-allocated after a *_workspace_bytes() query;
  *   - every launch takes an explicit hipStream_t (as void*) and is asynchronous.
- *     Process-global state is limited to (a) the optional event profiler, (b) the
- *     route counters below and (c) the TEST / TUNING hooks (simhand_*_enable,
- *     simhand_*_set_*, simhand_*_route ...): atomics that select between
- *     kernels computing the same result; a product caller never touches them
- *     (defaults are the measured-best routes), tests restore the defaults in
- *     try/finally, and simhand_hooks_reset() puts all of them back at once;
+ *     The PRODUCT surface (everything not named simhand_test_* / simhand_prof_* /
+ *     simhand_route_*) holds no mutable global state: a call's result and kernel
+ *     choice depend on its arguments only, concurrent callers on different streams
+ *     do not interact.  Three diagnostic facilities are process-global by design
+ *     and are NOT part of the drop-in surface: (a) the optional event profiler
+ *     (simhand_prof_*), (b) the route counters (simhand_route_*), (c) the
+ *     simhand_test_* namespace -- relaxed atomics that pick between kernels
+ *     computing the same result, for A/B timing and for tests that must force a
+ *     route at small sizes; their defaults are the measured-best routes, a product
+ *     caller never calls them, and simhand_test_hooks_reset() restores them all;
+ *   - entry points marked EXPERIMENTAL were built, tested and measured slower than
+ *     the default path; they stay for the experiment record,
+ *     the engine does not call them by default and they may go away;
  *   - return 0 on success, non-zero on error; simhand_last_error() returns a
  *     thread-local message;
  *   - activations are NHWC, conv weights KRSC ([Cout][R][S][Cin]); dtype enum
@@ -84,7 +91,7 @@ enum sh_route {
 int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
 int simhand_route_reset(void);
 /* every test / tuning hook back to its default */
-int simhand_hooks_reset(void);
+int simhand_test_hooks_reset(void);
 
 /* ---- optional per-kernel-class HIP-event profiler (used by bench.py) ----- */
 enum sh_prof_class { SH_PROF_CONV_FWD = 0, SH_PROF_CONV_DGRAD = 1, SH_PROF_CONV_WGRAD = 2,
@@ -182,16 +189,19 @@ enum sh_pp_flags {
   SH_PP_ANGLE_AS_GIVEN = 4  /* angle[] is rotate_encoding's own argument (already negated by the caller) */
 };
 #define SH_PP_FUSED (SH_PP_NORM_IN | SH_PP_NORM_OUT)
+/* the projection kernels view a row as 64 2-D points: `width` (floats per row) MUST be SH_PROJ_DIM (output_dim of every
+ * *_config.json of the reference); any other value is refused with an error code, never read out of bounds */
+#define SH_PROJ_DIM 128
 /* translation: either raw collated jitters (int64; the kernel applies -(j / float(size))) or the ready
  * factors translate_x/translate_y that translate_encodings() receives (fp32) -- never both. */
-int simhand_proj_postprocess_fwd(const float* P /*[N][128]*/, int N, const int64_t* jitter_x, const int64_t* jitter_y,
+int simhand_proj_postprocess_fwd(const float* P /*[N][width]*/, int N, int width, const int64_t* jitter_x, const int64_t* jitter_y,
                                  const float* translate_x, const float* translate_y, const double* angle,
-                                 int img_h, int img_w, int flags, float* Z /*[N][128]*/, sh_stream_t stream);
-int simhand_proj_postprocess_bwd(const float* P, int N, const int64_t* jitter_x, const int64_t* jitter_y,
+                                 int img_h, int img_w, int flags, float* Z /*[N][width]*/, sh_stream_t stream);
+int simhand_proj_postprocess_bwd(const float* P, int N, int width, const int64_t* jitter_x, const int64_t* jitter_y,
                                  const float* translate_x, const float* translate_y, const double* angle,
                                  int img_h, int img_w, int flags, const float* dZ, float* dP, sh_stream_t stream);
 /* out[8] = batch means of per-row {x_mean,x_median,x_min,x_max,y_mean,y_median,y_min,y_max}; row_ws [N][8] */
-int simhand_proj_stats(const float* P, int N, float* row_ws, float* out, sh_stream_t stream);
+int simhand_proj_stats(const float* P, int N, int width, float* row_ws, float* out, sh_stream_t stream);
 
 /* ===========================================================================
  * Backbone operators (replace torchvision resnet -> torch.nn.Conv2d /
@@ -214,9 +224,9 @@ int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d);
 /* 64 -> 64 channel 3x3 / stride 1 / pad 1 bf16 layers (forward and store-only data gradient) run on the padded pixel
  * grid with the whole filter resident in registers (conv3x3_c64.hip); 0 routes them through the generic tile kernels
  * (tuning / test hook). */
-int simhand_conv3x3_c64_enable(int on);
+int simhand_test_conv3x3_c64_enable(int on);
 /* tuning / test hook of the short-K (cin or cout in {64,128,256}) bf16 stride-1 1x1 kernel: rows per block = 64*mf */
-int simhand_conv1x1_set_rows(int k, int mf);
+int simhand_test_conv1x1_set_rows(int k, int mf);
 int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void* y, float* bn_partial, sh_stream_t stream);
 /* Direct 7x7 / stride 2 / pad 3 / 3 -> 64 stem (torchvision ResNet conv1, src/models/resnet_model.py:13-26) without an
  * im2col matrix.  simhand_stem_pad_input repacks the NCHW fp32 image batch to zero-padded NHWC4
@@ -233,7 +243,7 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp, void* y, float* bn_par
 /* bf16 route of simhand_stem_conv_fwd: 1 (default) = persistent direct-stem kernel (weights resident in LDS, next tile's rows in
  * flight under the current tile's MFMAs), 2 = activation-stationary kernel, one block per 256 rows, 0 = 128 x 64 tile kernel
  * (same k order, bit-identical outputs; tuning / test hook) */
-int simhand_stem_conv_route(int mode);
+int simhand_test_stem_conv_route(int mode);
 size_t simhand_stem_conv_wgrad_workspace_bytes(int n, int h, int w, int dtype);
 int simhand_stem_conv_wgrad(const void* xp, const void* dy, float* dw_oihw, void* workspace, size_t workspace_bytes, int n, int h, int w, int dtype, sh_stream_t stream);
 /* dx = conv_transpose(dy, w).  wt = weights permuted to [Cin][R][S][Cout] (simhand_oihw_f32_to_crsk).
@@ -275,9 +285,9 @@ typedef struct sh_bn_bwd_fuse {
 } sh_bn_bwd_fuse;
 int simhand_conv2d_dgrad_stat_blocks(const sh_conv_desc* d, int accumulate, int relu_mode, int c2);
 /* 1 if the fused form is the faster choice for this layer (callers keep the standalone pass otherwise);
- * simhand_conv2d_dgrad_fuse_1x1(1) forces it for the short-K 1x1 layers too (tuning hook) */
+ * simhand_test_conv2d_dgrad_fuse_1x1(1) forces it for the short-K 1x1 layers too (tuning hook) */
 int simhand_conv2d_dgrad_fuse_pays(const sh_conv_desc* d);
-int simhand_conv2d_dgrad_fuse_1x1(int on);
+int simhand_test_conv2d_dgrad_fuse_1x1(int on);
 int simhand_conv2d_dgrad_fused(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
                                const uint8_t* res_mask, const sh_bn_bwd_fuse* fuse, sh_stream_t stream);
 /* General form: accumulate modes as above, optional fusion, optional fp32 per-channel bias (length cin) added to the
@@ -329,7 +339,7 @@ int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* w
  * Replaces (reference): the bn3 / add / relu tail of one torchvision Bottleneck and conv1 of the next (src/models/resnet_model.py:13-58). */
 int simhand_conv2d_fwd_chain_ok(const sh_conv_desc* d);
 /* test / tuning hook: which input widths chain (bit 0: 64, bit 1: 128; -1 = default = 64 only: the 128-wide form measured no faster) */
-int simhand_conv1x1_chain_mask(int mask);
+int simhand_test_conv1x1_chain_mask(int mask);
 int simhand_conv2d_fwd_chain_stat_blocks(const sh_conv_desc* d);
 int simhand_conv2d_fwd_bnact_chain(const sh_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                                    const void* residual, void* out, uint8_t* relu_mask, const void* chain_w, void* chain_y,
@@ -359,6 +369,7 @@ int simhand_conv2d_wgrad_colsum(const sh_conv_desc* d, const void* x, const void
  * (src/models/resnet_model.py:13-58). */
 int simhand_bn_apply_gram(const sh_conv_desc* d, const void* y, const float* scale, const float* shift, int relu, void* a, float* s2,
                           float* colsum_partial, void* workspace, size_t workspace_bytes, sh_stream_t stream);
+/* EXPERIMENTAL (off in the engine: measured -4.3 ms BatchNorm / +8.5 ms weight gradient per step) */
 int simhand_conv2d_wgrad_bnbwd(const sh_conv_desc* d, const void* x, const void* da, const void* y, const float* scale, const float* shift,
                                const float* coef_a, const float* coef_b, const float* coef_c, int relu, void* dy_out, float* dw_oihw,
                                int c_real, void* workspace, size_t workspace_bytes, sh_stream_t stream);
@@ -372,27 +383,27 @@ int simhand_conv2d_wgrad_oihw(const sh_conv_desc* d, const void* x, const void* 
 
 /* tuning hook: route the eligible bf16 layers (>= 256 destination channels, long reduction) to the 256x256 LDS-DMA
  * tile kernel (1 = default); the BN partial-sum block counts above follow the setting */
-int simhand_igemm256_enable(int on);
+int simhand_test_igemm256_enable(int on);
 /* 1 (default): a 256 x 256 launch whose last round of tiles would leave more than two thirds of the CUs idle hands those
  * m-tiles to a second launch of the 128-row kernel (same results bit for bit); 0 = single launch (tuning / test hook) */
-int simhand_igemm256_split_tail(int on);
+int simhand_test_igemm256_split_tail(int on);
 /* 224-row tiles of the 256 x 256 kernel (7 x 32 rows: 401 408 pixels = exactly 7 rounds of 256 CUs instead of 6.125): 0 off, 1 auto
  * (default: when they fill whole rounds and the 256-row plan does not), 2 forced whenever the pixel count is a multiple of 224 */
-int simhand_igemm256_tile224(int mode);
+int simhand_test_igemm256_tile224(int mode);
 
 /* tuning hook: non-temporal (streaming) loads / stores in the BatchNorm passes (1 = on [default]) */
-int simhand_bn_set_nt(int on);
+int simhand_test_bn_set_nt(int on);
 
 /* tuning hook: the all-taps 3x3 / stride-1 weight-gradient kernel (bf16; 1 = default, 0 = tap-by-tap kernel) */
-int simhand_wgrad3x3_enable(int on);
+int simhand_test_wgrad3x3_enable(int on);
 
 /* test hook: bf16 wgrad LDS transpose path (1 = ds_read_b64_tr_b16 [default], 0 = scalar LDS reads) */
-int simhand_wgrad_set_tr(int on);
+int simhand_test_wgrad_set_tr(int on);
 /* tuning hook: the bf16 1x1 / stride-1 weight gradient reduces 32 * kpm pixels per barrier (kpm 1 or 2, default 2) */
-int simhand_wgrad_plain_kpm(int kpm);
+int simhand_test_wgrad_plain_kpm(int kpm);
 /* tuning hook: blocks (tiles x split-K) a weight-gradient launch aims for: generic / 1x1 kernel, all-taps 3x3 kernel
  * (< 64 restores the default) */
-int simhand_wgrad_target_blocks(int n, int n3x3);
+int simhand_test_wgrad_target_blocks(int n, int n3x3);
 
 /* layout / dtype transforms.  k_pad = padded length of one flattened KRSC weight row
  * (>= r*s*c; rows are zero padded) -- r*s*c for ordinary convs, 192 for the im2col'd stem. */

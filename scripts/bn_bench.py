@@ -8,7 +8,7 @@ from simhand_amd import ops
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 if len(sys.argv) > 2:
-    ops._lib_dev().simhand_bn_set_nt(int(sys.argv[2]))
+    ops._lib_dev().simhand_test_bn_set_nt(int(sys.argv[2]))
 dtype = torch.bfloat16
 # (channels, side, count of non-residual units, count of residual units (+ downsample, which has no relu))
 SHAPES = [(64, 112, 1, 0), (64, 56, 6, 0), (256, 56, 1, 3), (128, 56, 1, 0), (128, 28, 7, 0), (512, 28, 1, 4), (256, 28, 1, 0),

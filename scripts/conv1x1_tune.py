@@ -19,7 +19,7 @@ for cin, cout, h in SH:
     out = []
     for mf in (4, 2, 1):
         for k in (64, 128, 256):
-            if not (mf == 4 and k == 256): lib.simhand_conv1x1_set_rows(k, mf)
+            if not (mf == 4 and k == 256): lib.simhand_test_conv1x1_set_rows(k, mf)
         tf = timeit(lambda: ops.conv2d_fwd(d, x, wk, True)) if cin <= 256 and not (mf == 4 and cin == 256) else float("nan")
         td = timeit(lambda: ops.conv2d_dgrad(d, dy, wt)) if cout <= 256 and not (mf == 4 and cout == 256) else float("nan")
         out.append(f"mf{mf}: fwd {tf:6.3f} dgrad {td:6.3f}")

@@ -6,7 +6,7 @@ from simhand_amd import ops
 N = 2048
 for c in sys.argv[1:]:  # k:mf pairs -> rows per block of the activation-stationary kernel
     k, mf = map(int, c.split(":"))
-    ops._lib_dev().simhand_conv1x1_set_rows(k, mf)
+    ops._lib_dev().simhand_test_conv1x1_set_rows(k, mf)
 dt = torch.bfloat16
 def timeit(fn, iters=10):
     fn(); torch.cuda.synchronize(); t0 = time.perf_counter()

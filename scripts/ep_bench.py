@@ -6,7 +6,7 @@ from simhand_amd import ops
 N = 2048; dt = torch.bfloat16
 for c in sys.argv[1:]:
     k, mf = map(int, c.split(":"))
-    ops._lib_dev().simhand_conv1x1_set_rows(k, mf)
+    ops._lib_dev().simhand_test_conv1x1_set_rows(k, mf)
 for w, h in ((64, 56), (128, 28), (256, 14), (512, 7)):
     cout = 4 * w
     d = ops.conv_desc(N, h, h, w, cout, 1, 1, 1, 0, dt)
@@ -23,7 +23,7 @@ for w, h in ((64, 56), (128, 28), (256, 14), (512, 7)):
     print(f"w={w:4d} @{h:3d}: {t:.3f} ms  {gb / t:.2f} TB/s")
     del x, res
 # stage 4 again on the 128 x 128 tile kernel (three blocks per CU overlap each other's epilogues)
-ops._lib_dev().simhand_igemm256_enable(0)
+ops._lib_dev().simhand_test_igemm256_enable(0)
 w, h = 512, 7
 cout = 4 * w
 d = ops.conv_desc(N, h, h, w, cout, 1, 1, 1, 0, dt)
@@ -35,4 +35,4 @@ fn = lambda: ops.conv2d_fwd_bnact(d, x, wk, st, True, res, want_mask=True)
 fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): fn()
 torch.cuda.synchronize(); print(f"w= 512 @  7 on the 128-row kernel: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms")
-ops._lib_dev().simhand_igemm256_enable(1)
+ops._lib_dev().simhand_test_igemm256_enable(1)

@@ -59,9 +59,9 @@ def main():
     args = ap.parse_args()
     from simhand_amd import _lib
     lib = _lib.load()
-    alts = {"default": lambda: None, "no256": lambda: lib.simhand_igemm256_enable(0), "force256": lambda: lib.simhand_igemm256_enable(2),
-            "no_c64": lambda: lib.simhand_conv3x3_c64_enable(0), "no_wgrad3": lambda: lib.simhand_wgrad3x3_enable(0),
-            "notail": lambda: lib.simhand_igemm256_split_tail(0)}
+    alts = {"default": lambda: None, "no256": lambda: lib.simhand_test_igemm256_enable(0), "force256": lambda: lib.simhand_test_igemm256_enable(2),
+            "no_c64": lambda: lib.simhand_test_conv3x3_c64_enable(0), "no_wgrad3": lambda: lib.simhand_test_wgrad3x3_enable(0),
+            "notail": lambda: lib.simhand_test_igemm256_split_tail(0)}
     n, dt, dev = args.images, torch.bfloat16, "cuda"
     rows = ["| layer (cin,cout,k,s,Hin) x count | op | kernel route | us | TFLOP/s | GB/s (algorithmic) | bound | fraction of bound |",
             "|---|---|---|---|---|---|---|---|"]

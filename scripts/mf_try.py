@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 from simhand_amd import ops
 for c in cfg:
     k, mf = map(int, c.split(":"))
-    ops._lib_dev().simhand_conv1x1_set_rows(k, mf)
+    ops._lib_dev().simhand_test_conv1x1_set_rows(k, mf)
 import bench
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):

@@ -4,7 +4,7 @@ a, b = int(sys.argv[1]), int(sys.argv[2])
 sys.argv = ["bench.py", "--no-cpu-baseline", "--steps", "10", "--warmup", "3"]
 sys.path.insert(0, ".")
 from simhand_amd import ops
-ops._lib_dev().simhand_wgrad_target_blocks(a, b)
+ops._lib_dev().simhand_test_wgrad_target_blocks(a, b)
 import bench
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):

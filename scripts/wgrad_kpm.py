@@ -1,4 +1,4 @@
-"""Weight gradients per ResNet-50 shape for several split-K block targets (simhand_wgrad_target_blocks): ms incl. the reduce."""
+"""Weight gradients per ResNet-50 shape for several split-K block targets (simhand_test_wgrad_target_blocks): ms incl. the reduce."""
 import sys, time, torch
 sys.path.insert(0, ".")
 from simhand_amd import ops
@@ -12,10 +12,10 @@ for cin, cout, k, st, h in shapes:
     x = torch.randn(N, h, h, cin, device="cuda").to(dt); dy = torch.randn(N, d.ho, d.wo, cout, device="cuda").to(dt)
     r = []
     for tb in targets:
-        lib.simhand_wgrad_target_blocks(tb, tb)
+        lib.simhand_test_wgrad_target_blocks(tb, tb)
         fn = lambda: ops.conv2d_wgrad(d, x, dy)
         fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): fn()
         torch.cuda.synchronize(); r.append((time.perf_counter() - t0) / 10 * 1e3)
-    lib.simhand_wgrad_target_blocks(0, 0)
+    lib.simhand_test_wgrad_target_blocks(0, 0)
     print(f"{cin:5d}->{cout:5d} k{k} s{st} @{h:3d}: " + "  ".join(f"{b}: {t:.3f}" for b, t in zip(targets, r)))

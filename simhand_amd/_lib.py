@@ -88,7 +88,7 @@ SIGNATURES = {
     "simhand_device_check": (_I, []),
     "simhand_route_counts": (_I, [_P]),
     "simhand_route_reset": (_I, []),
-    "simhand_hooks_reset": (_I, []),
+    "simhand_test_hooks_reset": (_I, []),
     "simhand_prof_enable": (_I, [_I]),
     "simhand_prof_set_classes": (_I, [C.c_uint32]),
     "simhand_prof_collect": (_I, [_P, _P, _P, _P]),
@@ -102,16 +102,16 @@ SIGNATURES = {
     "simhand_ntxent_bwd": (_I, [C.POINTER(NtxentParams), _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_ntxent_fwd_fused": (_I, [C.POINTER(NtxentParams), _P, _P, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_ntxent_bwd_fused": (_I, [C.POINTER(NtxentParams), _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _S, _P]),
-    "simhand_proj_postprocess_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
-    "simhand_proj_postprocess_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
-    "simhand_proj_stats": (_I, [_P, _I, _P, _P, _P]),
+    "simhand_proj_postprocess_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "simhand_proj_postprocess_bwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "simhand_proj_stats": (_I, [_P, _I, _I, _P, _P, _P]),
     "simhand_conv2d_fwd_stat_blocks": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "simhand_conv2d_dgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),
     "simhand_conv2d_dgrad_masked_residual": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "simhand_conv2d_wgrad_workspace_bytes": (_S, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _S, _P]),
-    "simhand_conv1x1_set_rows": (_I, [_I, _I]),
+    "simhand_test_conv1x1_set_rows": (_I, [_I, _I]),
     "simhand_stem_geometry": (_I, [_I, _I, _P, _P, _P, _P]),
     "simhand_stem_pad_input": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "simhand_stem_pack_weights": (_I, [_P, _P, _I, _P]),
@@ -125,12 +125,12 @@ SIGNATURES = {
     "simhand_bn_apply_gram": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _P, _P, _P, _S, _P]),
     "simhand_conv2d_wgrad_bnbwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _S, _P]),
     "simhand_bn_bwd_coefs": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
-    "simhand_wgrad_set_tr": (_I, [_I]),
-    "simhand_wgrad_plain_kpm": (_I, [_I]),
-    "simhand_wgrad_target_blocks": (_I, [_I, _I]),
-    "simhand_wgrad3x3_enable": (_I, [_I]),
-    "simhand_bn_set_nt": (_I, [_I]),
-    "simhand_igemm256_enable": (_I, [_I]),
+    "simhand_test_wgrad_set_tr": (_I, [_I]),
+    "simhand_test_wgrad_plain_kpm": (_I, [_I]),
+    "simhand_test_wgrad_target_blocks": (_I, [_I, _I]),
+    "simhand_test_wgrad3x3_enable": (_I, [_I]),
+    "simhand_test_bn_set_nt": (_I, [_I]),
+    "simhand_test_igemm256_enable": (_I, [_I]),
     "simhand_nchw_f32_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "simhand_oihw_f32_to_krsc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "simhand_oihw_f32_to_crsk": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
@@ -155,20 +155,20 @@ SIGNATURES = {
     "simhand_bn_bwd_finalize_raw_workspace_bytes": (_S, [_I, _I]),
     "simhand_bn_bwd_finalize_raw": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_conv2d_dgrad_stat_blocks": (_I, [C.POINTER(ConvDesc), _I, _I, _I]),
-    "simhand_conv3x3_c64_enable": (_I, [_I]),
-    "simhand_stem_conv_route": (_I, [_I]),
-    "simhand_igemm256_split_tail": (_I, [_I]),
-    "simhand_igemm256_tile224": (_I, [_I]),
+    "simhand_test_conv3x3_c64_enable": (_I, [_I]),
+    "simhand_test_stem_conv_route": (_I, [_I]),
+    "simhand_test_igemm256_split_tail": (_I, [_I]),
+    "simhand_test_igemm256_tile224": (_I, [_I]),
     "simhand_conv2d_dgrad_dysrc_ok": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_fwd_chain_ok": (_I, [C.POINTER(ConvDesc)]),
-    "simhand_conv1x1_chain_mask": (_I, [_I]),
+    "simhand_test_conv1x1_chain_mask": (_I, [_I]),
     "simhand_conv2d_fwd_chain_stat_blocks": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_fwd_bnact_chain": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "simhand_conv2d_dgrad_concat_ok": (_I, [C.POINTER(ConvDesc), _I]),
     "simhand_conv2d_fwd_bnact": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "simhand_conv2d_dgrad_ex": (_I, [C.POINTER(ConvDesc), _P, _P, _P, C.POINTER(DgradOpts), _P]),
     "simhand_conv2d_dgrad_fuse_pays": (_I, [C.POINTER(ConvDesc)]),
-    "simhand_conv2d_dgrad_fuse_1x1": (_I, [_I]),
+    "simhand_test_conv2d_dgrad_fuse_1x1": (_I, [_I]),
     "simhand_conv2d_dgrad_fused": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _P, C.POINTER(BnBwdFuse), _P]),
     "simhand_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P]),
     "simhand_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

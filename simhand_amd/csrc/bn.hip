@@ -999,7 +999,7 @@ static inline int stream_grid(int64_t nvec) {
   return (int)g;
 }
 
-static hook_t g_bn_nt{1};  // non-temporal loads / stores in the streaming kernels (test hook: simhand_bn_set_nt)
+static hook_t g_bn_nt{1};  // non-temporal loads / stores in the streaming kernels (test hook: simhand_test_bn_set_nt)
 
 void hooks_reset_bn() { g_bn_nt = 1; }
 
@@ -1030,7 +1030,7 @@ int simhand_bn_bwd_coefs(const float* mean, const float* invstd, const float* ga
   return check_launch("bn_bwd_coefs");
 }
 
-int simhand_bn_set_nt(int on) {
+int simhand_test_bn_set_nt(int on) {
   g_bn_nt = on ? 1 : 0;
   return 0;
 }

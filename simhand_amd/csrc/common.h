@@ -26,7 +26,7 @@ int check_launch(const char* what);
 // ---- route counters (core.hip): one relaxed atomic increment per launch ----
 void route_hit(int route);
 // test / tuning hooks are relaxed atomics (they only choose between kernels that compute the same result); every file that
-// owns some puts them back to their defaults here (simhand_hooks_reset)
+// owns some puts them back to their defaults here (simhand_test_hooks_reset)
 typedef std::atomic<int> hook_t;
 void hooks_reset_igemm();
 void hooks_reset_c64();

@@ -1268,24 +1268,24 @@ using namespace sh;
 extern "C" {
 
 // test / tuning hook: rows per block (64 * mf, mf in {1, 2, 4}; K = 256 supports {1, 2}) of the short-K 1x1 kernel
-int simhand_conv1x1_set_rows(int k, int mf) {
+int simhand_test_conv1x1_set_rows(int k, int mf) {
   SH_REQUIRE((k == 64 || k == 128 || k == 256) && (mf == 1 || mf == 2 || (mf == 4 && k != 256)), "conv1x1_set_rows: bad k=%d mf=%d", k, mf);
   gemm1x1_set_mf(k, mf);
   return 0;
 }
 
 // tuning hook: route eligible layers to the 256 x 256 LDS-DMA kernel (0 = never, 1 = default heuristic, 2 = whenever legal)
-int simhand_igemm256_split_tail(int on) {
+int simhand_test_igemm256_split_tail(int on) {
   g_split256 = on ? 1 : 0;
   return 0;
 }
 
-int simhand_igemm256_tile224(int mode) {
+int simhand_test_igemm256_tile224(int mode) {
   g_tile224 = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
   return 0;
 }
 
-int simhand_igemm256_enable(int on) {
+int simhand_test_igemm256_enable(int on) {
   g_use_256 = on < 0 ? 0 : (on > 2 ? 2 : on);
   return 0;
 }
@@ -1316,7 +1316,7 @@ static int launch_c64_conv(const sh_conv_desc* d, const void* x, const void* w, 
   return check_launch(dgrad ? "conv2d_dgrad (3x3 c64)" : "conv2d_fwd (3x3 c64)");
 }
 
-int simhand_conv3x3_c64_enable(int on) {
+int simhand_test_conv3x3_c64_enable(int on) {
   c64_enable(on);
   return 0;
 }
@@ -1407,7 +1407,7 @@ int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w
   return launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 
-int simhand_conv1x1_chain_mask(int mask) {
+int simhand_test_conv1x1_chain_mask(int mask) {
   gemm1x1_set_chain(mask);
   return 0;
 }
@@ -1509,7 +1509,7 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
   return dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 
-int simhand_stem_conv_route(int mode) {
+int simhand_test_stem_conv_route(int mode) {
   g_stem_1x1 = mode ? 1 : 0;
   gemm1x1_set_stem_persistent(mode != 2);
   return 0;
@@ -1632,8 +1632,8 @@ int simhand_conv2d_dgrad_masked_residual(const sh_conv_desc* d, const void* dy, 
 // 1 when fusing the previous unit's BatchNorm-backward sums into this data gradient is the faster choice: the
 // tile kernel hides the extra read of y behind its other resident blocks; the activation-stationary short-K 1x1
 // kernel would pay the read's latency once per 64-channel chunk (measured 2-3x slower), so those layers keep the
-// standalone simhand_bn_bwd_partial pass unless forced (simhand_conv2d_dgrad_fuse_1x1).
-int simhand_conv2d_dgrad_fuse_1x1(int on) {
+// standalone simhand_bn_bwd_partial pass unless forced (simhand_test_conv2d_dgrad_fuse_1x1).
+int simhand_test_conv2d_dgrad_fuse_1x1(int on) {
   g_fuse_1x1 = on ? 1 : 0;
   return 0;
 }

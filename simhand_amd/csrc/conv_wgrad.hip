@@ -821,25 +821,25 @@ using namespace sh;
 extern "C" {
 
 // tuning hook: all-taps 3x3 weight-gradient kernel for the bf16 stride-1 layers (1 = default)
-int simhand_wgrad3x3_enable(int on) {
+int simhand_test_wgrad3x3_enable(int on) {
   g_use_wgrad3 = on ? 1 : 0;
   return 0;
 }
 
 // test hook: choose the bf16 LDS transpose path (1 = ds_read_b64_tr_b16, 0 = scalar reads)
 // tuning hook: pixels per k-step of the 1x1 pointer-walking kernel, 32 * kpm (kpm = 1 or 2; 2 = default)
-int simhand_wgrad_target_blocks(int n, int n3x3) {
+int simhand_test_wgrad_target_blocks(int n, int n3x3) {
   g_wg_blocks = n >= 64 ? n : 512;
   g_wg3_blocks = n3x3 >= 64 ? n3x3 : 512;
   return 0;
 }
 
-int simhand_wgrad_plain_kpm(int kpm) {
+int simhand_test_wgrad_plain_kpm(int kpm) {
   g_plain_kpm = kpm == 1 ? 1 : 2;
   return 0;
 }
 
-int simhand_wgrad_set_tr(int on) {
+int simhand_test_wgrad_set_tr(int on) {
   g_use_tr = on ? 1 : 0;
   return 0;
 }

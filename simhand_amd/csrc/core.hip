@@ -118,7 +118,7 @@ int simhand_route_reset(void) {
   return 0;
 }
 
-int simhand_hooks_reset(void) {
+int simhand_test_hooks_reset(void) {
   sh::hooks_reset_igemm();
   sh::hooks_reset_c64();
   sh::hooks_reset_1x1();

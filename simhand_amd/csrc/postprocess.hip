@@ -194,20 +194,22 @@ static int pp_make(const void* a, const void* b, int N, const int64_t* jx, const
   return 0;
 }
 
-int simhand_proj_postprocess_fwd(const float* P, int N, const int64_t* jitter_x, const int64_t* jitter_y, const float* translate_x,
+int simhand_proj_postprocess_fwd(const float* P, int N, int width, const int64_t* jitter_x, const int64_t* jitter_y, const float* translate_x,
                                  const float* translate_y, const double* angle, int img_h, int img_w, int flags, float* Z,
                                  sh_stream_t stream) {
   PPArgs a;
+  SH_REQUIRE(width == SH_PROJ_DIM, "proj_postprocess_fwd: rows must be %d floats wide (64 2-D points), got %d", SH_PROJ_DIM, width);
   if (pp_make(P, Z, N, jitter_x, jitter_y, translate_x, translate_y, angle, img_h, img_w, flags, &a, "proj_postprocess_fwd")) return 1;
   ProfScope ps(SH_PROF_MISC, (hipStream_t)stream, 0, (double)N * 128 * 8);
   postprocess_fwd_kernel<<<ceil_div(N, 4), 256, 0, (hipStream_t)stream>>>(P, N, a, Z);
   return check_launch("proj_postprocess_fwd");
 }
 
-int simhand_proj_postprocess_bwd(const float* P, int N, const int64_t* jitter_x, const int64_t* jitter_y, const float* translate_x,
+int simhand_proj_postprocess_bwd(const float* P, int N, int width, const int64_t* jitter_x, const int64_t* jitter_y, const float* translate_x,
                                  const float* translate_y, const double* angle, int img_h, int img_w, int flags, const float* dZ,
                                  float* dP, sh_stream_t stream) {
   PPArgs a;
+  SH_REQUIRE(width == SH_PROJ_DIM, "proj_postprocess_bwd: rows must be %d floats wide (64 2-D points), got %d", SH_PROJ_DIM, width);
   if (pp_make(P, dP, N, jitter_x, jitter_y, translate_x, translate_y, angle, img_h, img_w, flags, &a, "proj_postprocess_bwd")) return 1;
   SH_REQUIRE(dZ, "proj_postprocess_bwd: dZ is NULL");
   ProfScope ps(SH_PROF_MISC, (hipStream_t)stream, 0, (double)N * 128 * 12);
@@ -215,8 +217,9 @@ int simhand_proj_postprocess_bwd(const float* P, int N, const int64_t* jitter_x,
   return check_launch("proj_postprocess_bwd");
 }
 
-int simhand_proj_stats(const float* P, int N, float* row_ws, float* out, sh_stream_t stream) {
+int simhand_proj_stats(const float* P, int N, int width, float* row_ws, float* out, sh_stream_t stream) {
   SH_REQUIRE(P && row_ws && out, "proj_stats: NULL pointer");
+  SH_REQUIRE(width == SH_PROJ_DIM, "proj_stats: rows must be %d floats wide (64 2-D points), got %d", SH_PROJ_DIM, width);
   SH_REQUIRE(N >= 1, "proj_stats: N must be >= 1");
   ProfScope ps(SH_PROF_MISC, (hipStream_t)stream, 0, (double)N * 128 * 4);
   proj_row_stats_kernel<<<ceil_div(N, 4), 256, 0, (hipStream_t)stream>>>(P, N, row_ws);

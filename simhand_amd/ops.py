@@ -153,7 +153,7 @@ def proj_postprocess_fwd(P, jx, jy, angle, hw, flags: int = _lib.PP_FUSED, tx=No
     lib = _lib_dev()
     _require_width(P, "proj_postprocess_fwd")
     Z = torch.empty_like(P)
-    check(lib.simhand_proj_postprocess_fwd(_ptr(P, _F32), P.shape[0], _ptr(jx, _I64), _ptr(jy, _I64), _ptr(tx, _F32), _ptr(ty, _F32), _ptr(angle, _F64), int(hw[0]),
+    check(lib.simhand_proj_postprocess_fwd(_ptr(P, _F32), P.shape[0], P.shape[1], _ptr(jx, _I64), _ptr(jy, _I64), _ptr(tx, _F32), _ptr(ty, _F32), _ptr(angle, _F64), int(hw[0]),
                                            int(hw[1]), flags, _ptr(Z), _stream()), "proj_postprocess_fwd")
     return Z
 
@@ -163,7 +163,7 @@ def proj_postprocess_bwd(P, jx, jy, angle, hw, dZ, flags: int = _lib.PP_FUSED, t
     _require_width(P, "proj_postprocess_bwd")
     _require_width(dZ, "proj_postprocess_bwd (dZ)")
     dP = torch.empty_like(P)
-    check(lib.simhand_proj_postprocess_bwd(_ptr(P, _F32), P.shape[0], _ptr(jx, _I64), _ptr(jy, _I64), _ptr(tx, _F32), _ptr(ty, _F32), _ptr(angle, _F64), int(hw[0]),
+    check(lib.simhand_proj_postprocess_bwd(_ptr(P, _F32), P.shape[0], P.shape[1], _ptr(jx, _I64), _ptr(jy, _I64), _ptr(tx, _F32), _ptr(ty, _F32), _ptr(angle, _F64), int(hw[0]),
                                            int(hw[1]), flags, _ptr(dZ, _F32), _ptr(dP), _stream()), "proj_postprocess_bwd")
     return dP
 
@@ -175,7 +175,7 @@ def proj_stats(P: torch.Tensor) -> torch.Tensor:
     n = P.shape[0]
     ws = torch.empty(n, 8, dtype=torch.float32, device=P.device)
     out = torch.empty(8, dtype=torch.float32, device=P.device)
-    check(lib.simhand_proj_stats(_ptr(P, _F32), n, _ptr(ws), _ptr(out), _stream()), "proj_stats")
+    check(lib.simhand_proj_stats(_ptr(P, _F32), n, P.shape[1], _ptr(ws), _ptr(out), _stream()), "proj_stats")
     return out
 
 
@@ -957,7 +957,7 @@ def route_counts() -> dict:
 
 def hooks_reset() -> None:
     """Every test / tuning hook of the library back to its default."""
-    _lib.load().simhand_hooks_reset()
+    _lib.load().simhand_test_hooks_reset()
 
 
 # --------------------------------------------------------------------- profiler

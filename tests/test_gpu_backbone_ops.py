@@ -109,12 +109,12 @@ def test_wgrad_transpose_read_matches_scalar_path(dtype):
     d = ops.conv_desc(n, h, w, cin, cout, 3, 3, 1, 1, dtype)
     lib = _lib.load()
     try:
-        lib.simhand_wgrad_set_tr(1)
+        lib.simhand_test_wgrad_set_tr(1)
         a = ops.conv2d_wgrad(d, x, dy).cpu()
-        lib.simhand_wgrad_set_tr(0)
+        lib.simhand_test_wgrad_set_tr(0)
         b = ops.conv2d_wgrad(d, x, dy).cpu()
     finally:
-        lib.simhand_wgrad_set_tr(1)
+        lib.simhand_test_wgrad_set_tr(1)
     assert torch.equal(a, b)
 
 
@@ -175,11 +175,11 @@ def test_stem_direct_conv(dtype, n, h, w):
     if dtype == torch.bfloat16:  # the default bf16 route is the activation-stationary kernel: same bits as the tile kernel
         lib = ops._lib_dev()
         for route in (0, 2):  # tile kernel, per-block activation-stationary kernel (default: the persistent kernel)
-            lib.simhand_stem_conv_route(route)
+            lib.simhand_test_stem_conv_route(route)
             try:
                 y_tile, part_tile = ops.stem_conv_fwd(xp, wpk, h, w)
             finally:
-                lib.simhand_stem_conv_route(1)
+                lib.simhand_test_stem_conv_route(1)
             assert torch.equal(yd, y_tile)
             _check(part.sum(0).cpu(), part_tile.sum(0).cpu(), 1e-5, f"partials vs route {route}")
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
@@ -374,9 +374,9 @@ def force_big_tile():
     from simhand_amd import ops
 
     lib = ops._lib_dev()
-    lib.simhand_igemm256_enable(2)
+    lib.simhand_test_igemm256_enable(2)
     yield
-    lib.simhand_igemm256_enable(1)
+    lib.simhand_test_igemm256_enable(1)
 
 
 @pytest.mark.parametrize("shape", BIG_TILE_SHAPES)
@@ -405,9 +405,9 @@ def test_big_tile_conv_fwd_dgrad(shape, force_big_tile):
     _check(part[:, 1].sum(0).cpu() / m, (yf * yf).mean(0), 1e-2, "stat sumsq")
     # bit-for-bit the 128x128 kernel's result: same k order, same fp32 MFMA accumulation
     lib = ops._lib_dev()
-    lib.simhand_igemm256_enable(0)
+    lib.simhand_test_igemm256_enable(0)
     y_ref, _ = ops.conv2d_fwd(d, xd, wd, want_stats=True)
-    lib.simhand_igemm256_enable(2)
+    lib.simhand_test_igemm256_enable(2)
     assert torch.equal(yd, y_ref)
 
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
@@ -470,12 +470,12 @@ def test_c64_conv3x3_fwd_dgrad(shape):
         assert (got2 - s2).abs().max().item() <= 1e-4 * s2.abs().max().item() + 1e-4, (mode, "sum g*y")
         fused[mode] = p2
 
-    lib.simhand_conv3x3_c64_enable(0)
+    lib.simhand_test_conv3x3_c64_enable(0)
     try:
         y_ref, part_ref = ops.conv2d_fwd(d, xd, wd, want_stats=True)
         dx_ref = ops.conv2d_dgrad(d, dyd, wtd)
     finally:
-        lib.simhand_conv3x3_c64_enable(1)
+        lib.simhand_test_conv3x3_c64_enable(1)
     assert part_ref.shape[0] == (m + 127) // 128
     assert torch.equal(yd, y_ref)
     assert torch.equal(dxd, dx_ref)
@@ -506,7 +506,7 @@ def test_dgrad_second_reduction_segment(route, mode):
     if mode == "accumulate":
         want = want + base.reshape(-1, cin)
     dev = lambda t: t.to(DEV).to(dtype).contiguous()
-    lib.simhand_igemm256_enable(2 if route == "big_tile" else 0)
+    lib.simhand_test_igemm256_enable(2 if route == "big_tile" else 0)
     try:
         kw = {}
         if mode == "accumulate":
@@ -519,7 +519,7 @@ def test_dgrad_second_reduction_segment(route, mode):
             kw = dict(fuse_mode=2, prev_y=y_prev, prev_st=st)
         dx, part = ops.conv2d_dgrad_ex(d, dev(dy), dev(wt), bias=bias.to(DEV), x2=dev(x2), wt2=dev(wt2), **kw)
     finally:
-        lib.simhand_igemm256_enable(1)
+        lib.simhand_test_igemm256_enable(1)
     _check(dx.float().cpu().reshape(-1, cin), want, 2 * _tol(dtype), mode)
     if mode == "fused_sums":
         s1, s2 = _bn_sums_reference(dx, y_prev, 2, st.scale, st.shift, None)
@@ -560,11 +560,11 @@ def test_big_tile_ragged_last_round_goes_to_the_128_row_kernel():
         return y, part, dx, fpart
 
     y1, p1, dx1, f1 = run()
-    lib.simhand_igemm256_split_tail(0)
+    lib.simhand_test_igemm256_split_tail(0)
     try:
         y0, p0, dx0, f0 = run()
     finally:
-        lib.simhand_igemm256_split_tail(1)
+        lib.simhand_test_igemm256_split_tail(1)
     assert p0.shape[0] == 264 and f0.shape[0] == 264
     if torch.cuda.get_device_properties(0).multi_processor_count == 256:
         assert p1.shape[0] == 256 + 16 and f1.shape[0] == 256 + 16
@@ -618,8 +618,8 @@ def test_dgrad_fused_bn_backward_sums(route, mode, dtype):
     one.shift.fill_(0.0)
     _, mask = ops.bn_apply(act, one, n * h * h, cin, True, None, want_mask=True)
     wtd = ops.pack_crsk(wt.to(DEV), dtype)
-    lib.simhand_igemm256_enable(2 if route == "big_tile" else 0)
-    lib.simhand_conv2d_dgrad_fuse_1x1(1)
+    lib.simhand_test_igemm256_enable(2 if route == "big_tile" else 0)
+    lib.simhand_test_conv2d_dgrad_fuse_1x1(1)
     try:
         for kind in ("store", "masked_residual"):
             if kind == "store":
@@ -636,8 +636,8 @@ def test_dgrad_fused_bn_backward_sums(route, mode, dtype):
             assert (got1 - s1).abs().max().item() <= tol * s1.abs().max().item() + 1e-4, (kind, "sum g")
             assert (got2 - s2).abs().max().item() <= tol * s2.abs().max().item() + 1e-4, (kind, "sum g*y")
     finally:
-        lib.simhand_igemm256_enable(1)
-        lib.simhand_conv2d_dgrad_fuse_1x1(0)
+        lib.simhand_test_igemm256_enable(1)
+        lib.simhand_test_conv2d_dgrad_fuse_1x1(0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -703,11 +703,11 @@ def test_wgrad_3x3_all_taps_kernel(shape):
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
     lib = ops._lib_dev()
     got = ops.conv2d_wgrad_oihw(d, xd, dyd, (cout, cin, 3, 3)).cpu()
-    lib.simhand_wgrad3x3_enable(0)
+    lib.simhand_test_wgrad3x3_enable(0)
     try:
         old = ops.conv2d_wgrad_oihw(d, xd, dyd, (cout, cin, 3, 3)).cpu()
     finally:
-        lib.simhand_wgrad3x3_enable(1)
+        lib.simhand_test_wgrad3x3_enable(1)
     _check(got, want, 2e-3, "wgrad 3x3 all taps")
     _check(got, old, 1e-4, "vs tap-by-tap kernel")  # same products, fp32 sums in another order
 
@@ -983,15 +983,15 @@ def test_big_tile_224_row_tiles_equal_256_row_tiles(k, force_big_tile):
         dxf, fpart = ops.conv2d_dgrad_fused(dd, dy, wt, y_prev, st, None)
         return y, part, dx, dxf, fpart
 
-    lib.simhand_igemm256_tile224(0)
+    lib.simhand_test_igemm256_tile224(0)
     try:
         ops.route_reset()
         y0, p0, dx0, dxf0, f0 = run()
         assert ops.route_counts()["igemm256_fwd"] == 1 and ops.route_counts()["igemm256_dgrad"] == 2
-        lib.simhand_igemm256_tile224(2)
+        lib.simhand_test_igemm256_tile224(2)
         y1, p1, dx1, dxf1, f1 = run()
     finally:
-        lib.simhand_igemm256_tile224(1)
+        lib.simhand_test_igemm256_tile224(1)
     assert p1.shape[0] == m // 224 and f1.shape[0] == m // 224
     assert torch.equal(y1, y0) and torch.equal(dx1, dx0) and torch.equal(dxf1, dxf0)
     _check(p1.sum(0).cpu(), p0.sum(0).cpu(), 1e-5, "forward statistics")
@@ -1008,7 +1008,7 @@ def test_conv_fwd_bnact_with_the_next_conv1_chained_on(n, h, cin, cout):
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(n + h + cout)
     d = ops.conv_desc(n, h, h, cin, cout, 1, 1, 1, 0, dt)
-    ops._lib_dev().simhand_conv1x1_chain_mask(3)  # the 128-wide form is off by default (no faster), but kept correct
+    ops._lib_dev().simhand_test_conv1x1_chain_mask(3)  # the 128-wide form is off by default (no faster), but kept correct
     assert ops.conv2d_fwd_chain_ok(d)
     a2 = torch.randn(n, h, h, cin, generator=g).to(DEV).to(dt)
     res = torch.randn(n, h, h, cout, generator=g).to(DEV).to(dt)
@@ -1044,7 +1044,7 @@ def test_engine_chained_conv1_equals_separate_launches():
     m = ResNetModel(cfg, "pretraining", torch.bfloat16).to(DEV).train()
     x = torch.randn(8, 3, 64, 64, device=DEV)   # stage 1 at 16 x 16: 2048 pixels, a multiple of the 128-row blocks
     outs = []
-    ops._lib_dev().simhand_conv1x1_chain_mask(1)  # stage 1 only: its launches are bit-identical to the separate ones (the 128-channel
+    ops._lib_dev().simhand_test_conv1x1_chain_mask(1)  # stage 1 only: its launches are bit-identical to the separate ones (the 128-channel
     # chain of stage 2 sums its BatchNorm partials over 64-row blocks instead of 128-row tiles: same values to fp32 round-off)
     for on in (False, True):
         m.engine.chain_conv1 = on

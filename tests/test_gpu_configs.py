@@ -121,7 +121,7 @@ def _run_case(cname, exp, size, wcfg, b, img, seed, force_256, gamma3=0.1):
     masks = []
     try:
         if force_256:
-            lib.simhand_igemm256_enable(2)  # "whenever legal": at 16 images the 14^2 / 7^2 layers are below the default size gate
+            lib.simhand_test_igemm256_enable(2)  # "whenever legal": at 16 images the 14^2 / 7^2 layers are below the default size gate
         ops.route_reset()
         with record_hip_relu_masks(masks):
             out = model.training_step(dev_batch, 0)

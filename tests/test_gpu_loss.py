@@ -305,3 +305,30 @@ def test_explicit_asymmetric_negative_weights_gradient():
             w2.backward()
             assert abs(loss.item() - w2.item()) <= 1e-5 * abs(w2.item())
             _close_grad(x1.grad.cpu().numpy(), c.grad.float().numpy(), "asymmetric (neg only) dz1")
+
+
+def test_projection_width_is_checked_at_the_c_abi():
+    """A direct ABI caller (the INTEGRATION.md route) that hands over rows of another width gets an error code and a message,
+    not an out-of-bounds access: `width` travels to simhand_proj_postprocess_{fwd,bwd} / simhand_proj_stats (SH_PROJ_DIM = 128)."""
+    import ctypes as C
+
+    from simhand_amd import _lib
+
+    lib = _lib.load()
+    P = torch.randn(8, 64, device=DEV)
+    Z = torch.empty_like(P)
+    ws = torch.empty(8, 8, device=DEV)
+    out = torch.empty(8, device=DEV)
+    null = C.c_void_p(0)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.simhand_proj_postprocess_fwd(C.c_void_p(P.data_ptr()), 8, 64, null, null, null, null, null, 0, 0, 3, C.c_void_p(Z.data_ptr()), s)
+    assert rc != 0 and b"128" in lib.simhand_last_error()
+    rc = lib.simhand_proj_postprocess_bwd(C.c_void_p(P.data_ptr()), 8, 64, null, null, null, null, null, 0, 0, 3, C.c_void_p(Z.data_ptr()),
+                                          C.c_void_p(Z.data_ptr()), s)
+    assert rc != 0
+    assert lib.simhand_proj_stats(C.c_void_p(P.data_ptr()), 8, 64, C.c_void_p(ws.data_ptr()), C.c_void_p(out.data_ptr()), s) != 0
+    P2 = torch.randn(8, 128, device=DEV)
+    Z2 = torch.empty_like(P2)
+    assert lib.simhand_proj_postprocess_fwd(C.c_void_p(P2.data_ptr()), 8, 128, null, null, null, null, null, 0, 0, 3, C.c_void_p(Z2.data_ptr()), s) == 0
+    torch.cuda.synchronize()
+    assert torch.allclose(Z2, torch.nn.functional.normalize(torch.nn.functional.normalize(P2)), atol=1e-6)
