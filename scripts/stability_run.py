@@ -63,10 +63,27 @@ def run(precision):
     return losses, pmax, time.perf_counter() - t0
 
 
-def run_oracle(bf16_storage):
-    """The CHECKER's curve: oracle.StepOracle (plain torch ops) on the same device, same initial weights / data / optimizer / schedule;
-    bf16_storage: its convolutions see bf16-rounded weights, inputs and outputs (differentiable casts: the gradients crossing them are
-    rounded too) -- the numerics model of the HIP bf16 path, independent of any of its kernels."""
+class _Round(torch.autograd.Function):
+    """x -> storage dtype -> fp32 in the forward (if fwd) and / or the same rounding of the gradient in the backward (if bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, dt, fwd, bwd):
+        ctx.dt, ctx.bwd = dt, bwd
+        return x.to(dt).to(torch.float32) if fwd else x
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(ctx.dt).to(torch.float32) if ctx.bwd else g), None, None, None
+
+
+def run_oracle(storage=None, parts="wag", scaler=False):
+    """The CHECKER's curve: oracle.StepOracle (plain torch ops) on the same device, same initial weights / data / optimizer / schedule.
+    storage = torch.bfloat16 / torch.float16: its encoder convolutions see storage-rounded operands -- the numerics model of a 16-bit
+    storage path with fp32 accumulators, independent of any HIP kernel.  parts: which tensors are rounded -- "w" the conv weights
+    (forward only: the weight GRADIENT stays fp32, as in the HIP path), "a" the conv inputs / outputs in the forward, "g" the
+    gradients crossing those same edges in the backward.  scaler: torch.cuda.amp.GradScaler semantics around the backward (the
+    reference's precision=16 policy, src/experiments/main.py:158-159: scale 2^16, halve + skip the step on inf / nan, double every
+    2000 clean steps) -- needed for fp16's 5-bit exponent, pointless for bf16."""
     import torch.nn as nn
     import torch.nn.functional as F
 
@@ -78,11 +95,12 @@ def run_oracle(bf16_storage):
     om = orc.StepOracle("simhand_w", "50", bench.AUG, weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg")
     om.load_state_dict(prod.state_dict(), strict=True)
     om = om.to(dev).train()
-    if bf16_storage:
-        rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    if storage is not None:
+        ra = lambda t: _Round.apply(t, storage, "a" in parts, "g" in parts)  # noqa: E731
+        rw = lambda t: _Round.apply(t, storage, "w" in parts, False)         # noqa: E731
         for m in om.encoder.modules():
             if isinstance(m, nn.Conv2d):
-                m.forward = (lambda x, m=m: rnd(F.conv2d(rnd(x), rnd(m.weight), None, m.stride, m.padding)))
+                m.forward = (lambda x, m=m: ra(F.conv2d(ra(x), rw(m.weight), None, m.stride, m.padding)))
 
     class _T:
         max_epochs, world_size = math.ceil(a.steps / a.batches), 1
@@ -95,33 +113,62 @@ def run_oracle(bf16_storage):
     (opt,), (sched,) = prod.configure_optimizers()
     data = dataset()
     losses = []
+    scale, clean, skipped = 65536.0, 0, 0
     for i in range(a.steps):
         opt.zero_grad(set_to_none=True)
         loss = om.contrastive_step(data[i % a.batches])
-        loss.backward()
-        opt.step()
+        if scaler:
+            (loss * scale).backward()
+            grads = [p.grad for p in om.parameters() if p.grad is not None]
+            finite = all(bool(torch.isfinite(g).all()) for g in grads)
+            if finite:
+                for g in grads:
+                    g.div_(scale)
+                opt.step()
+                clean += 1
+                if clean % 2000 == 0:
+                    scale *= 2.0
+            else:  # GradScaler.step skips the optimizer, update() halves the scale
+                scale *= 0.5
+                clean = 0
+                skipped += 1
+        else:
+            loss.backward()
+            opt.step()
         sched["scheduler"].step()
         losses.append(float(loss.detach()))
+    if scaler:
+        print(f"GradScaler twin: {skipped} skipped steps, final scale {scale:g}", flush=True)
     return losses
 
 
 bf, bf_pmax, bf_s = run("bf16")
 fp, fp_pmax, fp_s = run("32")
 ora = ora_bf = None
+twins = {}
 if os.environ.get("SIMHAND_STABILITY_ORACLE", "0") == "1":
-    ora, ora_bf = run_oracle(False), run_oracle(True)
+    ora, ora_bf = run_oracle(None), run_oracle(torch.bfloat16)
+    # the reference's own precision policy (fp16 storage under autocast + GradScaler) and the decomposition of the bf16 lag
+    twins = {"fp16 storage + GradScaler (the reference's precision=16)": run_oracle(torch.float16, "wag", scaler=True),
+             "bf16 weights only": run_oracle(torch.bfloat16, "w"),
+             "bf16 forward activations only": run_oracle(torch.bfloat16, "a"),
+             "bf16 backward gradients only": run_oracle(torch.bfloat16, "g")}
 lines = [f"# {a.steps} training steps, ResNet-50 handclr_w, {a.batches} fixed batches of {a.pairs} pairs @ {a.size}^2 revisited every epoch, LARS + Adam, "
          "linear warm-up + cosine schedule; same initial weights", "",
          "| step | loss bf16 (bf16 storage, fp32 accumulate / statistics / loss / optimizer, no loss scaling) | loss fp32 parity mode | bf16 / fp32 |"
-         + (" oracle fp32 (torch ops) | oracle with bf16-rounded conv weights / inputs / outputs |" if ora else ""), "|---|---|---|---|" + ("---|---|" if ora else "")]
+         + (" oracle fp32 (torch ops) | oracle with bf16-rounded conv weights / inputs / outputs |" if ora else "")
+         + "".join(f" oracle twin: {k} |" for k in twins), "|---|---|---|---|" + ("---|---|" if ora else "") + "---|" * len(twins)]
 for i in list(range(0, a.steps, max(1, a.steps // 16))) + [a.steps - 1]:
-    lines.append(f"| {i} | {bf[i]:.4f} | {fp[i]:.4f} | {bf[i] / fp[i]:.4f} |" + (f" {ora[i]:.4f} | {ora_bf[i]:.4f} |" if ora else ""))
+    lines.append(f"| {i} | {bf[i]:.4f} | {fp[i]:.4f} | {bf[i] / fp[i]:.4f} |" + (f" {ora[i]:.4f} | {ora_bf[i]:.4f} |" if ora else "")
+                 + "".join(f" {v[i]:.4f} |" for v in twins.values()))
 k = max(1, a.steps // 10)
 head_b, tail_b, tail_f = sum(bf[:k]) / k, sum(bf[-k:]) / k, sum(fp[-k:]) / k
 lines += ["", f"mean of the first {k} losses (bf16) {head_b:.4f}; mean of the last {k}: bf16 {tail_b:.4f}, fp32 {tail_f:.4f}; "
           f"max |parameter| bf16 {bf_pmax:.3f} / fp32 {fp_pmax:.3f}; wall {bf_s:.1f} s / {fp_s:.1f} s"]
 if ora:
     lines.append(f"oracle, mean of the last {k}: fp32 {sum(ora[-k:]) / k:.4f}, bf16-storage twin {sum(ora_bf[-k:]) / k:.4f}")
+for name, v in twins.items():
+    lines.append(f"oracle twin, mean of the last {k}: {name}: {sum(v[-k:]) / k:.4f}")
 text = "\n".join(lines)
 print(text)
 if a.out:

@@ -1143,15 +1143,22 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
 static hook_t g_use_256{1};
 static hook_t g_stem_1x1{1};  // bf16 stem forward on the activation-stationary kernel
 static hook_t g_fuse_1x1{0};  // BN-backward sums fused into the short-K 1x1 dgrad (slower: tuning hook)
-static bool use_256(int dtype, int Ng, int Ca, int taps, long long Mg) {
+static bool use_256(int dtype, int Ng, int Ca, int taps, long long Mg, int min_k = 512) {
   if (!g_use_256 || dtype != SH_BF16 || Ng % 256 != 0 || Ca % 64 != 0) return false;
-  return g_use_256 == 2 || ((long long)taps * Ca >= 512 && Mg >= 256 * 64);  // 2 = forced (tests)
+  return g_use_256 == 2 || ((long long)taps * Ca >= min_k && Mg >= 256 * 64);  // 2 = forced (tests)
+}
+// forward: a stride-2 1x1 (the stage-entry shortcuts) already pays at K = 256 -- its A rows are strided gathers the 128-row kernel's
+// register loader handles worse ((256 -> 512)/2 @ 56^2 + BN epilogue: 1008 -> 833 us, scripts/layer_table.py --alternates, round 3)
+static bool use_256_fwd(const sh_conv_desc* d, long long Mg) {
+  return use_256(d->dtype, d->cout, d->cin, d->r * d->s, Mg, d->stride == 2 && d->r == 1 ? 256 : 512);
 }
 
 // data gradient: the stride-2 parity classes (uneven work per class, three empty ones for a 1x1/2) run better as many
 // small tiles, so they stay on the 128 x 128 kernel unless forced
 static bool use_256_dgrad(const sh_conv_desc* d, long long Mg) {
-  if (d->stride == 2 && g_use_256 != 2) return false;
+  // stride 2: the 3x3 layers with >= 256 channels gain 5-7 % on the big tile ((256,256)/2 @ 28^2 741 -> 704 us, (512,512)/2 @ 14^2
+  // 572 -> 532, round 3); the 1x1 shortcuts (three empty parity classes) lose 30-38 % and stay on the 128-row kernel
+  if (d->stride == 2 && g_use_256 != 2 && !(d->r == 3 && d->cout >= 256)) return false;
   return use_256(d->dtype, d->cin, d->cout, d->r * d->s, Mg);
 }
 
@@ -1326,7 +1333,7 @@ int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d) {
   if (use_c64(d)) return c64_blocks(c64_q_total(d));
   const long long m = (long long)d->n * d->ho * d->wo;
   if (use_1x1(d, d->cin, d->cout)) return ceil_div(m, gemm1x1_rows_per_block(d->cin));
-  if (use_256(d->dtype, d->cout, d->cin, d->r * d->s, m)) return stat_rows256(m, d->cout, 1);
+  if (use_256_fwd(d, m)) return stat_rows256(m, d->cout, 1);
   return ceil_div(m, 128);
 }
 
@@ -1363,7 +1370,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
     return check_launch("conv2d_fwd (1x1)");
   }
   if (use_c64(d)) return launch_c64_conv(d, x, w, y, bn_partial, false, nullptr, (hipStream_t)stream);
-  if (use_256(d->dtype, a.Ng, a.Ca, d->r * d->s, a.Mg)) return launch_igemm256<false>(a, (hipStream_t)stream);
+  if (use_256_fwd(d, a.Mg)) return launch_igemm256<false>(a, (hipStream_t)stream);
   return d->dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 
@@ -1403,7 +1410,7 @@ int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w
     launch_gemm1x1(g, d->cin, false, (hipStream_t)stream);
     return check_launch("conv2d_fwd_bnact (1x1)");
   }
-  if (use_256(d->dtype, a.Ng, a.Ca, d->r * d->s, a.Mg)) return launch_igemm256<false>(a, (hipStream_t)stream);
+  if (use_256_fwd(d, a.Mg)) return launch_igemm256<false>(a, (hipStream_t)stream);
   return launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 

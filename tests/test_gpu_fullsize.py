@@ -33,17 +33,17 @@ SHAPES = {
     (256, 128, 1, 1, 56): ("gemm1x1_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (128, 128, 3, 2, 56): ("igemm128_fwd", "igemm128_dgrad", "wgrad_generic"),
     (128, 512, 1, 1, 28): ("gemm1x1_fwd", "igemm128_dgrad", "wgrad_plain"),
-    (256, 512, 1, 2, 56): ("igemm128_fwd", "igemm128_dgrad", "wgrad_generic"),
+    (256, 512, 1, 2, 56): ("igemm256_fwd", "igemm128_dgrad", "wgrad_generic"),
     (512, 128, 1, 1, 28): ("igemm128_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (128, 128, 3, 1, 28): ("igemm128_fwd", "igemm128_dgrad", "wgrad3x3"),
     (512, 256, 1, 1, 28): ("igemm256_fwd", "gemm1x1_dgrad", "wgrad_plain"),
-    (256, 256, 3, 2, 28): ("igemm256_fwd", "igemm128_dgrad", "wgrad_generic"),
+    (256, 256, 3, 2, 28): ("igemm256_fwd", "igemm256_dgrad", "wgrad_generic"),
     (256, 1024, 1, 1, 14): ("gemm1x1_fwd", "igemm256_dgrad", "wgrad_plain"),
     (512, 1024, 1, 2, 28): ("igemm256_fwd", "igemm128_dgrad", "wgrad_generic"),
     (1024, 256, 1, 1, 14): ("igemm256_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (256, 256, 3, 1, 14): ("igemm256_fwd", "igemm256_dgrad", "wgrad3x3"),
     (1024, 512, 1, 1, 14): ("igemm256_fwd", "igemm256_dgrad", "wgrad_plain"),
-    (512, 512, 3, 2, 14): ("igemm256_fwd+igemm256_tail", "igemm128_dgrad", "wgrad_generic"),
+    (512, 512, 3, 2, 14): ("igemm256_fwd+igemm256_tail", "igemm256_dgrad", "wgrad_generic"),
     (512, 2048, 1, 1, 7): ("igemm256_fwd", "igemm256_dgrad+igemm256_tail", "wgrad_plain"),
     (1024, 2048, 1, 2, 14): ("igemm256_fwd", "igemm128_dgrad", "wgrad_generic"),
     (2048, 512, 1, 1, 7): ("igemm256_fwd+igemm256_tail", "igemm256_dgrad", "wgrad_plain"),
@@ -52,7 +52,7 @@ SHAPES = {
 # forward route of the same shapes in the form the engine runs them when their BatchNorm is folded (conv + BN (+res+ReLU) epilogue)
 BNACT_ROUTES = {
     (64, 256, 1, 1, 56): "gemm1x1_fwd_bnact", (128, 512, 1, 1, 28): "gemm1x1_fwd_bnact", (256, 1024, 1, 1, 14): "gemm1x1_fwd_bnact",
-    (512, 2048, 1, 1, 7): "igemm256_fwd", (256, 512, 1, 2, 56): "igemm128_fwd", (512, 1024, 1, 2, 28): "igemm256_fwd",
+    (512, 2048, 1, 1, 7): "igemm256_fwd", (256, 512, 1, 2, 56): "igemm256_fwd", (512, 1024, 1, 2, 28): "igemm256_fwd",
     (1024, 2048, 1, 2, 14): "igemm256_fwd",
 }
 _AUX = ("fwd_bnact", "dgrad_fused_sums", "dgrad_parity", "dgrad_concat", "wgrad_colsum")
