@@ -547,6 +547,28 @@ size_t simhand_augment_workspace_bytes(int n);
 int simhand_augment_batch(const uint8_t* images, const float* joints, const float* angle, const float* crop_margin, const int32_t* jitter,
                           const float* hsab, int n, int h, int w, int out_w, int out_h, float* out_images, float* joints_aug, int32_t* rec,
                           void* workspace, size_t workspace_bytes, sh_stream_t stream);
+/* The same chain with the augmenter's COIN-FLIP operations (sample_augmenter.py:138-171, :254-272, :302-388): the flips and
+ * their draws are inputs.  flags [n]: bit 0 sobel_filter (first, on the raw frame: gray -> Sobel dx + dy, 3x3), bit 1 cut_out
+ * (rows [b0,b1) x columns [b2,b3) of the raw frame = cut_fill; box from get_random_cut_out_box -- computed by the caller),
+ * bit 2 gaussian_blur (kernel blur_kx x blur_ky [both odd: odd(0.1 * rows), odd(0.1 * cols)], sigma per sample), bit 3
+ * gaussian_noise (after the colour jitter: image += saturate_u8(rint(noise_std * z)), uint8 wrap-around; z = standard-normal
+ * draws [n][out_h][out_w][3]), bit 4 color_drop (last: all channels = BGR2GRAY).  any_* = whether any sample has that bit set
+ * (the pre-passes / scratch buffers of an operation nobody uses are skipped).  --flip exists on the reference's CLI but its
+ * augmenter never implements it.  Workspace: simhand_augment_workspace_bytes_ex(n, h, w, any pre-pass op, any blur). */
+typedef struct sh_augment_extra {
+  const int32_t* flags;      /* [n] */
+  const int32_t* cut_box;    /* [n][4] */
+  const uint8_t* cut_fill;   /* [n] */
+  const float* blur_sigma;   /* [n] */
+  const float* noise;        /* [n][out_h][out_w][3] */
+  float noise_std;
+  int blur_kx, blur_ky;
+  int any_sobel, any_cut_out, any_blur, any_noise;
+} sh_augment_extra;
+size_t simhand_augment_workspace_bytes_ex(int n, int h, int w, int pre_ops, int blur);
+int simhand_augment_batch_ex(const uint8_t* images, const float* joints, const float* angle, const float* crop_margin, const int32_t* jitter,
+                             const float* hsab, const sh_augment_extra* extra, int n, int h, int w, int out_w, int out_h, float* out_images,
+                             float* joints_aug, int32_t* rec, void* workspace, size_t workspace_bytes, sh_stream_t stream);
 
 /* ===========================================================================
  * Thin RCCL wrappers behind an opaque communicator handle -- the exchange steps of the path for a caller

@@ -10,6 +10,12 @@ recipes: rotate, crop + random_crop, resize, color_jitter):
   crop_sample     :173-195  numpy slicing (clipped at the canvas), joints - origin
   resize_sample   :197-224  cv2.resize(INTER_AREA) to resize_shape, joints * factor
   color_jitter    :292-318  BGR -> HSV (8-bit), hue*h, sat*s, value*a+b, clip, astype(uint8), HSV -> BGR
+  sobel_filter    :138-156  (first, coin flip) BGR2GRAY, Sobel dx + Sobel dy (CV_64F, ksize 3), assigned into the uint8 image
+  cut_out         :326-388  (coin flip) rectangle around a random joint filled with one random value (box: get_random_cut_out_box)
+  gaussian_blur   :302-324  (coin flip) kernel = odd(0.1 * image dims), sigma ~ U(0.1, 2), cv2.GaussianBlur
+  gaussian_noise  :158-171  (after colour jitter, coin flip) image += cv2.randn(uint8 zeros, 0, noise_std)
+  color_drop      :254-272  (last, coin flip) all channels = BGR2GRAY
+  flip                  --  the CLI has --flip (experiments/utils.py) but SampleAugmenter neither reads nor implements it: no-op
   transform             --  ToTensor + Normalize((0.485,0.456,0.406),(0.229,0.224,0.225))  src/data_loader/utils.py:279-285
   batch entries         --  src/data_loader/data_set.py:646-691, :804-838 (angle, jitter_x, jitter_y, h, s, a, b, crop_margin_scale)
 
@@ -19,7 +25,13 @@ stubbed): `get_crop_size` and the crop / jitter bookkeeping (tests/golden/augmen
 OpenCV's published definitions and therefore PARITY UNPINNED: getRotationMatrix2D (closed form), warpAffine (ideal bilinear
 in float instead of OpenCV's 5-bit fixed-point coordinates), INTER_AREA (exact area weights; for up-scaling the reference
 falls into OpenCV's linear branch, restated here as plain bilinear), the 8-bit HSV conversions (float formulas with
-round-half-up instead of OpenCV's LUT fixed point)."""
+round-half-up instead of OpenCV's LUT fixed point), BGR2GRAY (15-bit fixed point, coefficients 3735 / 19235 / 9798), Sobel
+(3x3, BORDER_REFLECT_101; the float64 result assigned into a uint8 array wraps modulo 256 -- numpy's C cast), GaussianBlur (float
+separable kernel exp(-x^2 / 2 sigma^2) normalised, REFLECT_101, one rounding at the end instead of OpenCV's 8.8 fixed-point
+kernel), cv2.randn on uint8 (saturate_cast: negative draws become 0) added with uint8 wrap-around.
+What of the new operations IS pinned to the reference's own code: get_random_cut_out_box (tests/golden/augment_crop.json,
+"cut_out" cases -- executed with random.uniform patched to the recorded ratio).
+Hand-derived known answers for every OpenCV-dependent piece (small integer images): tests/golden/augment_hand.json."""
 from __future__ import annotations
 
 import math
@@ -142,6 +154,86 @@ def color_jitter(img: np.ndarray, h: float, s: float, a: float, b: float) -> np.
     return hsv_to_bgr_u8(hue, sat, val)
 
 
+def gray_u8(img: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(BGR2GRAY) on uint8: 15-bit fixed point (B 0.114, G 0.587, R 0.299)."""
+    b, g, r = [img[..., i].astype(np.int64) for i in range(3)]
+    return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
+
+
+def _reflect101(i: np.ndarray, n: int) -> np.ndarray:
+    if n == 1:
+        return np.zeros_like(i)
+    p = 2 * (n - 1)
+    i = np.mod(i, p)
+    return np.where(i >= n, p - i, i)
+
+
+def sobel_sample(img: np.ndarray) -> np.ndarray:
+    """sobel_filter_sample :138-156: gray -> Sobel x + Sobel y (3x3, float64) -> written into the uint8 image (wraps mod 256)."""
+    g = gray_u8(img).astype(np.float64)
+    h, w = g.shape
+    ys, xs = np.arange(h), np.arange(w)
+    gp = lambda dy, dx: g[_reflect101(ys + dy, h)][:, _reflect101(xs + dx, w)]  # noqa: E731
+    sx = (gp(-1, 1) + 2 * gp(0, 1) + gp(1, 1)) - (gp(-1, -1) + 2 * gp(0, -1) + gp(1, -1))
+    sy = (gp(1, -1) + 2 * gp(1, 0) + gp(1, 1)) - (gp(-1, -1) + 2 * gp(-1, 0) + gp(-1, 1))
+    v = np.trunc(sx + sy).astype(np.int64) & 255
+    return np.repeat(v.astype(np.uint8)[..., None], 3, axis=2)
+
+
+def cut_out_box(dim0: int, dim1: int, center0: float, center1: float, ratio: float):
+    """get_random_cut_out_box :352-388 (its random.uniform(a, a) draws are degenerate: the box is centred)."""
+    c0, c1 = int(dim0 * ratio), int(dim1 * ratio)
+    t0, t1 = int(center0 - c0 / 2), int(center1 - c1 / 2)
+    cl = lambda v, hi: int(min(max(v, 0), hi))  # noqa: E731
+    return (cl(t0, dim0), cl(t0 + c0, dim0)), (cl(t1, dim1), cl(t1 + c1, dim1))
+
+
+def cut_out_sample(img: np.ndarray, joints: np.ndarray, joint_idx: int, ratio: float, fill: int) -> np.ndarray:
+    """cut_out_sample :326-350.  Quirk kept: the joint's X coordinate positions the box along image dim 0 (rows) and its Y along
+    dim 1 (the call passes joints[k, 0], joints[k, 1] as hand_center_dim0 / dim1)."""
+    (r0, r1), (c0, c1) = cut_out_box(img.shape[0], img.shape[1], float(joints[joint_idx, 0]), float(joints[joint_idx, 1]), ratio)
+    out = img.copy()
+    out[r0:r1, c0:c1] = np.uint8(fill)
+    return out
+
+
+def blur_kernel_sizes(shape) -> Tuple[int, int]:
+    """gaussian_blur_sample :316-321: (ksize.width, ksize.height) = odd(0.1 * rows), odd(0.1 * cols) -- the reference hands the
+    tuple built from image.shape[:2] to cv2 as (width, height): swapped for non-square frames, kept."""
+    k = [int(v * 0.1) for v in shape[:2]]
+    k = [v + 1 if v % 2 == 0 else v for v in k]
+    return k[0], k[1]
+
+
+def gaussian_blur(img: np.ndarray, kx: int, ky: int, sigma: float) -> np.ndarray:
+    def kern(n):
+        x = np.arange(n, dtype=np.float64) - (n - 1) / 2.0
+        k = np.exp(-(x * x) / (2.0 * sigma * sigma))
+        return (k / k.sum()).astype(np.float32)
+
+    h, w = img.shape[:2]
+    a = img.astype(np.float32)
+    kxv, kyv = kern(kx), kern(ky)
+    tmp = np.zeros_like(a)
+    xs, ys = np.arange(w), np.arange(h)
+    for t in range(kx):
+        tmp += kxv[t] * a[:, _reflect101(xs + t - kx // 2, w)]
+    out = np.zeros_like(a)
+    for t in range(ky):
+        out += kyv[t] * tmp[_reflect101(ys + t - ky // 2, h)]
+    return _round_u8(out).astype(np.uint8)
+
+
+def gaussian_noise(img: np.ndarray, z: np.ndarray, std: float) -> np.ndarray:
+    """image += cv2.randn(uint8 zeros, 0, std): the draw is saturate-cast to uint8 (negative -> 0), the sum wraps (numpy uint8)."""
+    n8 = np.clip(np.rint(z.astype(np.float32) * np.float32(std)), 0, 255).astype(np.int64)
+    return ((img.astype(np.int64) + n8) & 255).astype(np.uint8)
+
+
+def color_drop(img: np.ndarray) -> np.ndarray:
+    return np.repeat(gray_u8(img)[..., None], 3, axis=2)
+
+
 def transform_sample(image: np.ndarray, joints: np.ndarray, params: Dict[str, float], resize_shape=(128, 128), rotate=True,
                      do_color=True):
     """image uint8 (H,W,3); joints (21,3) float32 [x, y, depth]; params: angle, crop_margin, jitter (jx, jy), h, s, a, b.
@@ -149,6 +241,16 @@ def transform_sample(image: np.ndarray, joints: np.ndarray, params: Dict[str, fl
     img = image.copy()
     j = joints.astype(np.float32).copy()
     rec = {}
+    # the three coin-flip operations that run on the raw frame (params carry the outcome of the flips and their draws)
+    if params.get("sobel"):
+        img = sobel_sample(img)
+    if params.get("cut_out") is not None:
+        k, ratio, fill = params["cut_out"]
+        img = cut_out_sample(img, j, int(k), float(ratio), int(fill))
+    if params.get("blur_sigma") is not None:
+        kx, ky = blur_kernel_sizes(img.shape)
+        img = gaussian_blur(img, kx, ky, float(params["blur_sigma"]))
+    rec["blur_flag"] = params.get("blur_sigma") is not None
     if rotate:
         cb = crop_box(j[:, :2], (0, 0), 0.0)
         center = (int(cb["origin_x"] + cb["side"] / 2), int(cb["origin_y"] + cb["side"] / 2))
@@ -170,5 +272,9 @@ def transform_sample(image: np.ndarray, joints: np.ndarray, params: Dict[str, fl
     if do_color:
         img = color_jitter(img, params["h"], params["s"], params["a"], params["b"])
         rec.update(h=params["h"], s=params["s"], a=params["a"], b=params["b"])
+    if params.get("noise") is not None:
+        img = gaussian_noise(img, np.asarray(params["noise"]), float(params.get("noise_std", 25)))
+    if params.get("color_drop"):
+        img = color_drop(img)
     t = (img.astype(np.float32) / 255.0 - MEAN) / STD
     return np.ascontiguousarray(t.transpose(2, 0, 1)), j, rec

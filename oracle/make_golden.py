@@ -383,8 +383,33 @@ def golden_augment() -> None:
         # rotation centre of rotate_sample (:256-259): get_crop_size(joints, [0, 0], 0.0)
         ox0, oy0, s0 = aug.get_crop_size(j.clone(), [0, 0], 0.0)
         cases[-1]["rot_center"] = [int(ox0 + s0 / 2), int(oy0 + s0 / 2)]
+    # get_random_cut_out_box (:352-388) as the reference's own code: its first random.uniform draw is the box ratio, the other two are
+    # degenerate (uniform(a, a)); the draw is patched to a recorded value so the bounds are a pure function of the inputs
+    cut = []
+    real_uniform = sa.random.uniform
+    for i in range(16):
+        dim0, dim1 = (224, 224) if i % 3 else (160, 200)
+        c0 = float(torch.rand(1, generator=g) * (dim0 + 40) - 20)   # some centres outside the frame: the bounds are clipped
+        c1 = float(torch.rand(1, generator=g) * (dim1 + 40) - 20)
+        ratio = float(torch.rand(1, generator=g) * 0.16)
+        box = {"n": 0}
+
+        def fake(a, b, ratio=ratio, box=box):
+            box["n"] += 1
+            return ratio if box["n"] == 1 else real_uniform(a, b)
+
+        sa.random.uniform = fake
+        try:
+            b0, b1 = aug.get_random_cut_out_box(dim0, dim1, c0, c1)
+        finally:
+            sa.random.uniform = real_uniform
+        got = augment.cut_out_box(dim0, dim1, c0, c1, ratio)
+        want = ([int(b0[0]), int(b0[1])], [int(b1[0]), int(b1[1])])
+        assert [list(got[0]), list(got[1])] == [want[0], want[1]], (i, got, want)
+        cut.append({"dim0": dim0, "dim1": dim1, "center0": c0, "center1": c1, "ratio": ratio, "bounds0": want[0], "bounds1": want[1]})
     with open(os.path.join(OUT, "augment_crop.json"), "w") as f:
-        json.dump({"cases": cases, "resize_shape": list(params.resize_shape), "crop_box_jitter": list(params.crop_box_jitter),
+        json.dump({"cases": cases, "cut_out": cut, "cut_out_fraction": list(params.cut_out_fraction), "noise_std": params.noise_std,
+                   "sobel_kernel": params.sobel_kernel, "resize_shape": list(params.resize_shape), "crop_box_jitter": list(params.crop_box_jitter),
                    "crop_margin_range": list(params.crop_margin_range), "angle_range": [params.min_angle, params.max_angle],
                    "hue_factor_range": list(params.hue_factor_range), "sat_factor_range": list(params.sat_factor_range),
                    "value_factor_alpha_range": list(params.value_factor_alpha_range),

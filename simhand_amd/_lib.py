@@ -40,6 +40,12 @@ class SimhandHipError(RuntimeError):
     pass
 
 
+class AugmentExtra(C.Structure):  # == sh_augment_extra
+    _fields_ = [("flags", C.c_void_p), ("cut_box", C.c_void_p), ("cut_fill", C.c_void_p), ("blur_sigma", C.c_void_p), ("noise", C.c_void_p),
+                ("noise_std", C.c_float), ("blur_kx", C.c_int), ("blur_ky", C.c_int), ("any_sobel", C.c_int), ("any_cut_out", C.c_int),
+                ("any_blur", C.c_int), ("any_noise", C.c_int)]
+
+
 class NtxentParams(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("dim", C.c_int), ("b_loc", C.c_int), ("pair_off", C.c_int),
@@ -192,6 +198,8 @@ SIGNATURES = {
     "simhand_conv2d_fwd_fp8": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "simhand_augment_workspace_bytes": (_S, [_I]),
     "simhand_augment_batch": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _S, _P]),
+    "simhand_augment_workspace_bytes_ex": (_S, [_I, _I, _I, _I, _I]),
+    "simhand_augment_batch_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _S, _P]),
     "simhand_comm_unique_id": (_I, [_P]),
     "simhand_comm_init": (_I, [_P, _I, _I, C.POINTER(_P)]),
     "simhand_comm_destroy": (_I, [_P]),

@@ -11,6 +11,12 @@
 // OpenCV is not vendored by the reference: its resampling / colour arithmetic is restated from the published definitions
 // (see oracle/augment.py for what is pinned and what is not); every stage rounds to uint8 where OpenCV does.
 //
+// The coin-flip operations of the same chain (simhand_augment_batch_ex; the flips and their draws are inputs as well):
+// sobel_filter_sample (:138-156), cut_out_sample (:326-388) and gaussian_blur_sample (:302-324) run on the RAW frame before the
+// rotation -- three small pre-pass kernels write a processed uint8 copy of the frames that the chain above then reads;
+// gaussian_noise_sample (:158-171) and color_drop_sample (:254-272) are pointwise tails of kernel 2.  --flip exists on the CLI but
+// SampleAugmenter neither reads nor implements it: nothing to build.
+//
 // Kernel 1 (one thread per sample): rotation centre and matrix, rotated joints, crop box, final joints, the record.
 // Kernel 2 (one thread per output pixel): area-average over the crop footprint of bilinear samples of the rotated source,
 // HSV jitter, normalisation, written as CHW fp32.
@@ -164,9 +170,107 @@ __device__ __forceinline__ double foot_weight(const Foot& f, int k) {
   return fmax(0.0, fmin(f.hi, (double)(i + 1)) - fmax(f.lo, (double)i)) / f.scale;
 }
 
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  const int p = 2 * (n - 1);
+  i %= p;
+  if (i < 0) i += p;
+  return i >= n ? p - i : i;
+}
+// cv2.cvtColor(BGR2GRAY) on uint8: 15-bit fixed point
+__device__ __forceinline__ int gray15(int b, int g, int r) { return (b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15; }
+
+// pre-pass 1: Sobel (flag bit 0) then cut-out (bit 1) on the raw frame -> dst (uint8).  One thread per pixel.
+__global__ __launch_bounds__(256) void augment_pre_sobel_cut_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                                    const int* __restrict__ flags, const int* __restrict__ cut_box,
+                                                                    const unsigned char* __restrict__ cut_fill, int H, int W) {
+  const int n = blockIdx.y;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * W) return;
+  const int y = idx / W, x = idx - y * W;
+  const unsigned char* img = src + (long long)n * H * W * 3;
+  unsigned char* out = dst + ((long long)n * H * W + idx) * 3;
+  const int f = flags[n];
+  int v0, v1, v2;
+  if (f & 1) {
+    auto gp = [&](int dy, int dx) -> double {
+      const unsigned char* p = img + ((long long)reflect101(y + dy, H) * W + reflect101(x + dx, W)) * 3;
+      return (double)gray15(p[0], p[1], p[2]);
+    };
+    const double sx = (gp(-1, 1) + 2.0 * gp(0, 1) + gp(1, 1)) - (gp(-1, -1) + 2.0 * gp(0, -1) + gp(1, -1));
+    const double sy = (gp(1, -1) + 2.0 * gp(1, 0) + gp(1, 1)) - (gp(-1, -1) + 2.0 * gp(-1, 0) + gp(-1, 1));
+    v0 = v1 = v2 = (int)((long long)(sx + sy) & 255);  // float64 -> uint8 array assignment: truncation, modulo 256
+  } else {
+    const unsigned char* p = img + (long long)idx * 3;
+    v0 = p[0]; v1 = p[1]; v2 = p[2];
+  }
+  if (f & 2) {
+    const int* b = cut_box + 4 * n;  // rows [b0, b1), columns [b2, b3)
+    if (y >= b[0] && y < b[1] && x >= b[2] && x < b[3]) v0 = v1 = v2 = cut_fill[n];
+  }
+  out[0] = (unsigned char)v0; out[1] = (unsigned char)v1; out[2] = (unsigned char)v2;
+}
+
+// pre-pass 2 / 3: separable Gaussian blur (flag bit 2) of dst in place through a float scratch image: horizontal taps -> tmp,
+// vertical taps + the one rounding -> dst.  Samples without the flag are left alone.  Weights exp(-x^2 / 2 sigma^2) / sum in fp32.
+__global__ __launch_bounds__(256) void augment_blur_h_kernel(const unsigned char* __restrict__ img8, float* __restrict__ tmp,
+                                                             const int* __restrict__ flags, const float* __restrict__ sigma, int H, int W, int kx) {
+  const int n = blockIdx.y;
+  if (!(flags[n] & 4)) return;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * W) return;
+  const int y = idx / W, x = idx - y * W;
+  const unsigned char* img = img8 + (long long)n * H * W * 3;
+  // the oracle normalises in float64 and rounds the weights to fp32: k / k.sum() -> astype(float32)
+  double sum = 0.0;
+  const double sg = (double)sigma[n];
+  for (int t = 0; t < kx; ++t) {
+    const double xx = (double)t - (double)(kx - 1) / 2.0;
+    sum += exp(-(xx * xx) / (2.0 * sg * sg));
+  }
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int t = 0; t < kx; ++t) {
+    const double xx = (double)t - (double)(kx - 1) / 2.0;
+    const float wgt = (float)(exp(-(xx * xx) / (2.0 * sg * sg)) / sum);
+    const unsigned char* p = img + ((long long)y * W + reflect101(x + t - kx / 2, W)) * 3;
+    a0 = __fadd_rn(a0, __fmul_rn(wgt, (float)p[0]));
+    a1 = __fadd_rn(a1, __fmul_rn(wgt, (float)p[1]));
+    a2 = __fadd_rn(a2, __fmul_rn(wgt, (float)p[2]));
+  }
+  float* o = tmp + ((long long)n * H * W + idx) * 3;
+  o[0] = a0; o[1] = a1; o[2] = a2;
+}
+__global__ __launch_bounds__(256) void augment_blur_v_kernel(const float* __restrict__ tmp, unsigned char* __restrict__ img8,
+                                                             const int* __restrict__ flags, const float* __restrict__ sigma, int H, int W, int ky) {
+  const int n = blockIdx.y;
+  if (!(flags[n] & 4)) return;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * W) return;
+  const int y = idx / W, x = idx - y * W;
+  const float* src = tmp + (long long)n * H * W * 3;
+  double sum = 0.0;
+  const double sg = (double)sigma[n];
+  for (int t = 0; t < ky; ++t) {
+    const double xx = (double)t - (double)(ky - 1) / 2.0;
+    sum += exp(-(xx * xx) / (2.0 * sg * sg));
+  }
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int t = 0; t < ky; ++t) {
+    const double xx = (double)t - (double)(ky - 1) / 2.0;
+    const float wgt = (float)(exp(-(xx * xx) / (2.0 * sg * sg)) / sum);
+    const float* p = src + ((long long)reflect101(y + t - ky / 2, H) * W + x) * 3;
+    a0 = __fadd_rn(a0, __fmul_rn(wgt, p[0]));
+    a1 = __fadd_rn(a1, __fmul_rn(wgt, p[1]));
+    a2 = __fadd_rn(a2, __fmul_rn(wgt, p[2]));
+  }
+  unsigned char* o = img8 + ((long long)n * H * W + idx) * 3;
+  o[0] = (unsigned char)round_u8(a0); o[1] = (unsigned char)round_u8(a1); o[2] = (unsigned char)round_u8(a2);
+}
+
 __global__ __launch_bounds__(128) void augment_image_kernel(const unsigned char* __restrict__ images, const AugGeo* __restrict__ geo,
                                                             const float* __restrict__ hsab, int H, int W, int out_w, int out_h,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, const int* __restrict__ flags,
+                                                            const float* __restrict__ noise, float noise_std) {
   const int n = blockIdx.y, v = blockIdx.x;
   const AugGeo g = geo[n];
   const unsigned char* img = images + (long long)n * H * W * 3;
@@ -228,6 +332,20 @@ __global__ __launch_bounds__(128) void augment_image_kernel(const unsigned char*
       px[1] = round_u8(gg * 255.0f);
       px[2] = round_u8(rr * 255.0f);
     }
+    const int fl = flags != nullptr ? flags[n] : 0;
+    if ((fl & 8) && noise != nullptr) {
+      // image += cv2.randn(uint8 zeros, 0, std): the draw saturates to [0, 255] (negative -> 0, round half to even), the uint8 sum wraps
+      const float* z = noise + (((long long)n * out_h + v) * out_w + u) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float n8 = fminf(fmaxf(rintf(__fmul_rn(z[c], noise_std)), 0.f), 255.f);
+        px[c] = (float)(((int)px[c] + (int)n8) & 255);
+      }
+    }
+    if (fl & 16) {  // color_drop_sample: all channels = BGR2GRAY
+      const float gy = (float)gray15((int)px[0], (int)px[1], (int)px[2]);
+      px[0] = px[1] = px[2] = gy;
+    }
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -243,20 +361,70 @@ extern "C" {
 
 size_t simhand_augment_workspace_bytes(int n) { return (size_t)(n > 0 ? n : 0) * sizeof(AugGeo); }
 
+// geometry table + (with pre-pass operations) a processed uint8 copy of the frames + (with blur) its float scratch image
+size_t simhand_augment_workspace_bytes_ex(int n, int h, int w, int pre_ops, int blur) {
+  if (n <= 0 || h <= 0 || w <= 0) return 0;
+  size_t b = ((size_t)n * sizeof(AugGeo) + 255) & ~(size_t)255;
+  if (pre_ops || blur) b += (((size_t)n * h * w * 3) + 255) & ~(size_t)255;
+  if (blur) b += (size_t)n * h * w * 3 * sizeof(float);
+  return b;
+}
+
+static int augment_impl(const uint8_t* images, const float* joints, const float* angle, const float* crop_margin, const int32_t* jitter,
+                        const float* hsab, const sh_augment_extra* ex, int n, int h, int w, int out_w, int out_h, float* out_images,
+                        float* joints_aug, int32_t* rec, void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+  SH_REQUIRE(images && joints && crop_margin && jitter && out_images && joints_aug && rec && workspace, "augment_batch: NULL pointer");
+  SH_REQUIRE(n >= 1 && h >= 1 && w >= 1 && out_w >= 1 && out_h >= 1, "augment_batch: bad shape");
+  SH_REQUIRE((long long)h * w * 3 < (1ll << 31), "augment_batch: image too large");
+  const bool pre = ex != nullptr && ex->flags != nullptr && (ex->any_sobel || ex->any_cut_out || ex->any_blur);
+  const bool blur = pre && ex->any_blur;
+  const size_t need = ex == nullptr ? simhand_augment_workspace_bytes(n) : simhand_augment_workspace_bytes_ex(n, h, w, pre ? 1 : 0, blur ? 1 : 0);
+  SH_REQUIRE(workspace_bytes >= need, "augment_batch: workspace too small");
+  if (ex != nullptr && ex->flags != nullptr) {
+    SH_REQUIRE(!ex->any_cut_out || (ex->cut_box && ex->cut_fill), "augment_batch: cut-out needs its boxes and fill values");
+    SH_REQUIRE(!ex->any_blur || (ex->blur_sigma && ex->blur_kx >= 1 && ex->blur_ky >= 1 && (ex->blur_kx & 1) && (ex->blur_ky & 1)),
+               "augment_batch: blur needs sigma and odd kernel sizes");
+    SH_REQUIRE(!ex->any_noise || ex->noise, "augment_batch: noise needs its standard-normal draws");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_MISC, s, 0, (double)n * ((double)h * w * 3 * (pre ? 3 : 1) + (double)out_w * out_h * 12));
+  char* wsb = (char*)workspace;
+  AugGeo* geo = (AugGeo*)wsb;
+  const unsigned char* frames = images;
+  if (pre) {
+    unsigned char* img8 = (unsigned char*)(wsb + (((size_t)n * sizeof(AugGeo) + 255) & ~(size_t)255));
+    const dim3 grid(ceil_div(h * w, 256), n);
+    augment_pre_sobel_cut_kernel<<<grid, 256, 0, s>>>(images, img8, ex->flags, ex->cut_box, ex->cut_fill, h, w);
+    if (check_launch("augment_batch pre")) return 1;
+    if (blur) {
+      float* tmp = (float*)((char*)img8 + ((((size_t)n * h * w * 3) + 255) & ~(size_t)255));
+      augment_blur_h_kernel<<<grid, 256, 0, s>>>(img8, tmp, ex->flags, ex->blur_sigma, h, w, ex->blur_kx);
+      if (check_launch("augment_batch blur h")) return 1;
+      augment_blur_v_kernel<<<grid, 256, 0, s>>>(tmp, img8, ex->flags, ex->blur_sigma, h, w, ex->blur_ky);
+      if (check_launch("augment_batch blur v")) return 1;
+    }
+    frames = img8;
+  }
+  augment_geometry_kernel<<<ceil_div(n, 64), 64, 0, s>>>(joints, angle, crop_margin, jitter, n, h, w, out_w, out_h, joints_aug, rec, geo);
+  if (check_launch("augment_batch geometry")) return 1;
+  const bool tails = ex != nullptr && ex->flags != nullptr;
+  augment_image_kernel<<<dim3(out_h, n), 128, 0, s>>>(frames, geo, hsab, h, w, out_w, out_h, out_images, tails ? ex->flags : nullptr,
+                                                      tails && ex->any_noise ? ex->noise : nullptr, tails ? ex->noise_std : 0.f);
+  return check_launch("augment_batch image");
+}
+
 int simhand_augment_batch(const uint8_t* images, const float* joints, const float* angle, const float* crop_margin, const int32_t* jitter,
                           const float* hsab, int n, int h, int w, int out_w, int out_h, float* out_images, float* joints_aug, int32_t* rec,
                           void* workspace, size_t workspace_bytes, sh_stream_t stream) {
-  SH_REQUIRE(images && joints && crop_margin && jitter && out_images && joints_aug && rec && workspace, "augment_batch: NULL pointer");
-  SH_REQUIRE(n >= 1 && h >= 1 && w >= 1 && out_w >= 1 && out_h >= 1, "augment_batch: bad shape");
-  SH_REQUIRE(workspace_bytes >= simhand_augment_workspace_bytes(n), "augment_batch: workspace too small");
-  SH_REQUIRE((long long)h * w * 3 < (1ll << 31), "augment_batch: image too large");
-  hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(SH_PROF_MISC, s, 0, (double)n * ((double)h * w * 3 + (double)out_w * out_h * 12));
-  AugGeo* geo = (AugGeo*)workspace;
-  augment_geometry_kernel<<<ceil_div(n, 64), 64, 0, s>>>(joints, angle, crop_margin, jitter, n, h, w, out_w, out_h, joints_aug, rec, geo);
-  if (check_launch("augment_batch geometry")) return 1;
-  augment_image_kernel<<<dim3(out_h, n), 128, 0, s>>>(images, geo, hsab, h, w, out_w, out_h, out_images);
-  return check_launch("augment_batch image");
+  return augment_impl(images, joints, angle, crop_margin, jitter, hsab, nullptr, n, h, w, out_w, out_h, out_images, joints_aug, rec, workspace,
+                      workspace_bytes, stream);
+}
+
+int simhand_augment_batch_ex(const uint8_t* images, const float* joints, const float* angle, const float* crop_margin, const int32_t* jitter,
+                             const float* hsab, const sh_augment_extra* extra, int n, int h, int w, int out_w, int out_h, float* out_images,
+                             float* joints_aug, int32_t* rec, void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+  return augment_impl(images, joints, angle, crop_margin, jitter, hsab, extra, n, h, w, out_w, out_h, out_images, joints_aug, rec, workspace,
+                      workspace_bytes, stream);
 }
 
 }  // extern "C"

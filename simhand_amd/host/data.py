@@ -30,9 +30,14 @@ class GpuAugmenter:
         self.check = check
         self.rotate, self.crop, self.random_crop = bool(f["rotate"]), bool(f["crop"]), bool(f["random_crop"])
         self.resize, self.color_jitter = bool(f["resize"]), bool(f["color_jitter"])
-        for name in ("cut_out", "gaussian_blur", "gaussian_noise", "sobel_filter", "color_drop", "flip"):
-            if f.get(name, False):
-                raise NotImplementedError(f"augmentation '{name}' is not part of the contrastive pre-training recipes (README :53-125)")
+        # the coin-flip operations (sample_augmenter.py:138-171, :254-272, :302-388): each enabled flag fires with probability 1/2 per
+        # sample (random.getrandbits(1)).  --flip is on the reference's CLI, but SampleAugmenter neither reads nor implements it: accepted, no-op.
+        self.sobel, self.cut_out, self.blur = bool(f.get("sobel_filter", False)), bool(f.get("cut_out", False)), bool(f.get("gaussian_blur", False))
+        self.noise, self.color_drop = bool(f.get("gaussian_noise", False)), bool(f.get("color_drop", False))
+        self.cut_frac = tuple(p.get("cut_out_fraction", (0.0, 0.16)))
+        self.noise_std = float(p.get("noise_std", 25))
+        if self.sobel and int(p.get("sobel_kernel", 3)) != 3:
+            raise NotImplementedError("sobel_kernel != 3 (training_config.json ships 3)")
         if not self.resize:
             raise NotImplementedError("a batch needs one image size: the recipes always pass --resize (the reference cannot collate otherwise)")
         # set_augmenation_params swaps min / max angle (sample_augmenter.py:484-485, harmless for uniform draws: App. D #7)
@@ -55,16 +60,53 @@ class GpuAugmenter:
             d["jitter"] = torch.zeros(n, 2, dtype=torch.int32, device=device)  # override_jitter = [0, 0] (data_set.py:651-656)
         if self.color_jitter:
             d["hsab"] = torch.stack((u(*self.hue), u(*self.sat), u(*self.alpha), u(*self.beta)), dim=1)
+        if self.sobel or self.cut_out or self.blur or self.noise or self.color_drop:
+            coin = lambda on: (torch.rand(n, generator=generator, device=device) < 0.5) if on else torch.zeros(n, dtype=torch.bool, device=device)  # noqa: E731
+            bits = [coin(self.sobel), coin(self.cut_out), coin(self.blur), coin(self.noise), coin(self.color_drop)]
+            d["flags"] = sum(b.to(torch.int32) << i for i, b in enumerate(bits))
+            if self.cut_out:  # np.random.randint(0, 20) joint, uniform ratio, np.uint8(np.random.randint(0, 255)) fill
+                d["cut_joint"] = torch.randint(0, 20, (n,), generator=generator, device=device)
+                d["cut_ratio"] = u(*self.cut_frac)
+                d["cut_fill"] = torch.randint(0, 255, (n,), generator=generator, device=device).to(torch.uint8)
+            if self.blur:
+                d["blur_sigma"] = u(0.1, 2.0)
+            if self.noise:
+                d["noise"] = torch.randn(n, self.resize_shape[1], self.resize_shape[0], 3, generator=generator, device=device)
         return d
+
+    @staticmethod
+    def cut_out_boxes(joints: torch.Tensor, joint_idx: torch.Tensor, ratio: torch.Tensor, h: int, w: int) -> torch.Tensor:
+        """get_random_cut_out_box (sample_augmenter.py:352-388) for a batch: [n][4] = rows [r0, r1), columns [c0, c1).  Quirk kept: the
+        chosen joint's X positions the box along the rows, its Y along the columns (cut_out_sample :339-345)."""
+        k = joint_idx.view(-1, 1, 1).expand(-1, 1, 2)
+        c = torch.gather(joints[:, :, :2].double(), 1, k).squeeze(1)          # (x, y) of the chosen joint
+        cut0, cut1 = torch.trunc(h * ratio.double()), torch.trunc(w * ratio.double())
+        t0, t1 = torch.trunc(c[:, 0] - cut0 / 2), torch.trunc(c[:, 1] - cut1 / 2)
+        box = torch.stack((t0.clamp(0, h), (t0 + cut0).clamp(0, h), t1.clamp(0, w), (t1 + cut1).clamp(0, w)), dim=1)
+        return box.to(torch.int32).contiguous()
 
     def transform(self, images_u8: torch.Tensor, joints: torch.Tensor, draws: Dict[str, torch.Tensor]):
         """One view of a batch: (images fp32 (n,3,H,W) normalised, joints_aug (n,21,3), per-sample entries as collated)."""
+        extra = None
+        if "flags" in draws:
+            h, w = images_u8.shape[1:3]
+            k = [int(v * 0.1) for v in (h, w)]  # gaussian_blur_sample :316-321 (ksize = odd(0.1 * rows), odd(0.1 * cols), in that order)
+            extra = {"flags": draws["flags"].contiguous(), "blur_k": tuple(v + 1 if v % 2 == 0 else v for v in k), "noise_std": self.noise_std,
+                     "any_sobel": self.sobel, "any_cut_out": self.cut_out, "any_blur": self.blur, "any_noise": self.noise}
+            if self.cut_out:
+                extra["cut_box"] = self.cut_out_boxes(joints.float(), draws["cut_joint"], draws["cut_ratio"], h, w)
+                extra["cut_fill"] = draws["cut_fill"].contiguous()
+            if self.blur:
+                extra["blur_sigma"] = draws["blur_sigma"].float().contiguous()
+            if self.noise:
+                extra["noise"] = draws["noise"].contiguous()
         img, ja, rec = ops.augment_batch(images_u8.contiguous(), joints.contiguous().float(), draws.get("angle"), draws["crop_margin"].float().contiguous(),
-                                         draws["jitter"].contiguous(), draws.get("hsab"), out_hw=(self.resize_shape[1], self.resize_shape[0]))
+                                         draws["jitter"].contiguous(), draws.get("hsab"), out_hw=(self.resize_shape[1], self.resize_shape[0]), extra=extra)
         if self.check and bool((rec[:, 4:6] <= 0).any()):
             raise ValueError("augment_batch: empty crop (the crop box of a sample lies outside its frame)")
         ent = {"jitter_x": rec[:, 0].to(torch.int64), "jitter_y": rec[:, 1].to(torch.int64),
-               "crop_margin_scale": draws["crop_margin"].to(torch.float64), "blur_flag": torch.zeros(img.shape[0], dtype=torch.bool, device=img.device)}
+               "crop_margin_scale": draws["crop_margin"].to(torch.float64),
+               "blur_flag": ((draws["flags"] >> 2) & 1).bool() if "flags" in draws else torch.zeros(img.shape[0], dtype=torch.bool, device=img.device)}
         if "angle" in draws:
             ent["angle"] = draws["angle"].to(torch.float64)
         if "hsab" in draws:

@@ -871,9 +871,12 @@ def conv2d_fwd_fp8(d: ConvDesc, x_q, w_q, x_scaler: FP8Scaler, w_scaler: FP8Scal
 
 
 # ---------------------------------------------------------------- batch producer
-def augment_batch(images_u8: torch.Tensor, joints: torch.Tensor, angle, crop_margin, jitter, hsab, out_hw=(128, 128)):
+def augment_batch(images_u8: torch.Tensor, joints: torch.Tensor, angle, crop_margin, jitter, hsab, out_hw=(128, 128), extra: Optional[dict] = None):
     """images [n][h][w][3] uint8, joints [n][21][3] fp32, angle [n] fp32 or None, crop_margin [n] fp32, jitter [n][2] int32,
-    hsab [n][4] fp32 or None -> (images [n][3][oh][ow] fp32 normalised, joints_aug [n][21][3], rec [n][6] int32)."""
+    hsab [n][4] fp32 or None -> (images [n][3][oh][ow] fp32 normalised, joints_aug [n][21][3], rec [n][6] int32).
+    extra (the coin-flip operations, simhand_augment_batch_ex): dict with flags [n] int32 (bit 0 sobel, 1 cut-out, 2 blur, 3 noise,
+    4 colour drop) and, as used, cut_box [n][4] int32, cut_fill [n] uint8, blur_sigma [n] fp32, blur_k (kx, ky), noise [n][oh][ow][3]
+    fp32 standard-normal draws, noise_std; any_* (host booleans: does any sample carry the bit)."""
     lib = _lib_dev()
     n, h, w, _ = images_u8.shape
     oh, ow = out_hw
@@ -881,6 +884,24 @@ def augment_batch(images_u8: torch.Tensor, joints: torch.Tensor, angle, crop_mar
     out = torch.empty(n, 3, oh, ow, dtype=torch.float32, device=dev)
     ja = torch.empty(n, 21, 3, dtype=torch.float32, device=dev)
     rec = torch.empty(n, 6, dtype=torch.int32, device=dev)
+    if extra is not None:
+        ex = _lib.AugmentExtra()
+        ex.flags = _ptr(extra["flags"], torch.int32).value
+        ex.cut_box = _ptr(extra.get("cut_box"), torch.int32).value
+        ex.cut_fill = _ptr(extra.get("cut_fill"), torch.uint8).value
+        ex.blur_sigma = _ptr(extra.get("blur_sigma"), _F32).value
+        ex.noise = _ptr(extra.get("noise"), _F32).value
+        ex.noise_std = float(extra.get("noise_std", 0.0))
+        ex.blur_kx, ex.blur_ky = (int(v) for v in extra.get("blur_k", (1, 1)))
+        ex.any_sobel, ex.any_cut_out = int(bool(extra.get("any_sobel"))), int(bool(extra.get("any_cut_out")))
+        ex.any_blur, ex.any_noise = int(bool(extra.get("any_blur"))), int(bool(extra.get("any_noise")))
+        pre = ex.any_sobel or ex.any_cut_out or ex.any_blur
+        nb = lib.simhand_augment_workspace_bytes_ex(n, h, w, int(pre), ex.any_blur)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        check(lib.simhand_augment_batch_ex(_ptr(images_u8, torch.uint8), _ptr(joints, _F32), _ptr(angle, _F32), _ptr(crop_margin, _F32),
+                                           _ptr(jitter, torch.int32), _ptr(hsab, _F32), C.byref(ex), n, h, w, ow, oh, _ptr(out), _ptr(ja), _ptr(rec),
+                                           _ptr(ws), nb, _stream()), "augment_batch_ex")
+        return out, ja, rec
     nb = lib.simhand_augment_workspace_bytes(n)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     check(lib.simhand_augment_batch(_ptr(images_u8, torch.uint8), _ptr(joints, _F32), _ptr(angle, _F32), _ptr(crop_margin, _F32),

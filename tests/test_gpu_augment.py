@@ -54,6 +54,112 @@ def test_augment_batch_against_oracle(size, out, rotate, color):
         assert (diff <= 0.01).mean() >= 0.97, float((diff <= 0.01).mean())  # and the vast majority bit-identical
 
 
+def test_augment_coin_flip_operations_against_oracle():
+    """simhand_augment_batch_ex: sobel / cut-out / blur on the raw frame, noise / colour drop after the colour jitter -- every sample a
+    different combination of the five flags -- against oracle/augment.py (itself pinned by the hand-derived known answers and, for the
+    cut-out box, by the reference's own code).  Noise and Sobel wrap modulo 256, so a one-level difference upstream can become a large
+    one downstream: levels are compared on the 8-bit circle and the tail is bounded by a fraction, not a maximum."""
+    from simhand_amd import ops
+    from simhand_amd.host.data import GpuAugmenter
+
+    n, size, out = 10, 224, 128
+    img, j = _raw(n, size, 91)
+    g = np.random.default_rng(17)
+    angle = np.floor(g.uniform(-45, 45, n)).astype(np.float32)
+    margin = g.uniform(0.9, 1.5, n).astype(np.float32)
+    jitter = g.integers(0, 15, (n, 2)).astype(np.int32)
+    hsab = np.stack([g.uniform(0.01, 1, n), g.uniform(0.01, 1, n), g.uniform(0.5, 1, n), g.uniform(5, 20, n)], axis=1).astype(np.float32)
+    flags = np.array([1, 2, 4, 8, 16, 31, 6, 24, 5, 0], dtype=np.int32)
+    cut_joint = g.integers(0, 20, n)
+    cut_ratio = g.uniform(0.02, 0.16, n)
+    cut_fill = g.integers(0, 255, n).astype(np.uint8)
+    sigma = g.uniform(0.1, 2.0, n).astype(np.float32)
+    z = g.normal(0, 1, (n, out, out, 3)).astype(np.float32)
+    box = GpuAugmenter.cut_out_boxes(j.to(DEV), torch.from_numpy(cut_joint).to(DEV), torch.from_numpy(cut_ratio).to(DEV), size, size)
+    extra = {"flags": torch.from_numpy(flags).to(DEV), "cut_box": box, "cut_fill": torch.from_numpy(cut_fill).to(DEV),
+             "blur_sigma": torch.from_numpy(sigma).to(DEV), "blur_k": oaug.blur_kernel_sizes((size, size)), "noise": torch.from_numpy(z).to(DEV),
+             "noise_std": 25.0, "any_sobel": True, "any_cut_out": True, "any_blur": True, "any_noise": True}
+    got_img, got_j, rec = ops.augment_batch(img.to(DEV), j.to(DEV), torch.from_numpy(angle).to(DEV), torch.from_numpy(margin).to(DEV),
+                                            torch.from_numpy(jitter).to(DEV), torch.from_numpy(hsab).to(DEV), out_hw=(out, out), extra=extra)
+    got_img, got_j = got_img.cpu().numpy(), got_j.cpu().numpy()
+    box = box.cpu().numpy()
+    mean, std = oaug.MEAN.reshape(3, 1, 1), oaug.STD.reshape(3, 1, 1)
+    lev = lambda t: np.rint((t * std + mean) * 255.0)  # noqa: E731
+    for i in range(n):
+        f = int(flags[i])
+        params = {"angle": float(angle[i]), "crop_margin": float(margin[i]), "jitter": (int(jitter[i, 0]), int(jitter[i, 1])),
+                  "h": float(hsab[i, 0]), "s": float(hsab[i, 1]), "a": float(hsab[i, 2]), "b": float(hsab[i, 3]),
+                  "sobel": bool(f & 1), "cut_out": (int(cut_joint[i]), float(cut_ratio[i]), int(cut_fill[i])) if f & 2 else None,
+                  "blur_sigma": float(sigma[i]) if f & 4 else None, "noise": z[i] if f & 8 else None, "noise_std": 25.0, "color_drop": bool(f & 16)}
+        if f & 2:  # the batched box == the oracle's (== the reference's own code, tests/golden/augment_crop.json)
+            (r0, r1), (c0, c1) = oaug.cut_out_box(size, size, float(j[i, cut_joint[i], 0]), float(j[i, cut_joint[i], 1]), float(cut_ratio[i]))
+            assert box[i].tolist() == [r0, r1, c0, c1], (i, box[i], (r0, r1, c0, c1))
+        want_img, want_j, _ = oaug.transform_sample(img[i].numpy(), j[i].numpy(), params, (out, out), rotate=True, do_color=True)
+        np.testing.assert_allclose(got_j[i], want_j, rtol=1e-6, atol=1e-4)
+        d = np.abs(lev(got_img[i]) - lev(want_img))
+        d = np.minimum(d, 256 - d)
+        assert (d <= 1).mean() >= 0.99, (i, f, float((d <= 1).mean()))
+        assert (d == 0).mean() >= 0.95, (i, f, float((d == 0).mean()))
+        if not (f & (1 | 8 | 16)):  # no wrap-around operation in the chain: the usual hard bound
+            assert d.max() <= 3, (i, f, float(d.max()))
+
+
+def test_augment_chain_reproduces_hand_derived_known_answers(golden_dir):
+    """The kernel chain itself on the hand-derived cases of tests/golden/augment_hand.json that fit its interface: INTER_AREA (the crop is
+    the whole small frame), grey conversion via colour drop, Sobel, noise.  Joints are placed so that get_crop_size yields exactly the
+    frame (centre = frame centre, max radius = half the side, margin 1.0)."""
+    from simhand_amd import ops
+
+    fx = json.load(open(os.path.join(golden_dir, "augment_hand.json")))
+    mean, std = oaug.MEAN.reshape(3, 1, 1), oaug.STD.reshape(3, 1, 1)
+
+    def run(frame, out_w, out_h, flags=0, noise=None, noise_std=0.0):
+        h, w = frame.shape[:2]
+        cx, cy = w // 2, h // 2
+        jt = np.tile(np.array([[cx, cy, 1.0]], dtype=np.float32), (21, 1))
+        jt[0, 0] = cx + (w + 1) // 2  # one joint at distance ceil(w / 2): side = that radius, the box [0, 2 side) clipped to the frame
+        img = torch.from_numpy(np.ascontiguousarray(frame))[None].to(DEV)
+        extra = None
+        if flags:
+            extra = {"flags": torch.tensor([flags], dtype=torch.int32, device=DEV), "noise_std": noise_std, "any_sobel": bool(flags & 1),
+                     "any_noise": bool(flags & 8), "noise": None if noise is None else torch.from_numpy(noise)[None].to(DEV)}
+        o, _, rec = ops.augment_batch(img, torch.from_numpy(jt)[None].to(DEV), None, torch.ones(1, device=DEV), torch.zeros(1, 2, dtype=torch.int32, device=DEV),
+                                      None, out_hw=(out_h, out_w), extra=extra)
+        assert rec[0, 2:].tolist() == [0, 0, w, h], rec
+        return np.rint((o[0].cpu().numpy() * std + mean) * 255.0).astype(np.int64)  # (3, out_h, out_w) 8-bit levels
+
+    rgb = lambda a: np.repeat(np.asarray(a, dtype=np.uint8)[..., None], 3, axis=-1)  # noqa: E731
+    for c in fx["resize_area"]:
+        assert run(rgb(c["src"]), c["out_w"], c["out_h"])[1].tolist() == c["out"], c["why"]
+    g = fx["gray"]
+    frame = np.asarray(g["bgr"], dtype=np.uint8).reshape(2, 2, 3)
+    assert run(frame, 2, 2, flags=16)[0].reshape(-1).tolist() == g["gray"]
+    for c in fx["sobel"]:
+        src = rgb(c["gray"])
+        assert run(src, src.shape[1], src.shape[0], flags=1)[2].tolist() == c["out"], c["why"]
+    nz = fx["gaussian_noise"]
+    frame = np.tile(np.asarray(nz["pixel"], dtype=np.uint8), (2, 2, 1))
+    zz = np.tile(np.asarray(nz["z"], dtype=np.float32), (2, 2, 1))
+    assert run(frame, 2, 2, flags=8, noise=zz, noise_std=nz["std"])[:, 0, 0].tolist() == nz["out"]
+
+
+def test_gpu_augmenter_with_every_flag_enabled():
+    """GpuAugmenter with all eleven CLI flags on (--flip included: accepted, and -- like the reference's augmenter -- not implemented):
+    a finite batch with the Appendix-B entries; blur_flag carries the blur coin."""
+    from simhand_amd.host import config as C
+    from simhand_amd.host.config import edict, read_json
+    from simhand_amd.host.data import GpuAugmenter, SyntheticRawPairs
+
+    tp = edict(read_json(C.TRAINING_CONFIG_PATH))
+    for k in list(tp.augmentation_flags):
+        tp.augmentation_flags[k] = True
+    aug = GpuAugmenter(tp.augmentation_flags, tp.augmentation_params, check=True)
+    batch = next(iter(SyntheticRawPairs(aug, 64, 32, 0, 1, 9, torch.device(DEV))))
+    assert torch.isfinite(batch["transformed_image1"]).all() and torch.isfinite(batch["transformed_image2"]).all()
+    assert batch["blur_flag_1"].dtype == torch.bool and 0 < int(batch["blur_flag_1"].sum()) < 32
+    assert tuple(batch["transformed_image1"].shape) == (32, 3, 128, 128)
+
+
 def test_augment_empty_crop_is_loud():
     """A crop box entirely off the canvas: the reference's cv2.resize raises; the kernel emits a NaN image + a zero-size record and
     GpuAugmenter(check=True) raises."""
