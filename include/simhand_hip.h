@@ -528,6 +528,15 @@ int simhand_fp8_scale_update(float* state, uint32_t* amax_new_bits, int history,
 int simhand_fp8_quantize(const void* x, void* q, int64_t count, int dtype, const float* state, uint32_t* amax_bits, sh_stream_t stream);
 int simhand_fp8_pack_krsc(const float* w_oihw, void* q, int k, int c, int r, int s, const float* state, sh_stream_t stream);
 int simhand_conv2d_fwd_fp8_supported(const sh_conv_desc* d);
+/* rows of the bn_partial buffer simhand_conv2d_fwd_fp8 fills ([rows][2][cout]): the layers with >= 256 output channels run on the e4m3
+ * variant of the 256 x 256 LDS-DMA kernel (one scaled K = 128 MFMA per tile pair and k-step), the others on the 128-row kernel */
+int simhand_conv2d_fwd_fp8_stat_blocks(const sh_conv_desc* d);
+/* 1 where the engine routes a layer's forward through fp8 by default: where it measured faster than the bf16 kernel it replaces */
+int simhand_conv2d_fwd_fp8_pays(const sh_conv_desc* d);
+/* BatchNorm-apply (+ReLU) of the unit in front of an fp8 convolution, bf16: a = act(y*scale + shift) AND q = e4m3(clamp(a * q_state[0]))
+ * in one pass, max|a| folded into amax_bits (for simhand_fp8_scale_update) -- replaces simhand_bn_apply + simhand_fp8_quantize. */
+int simhand_bn_apply_fp8(const void* y, const float* scale, const float* shift, int relu, void* a, void* q, const float* q_state,
+                         uint32_t* amax_bits, int64_t m, int c, sh_stream_t stream);
 int simhand_conv2d_fwd_fp8(const sh_conv_desc* d, const void* x_q, const void* w_q, const float* x_state, const float* w_state, void* y,
                            float* bn_partial, sh_stream_t stream);
 

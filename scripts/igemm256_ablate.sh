@@ -7,6 +7,6 @@ mkdir -p ../../scripts/abl build
 for n in ${ABL_SET:-0 4 5}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSH_ABL256=$n -c conv_igemm.hip -o build/conv_igemm_abl$n.o
   objs=$(ls build/*.o | grep -v conv_igemm)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs build/conv_igemm_abl$n.o -o ../../scripts/abl/libabl_$n.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs build/conv_igemm_abl$n.o -ldl -o ../../scripts/abl/libabl_$n.so
 done
 ls -la ../../scripts/abl

@@ -195,6 +195,9 @@ SIGNATURES = {
     "simhand_fp8_quantize": (_I, [_P, _P, _L, _I, _P, _P, _P]),
     "simhand_fp8_pack_krsc": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "simhand_conv2d_fwd_fp8_supported": (_I, [C.POINTER(ConvDesc)]),
+    "simhand_conv2d_fwd_fp8_stat_blocks": (_I, [_P]),
+    "simhand_conv2d_fwd_fp8_pays": (_I, [_P]),
+    "simhand_bn_apply_fp8": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, C.c_int64, _I, _P]),
     "simhand_conv2d_fwd_fp8": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "simhand_augment_workspace_bytes": (_S, [_I]),
     "simhand_augment_batch": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _S, _P]),

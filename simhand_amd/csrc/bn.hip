@@ -258,6 +258,71 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
   }
 }
 
+// bn_apply for the unit in front of an fp8 convolution (BASELINE configs[4]): a = act(y * scale + shift) as bf16 AND its e4m3
+// quantisation q = e4m3(clamp(a * q_state[0], +-448)) in the same pass, with max |a| of this tensor folded into amax_bits (the input of the
+// delayed-scaling ring update) -- the stand-alone simhand_fp8_quantize pass (one read of a, one write of q) disappears.  q is taken from the
+// bf16-ROUNDED value, so q and amax are bit-identical to quantising the stored a afterwards.
+template <bool NT>
+__global__ __launch_bounds__(256) void bn_apply_fp8_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int relu, bf16_t* __restrict__ a,
+                                                           unsigned char* __restrict__ q, const float* __restrict__ q_state,
+                                                           unsigned* __restrict__ amax_bits, int64_t m, int c) {
+  constexpr int VE = 8;
+  const RowWalk w = row_walk<VE>(m, c);
+  const float qs = q_state[0];
+  float amax = 0.f;
+  if (w.rl < w.rowlanes) {
+    for (int cv = w.cv; cv < c / VE; cv += w.span) {
+      float sc[VE], sh[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        sc[e] = scale[cv * VE + e];
+        sh[e] = shift[cv * VE + e];
+      }
+      auto finish = [&](int64_t r, const float(&v)[VE]) __attribute__((always_inline)) {
+        unsigned pk[4];
+        float o[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          o[e] = v[e] * sc[e] + sh[e];
+          if (relu) o[e] = o[e] > 0.f ? o[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
+        st16<NT>(a + r * c + cv * VE, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+        float rr[VE];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          rr[2 * e] = __uint_as_float(pk[e] << 16);
+          rr[2 * e + 1] = __uint_as_float(pk[e] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) amax = fmaxf(amax, fabsf(rr[e]));
+        uint2 qq;
+        qq.x = fp8_pack4(rr[0] * qs, rr[1] * qs, rr[2] * qs, rr[3] * qs);
+        qq.y = fp8_pack4(rr[4] * qs, rr[5] * qs, rr[6] * qs, rr[7] * qs);
+        *reinterpret_cast<uint2*>(q + r * c + cv * VE) = qq;
+      };
+      constexpr int U = 4;
+      int64_t r = w.r0 + w.rl;
+      for (; r + (U - 1) * w.rowlanes < w.r1; r += U * w.rowlanes) {
+        float v[U][VE];
+#pragma unroll
+        for (int u = 0; u < U; ++u) Vec16<bf16_t>::template load<NT>(y + (r + u * w.rowlanes) * c + cv * VE, v[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) finish(r + u * w.rowlanes, v[u]);
+      }
+      for (; r < w.r1; r += w.rowlanes) {
+        float v[VE];
+        Vec16<bf16_t>::template load<NT>(y + r * c + cv * VE, v);
+        finish(r, v);
+      }
+    }
+  }
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0 && amax_bits != nullptr) atomicMax(amax_bits, __float_as_uint(amax));  // bit pattern of a non-negative float: order-preserving
+}
+
 template <typename T, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ da, const T* __restrict__ a,
                                                              const T* __restrict__ y, const float* __restrict__ mean,
@@ -1099,6 +1164,19 @@ int simhand_bn_apply(const void* y, const float* scale, const float* shift, cons
   else { if (g_bn_nt) SH_BN_APPLY(bf16_t, true); else SH_BN_APPLY(bf16_t, false); }
 #undef SH_BN_APPLY
   return check_launch("bn_apply");
+}
+
+int simhand_bn_apply_fp8(const void* y, const float* scale, const float* shift, int relu, void* a, void* q, const float* q_state,
+                         uint32_t* amax_bits, int64_t m, int c, sh_stream_t stream) {
+  SH_REQUIRE(y && scale && shift && a && q && q_state, "bn_apply_fp8: NULL pointer");
+  SH_REQUIRE(c % 8 == 0 && m >= 1, "bn_apply_fp8: c=%d must be a multiple of 8", c);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * 5);
+  route_hit(SH_ROUTE_BN_APPLY);
+  const int grid = row_grid(m, c / 8);
+  if (g_bn_nt) bn_apply_fp8_kernel<true><<<grid, 256, 0, s>>>((const bf16_t*)y, scale, shift, relu, (bf16_t*)a, (unsigned char*)q, q_state, amax_bits, m, c);
+  else bn_apply_fp8_kernel<false><<<grid, 256, 0, s>>>((const bf16_t*)y, scale, shift, relu, (bf16_t*)a, (unsigned char*)q, q_state, amax_bits, m, c);
+  return check_launch("bn_apply_fp8");
 }
 
 int simhand_bn_bwd_partial(const void* da, const void* a, const void* y, const float* mean, const float* invstd,

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
 #include <atomic>
 #include <stdint.h>
 #include <stdio.h>
@@ -135,6 +136,16 @@ __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
   return v;
+}
+
+// 4 floats -> 4 e4m3 bytes (round-to-nearest-even; the clamp saturates: the hardware convert alone would give NaN past 448 in the
+// OCP "fn" encoding)
+__device__ __forceinline__ unsigned fp8_pack4(float a, float b, float c, float d) {
+  auto cl = [](float v) { return fminf(fmaxf(v, -448.f), 448.f); };
+  unsigned r = 0;
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), r, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), r, true);
+  return r;
 }
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

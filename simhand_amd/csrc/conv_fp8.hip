@@ -316,6 +316,13 @@ static inline int grid_for(long long n) {
 
 }  // namespace sh
 
+namespace sh {  // conv_igemm.hip: the e4m3 variant of the 256 x 256 LDS-DMA kernel
+bool igemm256_fp8_ok(const sh_conv_desc* d);
+int igemm256_fp8_stat_rows(const sh_conv_desc* d);
+int igemm256_fp8_fwd(const sh_conv_desc* d, const void* xq, const void* wq, const float* x_state, const float* w_state, void* y, float* bn_partial,
+                     hipStream_t s);
+}  // namespace sh
+
 using namespace sh;
 
 extern "C" {
@@ -362,6 +369,13 @@ int simhand_conv2d_fwd_fp8_supported(const sh_conv_desc* d) {
          (long long)d->n * d->h * d->w * d->cin < (1ll << 31);
 }
 
+/* 1 where the fp8 forward is FASTER than the bf16 one in the engine (round-3 measurements at 2048 images, scripts/fp8_bench.py): the 3x3
+ * layers that run on the e4m3 variant of the 256 x 256 kernel (500 -> 320 us at 256 ch @ 14^2).  The 128-channel 3x3 layers (128-row fp8
+ * kernel: 957 vs 586 us) and the long-K 1x1 layers (the e4m3 copy of their 4x wider input costs more than the matrix time saved) do not. */
+int simhand_conv2d_fwd_fp8_pays(const sh_conv_desc* d) {
+  return d && simhand_conv2d_fwd_fp8_supported(d) && d->r == 3 && d->s == 3 && igemm256_fp8_ok(d) ? 1 : 0;
+}
+
 int simhand_conv2d_fwd_fp8(const sh_conv_desc* d, const void* x_q, const void* w_q, const float* x_state, const float* w_state, void* y,
                            float* bn_partial, sh_stream_t stream) {
   SH_REQUIRE(d && x_q && w_q && x_state && w_state && y, "conv2d_fwd_fp8: NULL pointer");
@@ -382,8 +396,19 @@ int simhand_conv2d_fwd_fp8(const sh_conv_desc* d, const void* x_q, const void* w
   const double bytes = (double)d->n * d->h * d->w * d->cin + 2.0 * (double)a.Mo * d->cout + (double)d->cout * d->cin * d->r * d->s;
   ProfScope ps(SH_PROF_CONV_FWD, s, flops, bytes);
   route_hit(SH_ROUTE_FP8_FWD);
+  if (igemm256_fp8_ok(d)) {  // the matrix-bound layers: e4m3 variant of the 256 x 256 LDS-DMA kernel
+    route_hit(SH_ROUTE_IGEMM256_FWD);
+    return igemm256_fp8_fwd(d, x_q, w_q, x_state, w_state, y, bn_partial, s);
+  }
   igemm_fp8_fwd_kernel<<<a.m_tiles * a.n_tiles, 256, 0, s>>>(a);
   return check_launch("conv2d_fwd_fp8");
+}
+
+/* rows of the bn_partial buffer simhand_conv2d_fwd_fp8 fills: [rows][2][cout] */
+int simhand_conv2d_fwd_fp8_stat_blocks(const sh_conv_desc* d) {
+  if (!d) return 0;
+  if (igemm256_fp8_ok(d)) return igemm256_fp8_stat_rows(d);
+  return (int)(((long long)d->n * d->ho * d->wo + 127) / 128);
 }
 
 }  // extern "C"

@@ -79,6 +79,9 @@ struct IgemmArgs {
   // see split256) and writes its partial-sum rows from part_row_base on
   int m_tile_base = 0;
   int part_row_base = 0;
+  // fp8 forward on the 256 x 256 kernel (BASELINE configs[4]): e4m3 operands, result = acc * x_state[1] * w_state[1] (= 1 / (scale_x scale_w))
+  const float* x_state = nullptr;
+  const float* w_state = nullptr;
 };
 
 template <typename T> struct Mma;
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
   uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2 = make_uint4(0, 0, 0, 0), rb3 = make_uint4(0, 0, 0, 0);
   const char* zsrc = reinterpret_cast<const char*>(g_zero_page) + (tid & 7) * 16;
   auto load_step = [&](bool live) __attribute__((always_inline)) {
-    if (DGRAD && p.a2 != nullptr && l_cs == cs1) {
+    if constexpr (DGRAD) if (p.a2 != nullptr && l_cs == cs1) {
       // second K segment (1x1 / stride 1: pixel index == m): re-base the row and weight pointers so that the same
       // l_cs * KE offsets walk a2 / w2; dead rows keep their h0 = -2^20
       const T* a2 = reinterpret_cast<const T*>(p.a2);
@@ -690,10 +693,16 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
 // MI = 7: 224-row tiles (each wave 112 x 64).  401 408 pixels (256 channels @ 14^2 at 2048 images) are 1568 tiles of 256 rows =
 // 6.125 rounds of the 256 CUs, but exactly 7 rounds of 224-row tiles: no ragged round, no second launch (launch_igemm256).  The
 // A region of a stage keeps 256 rows; rows 224.. fetch the zero page (waves 4-7 skip that DMA altogether).
-template <bool DGRAD, int MI = 8>
+// FP8 (forward only): both operands are e4m3 bytes.  A tile row is still 128 B, now 128 k-elements, so the LDS image, the DMA map and
+// the swizzle do not change; a lane's two 16-B fragment chunks (g and g + 4) together are ONE operand of
+// v_mfma_scale_f32_16x16x128_f8f6f4 (twice the bf16 rate, K = 128 per instruction): 32 instead of 64 matrix instructions per k-step
+// for twice the reduction length -- and half the operand bytes per FLOP, which is what bounds this kernel's loop.
+template <bool DGRAD, int MI = 8, bool FP8 = false>
 __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
-  typedef bf16_t T;
-  constexpr int KE = 64, VE = 8, BM = MI * 32, BN = 256, NI = 4, WR = MI * 16;  // WR: rows per wave
+  static_assert(!(FP8 && DGRAD), "the fp8 variant is forward only");
+  typedef bf16_t T;                                                             // stored results (and bf16 operands)
+  typedef typename std::conditional<FP8, unsigned char, bf16_t>::type IT;     // operand element
+  constexpr int KE = FP8 ? 128 : 64, VE = 8, IVE = FP8 ? 16 : 8, BM = MI * 32, BN = 256, NI = 4, WR = MI * 16;  // WR: rows per wave
   constexpr int A_BYTES = 256 * 128, STAGE = A_BYTES + BN * 128;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   // LDS-DMA as inline asm: hipcc's waitcnt pass makes every ds_read wait for ALL outstanding builtin LDS-DMAs
@@ -756,12 +765,12 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   };
   const int chunk_a = slot ^ ((lrow >> 1) & 7);
   const int chunk_b = slot ^ key_b(lrow);
-  const T* __restrict__ asrc = reinterpret_cast<const T*>(p.a);
-  const T* __restrict__ wsrc = reinterpret_cast<const T*>(p.w);
+  const IT* __restrict__ asrc = reinterpret_cast<const IT*>(p.a);
+  const IT* __restrict__ wsrc = reinterpret_cast<const IT*>(p.w);
   const char* zsrc = reinterpret_cast<const char*>(g_zero_page) + slot * 16;
-  const T* pa0; const T* pa1; const T* pa2; const T* pa3;
+  const IT* pa0; const IT* pa1; const IT* pa2; const IT* pa3;
   int h00, h01, h02, h03, w00, w01, w02, w03;
-  auto init_row = [&](int i, const T*& pa, int& h0, int& w0) __attribute__((always_inline)) {
+  auto init_row = [&](int i, const IT*& pa, int& h0, int& w0) __attribute__((always_inline)) {
     const bool in_tile = lrow + 64 * i < BM;  // MI = 7: rows 224.. of the A region belong to no wave
     const Pixel px = decode(in_tile ? m0 + lrow + 64 * i : 0xffffffffu);
     if (DGRAD) {
@@ -771,7 +780,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
       h0 = px.hd * p.stride - p.pad;
       w0 = px.wd * p.stride - p.pad;
     }
-    pa = asrc + ((long long)px.img * p.Hs * p.Ws + (long long)h0 * p.Ws + w0) * p.lda + chunk_a * VE;
+    pa = asrc + ((long long)px.img * p.Hs * p.Ws + (long long)h0 * p.Ws + w0) * p.lda + chunk_a * IVE;
     if (!px.ok) h0 = -(1 << 20);
   };
   init_row(0, pa0, h00, w00);
@@ -779,7 +788,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   init_row(2, pa2, h02, w02);
   init_row(3, pa3, h03, w03);
   const long long wrow = (long long)p.R * p.S * p.lda;
-  const T* pb0 = wsrc + (long long)(n0 + lrow) * wrow + chunk_b * VE;
+  const IT* pb0 = wsrc + (long long)(n0 + lrow) * wrow + chunk_b * IVE;
   long long wrow64 = 64 * wrow;
   const int cs1 = p.lda / KE;  // k-steps of the first K segment (== csteps without a second one)
   const int dma_row0 = wave * 8 * 128;  // + i * 64 * 128: wave-uniform LDS offset of this wave's 8 rows
@@ -790,16 +799,16 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   unsigned n_dA = 0;
   bool n_live = true;  // false on the last k-step: its (branch-free) DMAs fetch the zero page into the idle stage
   auto next_step = [&](int stage) __attribute__((always_inline)) {
-    if (DGRAD && p.a2 != nullptr && l_cs == cs1) {
+    if constexpr (DGRAD) if (p.a2 != nullptr && l_cs == cs1) {
       // second K segment (1x1 / stride 1: pixel index == m): re-base the row and weight pointers so that the same
       // l_cs * KE offsets walk a2 / w2; dead rows keep their h0 = -2^20
-      const T* a2 = reinterpret_cast<const T*>(p.a2);
+      const IT* a2 = reinterpret_cast<const IT*>(p.a2);
       const long long back = -(long long)cs1 * KE;
       pa0 = a2 + (long long)(m0 + lrow) * p.Ca2 + chunk_a * VE + back;
       pa1 = a2 + (long long)(m0 + lrow + 64) * p.Ca2 + chunk_a * VE + back;
       pa2 = a2 + (long long)(m0 + lrow + 128) * p.Ca2 + chunk_a * VE + back;
       pa3 = a2 + (long long)(m0 + lrow + 192) * p.Ca2 + chunk_a * VE + back;
-      pb0 = reinterpret_cast<const T*>(p.w2) + (long long)(n0 + lrow) * p.Ca2 + chunk_b * VE + back;
+      pb0 = reinterpret_cast<const IT*>(p.w2) + (long long)(n0 + lrow) * p.Ca2 + chunk_b * VE + back;
       wrow64 = 64ll * p.Ca2;
     }
     n_hoff = dh * l_tr;
@@ -817,7 +826,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   };
   // part q of the 8 DMA instructions of a k-step: 0-3 = A rows lrow + 64 q, 4-7 = weight rows lrow + 64 (q - 4)
   auto dma_part = [&](int q) __attribute__((always_inline)) {
-    auto dma_a = [&](const T* pa, int h0, int w0, int i) __attribute__((always_inline)) {
+    auto dma_a = [&](const IT* pa, int h0, int w0, int i) __attribute__((always_inline)) {
       const bool ok = n_live && (unsigned)(h0 + n_hoff) < (unsigned)p.Hs && (unsigned)(w0 + n_woff) < (unsigned)p.Ws;
       const char* src = ok ? reinterpret_cast<const char*>(pa + n_aoff) : zsrc;
       dma16(src, n_dA + i * 64 * 128);
@@ -871,6 +880,49 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     n_live = kt + 1 < nk;  // last step: the (branch-free) DMAs fetch the zero page into the idle stage
     next_step((kt + 1) & 1);
     const char* st = smem + (kt & 1) * STAGE;
+    if constexpr (FP8) {
+      // one scaled MFMA per 16 x 16 tile pair and k-step: operand = the lane's chunks g (k 0..63 half) and g + 4 of its tile row
+      typedef __attribute__((ext_vector_type(8))) int i32x8;
+      uint4 fbl[NI], fbh[NI], fal[2][2], fah[2][2];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        fbl[ni] = *reinterpret_cast<const uint4*>(st + fbo + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
+        fbh[ni] = *reinterpret_cast<const uint4*>(st + (fbo ^ 64) + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
+      }
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        fal[0][h2] = *reinterpret_cast<const uint4*>(st + fa_base + h2 * 16 * 128 + fo0);
+        fah[0][h2] = *reinterpret_cast<const uint4*>(st + fa_base + h2 * 16 * 128 + (fo0 ^ 64));
+      }
+      auto pack8 = [](const uint4& lo, const uint4& hi) __attribute__((always_inline)) -> i32x8 {
+        i32x8 r = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        return r;
+      };
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < 3) {
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            if (2 * (q + 1) + h2 < MI) {
+              fal[(q + 1) & 1][h2] = *reinterpret_cast<const uint4*>(st + fa_base + (2 * (q + 1) + h2) * 16 * 128 + fo0);
+              fah[(q + 1) & 1][h2] = *reinterpret_cast<const uint4*>(st + fa_base + (2 * (q + 1) + h2) * 16 * 128 + (fo0 ^ 64));
+            }
+          }
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          if (2 * q + h2 < MI) {
+            const i32x8 xa = pack8(fal[q & 1][h2], fah[q & 1][h2]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[2 * q + h2][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pack8(fbl[ni], fbh[ni]), xa, acc[2 * q + h2][ni], 0, 0, 0,
+                                                                                     0x7f7f7f7f, 0, 0x7f7f7f7f);
+          }
+        }
+        dma_part(2 * q);
+        dma_part(2 * q + 1);
+      }
+    } else {
     uint4 fb[2][NI], fa[2][2];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) fb[0][ni] = *reinterpret_cast<const uint4*>(st + fbo + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
@@ -903,8 +955,16 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         dma_part(2 * grp + 1);
       }
     }
+      }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS is reused by the epilogues
+  if constexpr (FP8) {  // per-tensor scales: one multiply per accumulator, before the statistics and the stores
+    const float descale = p.x_state[1] * p.w_state[1];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] *= descale;
+  }
 
   // ---- fused BatchNorm partial statistics (forward): lane holds pixel wm*128 + mi*16 + li, channels wn*64 + chan_of(ni, 4g + r)
   if (!DGRAD && p.bn_partial != nullptr) {
@@ -1182,7 +1242,7 @@ static int launch_igemm(const IgemmArgs& a0, hipStream_t s) {
 // fraction of a round.  main_m = m-tiles of the 256-row launch, tail128 = 128-row m-tiles of the second one.
 static hook_t g_split256{1};
 static hook_t g_tile224{1};
-static void split256(long long Mg, int Ng, int classes, int* main_m, int* tail128, int* bm = nullptr) {
+static void split256(long long Mg, int Ng, int classes, int* main_m, int* tail128, int* bm = nullptr, bool allow_tail = true) {
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;
@@ -1206,7 +1266,7 @@ static void split256(long long Mg, int Ng, int classes, int* main_m, int* tail12
       return;
     }
   }
-  if (!g_split256 || classes != 1 || total <= cus || rem == 0 || 3 * rem > cus) return;
+  if (!allow_tail || !g_split256 || classes != 1 || total <= cus || rem == 0 || 3 * rem > cus) return;
   const int tail_m = ceil_div(rem, n_tiles);
   *main_m = tiles_m - tail_m;
   *tail128 = ceil_div(Mg - (long long)*main_m * 256, 128);
@@ -1233,6 +1293,46 @@ static int launch_igemm256(IgemmArgs a, hipStream_t s) {
     igemm_kernel<bf16_t, DGRAD, 128><<<t.m_tiles * t.n_tiles, 256, 0, s>>>(t);
   }
   return check_launch(DGRAD ? "conv2d_dgrad (256x256)" : "conv2d_fwd (256x256)");
+}
+
+// ---- fp8 forward on the 256 x 256 kernel (entry point: simhand_conv2d_fwd_fp8, conv_fp8.hip) ----------------------------------
+// eligibility mirrors use_256: >= 256 output channels in multiples of 256, cin a multiple of 128 (one k-step = 128 e4m3 bytes of a
+// row), a reduction of at least 8 k-steps, enough pixels to fill the chip.  No 128-row tail launch (there is no fp8 128-row twin of
+// the bf16 tail kernel): the last round of a launch may be ragged.
+bool igemm256_fp8_ok(const sh_conv_desc* d) {
+  if (!g_use_256 || d->cout % 256 != 0 || d->cin % 128 != 0) return false;
+  const long long mg = (long long)d->n * d->ho * d->wo;
+  return g_use_256 == 2 || ((long long)d->r * d->s * d->cin >= 1024 && mg >= 256 * 64);
+}
+int igemm256_fp8_stat_rows(const sh_conv_desc* d) {
+  int main_m, tail128, bm;
+  split256((long long)d->n * d->ho * d->wo, d->cout, 1, &main_m, &tail128, &bm, false);
+  return main_m;
+}
+int igemm256_fp8_fwd(const sh_conv_desc* d, const void* xq, const void* wq, const float* x_state, const float* w_state, void* y, float* bn_partial,
+                     hipStream_t s) {
+  IgemmArgs a;
+  a.a = xq; a.w = wq; a.out = y; a.bn_partial = bn_partial;
+  a.Mg = (long long)d->n * d->ho * d->wo;
+  a.Ng = d->cout; a.Ca = d->cin; a.lda = d->cin;
+  a.R = d->r; a.S = d->s; a.stride = d->stride; a.pad = d->pad;
+  a.Hd = d->ho; a.Wd = d->wo; a.Hs = d->h; a.Ws = d->w;
+  a.accumulate = 0; a.res_grad = nullptr; a.res_mask = nullptr;
+  a.classes = 1; a.Hq = a.Wq = 0;
+  a.stem_hp = a.stem_wp = 0;
+  a.fy = nullptr; a.fscale = a.fshift = nullptr; a.fmask = nullptr; a.fmode = 0; a.fpartial = nullptr; a.bias = nullptr;
+  a.ep_scale = a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_mask = nullptr; a.ep_relu = 0;
+  a.x_state = x_state; a.w_state = w_state;
+  a.div_hw = make_fastdiv((unsigned)(a.Hd * a.Wd));
+  a.div_w = make_fastdiv((unsigned)a.Wd);
+  int main_m, tail128, bm;
+  split256(a.Mg, a.Ng, 1, &main_m, &tail128, &bm, false);
+  a.m_tiles = main_m;
+  a.n_tiles = a.Ng / 256;
+  const int nblk = a.m_tiles * a.n_tiles;
+  if (bm == 224) igemm256_kernel<false, 7, true><<<nblk, 512, 0, s>>>(a);
+  else igemm256_kernel<false, 8, true><<<nblk, 512, 0, s>>>(a);
+  return check_launch("conv2d_fwd_fp8 (256x256)");
 }
 
 // rows of the partial-sum buffers a 256 x 256 launch writes

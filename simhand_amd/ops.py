@@ -845,6 +845,23 @@ class FP8Scaler:
         self.calls += 1
         return q
 
+    def bn_apply_quantize(self, y: torch.Tensor, st: "BNState", relu: bool):
+        """(a, q): a = act(y*scale + shift) in bf16 and its e4m3 codes with this site's scale from ONE pass over y (simhand_bn_apply_fp8);
+        bit-identical to bn_apply followed by quantize.  The first call of a delayed site has no history yet and runs the two-pass form."""
+        c = y.shape[-1]
+        m = y.numel() // c
+        if not self.delayed or self.calls == 0:
+            a = bn_apply(y, st, m, c, relu)
+            return a, self.quantize(a)
+        lib = _lib_dev()
+        a = torch.empty_like(y)
+        q = torch.empty(y.shape, dtype=torch.uint8, device=y.device)
+        check(lib.simhand_bn_apply_fp8(_ptr(y, torch.bfloat16), _ptr(st.scale), _ptr(st.shift), int(relu), _ptr(a), _ptr(q), _ptr(self.state),
+                                       _ptr(self.amax_bits), m, c, _stream()), "bn_apply_fp8")
+        self._update(True)
+        self.calls += 1
+        return a, q
+
     def pack_weights(self, w_oihw: torch.Tensor) -> torch.Tensor:
         lib = _lib_dev()
         k, c, r, s = w_oihw.shape
@@ -860,11 +877,16 @@ def conv2d_fwd_fp8_supported(d: ConvDesc) -> bool:
     return bool(_lib.load().simhand_conv2d_fwd_fp8_supported(C.byref(d)))
 
 
+def conv2d_fwd_fp8_pays(d: ConvDesc) -> bool:
+    """The layers whose fp8 forward measured faster than their bf16 kernel (the engine's default fp8 set)."""
+    return bool(_lib.load().simhand_conv2d_fwd_fp8_pays(C.byref(d)))
+
+
 def conv2d_fwd_fp8(d: ConvDesc, x_q, w_q, x_scaler: FP8Scaler, w_scaler: FP8Scaler, want_stats: bool = True):
     """y (bf16) = conv(x_q, w_q) / (scale_x * scale_w) on the e4m3 scaled-MFMA kernel; BN partial sums as conv2d_fwd."""
     lib = _lib_dev()
     y = torch.empty(d.n, d.ho, d.wo, d.cout, dtype=torch.bfloat16, device=x_q.device)
-    part = torch.empty((d.n * d.ho * d.wo + 127) // 128, 2, d.cout, dtype=torch.float32, device=x_q.device) if want_stats else None
+    part = torch.empty(lib.simhand_conv2d_fwd_fp8_stat_blocks(C.byref(d)), 2, d.cout, dtype=torch.float32, device=x_q.device) if want_stats else None
     check(lib.simhand_conv2d_fwd_fp8(C.byref(d), _ptr(x_q, torch.uint8), _ptr(w_q, torch.uint8), _ptr(x_scaler.state), _ptr(w_scaler.state), _ptr(y),
                                      _ptr(part), _stream()), "conv2d_fwd_fp8")
     return y, part

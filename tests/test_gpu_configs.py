@@ -364,3 +364,48 @@ def test_config2_loss_at_n16384_eight_row_shards():
     sp_all = (Z[:B] * Z[B:]).sum(dim=1)
     want_loss = float(-(torch.cat((wpos * sp_all, wpos * sp_all)) / t - torch.log(neg)).mean())
     assert abs(l8 - want_loss) <= 2e-5 * abs(want_loss), (l8, want_loss)
+
+
+def test_config4_simclr_loss_at_n32768_eight_row_shards():
+    """BASELINE configs[4] loss size: ResNet-50 `simclr` (no weighting), B = 16 384 pairs -> N = 32 768 rows, as the 8 row shards an 8-GPU
+    run uses (one GPU plays all ranks).  The loss arithmetic of that config is fp32 whatever the convolutions' operand type is.
+      (1) sharded == unsharded; (2) central finite difference along the gradient reproduces |dL/dz|;
+      (3) the loss and dL/dz of a 256-row slice against the closed form in fp64 on the host (src/models/utils.py:157-189:
+          S = z z^T, neg_i = sum_{j != i} exp(S_ij / tau), L = -mean_i [S_i,pair(i) / tau - log neg_i])."""
+    from tests.test_gpu_loss import _hip_loss
+
+    B = 16384
+    N = 2 * B
+    gen = torch.Generator().manual_seed(29)
+    z1 = torch.nn.functional.normalize(torch.randn(B, 128, generator=gen))
+    z2 = torch.nn.functional.normalize(z1 + 0.5 * torch.randn(B, 128, generator=gen))
+    l1, dz1 = _hip_loss(z1, z2, None, None, "mpjpe", None, "pos_neg", ranks=1)
+    l8, dz8 = _hip_loss(z1, z2, None, None, "mpjpe", None, "pos_neg", ranks=8)
+    assert abs(l1 - l8) <= 2e-6 * abs(l1), (l1, l8)
+    assert (dz1 - dz8).abs().max() <= 1e-5 * dz1.abs().max()
+    v = dz8 / dz8.norm()
+    eps = 0.25
+    lp, _ = _hip_loss(z1 + eps * v[:B], z2 + eps * v[B:], None, None, "mpjpe", None, "pos_neg", ranks=8, backward=False)
+    lm, _ = _hip_loss(z1 - eps * v[:B], z2 - eps * v[B:], None, None, "mpjpe", None, "pos_neg", ranks=8, backward=False)
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd - dz8.norm().item()) <= 2e-2 * dz8.norm().item(), (fd, dz8.norm().item())
+    # fp64 closed form on the host, chunked (N x N never materialised)
+    Z = torch.cat((z1, z2)).double()
+    t = 0.5
+    neg = torch.empty(N, dtype=torch.float64)
+    CH = 1024
+    for r0 in range(0, N, CH):
+        e = torch.exp(Z[r0:r0 + CH] @ Z.t() / t)
+        idx = torch.arange(r0, r0 + CH)
+        e[idx - r0, idx] = 0.0
+        neg[r0:r0 + CH] = e.sum(dim=1)
+    sp = (Z[:B] * Z[B:]).sum(dim=1)
+    want_loss = float(-(torch.cat((sp, sp)) / t - torch.log(neg)).mean())
+    assert abs(l8 - want_loss) <= 2e-5 * abs(want_loss), (l8, want_loss)
+    rows = torch.arange(9000, 9256)  # view-1 rows; partners are rows B + k
+    e = torch.exp(Z[rows] @ Z.t() / t)
+    e[torch.arange(256), rows] = 0.0
+    coef = e * (1.0 / neg[rows, None] + 1.0 / neg[None, :]) / (t * N)
+    want_dz = coef @ Z - 2.0 / (t * N) * Z[B + rows]
+    err = (dz8[rows].double() - want_dz).abs().max() / want_dz.abs().max()
+    assert err <= 2e-4, err
