@@ -319,8 +319,16 @@ __global__ __launch_bounds__(256) void bn_apply_fp8_kernel(const bf16_t* __restr
       }
     }
   }
+  // one atomic per BLOCK at most, and only when it would raise the running maximum; the bit pattern of a non-negative float is
+  // order-preserving
   amax = wave_max(amax);
-  if ((threadIdx.x & 63) == 0 && amax_bits != nullptr) atomicMax(amax_bits, __float_as_uint(amax));  // bit pattern of a non-negative float: order-preserving
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0 && amax_bits != nullptr) {
+    const unsigned bits = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (bits > __atomic_load_n(amax_bits, __ATOMIC_RELAXED)) atomicMax(amax_bits, bits);
+  }
 }
 
 template <typename T, bool NT>
