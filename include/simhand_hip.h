@@ -325,7 +325,16 @@ typedef struct sh_dgrad_opts {
   const void* wt2;
   int32_t c2;
   const sh_dy_src* dy_src;
+  /* fp8 data gradient (BASELINE configs[4]; only where simhand_conv2d_dgrad_fp8_pays(d)): the reduction runs over e4m3 operands on the
+   * 256 x 256 kernel's scaled-MFMA variant -- dy_q [pixels][cout] e4m3 codes of dy (scale state dy_state), wt_q CRSK e4m3 weights
+   * (state w_state); result = acc / (scale_dy scale_w) before every epilogue option above (bias, accumulate, merges, fused sums).
+   * `dy` / `wt` may still be passed (ignored).  No second reduction segment, no dy_src. */
+  const void* dy_q;
+  const void* wt_q;
+  const float* dy_state;
+  const float* w_state;
 } sh_dgrad_opts;
+int simhand_conv2d_dgrad_fp8_pays(const sh_conv_desc* d);
 int simhand_conv2d_dgrad_concat_ok(const sh_conv_desc* d, int c2);
 int simhand_conv2d_dgrad_dysrc_ok(const sh_conv_desc* d);
 int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, const sh_dgrad_opts* opts, sh_stream_t stream);
@@ -535,6 +544,11 @@ int simhand_conv2d_fwd_fp8_stat_blocks(const sh_conv_desc* d);
 int simhand_conv2d_fwd_fp8_pays(const sh_conv_desc* d);
 /* BatchNorm-apply (+ReLU) of the unit in front of an fp8 convolution, bf16: a = act(y*scale + shift) AND q = e4m3(clamp(a * q_state[0]))
  * in one pass, max|a| folded into amax_bits (for simhand_fp8_scale_update) -- replaces simhand_bn_apply + simhand_fp8_quantize. */
+/* simhand_bn_bwd_apply (modes as there, bf16) that ALSO emits q = e4m3(clamp(dy * q_state[0])) and folds max|dy| into amax_bits: the
+ * operand of the fp8 data gradient leaves the BatchNorm-backward pass that produces dy. */
+int simhand_bn_bwd_apply_fp8(const void* da, const void* a, const void* y, const float* mean, const float* invstd, const float* gamma,
+                             const float* dgamma, const float* dbeta, const float* scale, const float* shift, int relu, void* dy, void* q,
+                             const float* q_state, uint32_t* amax_bits, int64_t m, int c, sh_stream_t stream);
 int simhand_bn_apply_fp8(const void* y, const float* scale, const float* shift, int relu, void* a, void* q, const float* q_state,
                          uint32_t* amax_bits, int64_t m, int c, sh_stream_t stream);
 int simhand_conv2d_fwd_fp8(const sh_conv_desc* d, const void* x_q, const void* w_q, const float* x_state, const float* w_state, void* y,

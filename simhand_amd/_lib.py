@@ -70,7 +70,7 @@ class DgradOpts(C.Structure):
     """sh_dgrad_opts (include/simhand_hip.h)."""
     _fields_ = [("accumulate", C.c_int32), ("res_grad", C.c_void_p), ("res_mask", C.c_void_p), ("bias", C.c_void_p),
                 ("fuse", C.POINTER(BnBwdFuse)), ("x2", C.c_void_p), ("wt2", C.c_void_p), ("c2", C.c_int32),
-                ("dy_src", C.POINTER(DySrc))]
+                ("dy_src", C.POINTER(DySrc)), ("dy_q", C.c_void_p), ("wt_q", C.c_void_p), ("dy_state", C.c_void_p), ("w_state", C.c_void_p)]
 
 
 class ConvDesc(C.Structure):
@@ -197,6 +197,8 @@ SIGNATURES = {
     "simhand_conv2d_fwd_fp8_supported": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_fwd_fp8_stat_blocks": (_I, [_P]),
     "simhand_conv2d_fwd_fp8_pays": (_I, [_P]),
+    "simhand_conv2d_dgrad_fp8_pays": (_I, [_P]),
+    "simhand_bn_bwd_apply_fp8": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, C.c_int64, _I, _P]),
     "simhand_bn_apply_fp8": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, C.c_int64, _I, _P]),
     "simhand_conv2d_fwd_fp8": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "simhand_augment_workspace_bytes": (_S, [_I]),

@@ -470,6 +470,84 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 
+// bn_bwd_apply (bf16) that also emits the e4m3 codes of dy (from its bf16-rounded value) and folds max |dy| into amax_bits: the operand
+// of the fp8 data gradient leaves the pass that produces dy (see bn_apply_fp8_kernel).
+template <bool NT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fp8_kernel(const bf16_t* __restrict__ da, const bf16_t* __restrict__ a,
+                                                               const bf16_t* __restrict__ y, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                               bf16_t* __restrict__ dy, unsigned char* __restrict__ q,
+                                                               const float* __restrict__ q_state, unsigned* __restrict__ amax_bits, int64_t m,
+                                                               int c, float inv_m) {
+  constexpr int VE = 8;
+  const RowWalk w = row_walk<VE>(m, c);
+  const float qs = q_state[0];
+  float amax = 0.f;
+  if (w.rl < w.rowlanes) {
+    for (int cv = w.cv; cv < c / VE; cv += w.span) {
+      float mu[VE], is[VE], A[VE], k2[VE], k3[VE], sc[VE], sh[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const int ch = cv * VE + e;
+        mu[e] = mean[ch];
+        is[e] = invstd[ch];
+        A[e] = (gamma ? gamma[ch] : 1.0f) * is[e];
+        k2[e] = dbeta[ch] * inv_m;
+        k3[e] = A[e] * dgamma[ch] * inv_m;
+        sc[e] = relu == 2 ? scale[ch] : 0.f;
+        sh[e] = relu == 2 ? shift[ch] : 0.f;
+      }
+      for (int64_t r = w.r0 + w.rl; r < w.r1; r += w.rowlanes) {
+        const int64_t off = r * c + cv * VE;
+        float g[VE], yy[VE];
+        Vec16<bf16_t>::template load<NT>(da + off, g);
+        Vec16<bf16_t>::template load<NT>(y + off, yy);
+        if (relu == 1) {
+          float aa[VE];
+          Vec16<bf16_t>::load(a + off, aa);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) g[e] = aa[e] > 0.f ? g[e] : 0.f;
+        } else if (relu == 2) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) g[e] = yy[e] * sc[e] + sh[e] > 0.f ? g[e] : 0.f;
+        } else if (relu == 3) {
+          const unsigned bits = reinterpret_cast<const uint8_t*>(a)[r * (c / VE) + cv];
+#pragma unroll
+          for (int e = 0; e < VE; ++e) g[e] = (bits >> e) & 1u ? g[e] : 0.f;
+        }
+        unsigned pk[4];
+        float rr[VE];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float o0 = A[2 * e] * (g[2 * e] - k2[2 * e]) - (yy[2 * e] - mu[2 * e]) * is[2 * e] * k3[2 * e];
+          const float o1 = A[2 * e + 1] * (g[2 * e + 1] - k2[2 * e + 1]) - (yy[2 * e + 1] - mu[2 * e + 1]) * is[2 * e + 1] * k3[2 * e + 1];
+          pk[e] = pack_bf16x2(o0, o1);
+          rr[2 * e] = __uint_as_float(pk[e] << 16);
+          rr[2 * e + 1] = __uint_as_float(pk[e] & 0xffff0000u);
+        }
+        st16<NT>(dy + off, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+#pragma unroll
+        for (int e = 0; e < VE; ++e) amax = fmaxf(amax, fabsf(rr[e]));
+        uint2 qq;
+        qq.x = fp8_pack4(rr[0] * qs, rr[1] * qs, rr[2] * qs, rr[3] * qs);
+        qq.y = fp8_pack4(rr[4] * qs, rr[5] * qs, rr[6] * qs, rr[7] * qs);
+        *reinterpret_cast<uint2*>(q + off) = qq;
+      }
+    }
+  }
+  amax = wave_max(amax);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0 && amax_bits != nullptr) {
+    const unsigned bits = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (bits > __atomic_load_n(amax_bits, __ATOMIC_RELAXED)) atomicMax(amax_bits, bits);
+  }
+}
+
+
 // ---- stem block: BatchNorm + ReLU + MaxPool(3, 2, 1) fused, forward and backward ------------------------------------------
 // Replaces (reference): bn1 -> relu -> maxpool of torchvision's ResNet stem (src/models/resnet_model.py:13-26) and
 // their autograd backward.  The 112x112x64 activation between ReLU and the pool (3.3 GB at 2048 images, bf16) is never
@@ -1258,6 +1336,25 @@ int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const flo
   else { if (g_bn_nt) SH_BN_BA(bf16_t, true); else SH_BN_BA(bf16_t, false); }
 #undef SH_BN_BA
   return check_launch("bn_bwd_apply");
+}
+
+int simhand_bn_bwd_apply_fp8(const void* da, const void* a, const void* y, const float* mean, const float* invstd, const float* gamma,
+                             const float* dgamma, const float* dbeta, const float* scale, const float* shift, int relu, void* dy, void* q,
+                             const float* q_state, uint32_t* amax_bits, int64_t m, int c, sh_stream_t stream) {
+  SH_REQUIRE(da && y && mean && invstd && dgamma && dbeta && dy && q && q_state, "bn_bwd_apply_fp8: NULL pointer");
+  SH_REQUIRE(relu >= 0 && relu <= 3, "bn_bwd_apply_fp8: relu mode %d", relu);
+  SH_REQUIRE((relu != 1 && relu != 3) || a, "bn_bwd_apply_fp8: relu modes 1 / 3 need the activation output / its bit mask");
+  SH_REQUIRE(relu != 2 || (scale && shift), "bn_bwd_apply_fp8: relu mode 2 needs scale/shift");
+  SH_REQUIRE(c % 8 == 0, "bn_bwd_apply_fp8: c=%d not a multiple of 8", c);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * 7);
+  route_hit(SH_ROUTE_BN_BWD_APPLY);
+  const float inv_m = (float)(1.0 / (double)m);
+  const int grid = row_grid(m, c / 8);
+#define SH_BN_BAQ(NT) bn_bwd_apply_fp8_kernel<NT><<<grid, 256, 0, s>>>((const bf16_t*)da, (const bf16_t*)a, (const bf16_t*)y, mean, invstd, gamma, dgamma, dbeta, scale, shift, relu, (bf16_t*)dy, (unsigned char*)q, q_state, amax_bits, m, c, inv_m)
+  if (g_bn_nt) SH_BN_BAQ(true); else SH_BN_BAQ(false);
+#undef SH_BN_BAQ
+  return check_launch("bn_bwd_apply_fp8");
 }
 
 int simhand_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, void* ywin, int n, int h,

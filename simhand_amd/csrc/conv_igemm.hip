@@ -693,13 +693,12 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
 // MI = 7: 224-row tiles (each wave 112 x 64).  401 408 pixels (256 channels @ 14^2 at 2048 images) are 1568 tiles of 256 rows =
 // 6.125 rounds of the 256 CUs, but exactly 7 rounds of 224-row tiles: no ragged round, no second launch (launch_igemm256).  The
 // A region of a stage keeps 256 rows; rows 224.. fetch the zero page (waves 4-7 skip that DMA altogether).
-// FP8 (forward only): both operands are e4m3 bytes.  A tile row is still 128 B, now 128 k-elements, so the LDS image, the DMA map and
+// FP8: both operands are e4m3 bytes (forward; data gradient without a second reduction segment).  A tile row is still 128 B, now 128 k-elements, so the LDS image, the DMA map and
 // the swizzle do not change; a lane's two 16-B fragment chunks (g and g + 4) together are ONE operand of
 // v_mfma_scale_f32_16x16x128_f8f6f4 (twice the bf16 rate, K = 128 per instruction): 32 instead of 64 matrix instructions per k-step
 // for twice the reduction length -- and half the operand bytes per FLOP, which is what bounds this kernel's loop.
 template <bool DGRAD, int MI = 8, bool FP8 = false>
 __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
-  static_assert(!(FP8 && DGRAD), "the fp8 variant is forward only");
   typedef bf16_t T;                                                             // stored results (and bf16 operands)
   typedef typename std::conditional<FP8, unsigned char, bf16_t>::type IT;     // operand element
   constexpr int KE = FP8 ? 128 : 64, VE = 8, IVE = FP8 ? 16 : 8, BM = MI * 32, BN = 256, NI = 4, WR = MI * 16;  // WR: rows per wave
@@ -1335,6 +1334,32 @@ int igemm256_fp8_fwd(const sh_conv_desc* d, const void* xq, const void* wq, cons
   return check_launch("conv2d_fwd_fp8 (256x256)");
 }
 
+static int stat_rows256(long long Mg, int Ng, int classes);
+static bool dgrad_fp8_ok(const sh_conv_desc* d) {  // the 3x3 layers the 256 x 256 kernel takes, K = cout in whole 128-element k-steps
+  const long long mg = d->stride == 2 ? (long long)d->n * ((d->h + 1) / 2) * ((d->w + 1) / 2) : (long long)d->n * d->h * d->w;
+  return d->dtype == SH_BF16 && d->r == 3 && d->s == 3 && d->cout % 128 == 0 && d->cin % 256 == 0 && use_256_dgrad(d, mg) &&
+         (long long)d->r * d->s * d->cout >= 1024;
+}
+static int launch_igemm256_fp8_dgrad(IgemmArgs a, hipStream_t s) {
+  if (a.lda == 0) a.lda = a.Ca;
+  int main_m, tail128, bm;
+  split256(a.Mg, a.Ng, a.classes, &main_m, &tail128, &bm, false);
+  a.m_tiles = main_m;
+  a.n_tiles = a.Ng / 256;
+  const int nblk = a.classes * a.m_tiles * a.n_tiles;
+  route_hit(SH_ROUTE_IGEMM256_DGRAD);
+  route_hit(SH_ROUTE_FP8_DGRAD);
+  if (a.fpartial != nullptr) {
+    // the caller sized the partial-sum buffer with simhand_conv2d_dgrad_stat_blocks (the bf16 plan, which may hand a ragged last round
+    // to a 128-row tail launch = more rows than this single launch writes): rows nobody writes must read as zero
+    const size_t rows = (size_t)stat_rows256(a.Mg, a.Ng, a.classes);
+    if (hipMemsetAsync(a.fpartial, 0, rows * 2 * a.Ng * sizeof(float), s) != hipSuccess) return check_launch("conv2d_dgrad fp8 memset");
+  }
+  if (bm == 224) igemm256_kernel<true, 7, true><<<nblk, 512, 0, s>>>(a);
+  else igemm256_kernel<true, 8, true><<<nblk, 512, 0, s>>>(a);
+  return check_launch("conv2d_dgrad fp8 (256x256)");
+}
+
 // rows of the partial-sum buffers a 256 x 256 launch writes
 static int stat_rows256(long long Mg, int Ng, int classes) {
   int main_m, tail128, bm;
@@ -1640,8 +1665,15 @@ static bool concat_ok(const sh_conv_desc* d, int c2) {
 static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
                       const unsigned char* res_mask, sh_stream_t stream, const sh_bn_bwd_fuse* fuse = nullptr,
                       const float* bias = nullptr, const void* x2 = nullptr, const void* wt2 = nullptr, int c2 = 0,
-                      const sh_dy_src* src = nullptr) {
+                      const sh_dy_src* src = nullptr, const sh_dgrad_opts* f8 = nullptr) {
   if (check_desc(d, "conv2d_dgrad")) return 1;
+  if (f8 != nullptr && f8->dy_q == nullptr) f8 = nullptr;
+  if (f8 != nullptr) {
+    SH_REQUIRE(f8->wt_q && f8->dy_state && f8->w_state, "conv2d_dgrad_ex: fp8 operands need wt_q and both scale states");
+    SH_REQUIRE(x2 == nullptr && src == nullptr && dgrad_fp8_ok(d), "conv2d_dgrad_ex: fp8 operands only where simhand_conv2d_dgrad_fp8_pays(d)");
+    dy = f8->dy_q;
+    wt = f8->wt_q;
+  }
   if (src != nullptr) {
     SH_REQUIRE(src->da && src->y && src->scale && src->shift && src->coef_a && src->coef_b && src->coef_c && src->dy_out,
                "conv2d_dgrad_ex: dy_src has a NULL member");
@@ -1722,9 +1754,16 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   }
   if (use_c64_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr)
     return launch_c64_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream);
+  if (f8 != nullptr) {
+    a.x_state = f8->dy_state;
+    a.w_state = f8->w_state;
+    return launch_igemm256_fp8_dgrad(a, (hipStream_t)stream);
+  }
   if (use_256_dgrad(d, a.Mg)) return launch_igemm256<true>(a, (hipStream_t)stream);
   return d->dtype == SH_F32 ? launch_igemm<float, true>(a, (hipStream_t)stream) : launch_igemm<bf16_t, true>(a, (hipStream_t)stream);
 }
+
+int simhand_conv2d_dgrad_fp8_pays(const sh_conv_desc* d) { return d != nullptr && check_desc(d, "conv2d_dgrad_fp8_pays") == 0 && dgrad_fp8_ok(d) ? 1 : 0; }
 
 int simhand_conv2d_dgrad(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, sh_stream_t stream) {
   return dgrad_impl(d, dy, wt, dx, accumulate ? 1 : 0, nullptr, nullptr, stream);
@@ -1769,7 +1808,7 @@ int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* w
   SH_REQUIRE(o != nullptr, "conv2d_dgrad_ex: opts is NULL");
   SH_REQUIRE(o->accumulate >= 0 && o->accumulate <= 2, "conv2d_dgrad_ex: accumulate mode %d", o->accumulate);
   SH_REQUIRE(o->accumulate != 2 || (o->res_grad && o->res_mask), "conv2d_dgrad_ex: accumulate 2 needs res_grad / res_mask");
-  return dgrad_impl(d, dy, wt, dx, o->accumulate, o->res_grad, o->res_mask, stream, o->fuse, o->bias, o->x2, o->wt2, o->c2, o->dy_src);
+  return dgrad_impl(d, dy, wt, dx, o->accumulate, o->res_grad, o->res_mask, stream, o->fuse, o->bias, o->x2, o->wt2, o->c2, o->dy_src, o);
 }
 
 int simhand_conv2d_dgrad_dysrc_ok(const sh_conv_desc* d) { return d != nullptr && use_1x1(d, d->cout, d->cin) ? 1 : 0; }

@@ -280,6 +280,19 @@ class ResNetEngine:
             self._fp8_sites[id(w)] = site
         return site
 
+    def _fp8_site_bwd(self, conv, device):
+        """[dy scaler (delayed), weight scaler (current), e4m3 CRSK weights, version] of one fp8 data-gradient site."""
+        w = conv.weight
+        site = self._fp8_sites.get(("bwd", id(w)))
+        if site is None:
+            site = [ops.FP8Scaler(device, delayed=True), ops.FP8Scaler(device, delayed=False), None, None]
+            self._fp8_sites[("bwd", id(w))] = site
+        ver = (w._version, w.data_ptr())
+        if site[3] != ver:
+            site[2] = ops.fp8_pack_crsk(site[1], w)
+            site[3] = ver
+        return site
+
     def _conv_fwd_fp8(self, conv, d, x, training):
         w = conv.weight
         site = self._fp8_site(conv, x.device)
@@ -528,9 +541,17 @@ class ResNetEngine:
         fuse_dg = (self.fuse_bwd_apply_dgrad and not fuse_apply and self.dtype == torch.bfloat16 and not u.stem and relu_mask is None
                    and not u.has_res and need_dx and prev is not None and prev_masked_store and u.conv.kernel_size == (1, 1)
                    and u.conv.stride == (1, 1) and u.conv.padding == (0, 0) and ops.conv2d_dgrad_dysrc_ok(d))
-        dy, _, dg, db = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, False,
-                                        mask_from_y=u.relu and not u.has_res, relu_mask=relu_mask, raw_partial=raw_partial,
-                                        apply=not (fuse_apply or fuse_dg))
+        # fp8 configuration: the data gradient of the 3x3 layers with >= 256 channels runs on e4m3 operands; dy's codes leave the
+        # BatchNorm-backward apply pass (delayed scaling), the CRSK weights are re-quantised per parameter version
+        f8 = None
+        if (self.fp8 and need_dx and not u.stem and not fuse_apply and not fuse_dg and relu_mask is None and res_grad is None and dx_into is None
+                and not (prev is not None and prev_masked_store) and ops.conv2d_dgrad_fp8_pays(d)):
+            f8 = self._fp8_site_bwd(u.conv, da.device)
+        bw = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, False,
+                             mask_from_y=u.relu and not u.has_res, relu_mask=relu_mask, raw_partial=raw_partial,
+                             apply=not (fuse_apply or fuse_dg), fp8_scaler=f8[0] if f8 is not None else None)
+        dy, _, dg, db = bw[:4]
+        dyq = bw[4] if len(bw) > 4 else None
         grads[u.bn.weight] = dg
         grads[u.bn.bias] = db
         if fuse_dg:
@@ -558,6 +579,10 @@ class ResNetEngine:
             dxm, _ = ops.conv2d_dgrad_ex(d, dy, pk.crsk, dx=dx_into, accumulate=dx_into is not None, res_grad=res_grad, res_mask=res_mask,
                                          fuse_mode=4, prev_mask=prev.mask, want_sums=False)
             return dxm, None
+        if dyq is not None:  # e4m3 reduction (same epilogue options: the previous unit's BatchNorm-backward sums where they pay)
+            fuse = prev is not None and self.fuse_bn_bwd and ops.conv2d_dgrad_fuse_pays(d) and not prev.has_res
+            return ops.conv2d_dgrad_ex(d, dy, pk.crsk, fuse_mode=(2 if prev.relu else 0) if fuse else None, prev_y=prev.y if fuse else None,
+                                       prev_st=prev.st if fuse else None, fp8=(dyq, f8[2], f8[0], f8[1]))
         if prev is not None and self.fuse_bn_bwd and ops.conv2d_dgrad_fuse_pays(d):
             # prev's incoming gradient = this dx; residual units gate it with their output mask, the others with
             # the mask recomputed from their own y

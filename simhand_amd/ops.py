@@ -271,11 +271,12 @@ def conv2d_dgrad_fused(d: ConvDesc, dy, wt, prev_y, prev_st: Optional["BNState"]
 
 def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accumulate: bool = False, res_grad=None, res_mask=None,
                     bias=None, fuse_mode: Optional[int] = None, prev_y=None, prev_st: Optional["BNState"] = None, prev_mask=None,
-                    want_sums: bool = True, x2=None, wt2=None, dy_src=None):
+                    want_sums: bool = True, x2=None, wt2=None, dy_src=None, fp8=None):
     """General data gradient (simhand_conv2d_dgrad_ex): optional accumulate / masked-residual merge, fp32 per-channel
     bias, and epilogue fusion.  fuse_mode: None = none; 0 / 2 / 3 = BN-backward sums of the previous unit (no ReLU /
     mask from prev_y*scale+shift / bit mask); 4 = store the gradient masked by prev_mask and emit its channel sums.
     x2 / wt2: second reduction segment, dx = dy wt^T + x2 wt2^T in one pass (only where conv2d_dgrad_concat_ok).
+    fp8 = (dy_q, wt_q, dy scaler, weight scaler): the reduction runs over e4m3 operands (only where conv2d_dgrad_fp8_pays).
     dy_src = (da, y, BNState, (coef_a, coef_b, coef_c), relu, dy_out): the dy operand is derived on load as the BatchNorm-backward
     apply of the unit (sh_dy_src; `dy` is ignored, pass None) and written to dy_out; only where conv2d_dgrad_dysrc_ok.
     Returns (dx, partial or None)."""
@@ -297,6 +298,9 @@ def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accu
     o.bias = _ptr(bias)
     if x2 is not None:
         o.x2, o.wt2, o.c2 = _ptr(x2), _ptr(wt2), x2.shape[-1]
+    if fp8 is not None:
+        o.dy_q, o.wt_q = _ptr(fp8[0], torch.uint8), _ptr(fp8[1], torch.uint8)
+        o.dy_state, o.w_state = _ptr(fp8[2].state), _ptr(fp8[3].state)
     part = None
     if fuse_mode is not None:
         if want_sums or fuse_mode != 4:  # mode 4 may store the masked gradient without emitting its sums
@@ -597,7 +601,7 @@ def bn_apply(y, st: BNState, m: int, c: int, relu: bool, residual=None, out=None
 
 
 def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_dres: bool, mask_from_y: bool = False,
-                relu_mask=None, raw_partial=None, apply: bool = True):
+                relu_mask=None, raw_partial=None, apply: bool = True, fp8_scaler: "Optional[FP8Scaler]" = None):
     """Returns (dy, dres or None, dgamma, dbeta).  raw_partial: (sum g, sum g*y) tiles from conv2d_dgrad_fused -- the
     standalone partial-sum pass is skipped.  mask_from_y: the unit had no residual add, so the ReLU mask is
     recomputed from y (the stored activation is not read).  relu_mask: bit mask from bn_apply(want_mask=True) --
@@ -623,10 +627,22 @@ def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_d
         check(lib.simhand_bn_bwd_finalize(_ptr(part), nblk, c, _ptr(dg), _ptr(db), _stream()), "bn_bwd_finalize")
     if not apply:  # sums only: the caller fuses the apply into a consumer (conv2d_wgrad_bnbwd)
         return None, None, dg, db
+    if fp8_scaler is not None and fp8_scaler.calls > 0 and not want_dres:
+        # the apply pass also emits dy's e4m3 codes (operand of the fp8 data gradient) + its amax; returned as a 5th value
+        dy = torch.empty_like(y)
+        q = torch.empty(y.shape, dtype=torch.uint8, device=dev)
+        check(lib.simhand_bn_bwd_apply_fp8(_ptr(da), _ptr(aa), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(dg), _ptr(db),
+                                           _ptr(st.scale), _ptr(st.shift), mode, _ptr(dy), _ptr(q), _ptr(fp8_scaler.state), _ptr(fp8_scaler.amax_bits),
+                                           m, c, _stream()), "bn_bwd_apply_fp8")
+        fp8_scaler._update(True)
+        fp8_scaler.calls += 1
+        return dy, None, dg, db, q
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
     check(lib.simhand_bn_bwd_apply(_ptr(da), _ptr(aa), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(dg), _ptr(db),
                                    _ptr(st.scale), _ptr(st.shift), mode, _ptr(dy), _ptr(dres), m, c, dt(y.dtype), _stream()), "bn_bwd_apply")
+    if fp8_scaler is not None:  # first call of a delayed site: calibrate with the two-pass form
+        return dy, dres, dg, db, fp8_scaler.quantize(dy)
     return dy, dres, dg, db
 
 
@@ -873,8 +889,18 @@ class FP8Scaler:
         return wq
 
 
+def fp8_pack_crsk(scaler: FP8Scaler, w_oihw: torch.Tensor) -> torch.Tensor:
+    """e4m3 CRSK weights [cin][r][s][cout] for the fp8 data gradient: the KRSC packer applied to the (cin, cout)-transposed filter."""
+    return scaler.pack_weights(w_oihw.detach().permute(1, 0, 2, 3).contiguous())
+
+
 def conv2d_fwd_fp8_supported(d: ConvDesc) -> bool:
     return bool(_lib.load().simhand_conv2d_fwd_fp8_supported(C.byref(d)))
+
+
+def conv2d_dgrad_fp8_pays(d: ConvDesc) -> bool:
+    """The layers whose data gradient runs on the e4m3 variant of the 256 x 256 kernel in the fp8 configuration (3x3, >= 256 channels)."""
+    return bool(_lib.load().simhand_conv2d_dgrad_fp8_pays(C.byref(d)))
 
 
 def conv2d_fwd_fp8_pays(d: ConvDesc) -> bool:

@@ -124,6 +124,70 @@ def _fp8_conv_case(shape, big):
     assert rel <= 6e-2, rel
 
 
+@pytest.mark.parametrize("shape", [(3, 14, 14, 256, 256, 1), (2, 18, 18, 256, 512, 2), (5, 7, 7, 512, 512, 1), (33, 14, 14, 256, 256, 1)])
+@pytest.mark.parametrize("fused_sums", [False, True])
+def test_fp8_data_gradient_on_the_256x256_kernel(shape, fused_sums):
+    """conv2d_dgrad_ex with e4m3 operands (3x3, >= 256 channels; stride 1 and the stride-2 parity classes) against the fp32 data gradient
+    of the SAME dequantised operands; with the previous unit's BatchNorm-backward sums fused, the partials against a direct reduction of
+    the stored dx."""
+    from simhand_amd import _lib, ops
+
+    n, h, w, cin, cout, stride = shape
+    _lib.load().simhand_test_igemm256_enable(2)
+    g = torch.Generator().manual_seed(sum(shape))
+    d = ops.conv_desc(n, h, w, cin, cout, 3, 3, stride, 1, torch.bfloat16)
+    assert ops.conv2d_dgrad_fp8_pays(d)
+    dy = (torch.randn(n, d.ho, d.wo, cout, generator=g) * 0.3).to(torch.bfloat16).to(DEV)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).to(DEV)
+    sdy, sw = ops.FP8Scaler(DEV, delayed=True), ops.FP8Scaler(DEV, delayed=False)
+    dyq, wq = sdy.quantize(dy), ops.fp8_pack_crsk(sw, wt)
+    kw = {}
+    if fused_sums:
+        y_prev = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16).to(DEV)
+        st = ops.BNState(cin, DEV)
+        st.scale.copy_(torch.rand(cin, generator=g) + 0.5)
+        st.shift.copy_(torch.randn(cin, generator=g) * 0.3)
+        kw = dict(fuse_mode=2, prev_y=y_prev, prev_st=st)
+    ops.route_reset()
+    dx, part = ops.conv2d_dgrad_ex(d, dy, ops.pack_crsk(wt, torch.bfloat16), fp8=(dyq, wq, sdy, sw), **kw)
+    rc = ops.route_counts()
+    assert rc["fp8_dgrad"] == 1 and rc["igemm256_dgrad"] == 1, rc
+    dydq = (_deq(dyq) * float(sdy.state[1])).permute(0, 3, 1, 2).contiguous()
+    wdq = _deq(wq).view(cin, 3, 3, cout).permute(3, 0, 1, 2).contiguous() * float(sw.state[1])  # back to OIHW
+    want = torch.nn.grad.conv2d_input((n, cin, h, w), wdq, dydq, stride=stride, padding=1).permute(0, 2, 3, 1)
+    err = (dx.float().cpu() - want).abs().max() / want.abs().max()
+    assert err <= 1e-2, err
+    if fused_sums:
+        gate = (y_prev.float() * st.scale + st.shift) > 0
+        gdx = dx.float() * gate
+        s1, s2 = gdx.double().sum((0, 1, 2)), (gdx * y_prev.float()).double().sum((0, 1, 2))
+        got1, got2 = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+        assert (got1 - s1).abs().max().item() <= 2e-3 * s1.abs().max().item() + 1e-3
+        assert (got2 - s2).abs().max().item() <= 2e-3 * s2.abs().max().item() + 1e-3
+    else:
+        assert part is None
+
+
+def test_bn_backward_apply_with_fused_e4m3_emission_equals_the_two_pass_form():
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(13)
+    c, m = 256, 3 * 14 * 14
+    gamma = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(c, generator=g) * 0.2).to(DEV)
+    fused, plain = ops.FP8Scaler(DEV, delayed=True), ops.FP8Scaler(DEV, delayed=True)
+    for step in range(3):
+        y = (torch.randn(m, c, generator=g) * 1.3).to(torch.bfloat16).to(DEV)
+        da = (torch.randn(m, c, generator=g) * (0.1 + step)).to(torch.bfloat16).to(DEV)
+        part = ops.bn_partial_stats(y, m, c)
+        st = ops.bn_finalize(part, m, c, gamma, beta, torch.zeros(c, device=DEV), torch.ones(c, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV))
+        dy1, _, dg1, db1, q1 = ops.bn_backward(da, None, y, st, gamma, m, c, True, False, mask_from_y=True, fp8_scaler=fused)
+        dy2, _, dg2, db2 = ops.bn_backward(da, None, y, st, gamma, m, c, True, False, mask_from_y=True)
+        q2 = plain.quantize(dy2)
+        assert torch.equal(dy1, dy2) and torch.equal(q1, q2) and torch.equal(dg1, dg2) and torch.equal(db1, db2), step
+        assert torch.equal(fused.state, plain.state), step
+
+
 def test_bn_apply_with_fused_e4m3_emission_equals_the_two_pass_form():
     """simhand_bn_apply_fp8: a (bf16) and q (e4m3 codes) from one pass over y == simhand_bn_apply followed by simhand_fp8_quantize, bit for
     bit, and the delayed-scaling state evolves identically (same amax enters the ring)."""
@@ -183,11 +247,18 @@ def test_simclr_rn50_step_fp8_tracks_bf16_and_the_oracle_over_several_steps():
                     z0 = torch.cat(model.get_transformed_projections(batch)).float().cpu()
                 grads_ok = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
                 assert grads_ok
+                g0 = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
             opt.step()
             losses.append(float(out["loss"]))
-        runs[mode] = (losses, z0, ops.route_counts()["fp8_fwd"])
-    lb, zb, nb = runs["bf16"]
-    lf, zf, nf = runs["fp8"]
+        runs[mode] = (losses, z0, ops.route_counts()["fp8_fwd"], ops.route_counts()["fp8_dgrad"], g0)
+    lb, zb, nb, _, gb = runs["bf16"]
+    lf, zf, nf, ndg, gf = runs["fp8"]
+    assert ndg >= 5 * 9, ndg  # and their data gradients
+    # first step's parameter gradients (same weights in both runs) of the fp8 run against the bf16 run's: e4m3 operands in nine 3x3
+    # forwards and data gradients, ReLU kinks on top -- a sanity band (a wrong scale or layout gives cosines near 0), not parity
+    cosg = sorted(float(F.cosine_similarity(gf[k].flatten().double(), gb[k].flatten().double(), dim=0)) for k in gf if gb[k].abs().max() > 1e-7)
+    print("fp8 vs bf16 gradient cosines: median", cosg[len(cosg) // 2], "p10", cosg[len(cosg) // 10])
+    assert cosg[len(cosg) // 2] >= 0.9, cosg[len(cosg) // 2]
     assert nb == 0 and nf >= 5 * 9, (nb, nf)  # the nine 3x3 layers with >= 256 channels (stages 3 and 4), every step
     cos_o = F.cosine_similarity(zf.double(), z_o.double(), dim=1)
     print("fp8 vs oracle: loss", lf[0], lo, "z cosine mean / min", float(cos_o.mean()), float(cos_o.min()))
