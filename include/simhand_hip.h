@@ -55,6 +55,11 @@ enum sh_weight_type { SH_W_NONE = 0, SH_W_LINEAR = 1, SH_W_NONLINEAR = 2,
                       SH_W_EXPLICIT = 3 /* D_loc / d_pos already hold the weights (functional surface) */ };
 
 int simhand_abi_version(void);
+/* The library ships in two builds of the same sources: libsimhand_hip.so, whose 16-bit storage type (SH_BF16 below) is bfloat16 -- and
+ * libsimhand_hip_f16.so, where the same enum value means IEEE fp16 (11-bit significand: the storage type of the reference's
+ * precision=16 / native AMP, src/experiments/main.py:158-159; the caller scales the loss, see simhand_amd/host/amp.py).  Every entry
+ * point, layout and kernel is the same; only the unpack / round-to-nearest-even pack / MFMA operand type differ.  0 = bf16, 1 = fp16. */
+int simhand_half_format(void);
 const char* simhand_last_error(void);
 /* 0 when a gfx950 device is usable from this process */
 int simhand_device_check(void);

@@ -19,6 +19,8 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SIMHAND_LIB: another build of the same library (A/B timing of a kernel change on one GPU box)
 LIB_PATH = os.environ.get("SIMHAND_LIB") or os.path.join(_HERE, "libsimhand_hip.so")
+# the fp16-storage build of the same sources (csrc/Makefile, -DSH_H16_FP16): the reference's precision=16
+LIB_PATH_F16 = os.environ.get("SIMHAND_LIB_F16") or os.path.join(_HERE, "libsimhand_hip_f16.so")
 
 # enums of include/simhand_hip.h
 SH_F32, SH_BF16, SH_FP8_E4M3 = 0, 1, 2
@@ -90,6 +92,7 @@ _S = C.c_size_t
 # name -> (restype, argtypes); every symbol include/simhand_hip.h declares
 SIGNATURES = {
     "simhand_abi_version": (_I, []),
+    "simhand_half_format": (_I, []),
     "simhand_last_error": (C.c_char_p, []),
     "simhand_device_check": (_I, []),
     "simhand_route_counts": (_I, [_P]),
@@ -214,30 +217,57 @@ SIGNATURES = {
     "simhand_lars_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P]),
 }
 
-_lib = None
+_libs: dict = {}          # "bf16" / "f16" -> CDLL
+_current = "bf16"         # which build load() hands out: the 16-bit storage format of the tensors the caller works with
 _lock = threading.Lock()
 
 
+def use_half(fmt: str) -> None:
+    """Select the library build by its 16-bit storage format: "bf16" (default; BASELINE's benchmark dtype) or "f16" (IEEE fp16, the
+    reference's precision=16).  Process-wide: one model / one format at a time (the fp32 parity mode works with either build)."""
+    global _current, _device_ok
+    if fmt not in ("bf16", "f16"):
+        raise ValueError(fmt)
+    if fmt != _current:
+        _current = fmt
+        _device_ok = False
+
+
+def half_format() -> str:
+    return _current
+
+
+def half_dtype():
+    import torch
+
+    return torch.float16 if _current == "f16" else torch.bfloat16
+
+
 def load() -> C.CDLL:
-    """Load the in-tree shared library (built by ``__graft_entry__.build()`` /
+    """Load the in-tree shared library of the current 16-bit format (built by ``__graft_entry__.build()`` /
     ``make -C simhand_amd/csrc``).  Raises if it is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
+    lib = _libs.get(_current)
+    if lib is not None:
+        return lib
     with _lock:
-        if _lib is not None:
-            return _lib
-        if not os.path.exists(LIB_PATH):
+        lib = _libs.get(_current)
+        if lib is not None:
+            return lib
+        path = LIB_PATH_F16 if _current == "f16" else LIB_PATH
+        if not os.path.exists(path):
             raise SimhandHipError(
-                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the SiMHand hot path)")
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI and this table disagree
             fn.restype = res
             fn.argtypes = args
-        _lib = lib
-    return _lib
+        want = 1 if _current == "f16" else 0
+        if lib.simhand_half_format() != want:
+            raise SimhandHipError(f"{path} was built with 16-bit format {lib.simhand_half_format()}, expected {want}")
+        _libs[_current] = lib
+    return lib
 
 
 def check(rc: int, what: str = "") -> None:

@@ -293,8 +293,8 @@ __global__ __launch_bounds__(256) void bn_apply_fp8_kernel(const bf16_t* __restr
         float rr[VE];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          rr[2 * e] = __uint_as_float(pk[e] << 16);
-          rr[2 * e + 1] = __uint_as_float(pk[e] & 0xffff0000u);
+          rr[2 * e] = h16_lo(pk[e]);
+          rr[2 * e + 1] = h16_hi(pk[e]);
         }
 #pragma unroll
         for (int e = 0; e < VE; ++e) amax = fmaxf(amax, fabsf(rr[e]));
@@ -524,8 +524,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fp8_kernel(const bf16_t* __r
           const float o0 = A[2 * e] * (g[2 * e] - k2[2 * e]) - (yy[2 * e] - mu[2 * e]) * is[2 * e] * k3[2 * e];
           const float o1 = A[2 * e + 1] * (g[2 * e + 1] - k2[2 * e + 1]) - (yy[2 * e + 1] - mu[2 * e + 1]) * is[2 * e + 1] * k3[2 * e + 1];
           pk[e] = pack_bf16x2(o0, o1);
-          rr[2 * e] = __uint_as_float(pk[e] << 16);
-          rr[2 * e + 1] = __uint_as_float(pk[e] & 0xffff0000u);
+          rr[2 * e] = h16_lo(pk[e]);
+          rr[2 * e + 1] = h16_hi(pk[e]);
         }
         st16<NT>(dy + off, make_uint4(pk[0], pk[1], pk[2], pk[3]));
 #pragma unroll
@@ -611,8 +611,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
         const unsigned w4[4] = {tv[t9].x, tv[t9].y, tv[t9].z, tv[t9].w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          v[2 * q] = __uint_as_float(w4[q] << 16);
-          v[2 * q + 1] = __uint_as_float(w4[q] & 0xffff0000u);
+          v[2 * q] = h16_lo(w4[q]);
+          v[2 * q + 1] = h16_hi(w4[q]);
         }
       } else {
         v[0] = __uint_as_float(tv[t9].x); v[1] = __uint_as_float(tv[t9].y); v[2] = __uint_as_float(tv[t9].z); v[3] = __uint_as_float(tv[t9].w);

@@ -50,14 +50,44 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;  // 8 bf16 in 4 VGPRs
 typedef unsigned short bf16_t;                              // raw bf16 bits
 
+// The library is built twice from the same sources (csrc/Makefile): libsimhand_hip.so stores 16-bit tensors as bf16 (8-bit
+// significand, fp32's exponent range: BASELINE's benchmark dtype), libsimhand_hip_f16.so (-DSH_H16_FP16) as IEEE fp16 (11-bit
+// significand, 5-bit exponent: the storage type of the reference's precision=16 / native AMP, src/experiments/main.py:158-159).  Everything
+// that depends on the format goes through the helpers below -- unpack (h16_lo / h16_hi / bf16_to_f32), round-to-nearest-even pack
+// (pack_bf16x2 / f32_to_bf16) and the 16x16x32 MFMA (sh_mfma16); the names keep "bf16" for "the build's 16-bit storage type".  Layouts,
+// tiles, swizzles, LDS-DMA and the transpose reads move raw 16-bit words and do not care.
+typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
+#ifdef SH_H16_FP16
+typedef _Float16 hw_h16x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(8))) _Float16 hw_h16x8_t;
+__device__ __forceinline__ float h16_lo(unsigned w) { return (float)__builtin_bit_cast(hw_h16x2_t, w)[0]; }  // v_cvt_f32_f16
+__device__ __forceinline__ float h16_hi(unsigned w) { return (float)__builtin_bit_cast(hw_h16x2_t, w)[1]; }  // v_cvt_f32_f16 (SDWA word 1)
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return h16_lo((unsigned)v); }
+// round-to-nearest-even, overflow -> inf (what the loss scaler's overflow check looks for): gfx950's v_cvt_pk_f16_f32
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  const hw_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hw_h16x2_t));
+}
+__device__ __forceinline__ f32x4 sh_mfma16(const uint4& a, const uint4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hw_h16x8_t, a), __builtin_bit_cast(hw_h16x8_t, b), c, 0, 0, 0);
+}
+#define SH_H16_FORMAT 1
+#else
+typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(8))) __bf16 hw_h16x8_t;
+__device__ __forceinline__ float h16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float h16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 // round-to-nearest-even, NaN stays NaN (same rounding as torch's .to(bfloat16)): gfx950's v_cvt_pk_bf16_f32
-typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   const hw_f32x2_t v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hw_bf16x2_t));
 }
+__device__ __forceinline__ f32x4 sh_mfma16(const uint4& a, const uint4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hw_h16x8_t, a), __builtin_bit_cast(hw_h16x8_t, b), c, 0, 0, 0);
+}
+#define SH_H16_FORMAT 0
+#endif
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
@@ -110,8 +140,8 @@ template <> struct Vec16<bf16_t> {
     unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      o[2 * i] = __uint_as_float(w[i] << 16);
-      o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+      o[2 * i] = h16_lo(w[i]);
+      o[2 * i + 1] = h16_hi(w[i]);
     }
   }
   template <bool NT = false> __device__ static __forceinline__ void store(bf16_t* p, const float (&o)[8]) {

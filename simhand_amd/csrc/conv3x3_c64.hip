@@ -191,8 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(c64_frag_t, wf[t][kk][ni]),
-                                                                  __builtin_bit_cast(c64_frag_t, fr[t & 1][kk * 2 + mi]), acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = sh_mfma16(wf[t][kk][ni], fr[t & 1][kk * 2 + mi], acc[mi][ni]);
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragment reads are done before the next barrier
@@ -232,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
           float yy[8], fsc[8], fsh[8];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            yy[2 * i] = __uint_as_float(y4[i] << 16);
-            yy[2 * i + 1] = __uint_as_float(y4[i] & 0xffff0000u);
+            yy[2 * i] = h16_lo(y4[i]);
+            yy[2 * i + 1] = h16_hi(y4[i]);
           }
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
@@ -248,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               const int e = 2 * i + h;
-              const float gq = h == 0 ? __uint_as_float(w4[i] << 16) : __uint_as_float(w4[i] & 0xffff0000u);
+              const float gq = h == 0 ? h16_lo(w4[i]) : h16_hi(w4[i]);
               const bool on = valid && yy[e] * fsc[e] + fsh[e] > 0.f;
               const float gv = on ? gq : 0.f;
               s1[e] += gv;

@@ -25,7 +25,7 @@ namespace sh {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16_frag_t;
 
 __device__ __forceinline__ f32x4 mma_bf16(const uint4& a, const uint4& b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16_frag_t, a), __builtin_bit_cast(bf16_frag_t, b), c, 0, 0, 0);
+  return sh_mfma16(a, b, c);
 }
 
 __device__ __forceinline__ float row16_sum_g1(float v) {
@@ -38,8 +38,8 @@ __device__ __forceinline__ float row16_sum_g1(float v) {
 
 
 __device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
-  const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
-  const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+  const float lo = h16_lo(a) + h16_lo(b);
+  const float hi = h16_hi(a) + h16_hi(b);
   return pack_bf16x2(lo, hi);
 }
 
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
               const int e = 2 * q + hh;
-              const float gv = hh == 0 ? __uint_as_float(g4[q] << 16) : __uint_as_float(g4[q] & 0xffff0000u);
-              const float yy = hh == 0 ? __uint_as_float(y4[q] << 16) : __uint_as_float(y4[q] & 0xffff0000u);
+              const float gv = hh == 0 ? h16_lo(g4[q]) : h16_hi(g4[q]);
+              const float yy = hh == 0 ? h16_lo(y4[q]) : h16_hi(y4[q]);
               const bool on = !p.xf_relu || (yy * cs[e] + ch[e] > 0.f);
               r2[hh] = ca[e] * (on ? gv : 0.f) - cb[e] * yy + cc[e];  // same expression as the weight-gradient loader's (XFORM 2)
             }
@@ -423,8 +423,8 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
               const unsigned w4[4] = {rq[mi][j].x, rq[mi][j].y, rq[mi][j].z, rq[mi][j].w};  // prefetched a chunk ago
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                o[2 * i] += __uint_as_float(w4[i] << 16);
-                o[2 * i + 1] += __uint_as_float(w4[i] & 0xffff0000u);
+                o[2 * i] += h16_lo(w4[i]);
+                o[2 * i + 1] += h16_hi(w4[i]);
               }
             }
             if (EP == 2 || p.ep_relu) {
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kerne
 #pragma unroll
                   for (int h = 0; h < 2; ++h) {
                     const int e = 2 * i + h;
-                    const float gq = h == 0 ? __uint_as_float(w4[i] << 16) : __uint_as_float(w4[i] & 0xffff0000u);
+                    const float gq = h == 0 ? h16_lo(w4[i]) : h16_hi(w4[i]);
                     bool on = true;
                     if (p.fmode == 2) on = yy[e] * sc[e] + sh[e] > 0.f;
                     else if (p.fmode == 3) on = (bits >> e) & 1u;  // mode 4: the value is already masked

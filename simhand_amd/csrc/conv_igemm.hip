@@ -89,7 +89,7 @@ template <> struct Mma<bf16_t> {
   typedef __attribute__((ext_vector_type(8))) __bf16 frag_t;
   // 16 bytes = 8 bf16 = the whole K=32 slice of one lane
   __device__ static __forceinline__ f32x4 run(const uint4& a, const uint4& b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag_t, a), __builtin_bit_cast(frag_t, b), c, 0, 0, 0);
+    return sh_mfma16(a, b, c);
   }
 };
 template <> struct Mma<float> {
@@ -116,8 +116,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 __device__ __forceinline__ unsigned add_bf16x2(unsigned a, unsigned b) {
-  const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
-  const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+  const float lo = h16_lo(a) + h16_lo(b);
+  const float hi = h16_hi(a) + h16_hi(b);
   return pack_bf16x2(lo, hi);
 }
 
@@ -631,8 +631,8 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
             const unsigned y4[4] = {yq[mi].x, yq[mi].y, yq[mi].z, yq[mi].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              yy[(2 * i) % VE] = __uint_as_float(y4[i] << 16);
-              yy[(2 * i + 1) % VE] = __uint_as_float(y4[i] & 0xffff0000u);
+              yy[(2 * i) % VE] = h16_lo(y4[i]);
+              yy[(2 * i + 1) % VE] = h16_hi(y4[i]);
             }
           }
           const unsigned bits = bq[mi];
@@ -643,8 +643,8 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
             const unsigned w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              gg[(2 * i) % VE] = __uint_as_float(w4[i] << 16);
-              gg[(2 * i + 1) % VE] = __uint_as_float(w4[i] & 0xffff0000u);
+              gg[(2 * i) % VE] = h16_lo(w4[i]);
+              gg[(2 * i + 1) % VE] = h16_hi(w4[i]);
             }
           }
 #pragma unroll
@@ -1096,8 +1096,8 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
             const unsigned w4[4] = {rq[mi].x, rq[mi].y, rq[mi].z, rq[mi].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              o[2 * e] += __uint_as_float(w4[e] << 16);
-              o[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+              o[2 * e] += h16_lo(w4[e]);
+              o[2 * e + 1] += h16_hi(w4[e]);
             }
           }
           if (p.ep_relu) {
@@ -1166,8 +1166,8 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               const int e = 2 * i + h;
-              const float gq = h == 0 ? __uint_as_float(w4[i] << 16) : __uint_as_float(w4[i] & 0xffff0000u);
-              const float yy = h == 0 ? __uint_as_float(y4[i] << 16) : __uint_as_float(y4[i] & 0xffff0000u);
+              const float gq = h == 0 ? h16_lo(w4[i]) : h16_hi(w4[i]);
+              const float yy = h == 0 ? h16_lo(y4[i]) : h16_hi(y4[i]);
               bool on = true;
               if (p.fmode == 2) on = yy * sc[e] + sh[e] > 0.f;
               else if (p.fmode == 3) on = (bits >> e) & 1u;  // mode 4: the value is already masked

@@ -235,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
     unsigned o[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float lo = __uint_as_float(w4[q] << 16) * sc[2 * q] + sh[2 * q];
-      float hi = __uint_as_float(w4[q] & 0xffff0000u) * sc[2 * q + 1] + sh[2 * q + 1];
+      float lo = h16_lo(w4[q]) * sc[2 * q] + sh[2 * q];
+      float hi = h16_hi(w4[q]) * sc[2 * q + 1] + sh[2 * q + 1];
       if (p.xrelu) {
         lo = fmaxf(lo, 0.f);
         hi = fmaxf(hi, 0.f);
@@ -346,8 +346,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
               const int e = 2 * q + hh;
-              const float g = hh == 0 ? __uint_as_float(g4[q] << 16) : __uint_as_float(g4[q] & 0xffff0000u);
-              const float y = hh == 0 ? __uint_as_float(y4[q] << 16) : __uint_as_float(y4[q] & 0xffff0000u);
+              const float g = hh == 0 ? h16_lo(g4[q]) : h16_hi(g4[q]);
+              const float y = hh == 0 ? h16_lo(y4[q]) : h16_hi(y4[q]);
               const bool on = !p.xrelu || (y * ca_s[e] + ca_h[e] > 0.f);
               r2[hh] = ca_a[e] * (on ? g : 0.f) - ca_b[e] * y + ca_c[e];
             }
@@ -377,8 +377,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
         const unsigned w4[4] = {R.a[i].x, R.a[i].y, R.a[i].z, R.a[i].w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          csum[2 * q] += __uint_as_float(w4[q] << 16);
-          csum[2 * q + 1] += __uint_as_float(w4[q] & 0xffff0000u);
+          csum[2 * q] += h16_lo(w4[q]);
+          csum[2 * q + 1] += h16_hi(w4[q]);
         }
       }
     }
@@ -422,13 +422,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) fb[ni] = frag_bf16_scalar(uB, SB, wn * (BN / 2) + ni * 16, lane);
         }
-        typedef __attribute__((ext_vector_type(8))) __bf16 frag_t;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag_t, fa[mi]),
-                                                                  __builtin_bit_cast(frag_t, fb[ni]), acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = sh_mfma16(fa[mi], fb[ni], acc[mi][ni]);
       }
     } else {
 #pragma unroll
@@ -680,7 +678,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args p) {
   for (int c = 0; c < AHEAD; ++c) dma_chunk(c, true);
 
   typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
-  typedef __attribute__((ext_vector_type(8))) __bf16 frag_t;
   auto tr2 = [](const char* a_lo, const char* a_hi) __attribute__((always_inline)) -> uint4 {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a_lo));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a_hi));
@@ -724,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args p) {
       const uint4 fb = tr2(ring + r_lo * 128 + tcol[t], ring + r_hi * 128 + tcol[t]);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
-        acc[t][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag_t, fa[mi]), __builtin_bit_cast(frag_t, fb), acc[t][mi], 0, 0, 0);
+        acc[t][mi] = sh_mfma16(fa[mi], fb, acc[t][mi]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragment reads are done before the next barrier
   }

@@ -78,6 +78,8 @@ ProfScope::~ProfScope() {
 extern "C" {
 
 int simhand_abi_version(void) { return 1; }
+// 0: this build's 16-bit storage type (enum SH_BF16) is bfloat16; 1: IEEE fp16 (libsimhand_hip_f16.so)
+int simhand_half_format(void) { return SH_H16_FORMAT; }
 
 const char* simhand_last_error(void) { return sh::g_err; }
 

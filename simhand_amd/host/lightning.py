@@ -109,9 +109,13 @@ class Trainer:
     """fit loop for the contrastive step classes.  Mixed-precision policy (the reference runs fp16 autocast +
     GradScaler, main.py:158-159):
       precision 32        -> exact-fp32 MFMA kernels, fp32 storage (parity mode);
-      precision "bf16"/16 -> bf16 storage + bf16 MFMA, fp32 accumulators, fp32 BatchNorm statistics / loss / optimizer, fp32
-                             master weights.  No loss scaling: bf16 has fp32's exponent range, so the overflow the reference's
-                             GradScaler guards against cannot occur;
+      precision 16        -> THE REFERENCE'S POLICY: fp16 storage (fp16 build of the library: 11-bit significand) + fp16 MFMA, fp32
+                             accumulators / BatchNorm statistics / loss / optimizer / master weights, dynamic loss scaling with
+                             GradScaler semantics (host/amp.py: 2^16, x0.5 and a skipped step on overflow, x2 every 2000 clean steps);
+      precision "bf16"    -> bf16 storage + bf16 MFMA, otherwise the same (BASELINE's benchmark dtype).  No loss scaling: bf16 has
+                             fp32's exponent range.  Its 8-bit significand is what profiles/r03_stability_160steps.md shows as a
+                             ~10 % slower-learning run on the noise-memorisation task, all of it from the FORWARD activations'
+                             rounding -- which is why 16 maps to fp16, as in the reference, and not to bf16;
       precision "fp8"     -> as bf16, plus e4m3 forward operands (per-tensor scales: weights current, activations delayed
                              with a 16-entry amax ring and 1 bit of margin, ops.FP8Scaler) for the matrix-core-bound layers.
     tests/test_gpu_fp8.py / test_gpu_main.py and profiles/r02_stability_160steps.md (scripts/stability_run.py: 160 steps, fp32 mode ==
@@ -132,6 +136,9 @@ class Trainer:
         self.history: List[Dict[str, float]] = []
         self.optimizers: list = []
         self.schedulers: list = []
+        from .amp import GradScaler
+
+        self.scaler = GradScaler(enabled=str(precision) == "16")  # the reference's native-AMP loss scaling (fp16 storage only)
 
     @property
     def world_size(self) -> int:
@@ -143,7 +150,10 @@ class Trainer:
 
     @property
     def compute_dtype(self) -> torch.dtype:
-        return torch.float32 if str(self.precision) == "32" else torch.bfloat16
+        p = str(self.precision)
+        if p == "32":
+            return torch.float32
+        return torch.float16 if p == "16" else torch.bfloat16  # "bf16", "fp8"
 
     @property
     def fp8(self) -> bool:
@@ -158,6 +168,7 @@ class Trainer:
             "state_dict": module.state_dict(), "hyper_parameters": module.hparams,
             "optimizer_states": [o.state_dict() for o in self.optimizers],
             "lr_schedulers": [s["scheduler"].state_dict() for s in self.schedulers],
+            "native_amp_scaling_state": self.scaler.state_dict() if self.scaler.enabled else None,  # Lightning's key for the GradScaler
         }
 
     def fit(self, model: LightningModule, train_dataloaders=None, val_dataloaders=None, ckpt_path: Optional[str] = None):
@@ -179,6 +190,8 @@ class Trainer:
                 o.load_state_dict(s)
             for s, st in zip(scheds, ck.get("lr_schedulers", [])):
                 s["scheduler"].load_state_dict(st)
+            if self.scaler.enabled and ck.get("native_amp_scaling_state"):
+                self.scaler.load_state_dict(ck["native_amp_scaling_state"])
             self.global_step = ck.get("global_step", 0)
             if ck.get("epoch_complete", True):
                 start_epoch = ck.get("epoch", -1) + 1
@@ -209,12 +222,14 @@ class Trainer:
                 loss = out["loss"]
                 for o in opts:
                     o.zero_grad(set_to_none=True)
-                loss.backward()
+                self.scaler.scale(loss).backward()
                 if self.world_size > 1:
                     allreduce_gradients(model.parameters(), group=getattr(model, "process_group", None),
                                         skip=reducer.reduced if reducer is not None else None)
+                self.scaler.unscale_(model.parameters())
                 for o in opts:
-                    o.step()
+                    self.scaler.step(o)  # skipped when the fp16 gradients overflowed (every rank sees the same reduced gradients)
+                self.scaler.update()
                 for s in scheds:
                     if s.get("interval", "epoch") == "step":
                         s["scheduler"].step()

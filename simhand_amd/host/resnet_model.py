@@ -29,7 +29,9 @@ from typing import Dict, List, Optional, Tuple
 import torch
 from torch import Tensor, nn
 
-from .. import ops
+from .. import _lib, ops
+
+_H16 = (torch.bfloat16, torch.float16)  # the 16-bit storage formats (which one: the library build, _lib.use_half)
 
 
 
@@ -209,7 +211,7 @@ class ResNetEngine:
     def _fold_fwd_ok(self, conv, relu, residual) -> bool:
         """1x1 convolutions with a narrow input whose BatchNorm statistics follow from the input's Gram matrix: a
         Bottleneck's conv3 (+ identity + ReLU) and its shortcut conv (no ReLU)."""
-        return (self.fold_bn3 and self._bottleneck and self.dtype == torch.bfloat16 and conv.kernel_size == (1, 1) and conv.padding == (0, 0)
+        return (self.fold_bn3 and self._bottleneck and self.dtype in _H16 and conv.kernel_size == (1, 1) and conv.padding == (0, 0)
                 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and conv.out_channels >= 2 * conv.in_channels
                 and (residual is not None or not relu))
 
@@ -329,7 +331,7 @@ class ResNetEngine:
         mask = None
         if save is not None and residual is not None and relu:
             a, mask = ops.bn_apply(y, st, m, conv.out_channels, relu, residual, want_mask=True)
-        elif gram_next and training and residual is None and self.fuse_apply_gram and self.dtype == torch.bfloat16:
+        elif gram_next and training and residual is None and self.fuse_apply_gram and self.dtype in _H16:
             a, s2, t2 = ops.bn_apply_gram(y, st, relu)
             self._gram = (a, s2, t2)
         elif fp8_next is not None and residual is None and self._fp8_next_ok(fp8_next, y):
@@ -448,8 +450,8 @@ class ResNetEngine:
         f32 = torch.float32
         d1 = ops.conv_desc(n, ho, wo, cw, cc, 1, 1, 1, 0, self.dtype)
         wmaster = u.conv.weight.detach().view(cc, cw)
-        rnd = self.dtype == torch.bfloat16                                  # the algebra uses the weights the MFMAs saw
-        if s is None and self.dtype == torch.bfloat16:
+        rnd = self.dtype in _H16                                  # the algebra uses the weights the MFMAs saw
+        if s is None and self.dtype in _H16:
             gmat, s = ops.conv2d_wgrad_colsum(d1, a_in, g)                  # [cc][cw] fp32, [cc]: sum g rides along
         else:
             gmat = ops.conv2d_wgrad(d1, a_in, g)
@@ -536,9 +538,9 @@ class ResNetEngine:
         if u.y is None:
             raise RuntimeError("this unit ran the folded forward (its raw conv output was never stored): its backward must be folded too")
         w = u.conv.weight
-        fuse_apply = (self.fuse_bwd_apply_wgrad and self.dtype == torch.bfloat16 and not u.stem and relu_mask is None and not u.has_res
+        fuse_apply = (self.fuse_bwd_apply_wgrad and self.dtype in _H16 and not u.stem and relu_mask is None and not u.has_res
                       and u.conv.kernel_size == (1, 1) and u.conv.stride == (1, 1) and u.conv.padding == (0, 0))
-        fuse_dg = (self.fuse_bwd_apply_dgrad and not fuse_apply and self.dtype == torch.bfloat16 and not u.stem and relu_mask is None
+        fuse_dg = (self.fuse_bwd_apply_dgrad and not fuse_apply and self.dtype in _H16 and not u.stem and relu_mask is None
                    and not u.has_res and need_dx and prev is not None and prev_masked_store and u.conv.kernel_size == (1, 1)
                    and u.conv.stride == (1, 1) and u.conv.padding == (0, 0) and ops.conv2d_dgrad_dysrc_ok(d))
         # fp8 configuration: the data gradient of the 3x3 layers with >= 256 channels runs on e4m3 operands; dy's codes leave the
@@ -699,6 +701,10 @@ class ResNetModel(nn.Module):
         self.engine = ResNetEngine(self.features, compute_dtype)
 
     def set_compute_dtype(self, dtype: torch.dtype, fp8: bool = False) -> None:
+        """torch.float32 (exact-fp32 parity mode), torch.bfloat16, or torch.float16 (the reference's precision=16 storage type: selects
+        the fp16 build of the library; the caller scales the loss, host/amp.py)."""
+        if dtype in _H16:
+            _lib.use_half("f16" if dtype == torch.float16 else "bf16")
         self.engine = ResNetEngine(self.features, dtype, fp8=fp8)
 
     def forward(self, x) -> Tensor:

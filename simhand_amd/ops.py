@@ -16,7 +16,9 @@ import torch
 from . import _lib
 from ._lib import BnBwdFuse, ConvDesc, DgradOpts, DySrc, NtxentParams, check
 
-_DT = {torch.float32: _lib.SH_F32, torch.bfloat16: _lib.SH_BF16}
+# torch.float16 maps to the same enum as torch.bfloat16: "the 16-bit storage type" -- which of the two it is, is a property of the library
+# BUILD (libsimhand_hip.so / libsimhand_hip_f16.so, selected with _lib.use_half): dt() refuses a tensor of the other format
+_DT = {torch.float32: _lib.SH_F32, torch.bfloat16: _lib.SH_BF16, torch.float16: _lib.SH_BF16}
 
 
 def _stream() -> C.c_void_p:
@@ -53,7 +55,15 @@ def _lib_dev():
 
 
 def dt(dtype: torch.dtype) -> int:
+    if dtype is not torch.float32 and dtype is not _lib.half_dtype():
+        raise _lib.SimhandHipError(f"{dtype} tensors with the {_lib.half_format()} build of the library: call _lib.use_half() / "
+                                   f"set_compute_dtype() for the format you store in")
     return _DT[dtype]
+
+
+def H16() -> torch.dtype:
+    """torch dtype of the current build's 16-bit storage format."""
+    return _lib.half_dtype()
 
 
 # --------------------------------------------------------------------------- loss
@@ -221,8 +231,8 @@ def conv2d_fwd_bnact_chain(d: ConvDesc, x, w, st: "BNState", residual, chain_w):
     mask = torch.empty(m, d.cout // 8, dtype=torch.uint8, device=x.device)
     cy = torch.empty(d.n, d.ho, d.wo, d.cin, dtype=x.dtype, device=x.device)
     part = torch.empty(lib.simhand_conv2d_fwd_chain_stat_blocks(C.byref(d)), 2, d.cin, dtype=torch.float32, device=x.device)
-    check(lib.simhand_conv2d_fwd_bnact_chain(C.byref(d), _ptr(x, torch.bfloat16), _ptr(w, torch.bfloat16), _ptr(st.scale), _ptr(st.shift),
-                                             _ptr(residual, torch.bfloat16), _ptr(out), _ptr(mask), _ptr(chain_w, torch.bfloat16), _ptr(cy),
+    check(lib.simhand_conv2d_fwd_bnact_chain(C.byref(d), _ptr(x, H16()), _ptr(w, H16()), _ptr(st.scale), _ptr(st.shift),
+                                             _ptr(residual, H16()), _ptr(out), _ptr(mask), _ptr(chain_w, H16()), _ptr(cy),
                                              _ptr(part), _stream()), "conv2d_fwd_bnact_chain")
     return out, mask, cy, part
 
@@ -288,8 +298,8 @@ def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accu
     if dy_src is not None:
         da, ysrc, st_, coefs, relu_, dy_out = dy_src
         sdy = DySrc()
-        sdy.da, sdy.y, sdy.scale, sdy.shift = _ptr(da, torch.bfloat16), _ptr(ysrc, torch.bfloat16), _ptr(st_.scale), _ptr(st_.shift)
-        sdy.coef_a, sdy.coef_b, sdy.coef_c, sdy.relu, sdy.dy_out = _ptr(coefs[0]), _ptr(coefs[1]), _ptr(coefs[2]), int(relu_), _ptr(dy_out, torch.bfloat16)
+        sdy.da, sdy.y, sdy.scale, sdy.shift = _ptr(da, H16()), _ptr(ysrc, H16()), _ptr(st_.scale), _ptr(st_.shift)
+        sdy.coef_a, sdy.coef_b, sdy.coef_c, sdy.relu, sdy.dy_out = _ptr(coefs[0]), _ptr(coefs[1]), _ptr(coefs[2]), int(relu_), _ptr(dy_out, H16())
         o.dy_src = C.pointer(sdy)
         dy = da
     o.accumulate = 2 if res_grad is not None else int(accumulate)
@@ -363,7 +373,7 @@ def bn_apply_gram(y: torch.Tensor, st: "BNState", relu: bool = True):
     a = torch.empty_like(y)
     s2 = torch.empty(c, c, dtype=torch.float32, device=y.device)
     part = torch.empty(lib.simhand_conv2d_wgrad_splits(C.byref(d)), 2, c, dtype=torch.float32, device=y.device)
-    check(lib.simhand_bn_apply_gram(C.byref(d), _ptr(y, torch.bfloat16), _ptr(st.scale), _ptr(st.shift), int(relu), _ptr(a), _ptr(s2), _ptr(part),
+    check(lib.simhand_bn_apply_gram(C.byref(d), _ptr(y, H16()), _ptr(st.scale), _ptr(st.shift), int(relu), _ptr(a), _ptr(s2), _ptr(part),
                                     _ptr(ws), nb, _stream()), "bn_apply_gram")
     return a, s2, bn_channel_sums(part, c)
 

@@ -59,13 +59,14 @@ def _product(cname, size, wcfg, om, dtype, b):
     return model.to(DEV).train()
 
 
-def _bf16_storage_twin(om: nn.Module) -> nn.Module:
-    """The oracle with the HIP path's storage model: encoder weights rounded to bf16, every encoder convolution's
-    input and output rounded to bf16 (the cast is differentiable, so gradients crossing it are rounded as well)."""
+def _bf16_storage_twin(om: nn.Module, storage: torch.dtype = torch.bfloat16) -> nn.Module:
+    """The oracle with the HIP path's storage model: encoder weights rounded to the 16-bit storage type (bf16, or fp16 for the
+    precision=16 mode), every encoder convolution's input and output rounded to it (the cast is differentiable, so gradients
+    crossing it are rounded as well)."""
     keep, om.last = om.last, {}  # non-leaf tensors of the last step cannot be deep-copied
     twin = copy.deepcopy(om)
     om.last = keep
-    rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    rnd = lambda t: t.to(storage).to(torch.float32)  # noqa: E731
     with torch.no_grad():
         for m in twin.encoder.modules():
             if isinstance(m, nn.Conv2d):
