@@ -64,8 +64,9 @@ def parse():
     ap.add_argument("--per-gpu-batch", type=int, default=1024, help="pairs per GPU (BASELINE config: 1024)")
     ap.add_argument("--resnet", default="50", choices=["18", "34", "50", "101", "152"])
     ap.add_argument("--image-size", type=int, default=224)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "32", "fp8"],
-                    help="fp8 = BASELINE configs[4] slice: bf16 storage, e4m3 forward operands on the MFMA-bound layers (parity n/a)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "32", "fp8", "16"],
+                    help="bf16 = BASELINE's dtype (default); 16 = the reference's own policy: fp16 storage + dynamic loss scaling (fp16 build of the "
+                         "library); fp8 = BASELINE configs[4]: bf16 storage, e4m3 operands where they pay (parity n/a); 32 = exact-fp32 parity mode")
     ap.add_argument("--experiment", default="handclr_w", choices=["handclr_w", "peclr_w", "simclr"])
     ap.add_argument("--comm", default="torch", choices=["torch", "abi"],
                     help="N > 1: collectives through torch.distributed (nccl = RCCL) or through the C ABI's own RCCL wrappers (simhand_comm_*)")
@@ -132,7 +133,7 @@ def make_model(args, world):
     cls = {"handclr_w": unsupervised.HandCLR_W, "peclr_w": unsupervised.PeCLR_W, "simclr": unsupervised.SimCLR}[args.experiment]
     torch.manual_seed(5)
     model = cls(cfg, None, "train")
-    model.set_compute_dtype(torch.float32 if args.precision == "32" else torch.bfloat16, fp8=args.precision == "fp8")
+    model.set_compute_dtype({"32": torch.float32, "16": torch.float16}.get(args.precision, torch.bfloat16), fp8=args.precision == "fp8")
     return model
 
 
@@ -256,12 +257,18 @@ def main():
         reducer = shdist.OverlappedGradReducer(group, wire=args.grad_wire)
         model.encoder.engine.grad_reducer = reducer
 
+    from simhand_amd.host.amp import GradScaler
+
+    scaler = GradScaler(enabled=args.precision == "16")  # the reference's native-AMP loss scaling; a no-op for the other precisions
+
     def step(i):
         opt.zero_grad(set_to_none=True)
         out = model.training_step(batch, i)
-        out["loss"].backward()
+        scaler.scale(out["loss"]).backward()
         shdist.allreduce_gradients(params, group=group, skip=reducer.reduced if reducer is not None else None, wire=args.grad_wire)
-        opt.step()
+        scaler.unscale_(params)
+        scaler.step(opt)
+        scaler.update()
         sched["scheduler"].step()
         return out["loss"]
 
@@ -320,7 +327,7 @@ def main():
         conv = {k: prof[k] for k in conv_classes}
         dom = max(conv, key=lambda k: conv[k]["ms"])
         d = conv[dom]  # measured in the timed region
-        peak = {"bf16": BF16_DENSE_PEAK_TFLOPS, "fp8": FP8_DENSE_PEAK_TFLOPS, "32": F32_PEAK_TFLOPS}[args.precision]
+        peak = {"bf16": BF16_DENSE_PEAK_TFLOPS, "16": BF16_DENSE_PEAK_TFLOPS, "fp8": FP8_DENSE_PEAK_TFLOPS, "32": F32_PEAK_TFLOPS}[args.precision]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
         breakdown, bsteps = (warm_prof, 1) if warm_prof is not None else (prof, args.steps)
         all_conv_flops = sum(breakdown[k]["flops"] for k in conv_classes)
@@ -347,7 +354,7 @@ def main():
         res = {
             "metric": "hand-image-pairs/sec", "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"bf16": "bf16", "32": "f32", "fp8": "fp8-e4m3 forward operands / bf16"}[args.precision], "data": "synthetic",
+            "vs_baseline": None, "dtype": {"bf16": "bf16", "32": "f32", "16": "f16 (loss-scaled)", "fp8": "fp8-e4m3 operands where they pay / bf16"}[args.precision], "data": "synthetic",
             "config": {"workload": f"ResNet-{args.resnet} {args.experiment} contrastive step (fwd+bwd+allreduce+LARS/Adam), "
                                    f"{args.per_gpu_batch} pairs/GPU of 2x{args.image_size}x{args.image_size}x3, linear MPJPE weighting, "
                                    f"crop+rotate un-warp, global negatives",

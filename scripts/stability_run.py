@@ -49,16 +49,24 @@ def run(precision):
     model.setup("fit")
     (opt,), (sched,) = model.configure_optimizers()
     data = dataset()
+    from simhand_amd.host.amp import GradScaler
+
+    scaler = GradScaler(enabled=precision == "16")  # precision 16 = fp16 storage + the reference's native-AMP loss scaling
+    params = list(model.parameters())
     losses = []
     t0 = time.perf_counter()
     for i in range(a.steps):
         opt.zero_grad(set_to_none=True)
         loss = model.training_step(data[i % a.batches], i)["loss"]
-        loss.backward()
-        opt.step()
+        scaler.scale(loss).backward()
+        scaler.unscale_(params)
+        scaler.step(opt)
+        scaler.update()
         sched["scheduler"].step()
         losses.append(float(loss.detach()))
     torch.cuda.synchronize()
+    if precision == "16":
+        print(f"product fp16 run: {scaler.skipped_steps} skipped steps, final scale {scaler.get_scale():g}", flush=True)
     pmax = max(float(p.detach().abs().max()) for p in model.parameters())
     return losses, pmax, time.perf_counter() - t0
 
@@ -144,6 +152,7 @@ def run_oracle(storage=None, parts="wag", scaler=False):
 
 bf, bf_pmax, bf_s = run("bf16")
 fp, fp_pmax, fp_s = run("32")
+h16, h16_pmax, h16_s = run("16")
 ora = ora_bf = None
 twins = {}
 if os.environ.get("SIMHAND_STABILITY_ORACLE", "0") == "1":
@@ -156,14 +165,16 @@ if os.environ.get("SIMHAND_STABILITY_ORACLE", "0") == "1":
 lines = [f"# {a.steps} training steps, ResNet-50 handclr_w, {a.batches} fixed batches of {a.pairs} pairs @ {a.size}^2 revisited every epoch, LARS + Adam, "
          "linear warm-up + cosine schedule; same initial weights", "",
          "| step | loss bf16 (bf16 storage, fp32 accumulate / statistics / loss / optimizer, no loss scaling) | loss fp32 parity mode | bf16 / fp32 |"
+         " loss precision=16 (fp16 storage build + GradScaler: the reference's policy) |"
          + (" oracle fp32 (torch ops) | oracle with bf16-rounded conv weights / inputs / outputs |" if ora else "")
-         + "".join(f" oracle twin: {k} |" for k in twins), "|---|---|---|---|" + ("---|---|" if ora else "") + "---|" * len(twins)]
+         + "".join(f" oracle twin: {k} |" for k in twins), "|---|---|---|---|---|" + ("---|---|" if ora else "") + "---|" * len(twins)]
 for i in list(range(0, a.steps, max(1, a.steps // 16))) + [a.steps - 1]:
-    lines.append(f"| {i} | {bf[i]:.4f} | {fp[i]:.4f} | {bf[i] / fp[i]:.4f} |" + (f" {ora[i]:.4f} | {ora_bf[i]:.4f} |" if ora else "")
+    lines.append(f"| {i} | {bf[i]:.4f} | {fp[i]:.4f} | {bf[i] / fp[i]:.4f} | {h16[i]:.4f} |" + (f" {ora[i]:.4f} | {ora_bf[i]:.4f} |" if ora else "")
                  + "".join(f" {v[i]:.4f} |" for v in twins.values()))
 k = max(1, a.steps // 10)
 head_b, tail_b, tail_f = sum(bf[:k]) / k, sum(bf[-k:]) / k, sum(fp[-k:]) / k
-lines += ["", f"mean of the first {k} losses (bf16) {head_b:.4f}; mean of the last {k}: bf16 {tail_b:.4f}, fp32 {tail_f:.4f}; "
+tail_h = sum(h16[-k:]) / k
+lines += ["", f"mean of the first {k} losses (bf16) {head_b:.4f}; mean of the last {k}: bf16 {tail_b:.4f}, fp32 {tail_f:.4f}, precision=16 (fp16) {tail_h:.4f}; "
           f"max |parameter| bf16 {bf_pmax:.3f} / fp32 {fp_pmax:.3f}; wall {bf_s:.1f} s / {fp_s:.1f} s"]
 if ora:
     lines.append(f"oracle, mean of the last {k}: fp32 {sum(ora[-k:]) / k:.4f}, bf16-storage twin {sum(ora_bf[-k:]) / k:.4f}")
@@ -173,5 +184,7 @@ text = "\n".join(lines)
 print(text)
 if a.out:
     open(a.out, "w").write(text + "\n")
-ok = all(math.isfinite(v) for v in bf + fp) and tail_b < head_b - 0.05 and abs(tail_b - tail_f) <= 0.1 * abs(tail_f) + 0.05
+# gates: everything finite, bf16 learns and stays within 10 % of fp32, and the REFERENCE's policy (fp16 + GradScaler) tracks fp32 to 2.5 %
+ok = (all(math.isfinite(v) for v in bf + fp + h16) and tail_b < head_b - 0.05 and abs(tail_b - tail_f) <= 0.1 * abs(tail_f) + 0.05
+      and abs(tail_h - tail_f) <= 0.025 * abs(tail_f))
 sys.exit(0 if ok else 1)
