@@ -1241,7 +1241,7 @@ static int launch_igemm(const IgemmArgs& a0, hipStream_t s) {
 // fraction of a round.  main_m = m-tiles of the 256-row launch, tail128 = 128-row m-tiles of the second one.
 static hook_t g_split256{1};
 static hook_t g_tile224{1};
-static void split256(long long Mg, int Ng, int classes, int* main_m, int* tail128, int* bm = nullptr, bool allow_tail = true) {
+static int num_cus() {
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;
@@ -1249,6 +1249,10 @@ static void split256(long long Mg, int Ng, int classes, int* main_m, int* tail12
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
               ? prop.multiProcessorCount : 256;
   }
+  return cus;
+}
+static void split256(long long Mg, int Ng, int classes, int* main_m, int* tail128, int* bm = nullptr, bool allow_tail = true) {
+  const int cus = num_cus();
   const int tiles_m = ceil_div(Mg, 256), n_tiles = Ng / 256;
   *main_m = tiles_m;
   *tail128 = 0;
