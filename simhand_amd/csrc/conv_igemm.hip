@@ -1792,7 +1792,8 @@ int simhand_conv2d_dgrad_fuse_pays(const sh_conv_desc* d) {
   // stride-2 3x3: each of the four parity-class launches pays the extra read of y against a quarter of the MFMA work; the
   // standalone pass is faster (same-box A/B of the whole step: 126.4 -> 125.9 ms)
   static const int fuse_s2 = getenv("SIMHAND_FUSE_S2") ? atoi(getenv("SIMHAND_FUSE_S2")) : 0;  // A/B timing
-  if (d->stride == 2 && d->r == 3 && !g_fuse_1x1 && !fuse_s2) return 0;
+  // (SIMHAND_FUSE_S2: 1 = all stride-2 3x3 layers, 2 = only those on the 256 x 256 kernel -- round-3 A/B)
+  if (d->stride == 2 && d->r == 3 && !g_fuse_1x1 && !(fuse_s2 == 1 || (fuse_s2 == 2 && d->cin >= 256 && d->cout >= 256))) return 0;
   return (!use_1x1(d, d->cout, d->cin) || g_fuse_1x1) ? 1 : 0;
 }
 

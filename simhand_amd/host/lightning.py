@@ -120,8 +120,8 @@ class Trainer:
                              with a 16-entry amax ring and 1 bit of margin, ops.FP8Scaler) for the matrix-core-bound layers.
     tests/test_gpu_fp8.py / test_gpu_main.py and profiles/r02_stability_160steps.md (scripts/stability_run.py: 160 steps, fp32 mode ==
     the oracle's curve, bf16 mode == the oracle's bf16-storage twin) hold the multi-step stability evidence.
-    Resume: bf16 / fp32 runs continue bit for bit (tests/test_gpu_main.py); the fp8 delayed-scaling amax rings are NOT part of the
-    checkpoint -- a resumed fp8 run re-seeds them with a current-scaling first step (documented limitation)."""
+    Resume: bf16 / fp32 runs continue bit for bit (tests/test_gpu_main.py); the GradScaler state (precision 16) and the fp8
+    delayed-scaling amax rings travel in the checkpoint ("native_amp_scaling_state", "fp8_scaling_state")."""
 
     def __init__(self, max_epochs: int = 1, precision=32, callbacks: Optional[list] = None, log_every_n_steps: int = 5,
                  default_root_dir: str = ".", max_steps: int = -1, logger=None, keep_step_losses: int = 4096, **_ignored):
@@ -169,6 +169,8 @@ class Trainer:
             "optimizer_states": [o.state_dict() for o in self.optimizers],
             "lr_schedulers": [s["scheduler"].state_dict() for s in self.schedulers],
             "native_amp_scaling_state": self.scaler.state_dict() if self.scaler.enabled else None,  # Lightning's key for the GradScaler
+            # fp8 configuration: the delayed-scaling amax rings of every quantisation site (a resumed run continues with the same scales)
+            "fp8_scaling_state": (module.encoder.engine.fp8_state_dict() if self.fp8 and hasattr(getattr(module, "encoder", None), "engine") else None),
         }
 
     def fit(self, model: LightningModule, train_dataloaders=None, val_dataloaders=None, ckpt_path: Optional[str] = None):
@@ -192,6 +194,8 @@ class Trainer:
                 s["scheduler"].load_state_dict(st)
             if self.scaler.enabled and ck.get("native_amp_scaling_state"):
                 self.scaler.load_state_dict(ck["native_amp_scaling_state"])
+            if self.fp8 and ck.get("fp8_scaling_state") and hasattr(getattr(model, "encoder", None), "engine"):
+                model.encoder.engine.load_fp8_state_dict(ck["fp8_scaling_state"], device)
             self.global_step = ck.get("global_step", 0)
             if ck.get("epoch_complete", True):
                 start_epoch = ck.get("epoch", -1) + 1

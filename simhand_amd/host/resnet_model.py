@@ -282,6 +282,28 @@ class ResNetEngine:
             self._fp8_sites[id(w)] = site
         return site
 
+    # -- fp8 scaling state <-> checkpoints (delayed-scaling amax rings; the e4m3 weight copies are rebuilt from the masters) ------------
+    def fp8_state_dict(self) -> dict:
+        names = {id(p): k for k, p in self.features.named_parameters()}
+        out = {}
+        for key, site in self._fp8_sites.items():
+            wid, tag = (key[1], "bwd") if isinstance(key, tuple) else (key, "fwd")
+            if wid in names:
+                out[f"{tag}:{names[wid]}"] = {"state": site[0].state.detach().cpu().clone(), "calls": site[0].calls}
+        return out
+
+    def load_fp8_state_dict(self, state: dict, device) -> None:
+        params = dict(self.features.named_parameters())
+        for key, rec in (state or {}).items():
+            tag, name = key.split(":", 1)
+            if name not in params:
+                continue
+            wid = id(params[name])
+            site = [ops.FP8Scaler(device, delayed=True), ops.FP8Scaler(device, delayed=False), None, None]
+            site[0].state.copy_(rec["state"].to(device))
+            site[0].calls = int(rec["calls"])
+            self._fp8_sites[("bwd", wid) if tag == "bwd" else wid] = site
+
     def _fp8_site_bwd(self, conv, device):
         """[dy scaler (delayed), weight scaler (current), e4m3 CRSK weights, version] of one fp8 data-gradient site."""
         w = conv.weight

@@ -54,3 +54,51 @@ def test_main_fit_checkpoint_resume_export(tmp_path):
         assert dk.split(".")[-1] == sk.split(".")[-1] and torch.equal(dv, sv.cpu()), (dk, sk)
     hub = export.resnet50_simhand(pretrained=True, path=str(out))
     assert torch.equal(hub.state_dict()["layer4.2.conv3.weight"], ck["state_dict"]["encoder.features.7.2.conv3.weight"].cpu())
+
+
+def test_precision_16_resume_continues_bit_for_bit(tmp_path):
+    """--precision 16 (fp16 storage + GradScaler, the reference's default precision): the scaler state travels in the checkpoint and the
+    resumed run's next step equals the uninterrupted run's."""
+    from simhand_amd.host.main import main
+
+    def argv(d, extra):
+        a = _argv(d, extra)
+        a[a.index("--precision") + 1] = "16"
+        return a
+
+    ta = main(argv(tmp_path / "a", ["--max_steps", "4"]))
+    la = [float(x) for x in ta.step_losses]
+    tb = main(argv(tmp_path / "b", ["--max_steps", "3"]))
+    assert [float(x) for x in tb.step_losses] == la[:3]
+    ckdir = tmp_path / "b" / "checkpoints"
+    name = os.listdir(ckdir)[0]
+    ck = torch.load(ckdir / name, map_location="cpu", weights_only=False)
+    assert ck["native_amp_scaling_state"]["scale"] == 65536.0 and ck["native_amp_scaling_state"]["_growth_tracker"] == 3
+    tc = main(argv(tmp_path / "c", ["--resume", "--resume_path", str(ckdir / name), "--max_steps", "4"]))
+    assert [float(x) for x in tc.step_losses] == la[3:], (list(tc.step_losses), la)
+    assert tc.scaler._growth_tracker == 4
+
+
+def test_fp8_scaling_state_round_trips_through_the_engine():
+    """The delayed-scaling amax rings of the fp8 sites (forward and data gradient) as a checkpointable dict: a fresh engine that loads it
+    continues with the same scales."""
+    from oracle import step as orc
+    from simhand_amd import _lib, ops
+    from tests.test_gpu_configs import _oracle, _product
+
+    om = _oracle("simclr", "50", {}, 3, 0.1)
+    batch = {k: v.to("cuda") for k, v in orc.synthetic_batch(4, size=224, seed=3).items()}
+    _lib.load().simhand_test_igemm256_enable(2)
+    m1 = _product("SimCLR", "50", {}, om, torch.bfloat16, 4)
+    m1.set_compute_dtype(torch.bfloat16, fp8=True)
+    for i in range(2):
+        m1.zero_grad()
+        m1.training_step(batch, i)["loss"].backward()
+    sd = m1.encoder.engine.fp8_state_dict()
+    assert len([k for k in sd if k.startswith("fwd:")]) == 9 and len([k for k in sd if k.startswith("bwd:")]) == 9, sorted(sd)
+    m2 = _product("SimCLR", "50", {}, om, torch.bfloat16, 4)
+    m2.set_compute_dtype(torch.bfloat16, fp8=True)
+    m2.encoder.engine.load_fp8_state_dict(sd, torch.device("cuda"))
+    l1 = m1.training_step(batch, 2)["loss"]
+    l2 = m2.training_step(batch, 2)["loss"]
+    assert torch.equal(l1, l2), (float(l1), float(l2))
