@@ -73,10 +73,12 @@ def test_precision_16_resume_continues_bit_for_bit(tmp_path):
     ckdir = tmp_path / "b" / "checkpoints"
     name = os.listdir(ckdir)[0]
     ck = torch.load(ckdir / name, map_location="cpu", weights_only=False)
-    assert ck["native_amp_scaling_state"]["scale"] == 65536.0 and ck["native_amp_scaling_state"]["_growth_tracker"] == 3
+    # (at random init a ResNet-50's scaled gradients may overflow fp16 once: the scaler then halves the scale and skips that step)
+    st = ck["native_amp_scaling_state"]
+    assert st["scale"] == tb.scaler.get_scale() and st["scale"] in (65536.0, 32768.0, 16384.0) and st["_growth_tracker"] == tb.scaler._growth_tracker
     tc = main(argv(tmp_path / "c", ["--resume", "--resume_path", str(ckdir / name), "--max_steps", "4"]))
     assert [float(x) for x in tc.step_losses] == la[3:], (list(tc.step_losses), la)
-    assert tc.scaler._growth_tracker == 4
+    assert tc.scaler.get_scale() == ta.scaler.get_scale() and tc.scaler._growth_tracker == ta.scaler._growth_tracker
 
 
 def test_fp8_scaling_state_round_trips_through_the_engine():
