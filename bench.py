@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--comm", default="torch", choices=["torch", "abi"],
                     help="N > 1: collectives through torch.distributed (nccl = RCCL) or through the C ABI's own RCCL wrappers (simhand_comm_*)")
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="N > 1: wire format of the gradient all-reduce buckets")
+    ap.add_argument("--event-every", type=int, default=1,
+                    help="HIP events bracket every launch of the roofline's kernel class in every Nth timed step (1 = every step, the default; "
+                         "measured: sampling every 4th step moves the step time by < 0.1 ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=32,
                     help="pairs in the CPU-baseline sample (default = the SURVEY 8d point B = 32; ~40 s on the box's host for ResNet-50)")
@@ -298,9 +301,10 @@ def main():
     else:
         ops.prof_set_classes(None)
     ops.prof_reset()
-    ops.prof_enable(True)
+    every = max(1, args.event_every)
     t0 = time.perf_counter()
     for i in range(args.steps):
+        ops.prof_enable(i % every == 0)  # live HIP events on the dominant class's launches, in every `every`-th timed step
         loss = step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -329,7 +333,7 @@ def main():
         d = conv[dom]  # measured in the timed region
         peak = {"bf16": BF16_DENSE_PEAK_TFLOPS, "16": BF16_DENSE_PEAK_TFLOPS, "fp8": FP8_DENSE_PEAK_TFLOPS, "32": F32_PEAK_TFLOPS}[args.precision]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-        breakdown, bsteps = (warm_prof, 1) if warm_prof is not None else (prof, args.steps)
+        breakdown, bsteps = (warm_prof, 1) if warm_prof is not None else (prof, len(range(0, args.steps, every)))
         all_conv_flops = sum(breakdown[k]["flops"] for k in conv_classes)
         all_conv_ms = sum(breakdown[k]["ms"] for k in conv_classes)
         # HBM view of the step.  The PMC counters (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) need rocprofv3's
@@ -366,6 +370,7 @@ def main():
                        "grad_wire": args.grad_wire if world > 1 else "n/a"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "hbm": hbm, "launches": d["count"], "avg_launch_ms": d["ms"] / max(1, d["count"]),
+                         "event_steps": f"{len(range(0, args.steps, every))} of the {args.steps} timed steps (every {every})",
                          "all_conv_tflops": all_conv_flops / (all_conv_ms * 1e-3) / 1e12 if all_conv_ms > 0 else 0.0,
                          "step_tflops_per_gpu": TRAIN_GFLOP_PER_PAIR.get(args.resnet, 0.0) * (args.image_size / 224.0) ** 2
                                                 * args.per_gpu_batch * args.steps / elapsed / 1e3},

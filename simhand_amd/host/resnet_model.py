@@ -165,6 +165,8 @@ class ResNetEngine:
         # output is written but not read back by that conv1 (env: A/B timing only)
         self.chain_conv1 = os.environ.get("SIMHAND_CHAIN", "1") == "1"
         self._chain = None  # (block output tensor, the chained conv module, its raw output, its BatchNorm partial sums)
+        # folded stride-2 shortcut convolutions run as dense 1x1 / stride-1 launches over the subsampled input (env: A/B timing only)
+        self.dense_shortcut = os.environ.get("SIMHAND_DENSE_DS", "1") == "1"
         # multi-GPU: host.dist.OverlappedGradReducer -- finished parameter gradients go out block by block during backward
         self.grad_reducer = None
 
@@ -248,7 +250,12 @@ class ResNetEngine:
             a, mask, cy, cpart = ops.conv2d_fwd_bnact_chain(d, x, pk.krsc, st, residual, self._pack(chain_conv, need_t=True).krsc)
             self._chain = (a, chain_conv, cy, cpart)
         else:
-            res = ops.conv2d_fwd_bnact(d, x, pk.krsc, st, relu, residual, want_mask=want_mask)
+            if s == 2 and self.dense_shortcut:
+                # the subsampled copy exists anyway (Gram launch, backward): a dense stride-1 1x1 over it instead of a strided walk over x
+                dd = ops.conv_desc(n, d.ho, d.wo, cin, cout, 1, 1, 1, 0, self.dtype)
+                res = ops.conv2d_fwd_bnact(dd, x_in, pk.krsc, st, relu, residual, want_mask=want_mask)
+            else:
+                res = ops.conv2d_fwd_bnact(d, x, pk.krsc, st, relu, residual, want_mask=want_mask)
             a, mask = res if want_mask else (res, None)
         if save is not None:
             u = _Unit()
