@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--event-every", type=int, default=1,
                     help="HIP events bracket every launch of the roofline's kernel class in every Nth timed step (1 = every step, the default; "
                          "measured: sampling every 4th step moves the step time by < 0.1 ms)")
+    ap.add_argument("--sync-bn", action="store_true", help="N > 1: synchronised BatchNorm (statistics over the global batch; not the headline configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=32,
                     help="pairs in the CPU-baseline sample (default = the SURVEY 8d point B = 32; ~40 s on the box's host for ResNet-50)")
@@ -259,6 +260,8 @@ def main():
             model.process_group = group
         reducer = shdist.OverlappedGradReducer(group, wire=args.grad_wire)
         model.encoder.engine.grad_reducer = reducer
+        if args.sync_bn:
+            shdist.enable_sync_bn(group)
 
     from simhand_amd.host.amp import GradScaler
 
@@ -367,7 +370,8 @@ def main():
                        "world_size_backend": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none",
                        "comm": ("abi (simhand_comm_*)" if group is not None else "torch.distributed") if world > 1 else "none",
-                       "grad_wire": args.grad_wire if world > 1 else "n/a"},
+                       "grad_wire": args.grad_wire if world > 1 else "n/a",
+                       "batchnorm": "synchronised" if (world > 1 and args.sync_bn) else "per-rank statistics"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "hbm": hbm, "launches": d["count"], "avg_launch_ms": d["ms"] / max(1, d["count"]),
                          "event_steps": f"{len(range(0, args.steps, every))} of the {args.steps} timed steps (every {every})",

@@ -220,6 +220,33 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) ->
             dist.broadcast(t.data, src=src, group=group)
 
 
+def enable_sync_bn(group=None) -> bool:
+    """Synchronised BatchNorm over `group` (a torch.distributed group, an RcclComm, or None = the default group): every train-mode
+    BatchNorm of the HIP engine and of the projection head then takes its statistics over the GLOBAL batch (ops.set_bn_sync; SURVEY
+    8e "optional SyncBN": one small all-reduce of 2 C sums in the forward and one in the backward of each BatchNorm).  Off by default
+    -- per-rank statistics are what the reference's DP replicas have (src/experiments/main.py:152-155).  Returns whether it is on
+    (a single-rank job has nothing to synchronise)."""
+    from .. import ops
+
+    if isinstance(group, RcclComm):
+        if group.world <= 1:
+            ops.set_bn_sync(None)
+            return False
+        ops.set_bn_sync(lambda t: group.all_reduce_(t, "sum"))
+        return True
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        ops.set_bn_sync(None)
+        return False
+    ops.set_bn_sync(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group))
+    return True
+
+
+def disable_sync_bn() -> None:
+    from .. import ops
+
+    ops.set_bn_sync(None)
+
+
 _GRAD_PLANS: dict = {}
 
 

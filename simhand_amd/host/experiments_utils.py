@@ -83,7 +83,7 @@ def build_parser(description: str = "Script for training baseline supervised mod
     return p
 
 
-BUILD_ONLY_FLAGS = ("synthetic", "synthetic_raw", "synthetic_samples", "precision", "image_size", "max_steps", "out_dir")
+BUILD_ONLY_FLAGS = ("synthetic", "synthetic_raw", "synthetic_samples", "precision", "image_size", "max_steps", "out_dir", "sync_batchnorm")
 
 
 def add_build_flags(p: argparse.ArgumentParser) -> argparse.ArgumentParser:
@@ -97,6 +97,8 @@ def add_build_flags(p: argparse.ArgumentParser) -> argparse.ArgumentParser:
     p.add_argument("--image_size", type=int, default=None, help="synthetic image side (default: resize_shape or 224)")
     p.add_argument("--max_steps", type=int, default=-1, help="stop after this many optimizer steps")
     p.add_argument("--out_dir", type=str, default=None, help="where checkpoints go (default $SAVED_MODELS_BASE_PATH or ./runs)")
+    p.add_argument("--sync_batchnorm", action="store_true",
+                   help="multi-GPU: BatchNorm statistics over the global batch instead of per rank (PL's Trainer(sync_batchnorm=True))")
     return p
 
 

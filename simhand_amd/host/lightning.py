@@ -124,8 +124,10 @@ class Trainer:
     delayed-scaling amax rings travel in the checkpoint ("native_amp_scaling_state", "fp8_scaling_state")."""
 
     def __init__(self, max_epochs: int = 1, precision=32, callbacks: Optional[list] = None, log_every_n_steps: int = 5,
-                 default_root_dir: str = ".", max_steps: int = -1, logger=None, keep_step_losses: int = 4096, **_ignored):
+                 default_root_dir: str = ".", max_steps: int = -1, logger=None, keep_step_losses: int = 4096, sync_batchnorm: bool = False,
+                 **_ignored):
         self.max_epochs, self.precision, self.callbacks = max_epochs, precision, callbacks or []
+        self.sync_batchnorm = bool(sync_batchnorm)  # PL's Trainer(sync_batchnorm=...): BatchNorm statistics over the global batch
         self.log_every_n_steps, self.default_root_dir, self.max_steps = log_every_n_steps, default_root_dir, max_steps
         self.global_step = 0
         self.current_epoch = 0
@@ -209,6 +211,10 @@ class Trainer:
             if isinstance(cb, ModelCheckpoint) and ckpt_path:
                 cb.rescan()  # earlier top-k files of the run being resumed stay subject to pruning
         reducer = None
+        if self.sync_batchnorm:
+            from .dist import enable_sync_bn
+
+            enable_sync_bn(getattr(model, "process_group", None))
         if self.world_size > 1 and hasattr(getattr(model, "encoder", None), "engine"):
             reducer = OverlappedGradReducer(getattr(model, "process_group", None))
             model.encoder.engine.grad_reducer = reducer  # backbone gradients are all-reduced during the backward pass

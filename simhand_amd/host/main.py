@@ -106,7 +106,7 @@ def main(argv=None):
                  f"{1024 * train_param.accumulate_grad_batches}_lr_{lr_str}_{{contrastive_loss:.6f}}")
     precision = args.precision or train_param.precision
     trainer = Trainer(max_epochs=train_param.epochs, precision=precision, callbacks=[ckpt], log_every_n_steps=5,
-                      default_root_dir=out_dir, max_steps=args.max_steps)
+                      default_root_dir=out_dir, max_steps=args.max_steps, sync_batchnorm=getattr(args, "sync_batchnorm", False))
     if args.eval:
         raise SystemExit("--eval drives the reference's visualisation path (simhand_vis), which is out of scope")
     if args.resume and args.resume_path is None:

@@ -144,7 +144,7 @@ class ResNetEngine:
         # BN-backward partial sums of a unit fused into the epilogue of the dgrad that produces its incoming gradient
         self.fuse_bn_bwd = True
         # bottleneck conv3 + bn3: BatchNorm backward folded into the 1x1 conv's own gradients (_unit3_bwd_folded)
-        self.fold_bn3 = True
+        self._fold_bn3 = True
         # both terms of the folded input gradient in one launch where the tile kernels take a second K segment
         self.concat_fold = True
         # the folds need every block's incoming gradient in masked form, which only the all-1x1 tails of Bottleneck nets give
@@ -154,12 +154,12 @@ class ResNetEngine:
         # BN-backward apply of a 1x1 / stride-1 unit without residual runs inside that unit's weight-gradient launch
         # (off: measured on MI355X at 2048 x 224^2 the BatchNorm class drops 4.3 ms but the weight-gradient class grows 8.5 ms --
         # every cin tile of the launch re-derives the dy operand from TWO tensors; kept for the experiment record)
-        self.fuse_bwd_apply_wgrad = os.environ.get("SIMHAND_FUSE_BWDW", "0") == "1"
+        self._fuse_bwd_apply_wgrad = os.environ.get("SIMHAND_FUSE_BWDW", "0") == "1"
         # BN-backward apply of a Bottleneck's conv1 + bn1 runs in the A-operand load of conv1's DATA gradient (the activation-
         # stationary kernel loads each gradient row exactly once, straight into MFMA operand registers): the stand-alone pass
         # (2 reads + 1 write of the narrow tensor) becomes 1 extra read + 1 write inside that launch; the weight gradient then
         # reads the dy it wrote (env: A/B timing only)
-        self.fuse_bwd_apply_dgrad = os.environ.get("SIMHAND_FUSE_BWDD", "1") == "1"
+        self._fuse_bwd_apply_dgrad = os.environ.get("SIMHAND_FUSE_BWDD", "1") == "1"
         self._gram = None  # (activation tensor, a^T a, sum a) of the unit just applied that way
         # the next block's conv1 chained onto this block's conv3 + bn3 + add + ReLU launch (ops.conv2d_fwd_bnact_chain): the block
         # output is written but not read back by that conv1 (env: A/B timing only)
@@ -169,6 +169,34 @@ class ResNetEngine:
         self.dense_shortcut = os.environ.get("SIMHAND_DENSE_DS", "1") == "1"
         # multi-GPU: host.dist.OverlappedGradReducer -- finished parameter gradients go out block by block during backward
         self.grad_reducer = None
+
+    # Synchronised BatchNorm (ops.set_bn_sync, SURVEY 8e "optional SyncBN"): the statistics of every BatchNorm are all-reduced in its
+    # finalize step, so the forms that never materialise those sums as per-block partials -- the Gram-matrix fold of conv3 + bn3 / the
+    # shortcut, the BatchNorm-backward apply fused into a consumer's operand load -- are off; the fused partial sums in the dgrad
+    # epilogues stay (their finalize step is the synchronisation point).
+    @property
+    def fold_bn3(self) -> bool:
+        return self._fold_bn3 and not ops.bn_sync_active()
+
+    @fold_bn3.setter
+    def fold_bn3(self, on: bool) -> None:
+        self._fold_bn3 = bool(on)
+
+    @property
+    def fuse_bwd_apply_wgrad(self) -> bool:
+        return self._fuse_bwd_apply_wgrad and not ops.bn_sync_active()
+
+    @fuse_bwd_apply_wgrad.setter
+    def fuse_bwd_apply_wgrad(self, on: bool) -> None:
+        self._fuse_bwd_apply_wgrad = bool(on)
+
+    @property
+    def fuse_bwd_apply_dgrad(self) -> bool:
+        return self._fuse_bwd_apply_dgrad and not ops.bn_sync_active()
+
+    @fuse_bwd_apply_dgrad.setter
+    def fuse_bwd_apply_dgrad(self, on: bool) -> None:
+        self._fuse_bwd_apply_dgrad = bool(on)
 
     # -- weights -------------------------------------------------------------
     def _pack(self, conv: nn.Conv2d, need_t: bool, stem: bool = False) -> _Packed:

@@ -558,13 +558,36 @@ def nchw_to_nhwc(x: torch.Tensor, dtype, c_pad: Optional[int] = None) -> torch.T
 
 # -------------------------------------------------------------------------- BN
 class BNState:
-    """Per-call statistics of one train-mode BatchNorm (all fp32, length C)."""
+    """Per-call statistics of one train-mode BatchNorm (all fp32, length C).  m_total: under bn_sync, the number of positions
+    the statistics were taken over on ALL ranks (None = the local count the caller passes)."""
 
-    __slots__ = ("mean", "invstd", "scale", "shift")
+    __slots__ = ("mean", "invstd", "scale", "shift", "m_total")
 
     def __init__(self, c: int, device):
         buf = torch.empty(4, c, dtype=torch.float32, device=device)
         self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+        self.m_total = None
+
+
+# ---- synchronised BatchNorm (SURVEY 8e, optional): statistics over the GLOBAL batch ---------------------------------------------
+# Train-mode BatchNorm reduces over positions twice -- forward (sum y, sum y^2) and backward (sum g, sum g * yhat) -- and both
+# reductions end in a finalize step that takes per-block partial sums.  Under bn_sync the locally folded sums go through one
+# all-reduce (2 C + 1 doubles forward: the position count rides along, so ragged shards are fine; 2 C floats backward) before
+# that step: every rank then normalises with the same mean / variance and back-propagates through them.  dgamma / dbeta stay the
+# LOCAL sums (they are parameter gradients: the gradient all-reduce adds them up like every other parameter's).
+# The reference has no synchronised BatchNorm (its DP replicas keep per-replica statistics, src/experiments/main.py:152-155).
+_BN_SYNC = None  # callable(tensor) -> None: in-place SUM all-reduce over the data-parallel group
+
+
+def set_bn_sync(all_reduce_sum=None) -> None:
+    """all_reduce_sum(t): in-place SUM all-reduce of a contiguous fp32 / fp64 device tensor over the ranks whose batches form one
+    BatchNorm batch; None switches synchronisation off (per-rank statistics: the default, and what the reference's replicas do)."""
+    global _BN_SYNC
+    _BN_SYNC = all_reduce_sum
+
+
+def bn_sync_active() -> bool:
+    return _BN_SYNC is not None
 
 
 def bn_partial_stats(y: torch.Tensor, m: int, c: int) -> torch.Tensor:
@@ -579,6 +602,15 @@ def bn_finalize(part: torch.Tensor, m: int, c: int, gamma, beta, running_mean, r
                 eps: float = 1e-5, momentum: float = 0.1) -> BNState:
     lib = _lib_dev()
     st = BNState(c, part.device)
+    if _BN_SYNC is not None:
+        # fold the local per-block sums (double, as the finalize kernel does), add the position count, all-reduce, finalize one row
+        tot = torch.empty(2 * c + 1, dtype=torch.float64, device=part.device)
+        tot[:2 * c] = part.to(torch.float64).sum(0).view(-1)
+        tot[2 * c] = float(m)
+        _BN_SYNC(tot)
+        m = int(round(float(tot[2 * c])))  # (one host read per BatchNorm: the synchronised mode is not the benchmarked one)
+        part = tot[:2 * c].to(torch.float32).view(1, 2, c).contiguous()
+        st.m_total = m
     nblk = part.shape[0]
     nb = lib.simhand_bn_finalize_workspace_bytes(nblk, c)
     ws = torch.empty(nb, dtype=torch.uint8, device=part.device)
@@ -636,7 +668,17 @@ def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_d
                                          dt(y.dtype), _ptr(part), _stream()), "bn_bwd_partial")
         check(lib.simhand_bn_bwd_finalize(_ptr(part), nblk, c, _ptr(dg), _ptr(db), _stream()), "bn_bwd_finalize")
     if not apply:  # sums only: the caller fuses the apply into a consumer (conv2d_wgrad_bnbwd)
+        if _BN_SYNC is not None:
+            raise RuntimeError("bn_backward(apply=False): the fused-apply consumers take local sums; not available under bn_sync")
         return None, None, dg, db
+    dg_l, db_l = dg, db
+    if _BN_SYNC is not None:  # dy needs the sums over every rank's positions; the returned parameter gradients stay local
+        # (the apply kernels use the sums only as dgamma / m and dbeta / m, with m = the LOCAL row count they also iterate over:
+        # they get the global sums scaled by m / m_total)
+        both = torch.stack((dg, db))
+        _BN_SYNC(both)
+        both *= float(m) / float(st.m_total if st.m_total is not None else m)
+        dg, db = both[0], both[1]
     if fp8_scaler is not None and fp8_scaler.calls > 0 and not want_dres:
         # the apply pass also emits dy's e4m3 codes (operand of the fp8 data gradient) + its amax; returned as a 5th value
         dy = torch.empty_like(y)
@@ -646,14 +688,14 @@ def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_d
                                            m, c, _stream()), "bn_bwd_apply_fp8")
         fp8_scaler._update(True)
         fp8_scaler.calls += 1
-        return dy, None, dg, db, q
+        return dy, None, dg_l, db_l, q
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
     check(lib.simhand_bn_bwd_apply(_ptr(da), _ptr(aa), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(dg), _ptr(db),
                                    _ptr(st.scale), _ptr(st.shift), mode, _ptr(dy), _ptr(dres), m, c, dt(y.dtype), _stream()), "bn_bwd_apply")
     if fp8_scaler is not None:  # first call of a delayed site: calibrate with the two-pass form
-        return dy, dres, dg, db, fp8_scaler.quantize(dy)
-    return dy, dres, dg, db
+        return dy, dres, dg_l, db_l, fp8_scaler.quantize(dy)
+    return dy, dres, dg_l, db_l
 
 
 def bn_relu_maxpool_fwd(y: torch.Tensor, st: BNState, want_winner: bool = False):
@@ -692,10 +734,17 @@ def maxpool_bn_backward(dz: torch.Tensor, idx: torch.Tensor, y: torch.Tensor, st
     dg = torch.empty(c, dtype=torch.float32, device=dev)
     db = torch.empty(c, dtype=torch.float32, device=dev)
     check(lib.simhand_bn_bwd_finalize(_ptr(part), nblk, c, _ptr(dg), _ptr(db), _stream()), "bn_bwd_finalize")
+    dg_l, db_l = dg, db
+    if _BN_SYNC is not None:
+        # the apply kernel divides the two sums by its LOCAL position count m: hand it the global sums scaled by m / m_total
+        both = torch.stack((dg, db))
+        _BN_SYNC(both)
+        both *= float(m) / float(st.m_total if st.m_total is not None else m)
+        dg, db = both[0], both[1]
     dy = torch.empty_like(y)
     check(lib.simhand_maxpool_bn_bwd_apply(_ptr(dz), _ptr(idx), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(dg), _ptr(db),
                                            _ptr(st.scale), _ptr(st.shift), _ptr(dy), n, h, w, c, dt(y.dtype), _stream()), "maxpool_bn_bwd_apply")
-    return dy, dg, db
+    return dy, dg_l, db_l
 
 
 # ------------------------------------------------------------------------ pools

@@ -16,11 +16,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, backend, port):
+def _run(world, backend, port, worker="_dist_worker.py", extra=()):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), OMP_NUM_THREADS="4",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    worker = os.path.join(ROOT, "tests", "_dist_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, ROOT, backend], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+    worker = os.path.join(ROOT, "tests", worker)
+    procs = [subprocess.Popen([sys.executable, worker, ROOT, backend, *extra], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
@@ -31,6 +31,13 @@ def _run(world, backend, port):
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_sharded_step_matches_reference_golden(world):
     _run(world, "gloo", 29620 + world)
+
+
+@pytest.mark.parametrize("world,size", [(1, "18"), (2, "18"), (4, "18"), (1, "50"), (2, "50"), (4, "50")])
+def test_sync_batchnorm_sharded_step_equals_the_full_batch_step(world, size):
+    """SURVEY 8e "optional SyncBN": with every BatchNorm's sums all-reduced, R ranks on R shards reproduce the ONE-process step on
+    the concatenated batch (oracle: plain full-batch BatchNorm) -- loss, gradients after the all-reduce, running statistics."""
+    _run(world, "gloo", 29660 + world + (10 if size == "50" else 0), worker="_syncbn_worker.py", extra=(size,))
 
 
 def test_sharded_step_over_rccl():

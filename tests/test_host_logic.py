@@ -246,6 +246,22 @@ try:
     raise SystemExit("expected a RuntimeError")
 except RuntimeError:
     pass
+# synchronised BatchNorm switch (SURVEY 8e, optional): the callable it installs SUMs over the ranks; the packed forward message
+# (2 C sums + the position count, double) gives every rank the global mean / variance of ragged shards
+from simhand_amd import ops
+assert not ops.bn_sync_active()
+assert shdist.enable_sync_bn() and ops.bn_sync_active()
+gx = torch.Generator().manual_seed(11)
+full = torch.randn(40, 6, generator=gx, dtype=torch.float64) * 3 + 1
+cuts = [0] + [40 * (r + 1) // world - (1 if r + 1 < world else 0) * (r % 2) for r in range(world)]   # ragged shards
+mine = full[cuts[rank]:cuts[rank + 1]]
+msg = torch.cat((mine.sum(0), (mine * mine).sum(0), torch.tensor([float(mine.shape[0])], dtype=torch.float64)))
+ops._BN_SYNC(msg)
+m = int(round(float(msg[-1]))); assert m == 40
+mean, var = msg[:6] / m, msg[6:12] / m - (msg[:6] / m) ** 2
+assert torch.allclose(mean, full.mean(0), atol=1e-12) and torch.allclose(var, full.var(0, unbiased=False), atol=1e-10)
+shdist.disable_sync_bn()
+assert not ops.bn_sync_active()
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
