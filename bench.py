@@ -265,7 +265,7 @@ def main():
 
     from simhand_amd.host.amp import GradScaler
 
-    scaler = GradScaler(enabled=args.precision == "16")  # the reference's native-AMP loss scaling; a no-op for the other precisions
+    scaler = GradScaler(enabled=args.precision == "16" and os.environ.get("SIMHAND_NO_SCALER", "0") != "1")  # the reference's native-AMP loss scaling; a no-op for the other precisions
 
     def step(i):
         opt.zero_grad(set_to_none=True)

@@ -664,6 +664,13 @@ int simhand_pack_weights_multi(const sh_pack_item* items, const int32_t* chunks,
 int simhand_lars_adam_multi(const sh_opt_tensor* tensors, int n_tensors, const int32_t* chunks, int n_chunks, float* norm_partials,
                             float beta1, float beta2, float adam_eps, float lars_eta, float lars_eps, int lars_clip,
                             int64_t total_elems, sh_stream_t stream);
+/* The same update under dynamic loss scaling (the reference's precision = 16 policy, src/experiments/main.py:158-159): found_inf is
+ * GradScaler's DEVICE flag (one float; non-zero = this step's unscaled gradients held an inf / nan) -- the update launch then returns
+ * without touching parameters or moments, so the skipped step costs no host synchronisation.  found_inf = NULL: the plain update.
+ * The caller's step counters (bc1 / bc2_sqrt) must not advance over a skipped step (host/optim.py reads the flag one step late). */
+int simhand_lars_adam_multi_guarded(const sh_opt_tensor* tensors, int n_tensors, const int32_t* chunks, int n_chunks, float* norm_partials,
+                                    float beta1, float beta2, float adam_eps, float lars_eta, float lars_eps, int lars_clip,
+                                    int64_t total_elems, const float* found_inf, sh_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -192,6 +192,7 @@ SIGNATURES = {
     "simhand_pack_chunk_elems": (_I, []),
     "simhand_pack_weights_multi": (_I, [_P, _P, _I, _P, _I, _I, _P]),
     "simhand_lars_adam_multi": (_I, [_P, _I, _P, _I, _P, _F, _F, _F, _F, _F, _I, _L, _P]),
+    "simhand_lars_adam_multi_guarded": (_I, [_P, _I, _P, _I, _P, _F, _F, _F, _F, _F, _I, _L, _P, _P]),
     "simhand_fp8_state_floats": (_I, [_I]),
     "simhand_fp8_amax": (_I, [_P, _L, _I, _P, _P]),
     "simhand_fp8_scale_update": (_I, [_P, _P, _I, _F, _I, _P]),

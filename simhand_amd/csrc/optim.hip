@@ -97,8 +97,11 @@ __global__ __launch_bounds__(256) void opt_norms_kernel(const sh_opt_tensor* __r
 __global__ __launch_bounds__(256) void opt_update_kernel(const sh_opt_tensor* __restrict__ tensors, const int2* __restrict__ chunks,
                                                          const float* __restrict__ p_part, const float* __restrict__ g_part,
                                                          float beta1, float beta2, float adam_eps, float lars_eta, float lars_eps,
-                                                         int lars_clip) {
+                                                         int lars_clip, const float* __restrict__ found_inf) {
   __shared__ float coef[2];
+  // loss-scaled (fp16) training: the gradients of this step overflowed -> the step is skipped, decided here on the device
+  // (torch's fused optimizers do the same with GradScaler's found_inf): parameters and both moments stay as they are
+  if (found_inf != nullptr && found_inf[0] != 0.f) return;
   const int2 ck = chunks[blockIdx.x];
   const sh_opt_tensor t = tensors[ck.x];
   if (threadIdx.x == 0) {
@@ -177,17 +180,24 @@ int simhand_lars_adam_step(float* param, const float* grad, float* exp_avg, floa
 
 int simhand_opt_chunk_elems(void) { return OPT_CHUNK; }
 
-int simhand_lars_adam_multi(const sh_opt_tensor* tensors, int n_tensors, const int32_t* chunks, int n_chunks, float* norm_partials,
-                            float beta1, float beta2, float adam_eps, float lars_eta, float lars_eps, int lars_clip,
-                            int64_t total_elems, sh_stream_t stream) {
+int simhand_lars_adam_multi_guarded(const sh_opt_tensor* tensors, int n_tensors, const int32_t* chunks, int n_chunks, float* norm_partials,
+                                    float beta1, float beta2, float adam_eps, float lars_eta, float lars_eps, int lars_clip,
+                                    int64_t total_elems, const float* found_inf, sh_stream_t stream) {
   SH_REQUIRE(tensors && chunks && norm_partials, "lars_adam_multi: NULL pointer");
   SH_REQUIRE(n_tensors >= 1 && n_chunks >= 1, "lars_adam_multi: empty tables");
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(SH_PROF_OPT, st, 0, (double)total_elems * 36);
   opt_norms_kernel<<<n_chunks, 256, 0, st>>>(tensors, (const int2*)chunks, norm_partials, norm_partials + n_chunks);
   opt_update_kernel<<<n_chunks, 256, 0, st>>>(tensors, (const int2*)chunks, norm_partials, norm_partials + n_chunks, beta1, beta2,
-                                              adam_eps, lars_eta, lars_eps, lars_clip);
+                                              adam_eps, lars_eta, lars_eps, lars_clip, found_inf);
   return check_launch("lars_adam_multi");
+}
+
+int simhand_lars_adam_multi(const sh_opt_tensor* tensors, int n_tensors, const int32_t* chunks, int n_chunks, float* norm_partials,
+                            float beta1, float beta2, float adam_eps, float lars_eta, float lars_eps, int lars_clip,
+                            int64_t total_elems, sh_stream_t stream) {
+  return simhand_lars_adam_multi_guarded(tensors, n_tensors, chunks, n_chunks, norm_partials, beta1, beta2, adam_eps, lars_eta, lars_eps,
+                                         lars_clip, total_elems, nullptr, stream);
 }
 
 }  // extern "C"

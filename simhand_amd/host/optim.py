@@ -29,6 +29,26 @@ class LARSAdam(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self.multi_tensor = multi_tensor
         self._plans = {}
+        # Loss-scaled (fp16) training: step(found_inf=<GradScaler's device flag>) lets the update launch skip itself on the device.  The
+        # host-side step counters (Adam's bias corrections) must not advance over a skipped step: the flag is copied to pinned host
+        # memory behind the launch and read at the NEXT step -- by then it has long arrived, the launch queue never drains.
+        self._pending = None  # (pinned flag, event, parameters whose counters were advanced optimistically)
+
+    accepts_found_inf = True
+
+    def _resolve_pending(self) -> None:
+        if self._pending is None:
+            return
+        host, ev, ps = self._pending
+        self._pending = None
+        ev.synchronize()
+        if float(host[0]) != 0.0:  # that step was skipped on the device: take its count back
+            for p in ps:
+                self.state[p]["step"] -= 1
+
+    def state_dict(self):
+        self._resolve_pending()
+        return super().state_dict()
 
     def _state(self, p):
         st = self.state[p]
@@ -39,7 +59,12 @@ class LARSAdam(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, found_inf=None):
+        self._resolve_pending()
+        if found_inf is not None and not (self.multi_tensor and found_inf.is_cuda):
+            if float(found_inf) != 0.0:  # per-tensor launches have no device-side guard: read the flag (one synchronisation)
+                return
+            found_inf = None
         if not self.multi_tensor:
             for group in self.param_groups:
                 for p in group["params"]:
@@ -77,9 +102,15 @@ class LARSAdam(torch.optim.Optimizer):
                           plan.first[i], plan.nchunks[i], group["lr"], group["weight_decay"],
                           np.float32(1.0) - np.float32(betas[0]) ** np.float32(t),
                           np.sqrt(np.float32(1.0) - np.float32(betas[1]) ** np.float32(t)), int(bool(group["lars"])), 0)
-            ops.lars_adam_multi(plan, rec, betas, eps, eta, leps, clip)  # same stream as the producers of `keep`
+            ops.lars_adam_multi(plan, rec, betas, eps, eta, leps, clip, found_inf=found_inf)  # same stream as the producers of `keep`
             # the kernels wrote through raw pointers: tell torch, the packed-weight caches key on _version
             increment_version([p for _, p in items])
+        if found_inf is not None and buckets:
+            host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            host.copy_(found_inf, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (host, ev, [p for items in buckets.values() for _, p in items])
 
 
 class LinearWarmupCosineAnnealingLR:

@@ -1060,14 +1060,17 @@ class LarsAdamPlan:
 
 
 def lars_adam_multi(plan: LarsAdamPlan, records: "np.ndarray", betas=(0.9, 0.999), adam_eps: float = 1e-8, lars_eta: float = 0.02,
-                    lars_eps: float = 1e-8, lars_clip: bool = True) -> None:
-    """records: OPT_TENSOR_DTYPE array, one per tensor of the plan (device pointers as integers)."""
+                    lars_eps: float = 1e-8, lars_clip: bool = True, found_inf: Optional[torch.Tensor] = None) -> None:
+    """records: OPT_TENSOR_DTYPE array, one per tensor of the plan (device pointers as integers).  found_inf: GradScaler's device
+    flag (fp32 [1]); non-zero -> the update launch leaves parameters and moments untouched (simhand_lars_adam_multi_guarded)."""
     lib = _lib_dev()
     assert records.dtype == OPT_TENSOR_DTYPE and len(records) == len(plan.counts)
     host = torch.from_numpy(records.view(np.uint8)).pin_memory()  # caching host allocator: safe to reuse across async copies
     table = host.to(plan.chunks.device, non_blocking=True)
-    check(lib.simhand_lars_adam_multi(_ptr(table), len(records), _ptr(plan.chunks), plan.n_chunks, _ptr(plan.partials), betas[0],
-                                      betas[1], adam_eps, lars_eta, lars_eps, int(lars_clip), plan.total, _stream()),
+    if found_inf is not None:
+        assert found_inf.dtype == torch.float32 and found_inf.numel() == 1 and found_inf.device == plan.chunks.device
+    check(lib.simhand_lars_adam_multi_guarded(_ptr(table), len(records), _ptr(plan.chunks), plan.n_chunks, _ptr(plan.partials), betas[0],
+                                              betas[1], adam_eps, lars_eta, lars_eps, int(lars_clip), plan.total, _ptr(found_inf), _stream()),
           "lars_adam_multi")
 
 

@@ -354,6 +354,59 @@ def test_lars_adam_multi_tensor_matches_per_tensor_and_oracle():
             _check(a.detach().cpu(), c.detach(), 1e-5, f"multi vs oracle, tensor {i} step {t}")
 
 
+def test_lars_adam_guarded_step_skips_on_the_device_and_keeps_the_step_count():
+    """Loss-scaled training (the reference's precision 16): LARSAdam.step(found_inf=<device flag>) -- flag set: parameters and both
+    moments stay bit for bit and Adam's step count does not advance (the flag is read one step late, without draining the queue); flag
+    clear: the guarded launch equals the plain one.  A run with a skipped step in the middle == the run that never saw that step.
+    GradScaler semantics of torch.cuda.amp (src/experiments/main.py:158-159); torch's fused optimizers take found_inf the same way."""
+    from simhand_amd.host.amp import GradScaler
+    from simhand_amd.host.optim import LARSAdam
+
+    g = torch.Generator().manual_seed(8)
+    shapes = [(40000,), (64, 3, 7, 7), (5,)]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    grads = [[torch.randn(*s, generator=g) * 0.01 for s in shapes] for _ in range(4)]
+
+    def make():
+        ps = [torch.nn.Parameter(x.clone().to(DEV)) for x in init]
+        return ps, LARSAdam([{"params": ps[:2], "weight_decay": 1e-6, "lars": True}, {"params": ps[2:], "weight_decay": 0.0, "lars": False}], lr=3.2e-3)
+
+    pa, oa = make()  # steps 0, 1, [2 = overflow, skipped], 3   (guarded launches)
+    pb, ob = make()  # steps 0, 1, 3                           (plain launches)
+    zero, one = torch.zeros(1, device=DEV), torch.ones(1, device=DEV)
+    for t in range(4):
+        for p, gr in zip(pa, grads[t]):
+            p.grad = gr.clone().to(DEV)
+        if t == 2:
+            pa[0].grad[3] = float("inf")
+            before = [p.detach().clone() for p in pa] + [oa.state[p]["exp_avg"].clone() for p in pa] + [oa.state[p]["exp_avg_sq"].clone() for p in pa]
+            oa.step(found_inf=one)
+            after = [p.detach() for p in pa] + [oa.state[p]["exp_avg"] for p in pa] + [oa.state[p]["exp_avg_sq"] for p in pa]
+            assert all(torch.equal(x, y) for x, y in zip(before, after))
+            continue
+        oa.step(found_inf=zero)
+        for p, gr in zip(pb, grads[t]):
+            p.grad = gr.clone().to(DEV)
+        ob.step()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert torch.equal(a.detach(), b.detach()), (t, i)
+    assert oa.state_dict()["state"][0]["step"] == 3 == ob.state_dict()["state"][0]["step"]
+    # through GradScaler: no host read per step (the device flag goes straight to the launch), scale halves, count of skipped steps
+    pc, oc = make()
+    sc = GradScaler(init_scale=4.0, growth_interval=2)
+    for t in range(4):
+        for p, gr in zip(pc, grads[t]):
+            p.grad = (gr.clone() * sc.get_scale()).to(DEV)
+        if t == 2:
+            pc[0].grad[3] = float("inf")
+        sc.unscale_(pc)
+        assert sc.step(oc) is None  # decided on the device
+        sc.update()
+    assert sc.skipped_steps == 1 and sc.get_scale() == 4.0 and sc._growth_tracker == 1  # x2 after steps 0-1, x0.5 at the skip, one clean step
+    for i, (c, b) in enumerate(zip(pc, pb)):
+        _check(c.detach().cpu(), b.detach().cpu(), 1e-6, f"scaled run vs plain run, tensor {i}")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # 256 x 256 LDS-DMA tile kernel (bf16 layers with >= 256 destination channels) and the fused BN-backward sums
 # ---------------------------------------------------------------------------------------------------------------------
