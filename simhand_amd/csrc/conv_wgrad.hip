@@ -589,11 +589,19 @@ static void launch_reduce(const float* part, long long count, int splitk, float*
 //   rows are 128 B + 32 B pad (the 8 rows a 32-lane group of ds_read_b64_tr_b16 touches fall on distinct bank slots);
 //   x ring = 256 rows: window [32j - 64, 32j + 96) for step j, chunk j + 3 is staged during step j;
 //   one barrier per k-step.  Split-K over padded-pixel ranges; partials in the layout of wgrad_kernel.
+//
+// STRIDE 2 (S2; H, W even): the reduction runs over the padded OUTPUT grid ((Ho+1) x (Wo+1) per image, pixel (ho, wo) at (ho+1, wo+1)),
+// where dy lives; the input is seen as its four PARITY PLANES P_pq[h'][w'] = x[2h'+p][2w'+q], each on that same padded grid.  Filter
+// row r reads input row 2ho + r - 1: r = 1 -> plane p = 0 at h' = ho, r = 0 -> plane 1 at ho - 1, r = 2 -> plane 1 at ho (columns
+// alike), so every tap is again ONE plane at a constant row shift, now 0, -1, -(Wo+1) or -(Wo+2) -- never forward.  Four plane rings
+// of 128 rows (the window is the current chunk and the one before it; two chunks in flight), filled by LDS-DMA lanes that gather
+// every second pixel; the MFMA loop, fragment addressing and rotation keys are the stride-1 kernel's.  4x the x bytes per MFMA of
+// stride 1 (the input is 4x the output), against the tap-by-tap kernel's 9 re-staged x tiles.
 struct Wgrad3Args {
   const bf16_t* x;
   const bf16_t* dy;
   float* part;            // [splitk][Cout][9*Cin]
-  int Cout, Cin, H, W;
+  int Cout, Cin, H, W;    // H, W: the grid the reduction runs over (= output size; = input size for stride 1)
   int nt;                 // cin tiles
   long long q_total;      // N * (H+1) * (W+1): padded grid with SHARED pad rows / columns (see wgrad3x3_kernel)
   int per_split;          // padded pixels per split (multiple of 32)
@@ -602,15 +610,20 @@ struct Wgrad3Args {
 
 __device__ uint4 g_wg_zero_page[8];  // 128 B of zeros: source of the LDS-DMA lanes that fall on pad positions
 
+template <bool S2>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args p) {
-  constexpr int RING = 256;      // x ring rows (8 chunks of 32)
+  constexpr int NPL = S2 ? 4 : 1;          // x rings (parity planes)
+  constexpr int RING = S2 ? 128 : 256;     // rows per ring (chunks of 32)
   constexpr int KP = 32;
-  constexpr int D = 3;           // DMA distance in k-steps: 2 x D x 1 KB in flight per wave
-  constexpr int AHEAD = 2 + D;   // chunk issued at step j (x needs 2 chunks of look-ahead; dy rides along: one decode)
-  constexpr int NDY = AHEAD + 1; // dy buffers
-  __shared__ __attribute__((aligned(16))) char smem[RING * 128 + NDY * KP * 128];
+  constexpr int D = S2 ? 2 : 3;            // DMA distance in k-steps
+  constexpr int LOOK = S2 ? 0 : 2;         // chunks of look-ahead the tap shifts need (stride 2 only looks back)
+  constexpr int BACK = S2 ? 1 : 2;         // chunks of look-back: chunk c sits in ring slot (c + BACK) % (RING / 32)
+  constexpr int AHEAD = LOOK + D;          // chunk issued at step j (dy rides along: one decode)
+  constexpr int NDY = AHEAD + 1;           // dy buffers
+  constexpr int NDMA = NPL + 1;            // DMA instructions per wave and step
+  __shared__ __attribute__((aligned(16))) char smem[NPL * RING * 128 + NDY * KP * 128];
   char* ring = smem;
-  char* sdy = smem + RING * 128;
+  char* sdy = smem + NPL * RING * 128;
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
@@ -649,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args p) {
   const char* xb = reinterpret_cast<const char*>(p.x + c0 + ch_slot);
   const char* dyb = reinterpret_cast<const char*>(p.dy + k0 + ch_slot);
   const unsigned xstride = (unsigned)p.Cin * 2u, dystride = (unsigned)p.Cout * 2u;
-  // chunk c (>= -2): x rows -> ring slot (c + 2) % 8; dy rows (c >= 0, inside this block's range) -> buffer c % NDY
+  // chunk c (>= -BACK): x rows -> ring slot (c + BACK) % (RING / 32); dy rows (c >= 0, inside this block's range) -> buffer c % NDY
   auto dma_chunk = [&](int c, bool with_dy) __attribute__((always_inline)) {
     const long long q = q0 + (long long)c * KP + srow;
     const bool in = q >= 0 && q < p.q_total;
@@ -659,10 +672,22 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args p) {
     const unsigned hp = fdiv(rem, p.div_wp);
     const unsigned wp = rem - hp * p.div_wp.d;
     const bool ok = in && hp - 1u < (unsigned)p.H && wp - 1u < (unsigned)p.W;
-    const unsigned pix = (img * (unsigned)p.H + (hp - 1u)) * (unsigned)p.W + (wp - 1u);  // < 2^31 real pixels
-    dma16(ok ? xb + (unsigned long long)pix * xstride : zsrc, smem_addr + ((((c + 2) * KP) & (RING - 1)) + wave * 8) * 128);
+    const unsigned pix = (img * (unsigned)p.H + (hp - 1u)) * (unsigned)p.W + (wp - 1u);  // < 2^31 real pixels (of the reduction grid)
+    const unsigned dst = smem_addr + ((((c + BACK) * KP) & (RING - 1)) + wave * 8) * 128;
+    if constexpr (S2) {
+      // plane (pp, pq) of this position: input pixel (2 (hp-1) + pp, 2 (wp-1) + pq) of the 2H x 2W input
+      const unsigned pix00 = (img * (unsigned)(2 * p.H) + 2u * (hp - 1u)) * (unsigned)(2 * p.W) + 2u * (wp - 1u);
+      const unsigned long long rowb = (unsigned long long)(2 * p.W) * xstride;
+      const char* s00 = xb + (unsigned long long)pix00 * xstride;
+      dma16(ok ? s00 : zsrc, dst);
+      dma16(ok ? s00 + xstride : zsrc, dst + RING * 128);
+      dma16(ok ? s00 + rowb : zsrc, dst + 2 * RING * 128);
+      dma16(ok ? s00 + rowb + xstride : zsrc, dst + 3 * RING * 128);
+    } else {
+      dma16(ok ? xb + (unsigned long long)pix * xstride : zsrc, dst);
+    }
     if (with_dy)
-      dma16(ok && q < q1 ? dyb + (unsigned long long)pix * dystride : zsrc, smem_addr + RING * 128 + ((c % NDY) * KP + wave * 8) * 128);
+      dma16(ok && q < q1 ? dyb + (unsigned long long)pix * dystride : zsrc, smem_addr + NPL * RING * 128 + ((c % NDY) * KP + wave * 8) * 128);
   };
 
   f32x4 acc[9][4];
@@ -671,9 +696,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args p) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) acc[t][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // prologue, in the order the loop's counted vmcnt waits assume (two DMAs per step from chunk 0 on)
-  dma_chunk(-2, false);
-  dma_chunk(-1, false);
+  // prologue, in the order the loop's counted vmcnt waits assume (NDMA instructions per step from chunk 0 on)
+#pragma unroll
+  for (int c = -BACK; c < 0; ++c) dma_chunk(c, false);
 #pragma unroll
   for (int c = 0; c < AHEAD; ++c) dma_chunk(c, true);
 
@@ -696,20 +721,23 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args p) {
   int offa[4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) offa[mi] = frow * 128 + (((mi + key_a) & 3) * 32) + fcol;
-  // x fragment of tap t: ring row (32 (j + 2) + frow + off_t) & 255; its key does not depend on j (32 j = 0 mod 8)
+  // x fragment of tap t: ring row (32 (j + BACK) + frow + off_t) & (RING - 1) of the tap's plane; its key does not depend on j
+  // (32 j = 0 mod 8).  Stride 2: filter row r -> plane row parity (r != 1), shift -1 for r = 0 (columns alike)
   int trow[9], tcol[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    const int off = (t / 3 - 1) * WP + (t % 3 - 1);
-    trow[t] = 64 + frow + off;  // >= 0: off >= -(W + 3) >= -61
-    tcol[t] = (((wn + (trow[t] >> 1)) & 3) * 32) + fcol;
+    const int r = t / 3, sx = t % 3;
+    const int off = S2 ? ((r == 0 ? -1 : 0) * WP + (sx == 0 ? -1 : 0)) : ((r - 1) * WP + (sx - 1));
+    const int plane = S2 ? ((r != 1 ? 2 : 0) + (sx != 1 ? 1 : 0)) : 0;
+    trow[t] = BACK * 32 + frow + off;  // >= 0: stride 1 off >= -(W + 3) >= -61; stride 2 off >= -(W + 2) >= -32
+    tcol[t] = plane * (RING * 128) + (((wn + (trow[t] >> 1)) & 3) * 32) + fcol;
   }
   for (int j = 0; j < nk; ++j) {
-    // everything but the DMAs of the last D - 1 steps has landed (2 per step and wave); after the barrier every wave's
-    // part of dy chunk j / x chunk j + 2 is visible and every wave is done with step j - 1's operands
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (D - 1)) : "memory");
-    dma_chunk(j + AHEAD, true);  // ring slot (j + AHEAD + 2) % 8: outside the window (slots j .. j + 4) and the chunks in
-                                 // flight; dy buffer (j + AHEAD) % NDY = the one step j - 1 read
+    // everything but the DMAs of the last D - 1 steps has landed (NDMA per step and wave); after the barrier every wave's
+    // part of dy chunk j / x chunk j + LOOK is visible and every wave is done with step j - 1's operands
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NDMA * (D - 1)) : "memory");
+    dma_chunk(j + AHEAD, true);  // a ring slot outside the window (chunks j - BACK .. j + LOOK) and the chunks in flight; dy buffer
+                                 // (j + AHEAD) % NDY = the one step j - 1 read
     const char* tA = sdy + (j % NDY) * (KP * 128);
     uint4 fa[4];
 #pragma unroll
@@ -744,12 +772,18 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args p) {
 
 static hook_t g_use_wgrad3{1};
 static hook_t g_wg3_blocks{512};  // all-taps 3x3 kernel: two blocks per CU, one round (512 beats 768 by 4-10 %)
+static hook_t g_wgrad3_s2{-1};  // stride-2 form: -1 = env SIMHAND_WG3_S2 (default on), 0 / 1 forced
 static bool use_wgrad3(const sh_conv_desc* d) {
-  return g_use_wgrad3 && d->dtype == SH_BF16 && d->r == 3 && d->s == 3 && d->stride == 1 && d->pad == 1 && d->w + 3 <= 64 &&
-         (long long)d->n * (d->h + 1) * (d->w + 1) < (1ll << 31);
+  if (!g_use_wgrad3 || d->dtype != SH_BF16 || d->r != 3 || d->s != 3 || d->pad != 1) return false;
+  if (d->stride == 2) {  // parity-plane rings: even input, the largest tap shift -(wo + 2) inside one 32-row chunk
+    static const int env = getenv("SIMHAND_WG3_S2") ? atoi(getenv("SIMHAND_WG3_S2")) : 1;
+    const int h = g_wgrad3_s2;
+    return (h >= 0 ? h : env) && d->h % 2 == 0 && d->w % 2 == 0 && d->wo + 2 <= 32 && (long long)d->n * (d->ho + 1) * (d->wo + 1) < (1ll << 31);
+  }
+  return d->stride == 1 && d->w + 3 <= 64 && (long long)d->n * (d->h + 1) * (d->w + 1) < (1ll << 31);
 }
 static void plan3(const sh_conv_desc* d, int* splitk, int* per) {
-  const long long q_total = (long long)d->n * (d->h + 1) * (d->w + 1);
+  const long long q_total = (long long)d->n * (d->ho + 1) * (d->wo + 1);  // (ho, wo) == (h, w) for stride 1
   const long long tiles = (long long)(d->cout / 64) * (d->cin / 64);
   const long long ksteps = (q_total + 31) / 32;
   long long sk = g_wg3_blocks / tiles;            // one full round of resident blocks (see plan)
@@ -805,6 +839,7 @@ static void plan(const sh_conv_desc* d, int* bm, int* bn, int* splitk, int* pps,
 
 void hooks_reset_wgrad() {
   g_use_wgrad3 = 1;
+  g_wgrad3_s2 = -1;
   g_wg3_blocks = 512;
   g_use_tr = 1;
   g_wg_blocks = 512;
@@ -882,18 +917,19 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
     int sk, per;
     plan3(d, &sk, &per);
     b.x = (const bf16_t*)x; b.dy = (const bf16_t*)dy; b.part = (float*)workspace;
-    b.Cout = d->cout; b.Cin = d->cin; b.H = d->h; b.W = d->w;
+    b.Cout = d->cout; b.Cin = d->cin; b.H = d->ho; b.W = d->wo;  // the reduction grid (== the input grid for stride 1)
     b.nt = d->cin / 64;
-    b.q_total = (long long)d->n * (d->h + 1) * (d->w + 1);
+    b.q_total = (long long)d->n * (d->ho + 1) * (d->wo + 1);
     b.per_split = per;
-    b.div_pp = make_fastdiv((unsigned)((d->h + 1) * (d->w + 1)));
-    b.div_wp = make_fastdiv((unsigned)(d->w + 1));
+    b.div_pp = make_fastdiv((unsigned)((d->ho + 1) * (d->wo + 1)));
+    b.div_wp = make_fastdiv((unsigned)(d->wo + 1));
     hipStream_t s3 = (hipStream_t)stream;
     const double flops3 = 2.0 * (double)mo * d->cout * d->cin * 9;
     const double bytes3 = 2.0 * ((double)d->n * d->h * d->w * d->cin + (double)mo * d->cout) + 4.0 * d->cout * d->cin * 9;
     ProfScope ps3(SH_PROF_CONV_WGRAD, s3, flops3, bytes3);
     route_hit(SH_ROUTE_WGRAD3X3);
-    wgrad3x3_kernel<<<sk * (d->cout / 64) * (d->cin / 64), 256, 0, s3>>>(b);
+    if (d->stride == 2) wgrad3x3_kernel<true><<<sk * (d->cout / 64) * (d->cin / 64), 256, 0, s3>>>(b);
+    else wgrad3x3_kernel<false><<<sk * (d->cout / 64) * (d->cin / 64), 256, 0, s3>>>(b);
     if (check_launch("conv2d_wgrad (3x3)")) return 1;
     launch_reduce(b.part, (long long)d->cout * d->cin * 9, sk, dw, d->cin, 9, c_real, s3);
     return check_launch("conv2d_wgrad (3x3) reduce");

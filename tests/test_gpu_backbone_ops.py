@@ -765,6 +765,37 @@ def test_wgrad_3x3_all_taps_kernel(shape):
     _check(got, old, 1e-4, "vs tap-by-tap kernel")  # same products, fp32 sums in another order
 
 
+@pytest.mark.parametrize("shape", [(2, 56, 56, 128, 128), (3, 28, 28, 256, 128), (5, 14, 14, 128, 256), (1, 6, 10, 64, 64), (40, 14, 14, 64, 128),
+                                   (9, 60, 60, 64, 64)])
+def test_wgrad_3x3_stride2_all_taps_kernel(shape):
+    """bf16 3x3/2 weight gradient on the parity-plane rings (all nine taps per block, reduction over the padded OUTPUT grid) vs ATen and
+    vs the tap-by-tap kernel; input sides up to 60 (the largest tap shift must stay inside one 32-row chunk: wo + 2 <= 32)."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = _rnd(torch.randn(n, cin, h, w, generator=g), dtype)
+    dy = _rnd(torch.randn(n, cout, h // 2, w // 2, generator=g), dtype)
+    want = torch.nn.grad.conv2d_weight(x, (cout, cin, 3, 3), dy, stride=2, padding=1)
+    d = ops.conv_desc(n, h, w, cin, cout, 3, 3, 2, 1, dtype)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    lib = ops._lib_dev()
+    ops.route_reset()
+    got = ops.conv2d_wgrad_oihw(d, xd, dyd, (cout, cin, 3, 3)).cpu()
+    assert ops.route_counts()["wgrad3x3"] == 1
+    lib.simhand_test_wgrad3x3_enable(0)
+    try:
+        ops.route_reset()
+        old = ops.conv2d_wgrad_oihw(d, xd, dyd, (cout, cin, 3, 3)).cpu()
+        assert ops.route_counts()["wgrad_generic"] == 1
+    finally:
+        lib.simhand_test_wgrad3x3_enable(1)
+    _check(got, want, 2e-3, "wgrad 3x3 / 2 all taps")
+    _check(got, old, 1e-4, "vs tap-by-tap kernel")  # same products, fp32 sums in another order
+
+
 @pytest.mark.parametrize("shape", [(3, 14, 14, 64, 256, 1), (2, 13, 13, 256, 1024, 1), (2, 16, 16, 256, 512, 2), (5, 7, 7, 512, 2048, 1)])
 @pytest.mark.parametrize("with_res", [True, False])
 def test_conv_fwd_bnact_epilogue_and_gram_statistics(shape, with_res):

@@ -31,19 +31,19 @@ SHAPES = {
     (64, 256, 1, 1, 56): ("gemm1x1_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (256, 64, 1, 1, 56): ("gemm1x1_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (256, 128, 1, 1, 56): ("gemm1x1_fwd", "gemm1x1_dgrad", "wgrad_plain"),
-    (128, 128, 3, 2, 56): ("igemm128_fwd", "igemm128_dgrad", "wgrad_generic"),
+    (128, 128, 3, 2, 56): ("igemm128_fwd", "igemm128_dgrad", "wgrad3x3"),
     (128, 512, 1, 1, 28): ("gemm1x1_fwd", "igemm128_dgrad", "wgrad_plain"),
     (256, 512, 1, 2, 56): ("igemm256_fwd", "igemm128_dgrad", "wgrad_generic"),
     (512, 128, 1, 1, 28): ("igemm128_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (128, 128, 3, 1, 28): ("igemm128_fwd", "igemm128_dgrad", "wgrad3x3"),
     (512, 256, 1, 1, 28): ("igemm256_fwd", "gemm1x1_dgrad", "wgrad_plain"),
-    (256, 256, 3, 2, 28): ("igemm256_fwd", "igemm256_dgrad", "wgrad_generic"),
+    (256, 256, 3, 2, 28): ("igemm256_fwd", "igemm256_dgrad", "wgrad3x3"),
     (256, 1024, 1, 1, 14): ("gemm1x1_fwd", "igemm256_dgrad", "wgrad_plain"),
     (512, 1024, 1, 2, 28): ("igemm256_fwd", "igemm128_dgrad", "wgrad_generic"),
     (1024, 256, 1, 1, 14): ("igemm256_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (256, 256, 3, 1, 14): ("igemm256_fwd", "igemm256_dgrad", "wgrad3x3"),
     (1024, 512, 1, 1, 14): ("igemm256_fwd", "igemm256_dgrad", "wgrad_plain"),
-    (512, 512, 3, 2, 14): ("igemm256_fwd+igemm256_tail", "igemm256_dgrad", "wgrad_generic"),
+    (512, 512, 3, 2, 14): ("igemm256_fwd+igemm256_tail", "igemm256_dgrad", "wgrad3x3"),
     (512, 2048, 1, 1, 7): ("igemm256_fwd", "igemm256_dgrad+igemm256_tail", "wgrad_plain"),
     (1024, 2048, 1, 2, 14): ("igemm256_fwd", "igemm128_dgrad", "wgrad_generic"),
     (2048, 512, 1, 1, 7): ("igemm256_fwd+igemm256_tail", "igemm256_dgrad", "wgrad_plain"),
