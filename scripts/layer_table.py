@@ -47,7 +47,7 @@ def route_of(fn):
     ops.route_reset()
     fn()
     torch.cuda.synchronize()
-    skip = ("fwd_bnact", "dgrad_fused_sums", "dgrad_parity", "dgrad_concat", "wgrad_colsum")
+    skip = ("fwd_bnact", "dgrad_fused_sums", "dgrad_parity", "dgrad_concat", "wgrad_colsum", "subsample2", "scatter2_add")
     return "+".join(k for k, v in ops.route_counts().items() if v and k not in skip)
 
 
@@ -90,7 +90,28 @@ def main():
         b_dg = 2.0 * (x.numel() + m * cout + wk.numel())
         f_wg = lambda: ops.conv2d_wgrad_oihw(d, x, dy, (cout, cin, k, k))  # noqa: E731
         b_wg = 2.0 * (x.numel() + m * cout) + 4.0 * wk.numel()
-        for op, fn, by in (("fwd" + (" +bnact" if folded else ""), f_fwd, b_fwd), ("dgrad", f_dg, b_dg), ("wgrad", f_wg, b_wg)):
+        tag = ""
+        if k == 1 and s == 2:
+            # the stage-entry shortcuts, in the form the engine runs them (host/resnet_model.py _conv_bn_folded / _ds_bwd_folded): ONE
+            # subsample pass, then dense 1x1 / stride-1 launches over x[:, ::2, ::2] -- forward with the folded BN epilogue, both
+            # gradients at the output resolution, the data gradient scatter-added onto the even pixels of the main branch's dx
+            x_in = ops.subsample2(x)
+            dd = ops.conv_desc(n, d.ho, d.wo, cin, cout, 1, 1, 1, 0, dt)
+            dxm = torch.zeros(n, h, h, cin, device=dev, dtype=dt)
+            us_sub = timed(lambda: ops.subsample2(x))
+            b_sub = 2.0 * 2 * x_in.numel()
+            rows.append(f"| ({cin},{cout},{k},{s},{h}) x{cnt} | subsample x[:, ::2, ::2] (once: forward, Gram, both gradients) | subsample2 | {us_sub:.0f} | - | "
+                        f"{b_sub / us_sub / 1e3:.0f} | HBM | {b_sub / us_sub / 1e3 / PEAK_GB:.2f} |")
+            tot["fwd"] += us_sub * cnt
+            f_fwd = lambda: ops.conv2d_fwd_bnact(dd, x_in, wk, st, False, None)  # noqa: E731
+            b_fwd = 2.0 * (x_in.numel() + m * cout + wk.numel())
+            f_dg = lambda: ops.scatter2_add(ops.conv2d_dgrad(dd, dy, wc), dxm)  # noqa: E731
+            b_dg = 2.0 * (m * cout + 4 * x_in.numel() + wk.numel())  # dy, the dense result written + read, dx's even pixels read + written
+            f_wg = lambda: ops.conv2d_wgrad_oihw(dd, x_in, dy, (cout, cin, 1, 1))  # noqa: E731
+            b_wg = 2.0 * (x_in.numel() + m * cout) + 4.0 * wk.numel()
+            tag = ", dense over the subsampled input"
+        for op, fn, by in (("fwd" + (" +bnact" if folded else "") + tag, f_fwd, b_fwd), ("dgrad" + (" + scatter-add onto dx" if tag else ""), f_dg, b_dg),
+                           ("wgrad" + tag, f_wg, b_wg)):
             us = timed(fn)
             rt = route_of(fn)
             tf, gb = flops / us / 1e6, by / us / 1e3
