@@ -410,6 +410,8 @@ int simhand_test_bn_set_nt(int on);
 
 /* tuning hook: the all-taps 3x3 / stride-1 weight-gradient kernel (bf16; 1 = default, 0 = tap-by-tap kernel) */
 int simhand_test_wgrad3x3_enable(int on);
+/* test / tuning hook: the LDS-DMA 256 x 256 tile kernel for the bf16 1x1 weight gradients with >= 256 channels on both sides (1 = default) */
+int simhand_test_wgrad_dma_enable(int on);
 
 /* test hook: bf16 wgrad LDS transpose path (1 = ds_read_b64_tr_b16 [default], 0 = scalar LDS reads) */
 int simhand_test_wgrad_set_tr(int on);

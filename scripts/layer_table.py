@@ -119,7 +119,7 @@ def main():
             bound = "MFMA" if ai >= PEAK_TF * 1e3 / PEAK_GB else "HBM"
             frac = tf / PEAK_TF if bound == "MFMA" else gb / PEAK_GB
             rows.append(f"| ({cin},{cout},{k},{s},{h}) x{cnt} | {op} | {rt} | {us:.0f} | {tf:.0f} | {gb:.0f} | {bound} ({ai:.0f} FLOP/B) | {frac:.2f} |")
-            tot[op.split()[0]] += us * cnt
+            tot[op.split()[0].rstrip(',')] += us * cnt
             if args.alternates:
                 for an, setter in alts.items():
                     if an == "default":

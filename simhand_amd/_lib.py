@@ -138,6 +138,7 @@ SIGNATURES = {
     "simhand_test_wgrad_plain_kpm": (_I, [_I]),
     "simhand_test_wgrad_target_blocks": (_I, [_I, _I]),
     "simhand_test_wgrad3x3_enable": (_I, [_I]),
+    "simhand_test_wgrad_dma_enable": (_I, [_I]),
     "simhand_test_bn_set_nt": (_I, [_I]),
     "simhand_test_igemm256_enable": (_I, [_I]),
     "simhand_nchw_f32_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

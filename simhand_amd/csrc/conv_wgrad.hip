@@ -770,6 +770,178 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args p) {
       }
 }
 
+
+// ======================================================================================================================
+// 1x1 / stride-1 weight gradient for the layers with >= 256 channels on both sides (bf16): 256 x 256 tile, operands by LDS-DMA.
+// The pointer-walking kernel above stages a 256 x 128 tile through registers (192 B of operands per MFMA, one k-step of prefetch);
+// here both operand tiles of a 32-pixel k-step go global -> LDS by DMA three steps ahead (128 B per MFMA, nothing staged in VGPRs):
+//   8 waves as 2 (cout halves) x 4 (cin quarters), each 128 x 64 = 8 x 4 MFMA tiles (128 accumulator registers), one block per CU;
+//   a stage = eight 4-KB sub-tiles of [32 pixels][64 channels] (four of dy, four of x) in exactly the layout of wgrad3x3_kernel
+//   (128-B rows, 32-B channel groups rotated by row / 2: conflict-free ds_read_b64_tr_b16), wave w fills sub-tile w with four DMA
+//   instructions of 8 rows; four stages of 32 KB; one barrier and a counted vmcnt per k-step.
+// Split-K over pixel ranges; partials in the layout of wgrad_kernel.  dy's column sums (the by-product the folded BatchNorm backward
+// wants) come from the matrix pipes too: one extra MFMA of a dy fragment against an all-ones operand gives the pixel sums of its 16
+// channels; wave (wm, wn) does that for two of its eight channel groups (+2 MFMAs per 32), the cin-tile-0 blocks only.
+// Not for the launches with an operand transform (the BatchNorm-fold Gram launches stay on the pointer-walking kernel).
+struct Wgrad1Args {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* part;        // [splitk][Cout][Cin]
+  long long Mo;       // pixels
+  int Cout, Cin;
+  int mt, nt;         // 256-wide cout / cin tiles
+  int per_split;      // pixels per split (multiple of 32)
+  float* dy_colsum;   // [splitk][2][Cout] as in WgradArgs (row 0 = per-channel sums of dy over the split's pixels, row 1 = 0); null = off
+};
+
+__global__ __launch_bounds__(512, 1) void wgrad1x1_dma_kernel(Wgrad1Args p) {
+  constexpr int KP = 32, NS = 4, D = 3;  // D: DMA distance in k-steps (4 instructions per wave and step)
+  constexpr int SUB = KP * 128, STAGE = 8 * SUB;
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  int logical = xcd_remap_w(blockIdx.x, gridDim.x);
+  const int nt_i = logical % p.nt; logical /= p.nt;
+  const int mt_i = logical % p.mt;
+  const int split = logical / p.mt;
+  const int k0 = mt_i * 256, c0 = nt_i * 256;
+  const long long q0 = (long long)split * p.per_split;
+  long long q1 = q0 + p.per_split;
+  if (q1 > p.Mo) q1 = p.Mo;
+  const int rows_total = q0 < q1 ? (int)(q1 - q0) : 0;
+  const int nk = (rows_total + KP - 1) / KP;
+
+  auto dma16 = [](const void* src, unsigned lds_addr) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src));
+  };
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  // wave w fills sub-tile w (0-3: dy channel groups k0 + 64 w; 4-7: x channel groups c0 + 64 (w - 4)): instruction i covers tile rows
+  // 8 i .. 8 i + 7, lane l = row 8 i + (l >> 3), 16-B slot l & 7; the slot's channel offset carries the row's rotation (see wgrad3x3_kernel)
+  const int slot = lane & 7, r8 = lane >> 3;
+  const bool is_dy = wave < 4;
+  const unsigned stride = (unsigned)(is_dy ? p.Cout : p.Cin) * 2u;
+  const char* base = is_dy ? reinterpret_cast<const char*>(p.dy + k0 + wave * 64) : reinterpret_cast<const char*>(p.x + c0 + (wave - 4) * 64);
+  const char* zsrc = reinterpret_cast<const char*>(g_wg_zero_page) + slot * 16;
+  const char* ptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * i + r8;
+    const int ch_slot = ((((slot >> 1) - (row >> 1)) & 3) * 16) + (slot & 1) * 8;
+    ptr[i] = base + (unsigned long long)(q0 + row) * stride + ch_slot * 2;
+  }
+  const unsigned step_bytes = (unsigned)KP * stride;
+  auto dma_chunk = [&](int c) __attribute__((always_inline)) {
+    const int left = rows_total - c * KP;  // rows of chunk c inside the block's pixel range (<= 0: none -- the zero page)
+    const unsigned dst = smem_addr + (unsigned)(c & (NS - 1)) * STAGE + wave * SUB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma16(8 * i + r8 < left ? ptr[i] : zsrc, dst + i * 8 * 128);
+      ptr[i] += step_bytes;
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int c = 0; c < D; ++c) dma_chunk(c);
+  const bool want_cs = p.dy_colsum != nullptr && nt_i == 0;  // block-uniform
+  f32x4 acs[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  const unsigned one2 = pack_bf16x2(1.0f, 1.0f);
+  const uint4 ones = make_uint4(one2, one2, one2, one2);
+
+  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  auto tr2 = [](const char* a_lo, const char* a_hi) __attribute__((always_inline)) -> uint4 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a_lo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a_hi));
+    uint4 f;
+    f.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+    f.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+    f.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+    f.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+    return f;
+  };
+  // lane's rows inside a 32-row k-step: 4g + (li >> 2) and + 16; its 8 bytes inside the 32-B channel group: (li & 3) * 8
+  const int frow = 4 * g + (li >> 2);
+  const int fcol = (li & 3) * 8;
+  const int key = (frow >> 1) & 3;
+  int offs[4];  // channel group q (16 channels) of a sub-tile, rows frow / frow + 16 (same rotation key)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) offs[q] = frow * 128 + (((q + key) & 3) * 32) + fcol;
+
+  for (int j = 0; j < nk; ++j) {
+    // all but the DMAs of the last D - 1 steps have landed; after the barrier chunk j is visible and every wave is past step j - 1
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (D - 1)) : "memory");
+    dma_chunk(j + D);  // stage (j + D) % NS = the one step j - 1 read
+    const char* st = smem + (j & (NS - 1)) * STAGE;
+    const char* tA = st + (wm * 2) * SUB;
+    const char* tB = st + (4 + wn) * SUB;
+    uint4 fb[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) fb[ni] = tr2(tB + offs[ni], tB + offs[ni] + 16 * 128);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const char* sub = tA + (mi >> 2) * SUB;
+      const uint4 fa = tr2(sub + offs[mi & 3], sub + offs[mi & 3] + 16 * 128);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = sh_mfma16(fa, fb[ni], acc[mi][ni]);
+      if (want_cs && wn == (mi >> 1)) acs[mi & 1] = sh_mfma16(fa, ones, acs[mi & 1]);  // wave-uniform
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragment reads are done before the next barrier
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // C[m = cout][n = cin]: lane holds cin = c0 + wn*64 + ni*16 + li, couts k0 + wm*128 + mi*16 + 4g + r
+  float* dst = p.part + (long long)split * p.Cout * p.Cin;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = k0 + wm * 128 + mi * 16 + 4 * g + r;
+        const int c = c0 + wn * 64 + ni * 16 + li;
+        dst[(long long)k * p.Cin + c] = acc[mi][ni][r];
+      }
+  if (want_cs && li == 0) {  // every column of the ones-product holds the same sums: column 0 stores them
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = k0 + wm * 128 + (2 * wn + j) * 16 + 4 * g + r;
+        p.dy_colsum[((long long)split * 2 + 0) * p.Cout + k] = acs[j][r];
+        p.dy_colsum[((long long)split * 2 + 1) * p.Cout + k] = 0.f;
+      }
+  }
+}
+
+static hook_t g_wg_dma{-1};  // -1 = env SIMHAND_WG_DMA (default on), 0 / 1 forced
+static bool use_wg_dma(const sh_conv_desc* d) {
+  static const int env = getenv("SIMHAND_WG_DMA") ? atoi(getenv("SIMHAND_WG_DMA")) : 1;
+  const int h = g_wg_dma;
+  // cout != cin: never the Gram launches of the BatchNorm fold (x = dy = a, operand transforms), which share the splits query
+  return (h >= 0 ? h : env) && d->dtype == SH_BF16 && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && d->cout % 256 == 0 &&
+         d->cin % 256 == 0 && d->cout != d->cin && (long long)d->n * d->ho * d->wo >= 256 * 64;
+}
+// one block per CU, one round: split-K = CUs / tiles, at least 16 k-steps per block (the 3-chunk prologue is per block)
+static void plan_dma(const sh_conv_desc* d, int* splitk, int* per) {
+  const long long mo = (long long)d->n * d->ho * d->wo;
+  const long long tiles = (long long)(d->cout / 256) * (d->cin / 256);
+  const long long ksteps = (mo + 31) / 32;
+  long long sk = 256 / tiles;
+  const long long max_sk = (ksteps + 15) / 16;
+  if (sk > max_sk) sk = max_sk;
+  if (sk < 1) sk = 1;
+  const long long pr = (ksteps + sk - 1) / sk;
+  sk = (ksteps + pr - 1) / pr;
+  *splitk = (int)sk;
+  *per = (int)(pr * 32);
+}
+
 static hook_t g_use_wgrad3{1};
 static hook_t g_wg3_blocks{512};  // all-taps 3x3 kernel: two blocks per CU, one round (512 beats 768 by 4-10 %)
 static hook_t g_wgrad3_s2{-1};  // stride-2 form: -1 = env SIMHAND_WG3_S2 (default on), 0 / 1 forced
@@ -838,6 +1010,7 @@ static void plan(const sh_conv_desc* d, int* bm, int* bn, int* splitk, int* pps,
 }
 
 void hooks_reset_wgrad() {
+  g_wg_dma = -1;
   g_use_wgrad3 = 1;
   g_wgrad3_s2 = -1;
   g_wg3_blocks = 512;
@@ -853,6 +1026,11 @@ using namespace sh;
 extern "C" {
 
 // tuning hook: all-taps 3x3 weight-gradient kernel for the bf16 stride-1 layers (1 = default)
+int simhand_test_wgrad_dma_enable(int on) {
+  g_wg_dma = on ? 1 : 0;
+  return 0;
+}
+
 int simhand_test_wgrad3x3_enable(int on) {
   g_use_wgrad3 = on ? 1 : 0;
   return 0;
@@ -885,6 +1063,10 @@ size_t simhand_conv2d_wgrad_workspace_bytes(const sh_conv_desc* d) {
     plan(d, &bm, &bn, &sk, &pps);
     plan(d, &bm, &bn, &sk2, &pps, false);  // either tile plan may run (operand-transform launches take the 128-row one)
     if (sk2 > sk) sk = sk2;
+    if (use_wg_dma(d)) {
+      plan_dma(d, &sk2, &pps);
+      if (sk2 > sk) sk = sk2;
+    }
   }
   return (size_t)sk * d->cout * d->cin * d->r * d->s * sizeof(float);
 }
@@ -933,6 +1115,25 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
     if (check_launch("conv2d_wgrad (3x3)")) return 1;
     launch_reduce(b.part, (long long)d->cout * d->cin * 9, sk, dw, d->cin, 9, c_real, s3);
     return check_launch("conv2d_wgrad (3x3) reduce");
+  }
+  if (stem_wp == 0 && xf == nullptr && x != dy && d->cout != d->cin && g_use_tr && use_wg_dma(d)) {
+    Wgrad1Args b;
+    int sk, per;
+    plan_dma(d, &sk, &per);
+    b.x = (const bf16_t*)x; b.dy = (const bf16_t*)dy; b.part = (float*)workspace;
+    b.Mo = mo; b.Cout = d->cout; b.Cin = d->cin;
+    b.mt = d->cout / 256; b.nt = d->cin / 256;
+    b.per_split = per;
+    b.dy_colsum = dy_colsum;
+    if (dy_colsum != nullptr) route_hit(SH_ROUTE_WGRAD_COLSUM);
+    hipStream_t s1 = (hipStream_t)stream;
+    ProfScope ps1(SH_PROF_CONV_WGRAD, s1, 2.0 * (double)mo * d->cout * d->cin,
+                  2.0 * ((double)mo * d->cin + (double)mo * d->cout) + 4.0 * d->cout * d->cin);
+    route_hit(SH_ROUTE_WGRAD_PLAIN);
+    wgrad1x1_dma_kernel<<<sk * b.mt * b.nt, 512, 0, s1>>>(b);
+    if (check_launch("conv2d_wgrad (1x1, DMA tiles)")) return 1;
+    launch_reduce(b.part, (long long)d->cout * d->cin, sk, dw, d->cin, 1, c_real, s1);
+    return check_launch("conv2d_wgrad (1x1, DMA tiles) reduce");
   }
   WgradArgs a;
   int bm, bn;
@@ -1025,6 +1226,7 @@ int simhand_conv2d_wgrad_splits(const sh_conv_desc* d) {
   if (!d) return 0;
   int bm, bn, sk, pps;
   if (use_wgrad3(d)) plan3(d, &sk, &pps);
+  else if (g_use_tr && use_wg_dma(d)) plan_dma(d, &sk, &pps);
   else plan(d, &bm, &bn, &sk, &pps);
   return sk;
 }

@@ -765,6 +765,38 @@ def test_wgrad_3x3_all_taps_kernel(shape):
     _check(got, old, 1e-4, "vs tap-by-tap kernel")  # same products, fp32 sums in another order
 
 
+@pytest.mark.parametrize("shape", [(100, 14, 14, 1024, 256), (96, 14, 14, 256, 1024), (350, 7, 7, 512, 512), (21, 28, 28, 512, 256), (85, 14, 14, 256, 256)])
+def test_wgrad_1x1_dma_tile_kernel(shape):
+    """bf16 1x1 weight gradient on the LDS-DMA 256 x 256 tile kernel (>= 256 channels on both sides, >= 16 384 pixels) vs ATen and vs
+    the pointer-walking kernel; pixel counts that are not multiples of the 32-pixel k-step or of the split length."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 2)
+    x = _rnd(torch.randn(n * h * w, cin, generator=g), dtype)
+    dy = _rnd(torch.randn(n * h * w, cout, generator=g), dtype)
+    want = (dy.double().t() @ x.double()).float().view(cout, cin, 1, 1)
+    d = ops.conv_desc(n, h, w, cin, cout, 1, 1, 1, 0, dtype)
+    xd = x.view(n, h, w, cin).to(DEV).to(dtype)
+    dyd = dy.view(n, h, w, cout).to(DEV).to(dtype)
+    lib = ops._lib_dev()
+    got = ops.conv2d_wgrad_oihw(d, xd, dyd, (cout, cin, 1, 1)).cpu()
+    lib.simhand_test_wgrad_dma_enable(0)
+    try:
+        old = ops.conv2d_wgrad_oihw(d, xd, dyd, (cout, cin, 1, 1)).cpu()
+    finally:
+        ops.hooks_reset()
+    _check(got, want, 2e-3, "wgrad 1x1 DMA tiles")
+    _check(got, old, 1e-4, "vs the pointer-walking kernel")  # same products, fp32 sums in another order
+    if cin != cout:  # the by-product form (the folded BatchNorm backward's launch): dy's column sums from the ones-operand MFMAs
+        ops.route_reset()
+        gmat, csum = ops.conv2d_wgrad_colsum(d, xd, dyd)
+        assert ops.route_counts()["wgrad_colsum"] == 1
+        _check(gmat.cpu().view(cout, cin, 1, 1), want, 2e-3, "wgrad 1x1 DMA tiles + column sums")
+        _check(csum.cpu(), dy.double().sum(0).float(), 1e-4, "column sums of dy")
+
+
 @pytest.mark.parametrize("shape", [(2, 56, 56, 128, 128), (3, 28, 28, 256, 128), (5, 14, 14, 128, 256), (1, 6, 10, 64, 64), (40, 14, 14, 64, 128),
                                    (9, 60, 60, 64, 64)])
 def test_wgrad_3x3_stride2_all_taps_kernel(shape):
