@@ -8,6 +8,8 @@
 // (src/models/unsupervised/simclr_model.py:30-31), plus their autograd backward.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace sh {
 
 constexpr int kChunk = 256;  // level-1 partial blocks folded per level-2 block
@@ -181,6 +183,16 @@ __global__ __launch_bounds__(256) void bn_eval_params_kernel(const float* __rest
 // Streaming kernels: a thread owns ONE 16-B channel vector (its per-channel coefficients live in
 // registers for the whole launch) and walks rows; lanes run along the channel axis first so a wave
 // covers whole contiguous rows (coalesced), blocks split the row range.
+// VE consecutive fp32 per-channel coefficients by 16-B loads (VE = 4 or 8; the arrays are 16-B aligned: channel counts are multiples of VE)
+template <int VE>
+__device__ __forceinline__ void ld_coef(const float* __restrict__ p, float (&o)[VE]) {
+#pragma unroll
+  for (int e = 0; e < VE; e += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p + e);
+    o[e] = v.x; o[e + 1] = v.y; o[e + 2] = v.z; o[e + 3] = v.w;
+  }
+}
+
 struct RowWalk {
   int cv, rl, span, rowlanes;
   int64_t r0, r1;
@@ -209,11 +221,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
   const int cvecs = c / VE;
   for (int cv = w.cv; cv < c / VE; cv += w.span) {
     float sc[VE], sh[VE];
-#pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      sc[e] = scale[cv * VE + e];
-      sh[e] = shift[cv * VE + e];
-    }
+    ld_coef<VE>(scale + cv * VE, sc);
+    ld_coef<VE>(shift + cv * VE, sh);
     auto finish = [&](int64_t r, const float(&v)[VE], const float(&q)[VE]) __attribute__((always_inline)) {
       float o[VE];
 #pragma unroll
@@ -339,7 +348,19 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
                                                              int relu, int64_t m, int c, int rows_per_blk,
                                                              float* __restrict__ partial) {
   constexpr int VE = Vec16<T>::N;
+  // per-channel coefficients of the channel vector this thread walks, in registers (16-B loads, refreshed when cv changes: c / VE > 256 only)
+  float sc[VE], sh[VE], mu[VE], is[VE];
+  int cv_held = -1;
   column_reduce<T>(m, c, rows_per_blk, partial, [&](int64_t r, int cv, float(&s1)[VE], float(&s2)[VE]) {
+    if (cv != cv_held) {
+      cv_held = cv;
+      ld_coef<VE>(mean + cv * VE, mu);
+      ld_coef<VE>(invstd + cv * VE, is);
+      if (relu == 2) {
+        ld_coef<VE>(scale + cv * VE, sc);
+        ld_coef<VE>(shift + cv * VE, sh);
+      }
+    }
     float g[VE], yy[VE];
     Vec16<T>::template load<NT>(da + r * c + cv * VE, g);
     Vec16<T>::template load<NT>(y + r * c + cv * VE, yy);
@@ -350,7 +371,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
       for (int e = 0; e < VE; ++e) g[e] = aa[e] > 0.f ? g[e] : 0.f;
     } else if (relu == 2) {  // no residual: the ReLU input is recomputed from y (same fp32 expression as bn_apply)
 #pragma unroll
-      for (int e = 0; e < VE; ++e) g[e] = yy[e] * scale[cv * VE + e] + shift[cv * VE + e] > 0.f ? g[e] : 0.f;
+      for (int e = 0; e < VE; ++e) g[e] = yy[e] * sc[e] + sh[e] > 0.f ? g[e] : 0.f;
     } else if (relu == 3) {  // residual unit: 1-bit mask written by bn_apply (`a` points to it)
       const unsigned bits = reinterpret_cast<const uint8_t*>(a)[r * (c / VE) + cv];
 #pragma unroll
@@ -358,7 +379,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
     }
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-      const float xh = (yy[e] - mean[cv * VE + e]) * invstd[cv * VE + e];
+      const float xh = (yy[e] - mu[e]) * is[e];
       s1[e] += g[e];
       s2[e] += g[e] * xh;
     }
@@ -432,16 +453,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   for (int cv = w.cv; cv < c / VE; cv += w.span) {
     // dy = A*(g - k2) - xhat*k3 with xhat = (y - mu)*is ; A = gamma*is, k2 = dbeta/M, k3 = A*dgamma/M
     float mu[VE], is[VE], A[VE], k2[VE], k3[VE], sc[VE], sh[VE];
+    {  // per-channel coefficients by 16-B loads (a block's prologue: with many short blocks it is a visible share of its life)
+      float ga[VE], dg_[VE], db_[VE];
+      ld_coef<VE>(mean + cv * VE, mu);
+      ld_coef<VE>(invstd + cv * VE, is);
+      ld_coef<VE>(dgamma + cv * VE, dg_);
+      ld_coef<VE>(dbeta + cv * VE, db_);
+      if (gamma) ld_coef<VE>(gamma + cv * VE, ga);
+      if (relu == 2) {
+        ld_coef<VE>(scale + cv * VE, sc);
+        ld_coef<VE>(shift + cv * VE, sh);
+      }
 #pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      const int ch = cv * VE + e;
-      mu[e] = mean[ch];
-      is[e] = invstd[ch];
-      A[e] = (gamma ? gamma[ch] : 1.0f) * is[e];
-      k2[e] = dbeta[ch] * inv_m;
-      k3[e] = A[e] * dgamma[ch] * inv_m;
-      sc[e] = relu == 2 ? scale[ch] : 0.f;
-      sh[e] = relu == 2 ? shift[ch] : 0.f;
+      for (int e = 0; e < VE; ++e) {
+        A[e] = (gamma ? ga[e] : 1.0f) * is[e];
+        k2[e] = db_[e] * inv_m;
+        k3[e] = A[e] * dg_[e] * inv_m;
+        if (relu != 2) sc[e] = sh[e] = 0.f;
+      }
     }
     for (int64_t r = w.r0 + w.rl; r < w.r1; r += w.rowlanes) {
       const int64_t off = r * c + cv * VE;
@@ -1133,12 +1162,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   });
 }
 
-// blocks for the row-walking kernels: >= ~8 rows per row lane, at most 8 blocks per CU
-static inline int row_grid(int64_t m, int cvecs) {
+// blocks for the row-walking kernels: >= ~8 rows per row lane, at most `cap` blocks.  The two big streaming passes (bn_apply,
+// bn_bwd_apply) run with cap = 131072 (env SIMHAND_BN_GRID_APPLY / SIMHAND_BN_GRID_BWD: A/B timing): many short blocks keep more
+// loads in flight than 2048 long-lived ones -- 5.1 -> 6.0-6.2 TB/s (bn_apply), 5.1 -> 5.9 (bn_bwd_apply, whose per-block coefficient
+// prologue had to become 16-B loads first: with scalar loads more blocks made it slower), round 3, scripts/bn_bench.py
+static inline int row_grid(int64_t m, int cvecs, int cap = 2048) {
   const int span = cvecs < 256 ? cvecs : 256;
   const int rowlanes = 256 / span;
   int64_t g = (m + (int64_t)rowlanes * 8 - 1) / ((int64_t)rowlanes * 8);
-  if (g > 2048) g = 2048;
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -1244,7 +1276,8 @@ int simhand_bn_apply(const void* y, const float* scale, const float* shift, cons
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (residual ? 3 : 2));
   route_hit(SH_ROUTE_BN_APPLY);
-  const int grid = row_grid(m, c / ve);
+  static const int cap = getenv("SIMHAND_BN_GRID_APPLY") ? atoi(getenv("SIMHAND_BN_GRID_APPLY")) : 131072;
+  const int grid = row_grid(m, c / ve, cap);
 #define SH_BN_APPLY(T, NT) bn_apply_kernel<T, NT><<<grid, 256, 0, s>>>((const T*)y, scale, shift, (const T*)residual, relu, (T*)a, relu_mask, m, c)
   if (dtype == SH_F32) { if (g_bn_nt) SH_BN_APPLY(float, true); else SH_BN_APPLY(float, false); }
   else { if (g_bn_nt) SH_BN_APPLY(bf16_t, true); else SH_BN_APPLY(bf16_t, false); }
@@ -1330,7 +1363,8 @@ int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const flo
   ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (3 + (relu == 1 ? 1 : 0) + (dres ? 1 : 0)));
   route_hit(SH_ROUTE_BN_BWD_APPLY);
   const float inv_m = (float)(1.0 / (double)m);
-  const int grid = row_grid(m, c / ve);
+  static const int cap = getenv("SIMHAND_BN_GRID_BWD") ? atoi(getenv("SIMHAND_BN_GRID_BWD")) : 131072;
+  const int grid = row_grid(m, c / ve, cap);
 #define SH_BN_BA(T, NT) bn_bwd_apply_kernel<T, NT><<<grid, 256, 0, s>>>((const T*)da, (const T*)a, (const T*)y, mean, invstd, gamma, dgamma, dbeta, scale, shift, relu, (T*)dy, (T*)dres, m, c, inv_m)
   if (dtype == SH_F32) { if (g_bn_nt) SH_BN_BA(float, true); else SH_BN_BA(float, false); }
   else { if (g_bn_nt) SH_BN_BA(bf16_t, true); else SH_BN_BA(bf16_t, false); }
