@@ -69,7 +69,16 @@ template <int K, int MF, bool DGRAD, bool FUSE = false, int EP = 0, int PF = 0, 
 #ifndef SH_G1_FUSE_MINB
 #define SH_G1_FUSE_MINB 3
 #endif
-__global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : 2) void gemm1x1_kernel(Gemm1x1Args p) {
+// resident blocks per CU the register budget is set for: three for the FORWARD kernels with K <= 128 (their operand rows and
+// accumulators leave room: 64 -> 256 @ 56^2 with the BN epilogue 1619 -> 1527 us, 128 -> 512 @ 28^2 896 -> 867), two elsewhere (the data
+// gradients and K = 256 spill at three: 790 -> 1347 us, 532 -> 1268 us)
+#ifndef SH_G1_FWD_MINB
+#define SH_G1_FWD_MINB 3
+#endif
+#ifndef SH_G1_CH_MINB
+#define SH_G1_CH_MINB 2
+#endif
+__global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 && !ST) ? (CH ? SH_G1_CH_MINB : SH_G1_FWD_MINB) : 2)) void gemm1x1_kernel(Gemm1x1Args p) {
   constexpr int KC = K < 128 ? K : 128;   // k elements per weight tile
   constexpr int KSTEPS = K / KC;          // weight tiles per 64-channel chunk
   constexpr int KK = KC / 32;             // MFMA k-steps per weight tile
