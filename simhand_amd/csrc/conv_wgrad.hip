@@ -1169,7 +1169,20 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
   route_hit(stem_wp > 0 ? SH_ROUTE_WGRAD_STEM : (plain ? SH_ROUTE_WGRAD_PLAIN : SH_ROUTE_WGRAD_GENERIC));
   if (dy_colsum != nullptr) route_hit(SH_ROUTE_WGRAD_COLSUM);
 #define SH_WG(T, BM, BN) wgrad_kernel<T, BM, BN><<<nblk, 256, 0, s>>>(a)
-  if (stem_wp > 0) {  // cout 64 x 256 virtual channels -> the 64 x 128 tile with the NHWC4 address map
+  static const int stem256 = getenv("SIMHAND_STEM_WG256") ? atoi(getenv("SIMHAND_STEM_WG256")) : 1;  // (env: A/B timing; 1.68 -> 1.57 ms at 2048 images)
+  if (stem_wp > 0 && stem256 && d->dtype == SH_BF16) {
+    // all 256 virtual channels in one tile: dy is staged once per pixel range instead of once per 128-channel tile; 32-pixel k-steps
+    // (the 64 x 256 tile's LDS at 64 pixels would leave one block per CU); twice the splits keep the block count
+    const long long ksteps = (mo + 31) / 32;
+    long long sk = 2ll * a.splitk;
+    long long per = (ksteps + sk - 1) / sk;
+    sk = (ksteps + per - 1) / per;
+    a.splitk = (int)sk;
+    a.pix_per_split = (int)(per * 32);
+    a.nt = 1;
+    SH_REQUIRE(workspace_bytes >= (size_t)sk * d->cout * d->cin * sizeof(float), "stem_conv_wgrad: workspace too small");
+    wgrad_kernel<bf16_t, 64, 256, true, false, 1><<<a.splitk, 256, 0, s>>>(a);
+  } else if (stem_wp > 0) {  // cout 64 x 256 virtual channels -> the 64 x 128 tile with the NHWC4 address map
     if (d->dtype == SH_F32) wgrad_kernel<float, 64, 128, true><<<nblk, 256, 0, s>>>(a);
     else if (g_plain_kpm == 2) wgrad_kernel<bf16_t, 64, 128, true, false, 2><<<nblk, 256, 0, s>>>(a);  // 64-pixel k-steps: 16 MFMAs per barrier
     else wgrad_kernel<bf16_t, 64, 128, true><<<nblk, 256, 0, s>>>(a);
@@ -1274,7 +1287,7 @@ static void stem_wgrad_desc(sh_conv_desc* d, int n, int h, int w, int dtype) {
 size_t simhand_stem_conv_wgrad_workspace_bytes(int n, int h, int w, int dtype) {
   sh_conv_desc d;
   stem_wgrad_desc(&d, n, h, w, dtype);
-  return simhand_conv2d_wgrad_workspace_bytes(&d);
+  return 2 * simhand_conv2d_wgrad_workspace_bytes(&d) + 4096;  // (the single-tile form runs twice the splits)
 }
 
 int simhand_stem_conv_wgrad(const void* xp, const void* dy, float* dw_oihw, void* workspace, size_t workspace_bytes, int n, int h,
