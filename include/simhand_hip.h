@@ -91,7 +91,8 @@ enum sh_route {
   SH_ROUTE_NTXENT_FUSED_DIST = 31,                          /* loss tile kernel computing the joint distances in-tile (no D block) */
   SH_ROUTE_DGRAD_DYSRC = 32,                                /* BN-backward apply fused into the 1x1 data gradient's dy loader */
   SH_ROUTE_FWD_CHAIN = 33,                                  /* conv3 + BN + residual + ReLU with the next block's conv1 chained on */
-  SH_ROUTE_COUNT = 34
+  SH_ROUTE_R128_FWD = 34, SH_ROUTE_R128_DGRAD = 35,         /* 128->128 3x3: activation tile staged once in an LDS ring, weights streamed per tap */
+  SH_ROUTE_COUNT = 36
 };
 int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
 int simhand_route_reset(void);
@@ -230,6 +231,8 @@ int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d);
  * grid with the whole filter resident in registers (conv3x3_c64.hip); 0 routes them through the generic tile kernels
  * (tuning / test hook). */
 int simhand_test_conv3x3_c64_enable(int on);
+/* tuning hook: the 128 -> 128 channel 3x3 ring kernel (conv3x3_ring.hip): 1 on, 0 off (the 128 x 128 tile kernel), -1 back to the default */
+int simhand_test_conv3x3_r128_enable(int on);
 /* tuning / test hook of the short-K (cin or cout in {64,128,256}) bf16 stride-1 1x1 kernel: rows per block = 64*mf */
 int simhand_test_conv1x1_set_rows(int k, int mf);
 int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void* y, float* bn_partial, sh_stream_t stream);

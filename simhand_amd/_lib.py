@@ -34,8 +34,8 @@ ROUTES = ("igemm128_fwd", "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "i
           "gemm1x1_dgrad", "c64_fwd", "c64_dgrad", "stem_fwd", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
           "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
           "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram", "wgrad_bnbwd", "ntxent_fused_dist",
-          "dgrad_dysrc", "fwd_chain")
-ROUTE_COUNT = 34
+          "dgrad_dysrc", "fwd_chain", "r128_fwd", "r128_dgrad")
+ROUTE_COUNT = 36
 
 
 class SimhandHipError(RuntimeError):
@@ -166,6 +166,7 @@ SIGNATURES = {
     "simhand_bn_bwd_finalize_raw": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_conv2d_dgrad_stat_blocks": (_I, [C.POINTER(ConvDesc), _I, _I, _I]),
     "simhand_test_conv3x3_c64_enable": (_I, [_I]),
+    "simhand_test_conv3x3_r128_enable": (_I, [_I]),
     "simhand_test_stem_conv_route": (_I, [_I]),
     "simhand_test_igemm256_split_tail": (_I, [_I]),
     "simhand_test_igemm256_tile224": (_I, [_I]),

@@ -31,6 +31,7 @@ void route_hit(int route);
 typedef std::atomic<int> hook_t;
 void hooks_reset_igemm();
 void hooks_reset_c64();
+void hooks_reset_r128();
 void hooks_reset_1x1();
 void hooks_reset_wgrad();
 void hooks_reset_bn();

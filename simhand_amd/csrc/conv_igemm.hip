@@ -29,6 +29,7 @@
 
 #include <stdlib.h>
 #include "conv3x3_c64.h"
+#include "conv3x3_ring.h"
 
 namespace sh {
 
@@ -1457,9 +1458,40 @@ int simhand_test_conv3x3_c64_enable(int on) {
   return 0;
 }
 
+// 128 -> 128 channel 3x3 / stride 1: activation tile staged once per 256 padded positions, weights streamed per tap (conv3x3_ring.hip)
+static bool use_r128(const sh_conv_desc* d) {
+  return r128_supported(d->dtype, d->cin, d->cout, d->r, d->s, d->stride, d->pad, d->w, c64_q_total(d));
+}
+// the data-gradient form stores only (no accumulate / residual merge / bias) and fuses relu_mode 0 / 2 sums, as the c64 kernel
+static bool use_r128_dgrad(const sh_conv_desc* d, int accumulate, int relu_mode, bool has_bias) {
+  return use_r128(d) && accumulate == 0 && !has_bias && (relu_mode < 0 || relu_mode == 0 || relu_mode == 2);
+}
+static int launch_r128_conv(const sh_conv_desc* d, const void* x, const void* w, void* out, float* partial, bool dgrad,
+                            const sh_bn_bwd_fuse* fuse, hipStream_t s) {
+  R128Args c;
+  c.x = (const bf16_t*)x; c.w = (const bf16_t*)w; c.out = (bf16_t*)out; c.partial = partial;
+  c.fy = fuse ? (const bf16_t*)fuse->y : nullptr;
+  c.fscale = fuse ? fuse->scale : nullptr;
+  c.fshift = fuse ? fuse->shift : nullptr;
+  c.relu = fuse && fuse->relu_mode == 2 ? 1 : 0;
+  c.N = d->n; c.H = d->h; c.W = d->w; c.dgrad = dgrad ? 1 : 0;
+  c.q_total = c64_q_total(d);
+  c.tiles = 0;
+  c.div_pp = make_fastdiv((unsigned)((d->h + 1) * (d->w + 1)));
+  c.div_wp = make_fastdiv((unsigned)(d->w + 1));
+  launch_r128(c, s);
+  return check_launch(dgrad ? "conv2d_dgrad (3x3 ring)" : "conv2d_fwd (3x3 ring)");
+}
+
+int simhand_test_conv3x3_r128_enable(int on) {
+  r128_enable(on);
+  return 0;
+}
+
 int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d) {
   if (!d) return 0;
   if (use_c64(d)) return c64_blocks(c64_q_total(d));
+  if (use_r128(d)) return r128_blocks(c64_q_total(d));
   const long long m = (long long)d->n * d->ho * d->wo;
   if (use_1x1(d, d->cin, d->cout)) return ceil_div(m, gemm1x1_rows_per_block(d->cin));
   if (use_256_fwd(d, m)) return stat_rows256(m, d->cout, 1);
@@ -1499,6 +1531,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
     return check_launch("conv2d_fwd (1x1)");
   }
   if (use_c64(d)) return launch_c64_conv(d, x, w, y, bn_partial, false, nullptr, (hipStream_t)stream);
+  if (use_r128(d)) return launch_r128_conv(d, x, w, y, bn_partial, false, nullptr, (hipStream_t)stream);
   if (use_256_fwd(d, a.Mg)) return launch_igemm256<false>(a, (hipStream_t)stream);
   return d->dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
@@ -1654,6 +1687,7 @@ int simhand_test_stem_conv_route(int mode) {
 // tiles (= rows of the fused BatchNorm-backward partial buffer) of the data-gradient launch
 static int dgrad_stat_blocks(const sh_conv_desc* d, int accumulate, int relu_mode, int c2 = 0) {
   if (use_c64_dgrad(d, accumulate, relu_mode, false)) return c64_blocks(c64_q_total(d));
+  if (use_r128_dgrad(d, accumulate, relu_mode, false)) return r128_blocks(c64_q_total(d));
   if (c2 == 0 && use_1x1(d, d->cout, d->cin)) return ceil_div((long long)d->n * d->h * d->w, gemm1x1_rows_per_block(d->cout));
   const long long mg = d->stride == 2 ? (long long)d->n * ((d->h + 1) / 2) * ((d->w + 1) / 2) : (long long)d->n * d->h * d->w;
   if (use_256_dgrad(d, mg)) return stat_rows256(mg, d->cin, d->stride == 2 ? 4 : 1);
@@ -1758,6 +1792,9 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   }
   if (use_c64_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr)
     return launch_c64_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream);
+  if (use_r128_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr && x2 == nullptr && src == nullptr &&
+      f8 == nullptr)
+    return launch_r128_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream);
   if (f8 != nullptr) {
     a.x_state = f8->dy_state;
     a.w_state = f8->w_state;

@@ -123,6 +123,7 @@ int simhand_route_reset(void) {
 int simhand_test_hooks_reset(void) {
   sh::hooks_reset_igemm();
   sh::hooks_reset_c64();
+  sh::hooks_reset_r128();
   sh::hooks_reset_1x1();
   sh::hooks_reset_wgrad();
   sh::hooks_reset_bn();

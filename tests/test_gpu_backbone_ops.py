@@ -535,6 +535,75 @@ def test_c64_conv3x3_fwd_dgrad(shape):
     _check(part.sum(0).cpu(), part_ref.sum(0).cpu(), 1e-5, "partials vs tile kernel")
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# 128 -> 128 channel 3x3: activation tile staged once in an LDS ring, weights streamed per tap (conv3x3_ring.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+R128_SHAPES = [(24, 28, 28), (40, 20, 30), (64, 17, 15), (80, 9, 23)]  # n, h, w (w + 2 <= 32; >= 16384 positions of the padded grid)
+
+
+@pytest.mark.parametrize("shape", R128_SHAPES)
+def test_r128_conv3x3_fwd_dgrad(shape):
+    """Forward (+ BN partial statistics) and data gradient (plain, and with the previous unit's BN-backward sums) of the ring kernel
+    against fp32 torch, and against the generic tile kernel (another order of the fp32 sums: input-channel half outermost)."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    n, h, w = shape
+    lib = ops._lib_dev()
+    g = torch.Generator().manual_seed(n * 1000 + h)
+    x = _rnd(torch.randn(n, 128, h, w, generator=g), dtype)
+    wt = _rnd(torch.randn(128, 128, 3, 3, generator=g) / 34.0, dtype)
+    x.requires_grad_(True)
+    y = F.conv2d(x, wt, padding=1)
+    dy = _rnd(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    d = ops.conv_desc(n, h, w, 128, 128, 3, 3, 1, 1, dtype)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    wd = ops.pack_krsc(wt.detach().to(DEV), dtype)
+    wtd = ops.pack_crsk(wt.detach().to(DEV), dtype)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    m = n * h * w
+    tiles = (n * (h + 1) * (w + 1) + 255) // 256
+    ops.route_reset()
+    yd, part = ops.conv2d_fwd(d, xd, wd, want_stats=True)
+    y0, _ = ops.conv2d_fwd(d, xd, wd, want_stats=False)
+    assert ops.route_counts()["r128_fwd"] == 2 and part.shape[0] == tiles
+    assert torch.equal(yd, y0)
+    _check(yd.float().cpu().permute(0, 3, 1, 2), y.detach(), _tol(dtype), "fwd")
+    yf = y.detach().permute(0, 2, 3, 1).reshape(m, 128)
+    _check(part[:, 0].sum(0).cpu() / m, yf.mean(0), 1e-2, "stat mean")
+    _check(part[:, 1].sum(0).cpu() / m, (yf * yf).mean(0), 1e-2, "stat sumsq")
+    ops.route_reset()
+    dxd = ops.conv2d_dgrad(d, dyd, wtd)
+    assert ops.route_counts()["r128_dgrad"] == 1
+    _check(dxd.float().cpu().permute(0, 3, 1, 2), x.grad, _tol(dtype), "dgrad")
+
+    y_prev = _rnd(torch.randn(n, h, w, 128, generator=g), dtype).to(DEV).to(dtype)
+    st = ops.BNState(128, DEV)
+    st.scale.copy_(torch.randn(128, generator=g).to(DEV))
+    st.shift.copy_(torch.randn(128, generator=g).to(DEV) * 0.3)
+    for mode in (2, 0):
+        dx2, p2 = ops.conv2d_dgrad_fused(d, dyd, wtd, y_prev, st if mode == 2 else None, None)
+        assert torch.equal(dx2, dxd) and p2.shape[0] == tiles, mode
+        s1, s2 = _bn_sums_reference(dx2, y_prev, mode, st.scale, st.shift, None)
+        got1, got2 = p2[:, 0].double().sum(0), p2[:, 1].double().sum(0)
+        assert (got1 - s1).abs().max().item() <= 1e-4 * s1.abs().max().item() + 1e-4, (mode, "sum g")
+        assert (got2 - s2).abs().max().item() <= 1e-4 * s2.abs().max().item() + 1e-4, (mode, "sum g*y")
+
+    lib.simhand_test_conv3x3_r128_enable(0)
+    try:
+        y_ref, part_ref = ops.conv2d_fwd(d, xd, wd, want_stats=True)
+        dx_ref = ops.conv2d_dgrad(d, dyd, wtd)
+    finally:
+        lib.simhand_test_conv3x3_r128_enable(-1)
+    assert part_ref.shape[0] != tiles
+    # the same bf16 products summed in fp32 in another order (half-major here, tap-major there): equal up to the last rounding
+    assert (yd.float() - y_ref.float()).abs().max().item() <= 2.0 ** -7 * y_ref.float().abs().max().item()
+    assert (yd != y_ref).float().mean().item() < 0.05
+    assert (dxd.float() - dx_ref.float()).abs().max().item() <= 2.0 ** -7 * dx_ref.float().abs().max().item()
+    _check(part.sum(0).cpu(), part_ref.sum(0).cpu(), 1e-4, "partials vs tile kernel")
+
+
 @pytest.mark.parametrize("route", ["tile", "big_tile", "short_k"])
 @pytest.mark.parametrize("mode", ["store", "accumulate", "fused_sums"])
 def test_dgrad_second_reduction_segment(route, mode):

@@ -244,7 +244,8 @@ def test_config1_rn50_default_routing_at_88_images():
     out = model.training_step(dev_batch, 0)
     out["loss"].backward()
     routes = ops.route_counts()
-    for r in ("igemm256_fwd", "igemm256_dgrad", "c64_fwd", "c64_dgrad", "gemm1x1_fwd_bnact", "dgrad_concat", "bn_fold_fwd", "bn_fold_bwd", "wgrad3x3"):
+    for r in ("igemm256_fwd", "igemm256_dgrad", "c64_fwd", "c64_dgrad", "r128_fwd", "r128_dgrad", "gemm1x1_fwd_bnact", "dgrad_concat", "bn_fold_fwd",
+              "bn_fold_bwd", "wgrad3x3"):
         assert routes[r] > 0, f"default dispatch never took the {r} route at 88 images"
     for k, p in model.named_parameters():
         assert p.grad is None or bool(torch.isfinite(p.grad).all()), k

@@ -35,7 +35,7 @@ SHAPES = {
     (128, 512, 1, 1, 28): ("gemm1x1_fwd", "igemm128_dgrad", "wgrad_plain"),
     (256, 512, 1, 2, 56): ("igemm256_fwd", "igemm128_dgrad", "wgrad_generic"),
     (512, 128, 1, 1, 28): ("igemm128_fwd", "gemm1x1_dgrad", "wgrad_plain"),
-    (128, 128, 3, 1, 28): ("igemm128_fwd", "igemm128_dgrad", "wgrad3x3"),
+    (128, 128, 3, 1, 28): ("r128_fwd", "r128_dgrad", "wgrad3x3"),
     (512, 256, 1, 1, 28): ("igemm256_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (256, 256, 3, 2, 28): ("igemm256_fwd", "igemm256_dgrad", "wgrad3x3"),
     (256, 1024, 1, 1, 14): ("gemm1x1_fwd", "igemm256_dgrad", "wgrad_plain"),
@@ -171,6 +171,36 @@ def test_fullsize_dgrad(shape):
     want = torch.nn.grad.conv2d_input((len(SAMPLE), cin, h, h), o["w"].cpu(), _nchw(o["dy"], idx).contiguous(), stride=s, padding=o["pad"])
     _close(_nchw(dx, idx), want, 1e-2, "dgrad")
     assert bool(torch.isfinite(dx.float().sum()))  # no NaN / inf anywhere in the 2048 images
+
+
+def test_fullsize_ring_kernel_dgrad_with_fused_sums():
+    """The 128 -> 128 3x3 ring kernel in the form the step runs it for conv2 of stage 2: data gradient + the BatchNorm-backward sums of
+    conv1's unit (ReLU gate recomputed from its raw output), 2048 images: dx bit-equal to the plain launch, sums against a direct
+    fp64 reduction of the stored dx over all rows."""
+    from simhand_amd import ops
+
+    shape = (128, 128, 3, 1, 28)
+    o = _operands(shape, need=("w", "dy"))
+    d = o["d"]
+    wc = ops.pack_crsk(o["w"], DT)
+    g = torch.Generator(device=DEV).manual_seed(77)
+    y_prev = torch.randn(N, 28, 28, 128, device=DEV, generator=g).to(DT)
+    st = ops.BNState(128, DEV)
+    st.scale.copy_(torch.randn(128, device=DEV, generator=g))
+    st.shift.copy_(torch.randn(128, device=DEV, generator=g) * 0.3)
+    ops.hooks_reset()
+    ops.route_reset()
+    dx0 = ops.conv2d_dgrad(d, o["dy"], wc)
+    dx, part = ops.conv2d_dgrad_fused(d, o["dy"], wc, y_prev, st, None)
+    rc = ops.route_counts()
+    assert rc["r128_dgrad"] == 2 and torch.equal(dx, dx0), rc
+    assert part.shape[0] == (N * 29 * 29 + 255) // 256
+    yf = y_prev.view(-1, 128).float()
+    gq = torch.where(yf * st.scale + st.shift > 0, dx.view(-1, 128).float(), torch.zeros_like(yf))
+    s1, s2 = gq.double().sum(0), (gq.double() * yf.double()).sum(0)
+    got1, got2 = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    assert (got1 - s1).abs().max().item() <= 1e-5 * s1.abs().max().item() + 1e-3
+    assert (got2 - s2).abs().max().item() <= 1e-5 * s2.abs().max().item() + 1e-3
 
 
 def _cpu_wgrad(x, dy, wshape, stride, pad, chunk=128):
