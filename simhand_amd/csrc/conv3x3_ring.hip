@@ -26,6 +26,10 @@
 
 #include <stdlib.h>
 
+#ifndef SH_R128_YPF
+#define SH_R128_YPF 1  // MODE 2: request the previous unit's y rows during the last k-steps (0: in the epilogue -- A/B builds)
+#endif
+
 namespace sh {
 
 __device__ uint4 g_r128_zero_page[8];
@@ -132,6 +136,33 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // positions -> NHWC pixels of this lane's output rows (decoded inside the loop's tail, see below); MODE 2: the previous unit's y rows
+  unsigned pixs[MI];
+  bool oks[MI];
+  uint4 yq[MODE == 2 ? MI : 1][2];
+  const int ch0 = wn * 64 + g * 8;
+  auto decode_rows = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const long long q = m0 + wm * 64 + mi * 16 + pl;
+      const bool in = q < p.q_total;
+      const unsigned qu = in ? (unsigned)q : 0u;
+      const unsigned img = fdiv(qu, p.div_pp);
+      const unsigned rem = qu - img * p.div_pp.d;
+      const unsigned hp = fdiv(rem, p.div_wp);
+      const unsigned wp = rem - hp * p.div_wp.d;
+      oks[mi] = in && hp - 1u < (unsigned)p.H && wp - 1u < (unsigned)p.W;
+      pixs[mi] = (img * (unsigned)p.H + (hp - 1u)) * (unsigned)p.W + (wp - 1u);
+      if constexpr (MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const void* src = oks[mi] ? (const void*)(p.fy + (unsigned long long)pixs[mi] * 128 + ch0 + 32 * j) : (const void*)g_r128_zero_page;
+          yq[mi][j] = *reinterpret_cast<const uint4*>(src);
+        }
+      }
+    }
+  };
+
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -140,9 +171,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
       // vector-memory operations retire in order.  Issued so far: half 0, W0, W1, half 1, W2 .. W(ks+1); step ks needs W(ks) (and,
       // from ks = 9 on, half 1 -- older than W2, landed since step 2): after it may fly W1 + half 1 (ks = 0), half 1 + W2 (ks = 1),
       // W(ks+1) (ks >= 2)
+      // MODE 2: the 8 loads of the previous unit's y rows go out in step 15 (behind W17), so that their round trip is over when the
+      // epilogue wants them: steps 16 and 17 then leave 2 + 8 operations in flight
       if (ks < 2) asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
+      else if (MODE == 2 && SH_R128_YPF && h == 1 && t >= 7) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
       dma_w(ks + 2);  // stage (ks + 2) % 3 = the one step ks - 1 read: every wave is past it
+      if (MODE == 2 && SH_R128_YPF && t == 6 && h == 1) decode_rows();
       const char* sa = smem + h * HALF + a_base;
       const int ob = A_BYTES + (ks % NST) * BST + fbo;  // (A_BYTES, BST multiples of 128: ^ 64 flips the chunk's bit 2 only)
       uint4 fb[2][NI];
@@ -177,7 +212,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // LDS is reused by the reduction below
 
   // ---- epilogue: lane holds position m0 + wm*64 + mi*16 + pl, channels ch0 + 32 j .. + 7 (j = 0, 1) --------------------------------
-  const int ch0 = wn * 64 + g * 8;
   float s1[2][8], s2[2][8], fsc[2][8], fsh[2][8];
   if constexpr (MODE != 0) {
 #pragma unroll
@@ -196,29 +230,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
         fsh[j][4 * i] = b.x; fsh[j][4 * i + 1] = b.y; fsh[j][4 * i + 2] = b.z; fsh[j][4 * i + 3] = b.w;  // no ReLU: y * 0 + 1 > 0 is always open
       }
   }
-  // positions -> NHWC pixels (all decoded first; MODE 2 requests its y rows together: one exposed round trip, not one per row)
-  unsigned pixs[MI];
-  bool oks[MI];
-  uint4 yq[MODE == 2 ? MI : 1][2];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const long long q = m0 + wm * 64 + mi * 16 + pl;
-    const bool in = q < p.q_total;
-    const unsigned qu = in ? (unsigned)q : 0u;
-    const unsigned img = fdiv(qu, p.div_pp);
-    const unsigned rem = qu - img * p.div_pp.d;
-    const unsigned hp = fdiv(rem, p.div_wp);
-    const unsigned wp = rem - hp * p.div_wp.d;
-    oks[mi] = in && hp - 1u < (unsigned)p.H && wp - 1u < (unsigned)p.W;
-    pixs[mi] = (img * (unsigned)p.H + (hp - 1u)) * (unsigned)p.W + (wp - 1u);
-    if constexpr (MODE == 2) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const void* src = oks[mi] ? (const void*)(p.fy + (unsigned long long)pixs[mi] * 128 + ch0 + 32 * j) : (const void*)g_r128_zero_page;
-        yq[mi][j] = *reinterpret_cast<const uint4*>(src);
-      }
-    }
-  }
+  if constexpr (MODE != 2 || !SH_R128_YPF) decode_rows();
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
