@@ -985,12 +985,22 @@ static bool wg_big(const sh_conv_desc* d) {
   // cout != cin: never the Gram launches of the BatchNorm fold (x = dy = a: their operand transforms live in the 128-row tiles)
   return (h >= 0 ? h : env) && is_plain(d) && g_use_tr && d->cout % 256 == 0 && d->cin % 128 == 0 && d->cout != d->cin;
 }
+// one tile across the WIDE side of the stage-1 layers (64 <-> 256 channels): the narrow operand is then staged once per pixel range
+// instead of once per 128-channel tile of the wide side (4.7 -> 4.1 GB per launch at 2048 x 56^2); env SIMHAND_WG_WIDE=0: A/B timing
+static bool wg_wide(const sh_conv_desc* d) {
+  static const int env = getenv("SIMHAND_WG_WIDE") ? atoi(getenv("SIMHAND_WG_WIDE")) : 1;
+  return env && is_plain(d) && g_use_tr && ((d->cin == 64 && d->cout == 256) || (d->cout == 64 && d->cin == 256));
+}
 static void plan(const sh_conv_desc* d, int* bm, int* bn, int* splitk, int* pps, bool allow_big = true) {
   int kp = d->dtype == SH_F32 ? 16 : (is_plain(d) && g_use_tr ? 32 * g_plain_kpm : 32);
   *bm = d->cout % 128 == 0 ? 128 : 64;
   *bn = d->cin % 128 == 0 ? 128 : 64;
   if (allow_big && wg_big(d)) {  // (launches with an operand transform keep the 128-row tiles)
     *bm = 256;
+    kp = 32;
+  } else if (allow_big && wg_wide(d)) {
+    *bm = d->cout;
+    *bn = d->cin;
     kp = 32;
   }
   const long long mo = (long long)d->n * d->ho * d->wo;
@@ -1210,7 +1220,9 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
       else if (bm == 128) SH_WGX(128, 64, 2);
       else if (bn == 128) SH_WGX(64, 128, 2);
       else SH_WGX(64, 64, 2);
-    } else if (bm == 256) wgrad_kernel<bf16_t, 256, 128, false, true, 1><<<nblk, 256, 0, s>>>(a);
+    } else if (bm == 256 && bn == 64) wgrad_kernel<bf16_t, 256, 64, false, true, 1><<<nblk, 256, 0, s>>>(a);
+    else if (bm == 64 && bn == 256) wgrad_kernel<bf16_t, 64, 256, false, true, 1><<<nblk, 256, 0, s>>>(a);
+    else if (bm == 256) wgrad_kernel<bf16_t, 256, 128, false, true, 1><<<nblk, 256, 0, s>>>(a);
     else if (bm == 128 && bn == 128) SH_WGP(128, 128);
     else if (bm == 128) SH_WGP(128, 64);
     else if (bn == 128) SH_WGP(64, 128);
