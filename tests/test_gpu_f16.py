@@ -37,10 +37,12 @@ def _check(got, want, tol, tag):
 
 
 @pytest.mark.parametrize("shape", [(2, 14, 14, 64, 256, 1, 1, 0), (3, 9, 9, 128, 128, 3, 1, 1), (2, 16, 16, 64, 64, 3, 1, 1), (2, 16, 16, 128, 128, 3, 2, 1),
-                                   (2, 16, 16, 256, 512, 1, 2, 0), (2, 20, 20, 1024, 256, 1, 1, 0), (3, 14, 14, 256, 256, 3, 1, 1), (5, 7, 7, 512, 64, 1, 1, 0)])
+                                   (2, 16, 16, 256, 512, 1, 2, 0), (2, 20, 20, 1024, 256, 1, 1, 0), (3, 14, 14, 256, 256, 3, 1, 1), (5, 7, 7, 512, 64, 1, 1, 0),
+                                   (24, 28, 28, 128, 128, 3, 1, 1), (6, 56, 56, 128, 128, 3, 2, 1), (90, 14, 14, 1024, 256, 1, 1, 0)])
 def test_conv_fwd_dgrad_wgrad_fp16_storage(shape):
     """Every kernel family (activation-stationary 1x1, 128-row tile kernel, 256 x 256 LDS-DMA kernel [forced], register-resident 64-channel
-    3x3, all-taps / generic / pointer-walking weight gradients) in the fp16 build."""
+    3x3, the 128-channel LDS-ring 3x3 [>= 16 384 padded positions], all-taps (stride 1 and 2) / generic / pointer-walking / LDS-DMA 1x1
+    [>= 16 384 pixels] weight gradients) in the fp16 build."""
     from simhand_amd import _lib, ops
 
     _lib.load().simhand_test_igemm256_enable(2)
@@ -54,8 +56,11 @@ def test_conv_fwd_dgrad_wgrad_fp16_storage(shape):
     d = ops.conv_desc(n, h, w, cin, cout, k, k, stride, pad, H)
     xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).to(H)
     wd, wtd = ops.pack_krsc(wt.detach().to(DEV), H), ops.pack_crsk(wt.detach().to(DEV), H)
+    ops.route_reset()
     yd, part = ops.conv2d_fwd(d, xd, wd, want_stats=True)
     assert yd.dtype == H
+    if shape == (24, 28, 28, 128, 128, 3, 1, 1):
+        assert ops.route_counts()["r128_fwd"] == 1
     _check(yd.float().cpu().permute(0, 3, 1, 2), y.detach(), 2e-3, "fwd")
     m = n * d.ho * d.wo
     yf = y.detach().permute(0, 2, 3, 1).reshape(m, cout)
