@@ -341,6 +341,14 @@ typedef struct sh_dgrad_opts {
   const void* wt_q;
   const float* dy_state;
   const float* w_state;
+  /* sub_grad [n][h/2][w/2][cin] (h, w even; NULL = off): dx = gate(result + S), S = sub_grad at the EVEN pixels of dx and zero elsewhere --
+   * the data gradient of a stride-2 1x1 shortcut, computed densely at its output resolution, merged into the main branch's data
+   * gradient (the gate = the masked store of fuse->relu_mode 4 when given).  Merged inside the launch where the kernel the arguments
+   * select has that epilogue (the masked-store forms of the activation-stationary 1x1 kernel and of the 256 x 256 kernel); otherwise
+   * the call finishes with simhand_scatter2_add -- same result, one more pass over the even pixels.  Needs accumulate == 0.
+   * Replaces (reference): autograd's accumulation of the two input-gradient branches of a stage-entry Bottleneck
+   * (src/models/resnet_model.py:13-58). */
+  const void* sub_grad;
 } sh_dgrad_opts;
 int simhand_conv2d_dgrad_fp8_pays(const sh_conv_desc* d);
 int simhand_conv2d_dgrad_concat_ok(const sh_conv_desc* d, int c2);

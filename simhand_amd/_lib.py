@@ -72,7 +72,8 @@ class DgradOpts(C.Structure):
     """sh_dgrad_opts (include/simhand_hip.h)."""
     _fields_ = [("accumulate", C.c_int32), ("res_grad", C.c_void_p), ("res_mask", C.c_void_p), ("bias", C.c_void_p),
                 ("fuse", C.POINTER(BnBwdFuse)), ("x2", C.c_void_p), ("wt2", C.c_void_p), ("c2", C.c_int32),
-                ("dy_src", C.POINTER(DySrc)), ("dy_q", C.c_void_p), ("wt_q", C.c_void_p), ("dy_state", C.c_void_p), ("w_state", C.c_void_p)]
+                ("dy_src", C.POINTER(DySrc)), ("dy_q", C.c_void_p), ("wt_q", C.c_void_p), ("dy_state", C.c_void_p), ("w_state", C.c_void_p),
+                ("sub_grad", C.c_void_p)]
 
 
 class ConvDesc(C.Structure):

@@ -50,7 +50,12 @@ struct Gemm1x1Args {
   bf16_t* chain_y = nullptr;
   float* chain_partial = nullptr;
   int stem_hp = 0, stem_wp = 0;
-  FastDiv div_hw = {1, 0, 0}, div_w = {1, 0, 0};  // ho * wo, wo
+  FastDiv div_hw = {1, 0, 0}, div_w = {1, 0, 0};  // ho * wo, wo (stem); h * w, w of the rows' pixel grid (sub)
+  // data gradient, masked-store fast variant only (see gemm1x1_sub_ok): out = mask(result + S) where S is `sub` [n][h/2][w/2][N] at the
+  // EVEN pixels of the rows' [n][h][w] grid and zero elsewhere -- the data gradient of a stride-2 1x1 shortcut, computed densely at the
+  // output resolution, merged here instead of by a scatter-add pass over out.  sub null = off
+  const bf16_t* sub = nullptr;
+  int sub_h = 0, sub_w = 0;
 };
 
 bool gemm1x1_supported(int k, int n);
@@ -60,6 +65,7 @@ int gemm1x1_chain_rows(int k);                      // rows per block of that la
 int gemm1x1_rows_per_block(int k);
 void gemm1x1_set_mf(int k, int mf);
 int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s);
+bool gemm1x1_sub_ok(const Gemm1x1Args& a, int k);  // the launch these arguments select merges a.sub (else: the caller scatter-adds)
 int launch_gemm1x1_stem(const Gemm1x1Args& a, hipStream_t s);  // persistent direct-stem forward (or 256 rows per block)
 int gemm1x1_stem_stat_blocks(long long m);                      // rows of the BatchNorm partial-sum buffer that launch fills
 void gemm1x1_set_stem_persistent(int on);

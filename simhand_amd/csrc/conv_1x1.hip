@@ -28,6 +28,8 @@ __device__ __forceinline__ f32x4 mma_bf16(const uint4& a, const uint4& b, f32x4 
   return sh_mfma16(a, b, c);
 }
 
+__device__ uint4 g_g1_zero_page[8];  // 128 B of zeros: the PF == 3 lanes of odd pixels fetch it instead of being masked
+
 __device__ __forceinline__ float row16_sum_g1(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
@@ -51,6 +53,8 @@ __device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
 // EP == 2: the same with residual, ReLU and bit mask all present and M a multiple of the block's rows (the conv3 of every
 // identity block): no conditional anywhere near a global load or store, see the note on vmcnt below.
 // PF == 2: the same without a residual gradient (first block of a stage: masked store only, accumulate 0).
+// PF == 3: PF == 2 + the stride-2 shortcut's dense data gradient (Gemm1x1Args::sub) added at the even pixels before the mask: each row's
+// pixel is decoded once, its 16-B chunks ride with the chunk's mask bytes (odd pixels fetch a zero page: no branch near a load).
 // PF == 1 (data gradient; accumulate 2, masked store, full blocks): residual-gradient rows and both bit masks of the chunk are
 // requested when the chunk's MFMAs start (masks as one 8-byte load per pixel row instead of two byte loads per mask).
 //
@@ -271,10 +275,30 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
   // ---- PF: residual gradient + masks of chunk 0
   uint4 pg[PF ? MF : 1][2];
   uint2 pm[PF ? MF : 1], pk[PF ? MF : 1];
+  const bf16_t* sp[PF == 3 ? MF : 1];  // PF == 3: this lane's row in `sub` (+ its 8-channel offset), or the zero page for an odd pixel
+  if constexpr (PF == 3) {
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi) {
+      const unsigned ru = (unsigned)(mbase + mi * 16 + li);  // M < 2^31; full blocks
+      const unsigned img = fdiv(ru, p.div_hw);
+      const unsigned rem = ru - img * p.div_hw.d;
+      const unsigned hh = fdiv(rem, p.div_w);
+      const unsigned ww = rem - hh * p.div_w.d;
+      const unsigned srow = (img * (unsigned)(p.sub_h >> 1) + (hh >> 1)) * (unsigned)(p.sub_w >> 1) + (ww >> 1);
+      sp[mi] = ((hh | ww) & 1u) == 0 ? p.sub + (unsigned long long)srow * p.N + g * 8 : nullptr;
+    }
+  }
   auto load_pf = [&](int nc2) __attribute__((always_inline)) {
 #pragma unroll
     for (int mi = 0; mi < (PF ? MF : 1); ++mi) {
       const long long r = mbase + mi * 16 + li;
+      if constexpr (PF == 3) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bf16_t* q = sp[mi] != nullptr ? sp[mi] + nc2 * 64 + j * 32 : reinterpret_cast<const bf16_t*>(g_g1_zero_page);
+          pg[mi][j] = *reinterpret_cast<const uint4*>(q);
+        }
+      }
       if constexpr (PF == 1) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) pg[mi][j] = *reinterpret_cast<const uint4*>(p.res_grad + r * p.N + nc2 * 64 + j * 32 + g * 8);
@@ -476,6 +500,12 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
             v.y = add_bf16x2_g1(v.y, o.y & m1w);
             v.z = add_bf16x2_g1(v.z, o.z & m2w);
             v.w = add_bf16x2_g1(v.w, o.w & m3w);
+          } else if (DGRAD && PF == 3) {
+            const uint4 o = pg[mi][j];
+            v.x = add_bf16x2_g1(v.x, o.x);
+            v.y = add_bf16x2_g1(v.y, o.y);
+            v.z = add_bf16x2_g1(v.z, o.z);
+            v.w = add_bf16x2_g1(v.w, o.w);
           } else if (DGRAD && PF == 0 && p.accumulate) {
             const uint4 o = *reinterpret_cast<const uint4*>(dst);
             v.x = add_bf16x2_g1(v.x, o.x);
@@ -687,6 +717,12 @@ bool gemm1x1_chain_ok(int k, int n, long long m) {
 }
 int gemm1x1_chain_rows(int k) { return k == 64 ? 128 : 64; }
 
+bool gemm1x1_sub_ok(const Gemm1x1Args& a, int k) {
+  const int mf = mf_of(k);
+  return a.fpartial == nullptr && a.accumulate == 0 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && a.M % (64 * mf) == 0 &&
+         pf_of(k) && a.sub_h % 2 == 0 && a.sub_w % 2 == 0 && a.M < (1ll << 31);
+}
+
 int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
   if (a.chain_w != nullptr) {  // the caller checked gemm1x1_chain_ok and passes residual + ReLU + mask
     route_hit(SH_ROUTE_GEMM1X1_FWD_BNACT);
@@ -708,6 +744,8 @@ int launch_gemm1x1(const Gemm1x1Args& a, int k, bool dgrad, hipStream_t s) {
     if (dgrad && a.fpartial != nullptr) gemm1x1_kernel<KV, MFV, true, true><<<nblk, 256, 0, s>>>(a);  \
     else if (dgrad && a.accumulate == 2 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && full && pf_of(KV))  \
       gemm1x1_kernel<KV, MFV, true, false, 0, 1><<<nblk, 256, 0, s>>>(a);                       \
+    else if (dgrad && a.accumulate == 0 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && full && pf_of(KV) && a.sub != nullptr)  \
+      gemm1x1_kernel<KV, MFV, true, false, 0, 3><<<nblk, 256, 0, s>>>(a);                       \
     else if (dgrad && a.accumulate == 0 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && full && pf_of(KV))  \
       gemm1x1_kernel<KV, MFV, true, false, 0, 2><<<nblk, 256, 0, s>>>(a);                       \
     else if (dgrad) gemm1x1_kernel<KV, MFV, true><<<nblk, 256, 0, s>>>(a);                      \

@@ -83,6 +83,9 @@ struct IgemmArgs {
   // fp8 forward on the 256 x 256 kernel (BASELINE configs[4]): e4m3 operands, result = acc * x_state[1] * w_state[1] (= 1 / (scale_x scale_w))
   const float* x_state = nullptr;
   const float* w_state = nullptr;
+  // dgrad, 1x1 / stride 1, 256 x 256 kernel, masked store (fmode 4) only: out = mask(result + S), S = `sub` [n][Hd/2][Wd/2][Ng] at the even
+  // pixels and zero elsewhere (the stride-2 shortcut's dense data gradient: see Gemm1x1Args::sub).  null = off
+  const void* sub = nullptr;
 };
 
 template <typename T> struct Mma;
@@ -1046,6 +1049,21 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         v.z = add_bf16x2(v.z, o.z);
         v.w = add_bf16x2(v.w, o.w);
       }
+      if (DGRAD && p.sub != nullptr) {  // even pixels: + the shortcut's dense gradient row (odd ones: the zero page, no branch)
+        const unsigned pu = (unsigned)pix;
+        const unsigned img = fdiv(pu, p.div_hw);
+        const unsigned rem = pu - img * p.div_hw.d;
+        const unsigned hh = fdiv(rem, p.div_w);
+        const unsigned ww = rem - hh * p.div_w.d;
+        const unsigned srow = (img * (unsigned)(p.Hd >> 1) + (hh >> 1)) * (unsigned)(p.Wd >> 1) + (ww >> 1);
+        const void* q = ((hh | ww) & 1u) == 0 ? (const void*)(reinterpret_cast<const T*>(p.sub) + (unsigned long long)srow * p.Ng + ch)
+                                               : (const void*)g_zero_page;
+        const uint4 o = *reinterpret_cast<const uint4*>(q);
+        v.x = add_bf16x2(v.x, o.x);
+        v.y = add_bf16x2(v.y, o.y);
+        v.z = add_bf16x2(v.z, o.z);
+        v.w = add_bf16x2(v.w, o.w);
+      }
       if (DGRAD && p.fmode == 4) {  // the stored gradient is the masked one
         v.x &= ((keep & 1u) ? 0x0000ffffu : 0u) | ((keep & 2u) ? 0xffff0000u : 0u);
         v.y &= ((keep & 4u) ? 0x0000ffffu : 0u) | ((keep & 8u) ? 0xffff0000u : 0u);
@@ -1705,6 +1723,7 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
                       const float* bias = nullptr, const void* x2 = nullptr, const void* wt2 = nullptr, int c2 = 0,
                       const sh_dy_src* src = nullptr, const sh_dgrad_opts* f8 = nullptr) {
   if (check_desc(d, "conv2d_dgrad")) return 1;
+  const sh_dgrad_opts* f8sub = f8;  // (the whole option block: sub_grad is read from it below)
   if (f8 != nullptr && f8->dy_q == nullptr) f8 = nullptr;
   if (f8 != nullptr) {
     SH_REQUIRE(f8->wt_q && f8->dy_state && f8->w_state, "conv2d_dgrad_ex: fp8 operands need wt_q and both scale states");
@@ -1720,6 +1739,13 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
     dy = src->da;
   }
   SH_REQUIRE(dy && wt && dx, "conv2d_dgrad: NULL pointer");
+  const void* sub = f8sub != nullptr ? f8sub->sub_grad : nullptr;
+  SH_REQUIRE(sub == nullptr || (accumulate == 0 && d->stride == 1 && d->h % 2 == 0 && d->w % 2 == 0 && d->dtype == SH_BF16),
+             "conv2d_dgrad_ex: sub_grad needs accumulate 0, a stride-1 bf16 layer and even h / w");
+  // the merge where the selected kernel has no epilogue for it: one pass over the even pixels of dx (through the same gate)
+  auto sub_fallback = [&]() -> int {
+    return simhand_scatter2_add(sub, dx, fuse != nullptr && fuse->relu_mode == 4 ? fuse->mask : nullptr, d->n, d->h, d->w, d->cin, d->dtype, stream);
+  };
   SH_REQUIRE(x2 == nullptr || (wt2 != nullptr && concat_ok(d, c2)),
              "conv2d_dgrad_ex: a second reduction segment needs wt2 and a layer simhand_conv2d_dgrad_concat_ok accepts");
   const int ke = d->dtype == SH_F32 ? 32 : 64;
@@ -1787,21 +1813,38 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
       g.xf_c = src->coef_c; g.xf_out = (bf16_t*)src->dy_out; g.xf_relu = src->relu;
       route_hit(SH_ROUTE_DGRAD_DYSRC);
     }
+    bool merged = false;
+    if (sub != nullptr) {
+      g.sub = (const bf16_t*)sub; g.sub_h = d->h; g.sub_w = d->w;
+      g.div_hw = make_fastdiv((unsigned)(d->h * d->w));
+      g.div_w = make_fastdiv((unsigned)d->w);
+      merged = gemm1x1_sub_ok(g, d->cout);
+      if (!merged) g.sub = nullptr;
+    }
     launch_gemm1x1(g, d->cout, true, (hipStream_t)stream);
-    return check_launch("conv2d_dgrad (1x1)");
+    if (check_launch("conv2d_dgrad (1x1)")) return 1;
+    return sub != nullptr && !merged ? sub_fallback() : 0;
   }
-  if (use_c64_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr)
+  if (sub == nullptr && use_c64_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr)
     return launch_c64_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream);
-  if (use_r128_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr && x2 == nullptr && src == nullptr &&
-      f8 == nullptr)
+  if (sub == nullptr && use_r128_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr && x2 == nullptr &&
+      src == nullptr && f8 == nullptr)
     return launch_r128_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream);
   if (f8 != nullptr) {
     a.x_state = f8->dy_state;
     a.w_state = f8->w_state;
-    return launch_igemm256_fp8_dgrad(a, (hipStream_t)stream);
+    if (launch_igemm256_fp8_dgrad(a, (hipStream_t)stream)) return 1;
+    return sub != nullptr ? sub_fallback() : 0;
   }
-  if (use_256_dgrad(d, a.Mg)) return launch_igemm256<true>(a, (hipStream_t)stream);
-  return d->dtype == SH_F32 ? launch_igemm<float, true>(a, (hipStream_t)stream) : launch_igemm<bf16_t, true>(a, (hipStream_t)stream);
+  if (use_256_dgrad(d, a.Mg)) {
+    // the 256 x 256 kernel merges the shortcut's dense gradient in its masked-store epilogue (1x1 / stride 1, no parity classes)
+    const bool merged = sub != nullptr && d->stride == 1 && d->r == 1 && d->s == 1 && a.fmode == 4 && a.fpartial == nullptr && a.Mg < (1ll << 31);
+    if (merged) a.sub = sub;
+    if (launch_igemm256<true>(a, (hipStream_t)stream)) return 1;
+    return sub != nullptr && !merged ? sub_fallback() : 0;
+  }
+  if (d->dtype == SH_F32 ? launch_igemm<float, true>(a, (hipStream_t)stream) : launch_igemm<bf16_t, true>(a, (hipStream_t)stream)) return 1;
+  return sub != nullptr ? sub_fallback() : 0;
 }
 
 int simhand_conv2d_dgrad_fp8_pays(const sh_conv_desc* d) { return d != nullptr && check_desc(d, "conv2d_dgrad_fp8_pays") == 0 && dgrad_fp8_ok(d) ? 1 : 0; }

@@ -167,6 +167,9 @@ class ResNetEngine:
         self._chain = None  # (block output tensor, the chained conv module, its raw output, its BatchNorm partial sums)
         # folded stride-2 shortcut convolutions run as dense 1x1 / stride-1 launches over the subsampled input (env: A/B timing only)
         self.dense_shortcut = os.environ.get("SIMHAND_DENSE_DS", "1") == "1"
+        # backward of a stage-entry block: the shortcut's dense data gradient is merged into the main branch's conv1 data gradient
+        # (sh_dgrad_opts.sub_grad) instead of scatter-added onto it afterwards (env: A/B timing only)
+        self.merge_shortcut = os.environ.get("SIMHAND_MERGE_DS", "1") == "1"
         # multi-GPU: host.dist.OverlappedGradReducer -- finished parameter gradients go out block by block during backward
         self.grad_reducer = None
 
@@ -553,7 +556,7 @@ class ResNetEngine:
         da2, _ = ops.conv2d_dgrad_ex(dww, a2, wm, dx=da2, accumulate=True)
         return da2, None, s
 
-    def _ds_bwd_folded(self, u: _Unit, g, s, grads: dict, dx, below: Optional[_Unit], masked_store: bool):
+    def _ds_bwd_folded(self, u: _Unit, g, s, grads: dict, dx, below: Optional[_Unit], masked_store: bool, scatter: bool = True):
         """Shortcut conv1x1(/stride) + BN of a stage's first block, folded like conv3 + bn3: its incoming gradient is the
         same masked g (and the same s) as the block's bn3.  Both terms of the input gradient accumulate into `dx` (the
         main branch's input gradient); for a stride-2 shortcut they only touch the even pixels -- so does the bias."""
@@ -578,11 +581,13 @@ class ResNetEngine:
         else:
             dsub, _ = ops.conv2d_dgrad_ex(dd, g, wa, bias=bias)
             ops.conv2d_dgrad_ex(dterm, x_in, wm, dx=dsub, accumulate=True)
+        if not scatter:  # the caller merges it into the main branch's data gradient (sub_grad)
+            return dsub
         ops.scatter2_add(dsub, dx, below.mask if masked_store else None)
         return dx
 
     def _unit_bwd(self, u: _Unit, da, grads: dict, need_dx: bool, dx_into=None, relu_mask=None, res_grad=None, res_mask=None,
-                  raw_partial=None, prev: Optional[_Unit] = None, prev_masked_store: bool = False):
+                  raw_partial=None, prev: Optional[_Unit] = None, prev_masked_store: bool = False, sub_grad=None):
         """BN bwd -> wgrad (+ dgrad).  relu_mask: bit mask that gates `da` (residual units: their own output mask;
         downsample branch: the block output's mask).  res_grad/res_mask: merge the identity-branch gradient
         res_grad * bit(res_mask) into dx inside the dgrad epilogue.  raw_partial: this unit's BN-backward sums
@@ -620,7 +625,7 @@ class ResNetEngine:
             dy = torch.empty_like(u.y)
             dxm, _ = ops.conv2d_dgrad_ex(d, None, pk.crsk, dx=dx_into, accumulate=dx_into is not None, res_grad=res_grad, res_mask=res_mask,
                                          fuse_mode=4, prev_mask=prev.mask, want_sums=False,
-                                         dy_src=(da.contiguous(), u.y, u.st, coefs, u.relu, dy))
+                                         dy_src=(da.contiguous(), u.y, u.st, coefs, u.relu, dy), sub_grad=sub_grad)
             grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))
             return dxm, None
         if fuse_apply:
@@ -636,8 +641,10 @@ class ResNetEngine:
         if prev is not None and prev_masked_store:
             # store dx gated by prev's output ReLU mask + its channel sums: the form _unit3_bwd_folded consumes
             dxm, _ = ops.conv2d_dgrad_ex(d, dy, pk.crsk, dx=dx_into, accumulate=dx_into is not None, res_grad=res_grad, res_mask=res_mask,
-                                         fuse_mode=4, prev_mask=prev.mask, want_sums=False)
+                                         fuse_mode=4, prev_mask=prev.mask, want_sums=False, sub_grad=sub_grad)
             return dxm, None
+        if sub_grad is not None:
+            raise RuntimeError("sub_grad: only for the masked-store data gradient of a stage-entry conv1")
         if dyq is not None:  # e4m3 reduction (same epilogue options: the previous unit's BatchNorm-backward sums where they pay)
             fuse = prev is not None and self.fuse_bn_bwd and ops.conv2d_dgrad_fuse_pays(d) and not prev.has_res
             return ops.conv2d_dgrad_ex(d, dy, pk.crsk, fuse_mode=(2 if prev.relu else 0) if fuse else None, prev_y=prev.y if fuse else None,
@@ -685,8 +692,16 @@ class ResNetEngine:
                 # below folds its bn3 backward every kernel stores through its output mask (mask(mask(a) + b) = mask(a + b)).
                 below = blocks[bi - 1][0][-1] if bi > 0 else None
                 fold = self.fold_bn3 and self._foldable(below)
-                dx, _ = self._unit_bwd(first, dt_, grads, True, raw_partial=part, prev=below if fold else None, prev_masked_store=fold)
-                if dz_masked and self.fold_bn3 and ds.conv.in_channels % 64 == 0:
+                ds_folds = dz_masked and self.fold_bn3 and ds.conv.in_channels % 64 == 0
+                # stride-2 shortcut whose consumer stores through a mask: its dense gradient first, merged by conv1's data gradient
+                merge = (ds_folds and self.merge_shortcut and fold and ds.desc.stride == 2 and first.desc.h % 2 == 0 and first.desc.w % 2 == 0
+                         and first.conv.kernel_size == (1, 1) and first.conv.stride == (1, 1) and self.dtype in _H16)
+                sub = self._ds_bwd_folded(ds, dz, s_g, grads, None, below, fold, scatter=False) if merge else None
+                dx, _ = self._unit_bwd(first, dt_, grads, True, raw_partial=part, prev=below if fold else None, prev_masked_store=fold,
+                                       sub_grad=sub)
+                if merge:
+                    dz = dx
+                elif ds_folds:
                     dz = self._ds_bwd_folded(ds, dz, s_g, grads, dx, below, fold)
                 else:
                     dz, _ = self._unit_bwd(ds, dz, grads, True, relu_mask=last.mask, dx_into=dx, prev=below if fold else None,

@@ -281,7 +281,7 @@ def conv2d_dgrad_fused(d: ConvDesc, dy, wt, prev_y, prev_st: Optional["BNState"]
 
 def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accumulate: bool = False, res_grad=None, res_mask=None,
                     bias=None, fuse_mode: Optional[int] = None, prev_y=None, prev_st: Optional["BNState"] = None, prev_mask=None,
-                    want_sums: bool = True, x2=None, wt2=None, dy_src=None, fp8=None):
+                    want_sums: bool = True, x2=None, wt2=None, dy_src=None, fp8=None, sub_grad=None):
     """General data gradient (simhand_conv2d_dgrad_ex): optional accumulate / masked-residual merge, fp32 per-channel
     bias, and epilogue fusion.  fuse_mode: None = none; 0 / 2 / 3 = BN-backward sums of the previous unit (no ReLU /
     mask from prev_y*scale+shift / bit mask); 4 = store the gradient masked by prev_mask and emit its channel sums.
@@ -289,6 +289,7 @@ def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accu
     fp8 = (dy_q, wt_q, dy scaler, weight scaler): the reduction runs over e4m3 operands (only where conv2d_dgrad_fp8_pays).
     dy_src = (da, y, BNState, (coef_a, coef_b, coef_c), relu, dy_out): the dy operand is derived on load as the BatchNorm-backward
     apply of the unit (sh_dy_src; `dy` is ignored, pass None) and written to dy_out; only where conv2d_dgrad_dysrc_ok.
+    sub_grad [n][h/2][w/2][cin]: added at the even pixels of dx before the gate (a stride-2 shortcut's dense data gradient; accumulate off).
     Returns (dx, partial or None)."""
     lib = _lib_dev()
     ref = dy if dy is not None else dy_src[0]
@@ -306,6 +307,9 @@ def conv2d_dgrad_ex(d: ConvDesc, dy, wt, dx: Optional[torch.Tensor] = None, accu
     o.res_grad = _ptr(res_grad)
     o.res_mask = _ptr(res_mask)
     o.bias = _ptr(bias)
+    if sub_grad is not None:
+        assert not accumulate and res_grad is None and tuple(sub_grad.shape) == (d.n, d.h // 2, d.w // 2, d.cin) and d.h % 2 == 0 and d.w % 2 == 0
+        o.sub_grad = _ptr(sub_grad, ref.dtype)
     if x2 is not None:
         o.x2, o.wt2, o.c2 = _ptr(x2), _ptr(wt2), x2.shape[-1]
     if fp8 is not None:

@@ -1135,6 +1135,52 @@ def test_bn_backward_apply_fused_into_the_1x1_data_gradient(n, h, cin, cout, rel
     _check(dx.float().cpu(), want_dx.float().cpu(), 2e-2, "dx")
 
 
+@pytest.mark.parametrize("n,h,cin,cout,k,form", [(2, 16, 256, 128, 1, "dysrc"), (4, 8, 512, 256, 1, "dysrc"), (2, 16, 256, 128, 1, "masked"),
+                                                 (4, 16, 1024, 512, 1, "masked"), (2, 16, 256, 128, 1, "plain"), (2, 12, 128, 128, 3, "masked")])
+def test_dgrad_merges_the_shortcut_gradient_at_the_even_pixels(n, h, cin, cout, k, form):
+    """sh_dgrad_opts.sub_grad: dx = gate(result + S), S = the stride-2 shortcut's dense data gradient at the even pixels -- merged inside
+    the launch (masked-store forms of the activation-stationary 1x1 kernel, with and without the dy-source operand, and of the 256 x 256
+    kernel) or finished by the scatter-add pass (every other form): bit-equal to the same launch without sub_grad + simhand_scatter2_add."""
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(cin + cout + h + k)
+    dt = torch.bfloat16
+    m = n * h * h
+    d = ops.conv_desc(n, h, h, cin, cout, k, k, 1, k // 2, dt)
+    w = (torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cout * k * k)).to(DEV)
+    wt = ops.pack_crsk(w, dt)
+    dy = torch.randn(n, h, h, cout, generator=g).to(DEV).to(dt)
+    sub = torch.randn(n, h // 2, h // 2, cin, generator=g).to(DEV).to(dt)
+    one = ops.BNState(cin, DEV); one.scale.fill_(1.0); one.shift.fill_(0.0)
+    _, pmask = ops.bn_apply(torch.randn(m, cin, generator=g).to(DEV).to(dt), one, m, cin, True, None, want_mask=True)
+    kw = dict(fuse_mode=4, prev_mask=pmask, want_sums=False) if form != "plain" else {}
+    if form == "dysrc":
+        y = (torch.randn(n, h, h, cout, generator=g) * 1.3 + 0.1).to(DEV).to(dt)
+        gamma = (torch.rand(cout, generator=g) + 0.5).to(DEV)
+        st = ops.bn_finalize(ops.bn_partial_stats(y.view(m, cout), m, cout), m, cout, gamma, torch.zeros(cout, device=DEV), None, None, None)
+        _, _, dg, db = ops.bn_backward(dy.view(m, cout), None, y.view(m, cout), st, gamma, m, cout, True, False, mask_from_y=True)
+        coefs = ops.bn_bwd_coefs(st, gamma, dg, db, m)
+        run = lambda **k2: ops.conv2d_dgrad_ex(d, None, wt, dy_src=(dy, y, st, coefs, True, torch.empty_like(y)), **kw, **k2)[0]
+    else:
+        run = lambda **k2: ops.conv2d_dgrad_ex(d, dy, wt, **kw, **k2)[0]
+    if cout >= 512:
+        ops._lib_dev().simhand_test_igemm256_enable(2)  # the 256 x 256 kernel whatever the size gates say
+    try:
+        want = ops.scatter2_add(sub, run(), pmask if form != "plain" else None)
+        ops.route_reset()
+        got = run(sub_grad=sub)
+        rc = ops.route_counts()
+    finally:
+        ops.hooks_reset()
+    assert torch.equal(got, want), form
+    if cout >= 512:
+        assert rc["igemm256_dgrad"] == 1
+    # and the merge is what it says: even pixels differ from the launch without it, odd pixels do not
+    base = run()
+    diff = (got != base).view(n, h, h, cin).any(-1)
+    assert not bool(diff[:, 1::2, :].any()) and not bool(diff[:, :, 1::2].any()) and bool(diff[:, ::2, ::2].any())
+
+
 @pytest.mark.parametrize("k", [1, 3])
 def test_big_tile_224_row_tiles_equal_256_row_tiles(k, force_big_tile):
     """The 7 x 32-row variant of the 256 x 256 kernel (whole rounds at 2048 x 14^2): forced on a small shape whose pixel count is a
