@@ -56,13 +56,16 @@ if rank == 0:
     lo.backward()
     assert abs(loss.item() - lo.item()) <= 2e-4 * abs(lo.item()), (loss.item(), lo.item())
     og = dict(om.named_parameters())
-    errs = []
+    errs, named = [], {}
     for k, p in model.named_parameters():
         if og[k].grad is None or og[k].grad.abs().max() < 1e-6:
             continue
-        errs.append(((p.grad.cpu() - og[k].grad).norm() / og[k].grad.norm()).item())
+        named[k] = ((p.grad.cpu() - og[k].grad).norm() / og[k].grad.norm()).item()
+        errs.append(named[k])
     errs.sort()
-    assert errs[len(errs) // 2] <= 1e-2 and errs[-1] <= 6e-2, (errs[len(errs) // 2], errs[-1])
+    worst = sorted(named.items(), key=lambda kv: -kv[1])[:6]
+    assert errs[len(errs) // 2] <= 1e-2 and errs[-1] <= 6e-2, (errs[len(errs) // 2], errs[-1], worst,
+                                                                 [k for k, p in model.named_parameters() if not bool(torch.isfinite(p.grad).all())][:6])
     ob = dict(om.named_buffers())
     worst = 0.0
     for k, buf in model.named_buffers():
