@@ -69,5 +69,9 @@ bool gemm1x1_sub_ok(const Gemm1x1Args& a, int k);  // the launch these arguments
 int launch_gemm1x1_stem(const Gemm1x1Args& a, hipStream_t s);  // persistent direct-stem forward (or 256 rows per block)
 int gemm1x1_stem_stat_blocks(long long m);                      // rows of the BatchNorm partial-sum buffer that launch fills
 void gemm1x1_set_stem_persistent(int on);
+// stem_ring.hip: the 224 x 224 stem forward with the input rows staged in an LDS ring (one block per image, one partial row per image)
+bool stem_ring_ok(int n, int hp, int wp, int ho, int wo);
+int launch_stem_ring(const void* xp, const void* w, void* y, float* partial, int n, int hp, int wp, int ho, int wo, hipStream_t s);
+void stem_ring_enable(int on);
 
 }  // namespace sh

@@ -687,7 +687,7 @@ bool gemm1x1_supported(int k, int n) { return (k == 64 || k == 128 || k == 256) 
 // rows per block = 64 * MF; tuned per K on MI355X (scripts/conv_bench.py), overridable for experiments
 static hook_t g_mf[3] = {{4}, {2}, {2}};  // K = 64, 128, 256
 void gemm1x1_set_stem_persistent(int on);
-void hooks_reset_1x1() { g_mf[0] = 4; g_mf[1] = 2; g_mf[2] = 2; gemm1x1_set_chain(-1); gemm1x1_set_stem_persistent(1); }
+void hooks_reset_1x1() { g_mf[0] = 4; g_mf[1] = 2; g_mf[2] = 2; gemm1x1_set_chain(-1); gemm1x1_set_stem_persistent(1); stem_ring_enable(-1); }
 static int mf_of(int k) { return g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)]; }
 void gemm1x1_set_mf(int k, int mf) { g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)] = mf; }
 

@@ -1647,6 +1647,7 @@ int simhand_stem_conv_fwd_stat_blocks(int n, int h, int w, int dtype) {
   int hp, wp, ho, wo;
   if (n < 1 || simhand_stem_geometry(h, w, &hp, &wp, &ho, &wo)) return 0;
   const long long m = (long long)n * ho * wo;
+  if (dtype == SH_BF16 && g_stem_1x1 && stem_ring_ok(n, hp, wp, ho, wo)) return n;  // one partial row per image
   return dtype == SH_BF16 && g_stem_1x1 ? gemm1x1_stem_stat_blocks(m) : ceil_div(m, 128);  // partial rows of the kernel the same arguments select
 }
 
@@ -1680,6 +1681,10 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
   const double bytes = es * ((double)n * hp * wp * 4 + (double)a.Mg * 64 + 64.0 * 256);
   ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, flops, bytes);
   route_hit(SH_ROUTE_STEM_FWD);
+  if (dtype == SH_BF16 && g_stem_1x1 && stem_ring_ok(n, hp, wp, ho, wo)) {
+    launch_stem_ring(xp, wp_, y, bn_partial, n, hp, wp, ho, wo, (hipStream_t)stream);
+    return check_launch("stem_conv_fwd (input rows in an LDS ring)");
+  }
   if (dtype == SH_BF16 && g_stem_1x1) {
     // bf16: the activation-stationary kernel (conv_1x1.hip) with the stem's row addressing -- the layer writes 3.7x what it
     // reads and has only 4 k-steps per tile, the regime that kernel was built for (1.81 -> see DESIGN ms at 2048 x 224^2)

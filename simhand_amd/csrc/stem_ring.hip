@@ -1,0 +1,171 @@
+// Direct 7x7 / stride-2 stem forward (3 -> 64 channels, bf16) with the INPUT ROWS staged in an LDS ring: one block per image.
+//
+// Replaces (reference): conv1 of torchvision's ResNet (src/models/resnet_model.py:13-58; cuDNN there).
+//
+// The activation-stationary form (conv_1x1.hip, ST) fetches, for every output pixel, seven 64-B runs of the zero-padded NHWC4 input
+// straight into MFMA operand registers: 448 B per pixel = 11.5 GB through L2 at 2048 x 224^2 for 0.87 GB of input -- that traffic, not
+// HBM (3.3 GB of output) and not the matrix pipes, is what its 1.39 ms are made of.  Neighbouring output pixels share 3/4 of every run
+// and neighbouring output rows 5 of their 7 input rows, so here a block walks the 112 output rows of ONE image and keeps the input rows
+// in a 32-slot LDS ring (row y of the padded image in slot y & 31; two new rows per step, fetched D = 2 steps ahead by LDS-DMA): every
+// input byte crosses L2 -> LDS once.  (Vector-memory operations retire in order, so waiting for the rows requested D steps ago also
+// waits for the output stores older than that request; D = 6 -- seven steps of stores in flight instead of three -- measured 6 % SLOWER:
+// the kernel is not held by store latency but by the write rate itself, 3.3 GB in 1.12 ms next to 0.9 GB of reads.)
+// In the padded layout filter row r of output pixel (ho, wo) is the run of 8 taps x 4 channels at padded pixel (2 ho + r, 2 wo): the 8 k-elements of MFMA lane (li, g) -- taps 2g, 2g + 1 -- are the 16 bytes at byte 16 (wo + g) of
+// ring row 2 ho + r: ONE aligned ds_read_b128, consecutive lanes on consecutive chunks (conflict-free), no transposition, no gather.
+//   7 waves, one 16-pixel m-tile each (7 x 16 = 112 = the output row), all 64 output channels: 28 MFMAs per wave and output row against
+//   7 fragment reads; the 64 x 224 filter lives in registers (28 fragments = 112 VGPRs per lane) for the block's life;
+//   BatchNorm partial sums of the fp32 results ride in registers across the image: one [2][64] row per block (= per image).
+// Only for the 224 x 224 geometry (wo = 112); other sizes keep the activation-stationary kernel.
+#include "conv_1x1.h"
+
+#include <stdlib.h>
+
+namespace sh {
+
+__device__ uint4 g_sr_zero_page[8];
+
+__device__ __forceinline__ float row16_sum_sr(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+
+struct StemRingArgs {
+  const bf16_t* xp;   // [n][hp][wp][4] zero-padded input
+  const bf16_t* w;    // [64][256]: column r*32 + tap*4 + c (stem_pack_weights)
+  bf16_t* y;          // [n][ho][wo][64]
+  float* partial;     // [n][2][64] or null
+  int hp, wp, ho, wo;
+};
+
+__global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
+  constexpr int SLOT = 2048, NSLOT = 32, D = 2;  // D: steps between a row's request and its use
+  __shared__ __attribute__((aligned(16))) char ring[NSLOT * SLOT];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int img = blockIdx.x;
+  const int row_bytes = p.wp * 8;            // 1856 at 224^2
+  const int nchunk = row_bytes >> 4;         // 16-B chunks per input row
+  const char* xbase = reinterpret_cast<const char*>(p.xp) + (long long)img * p.hp * row_bytes;
+
+  auto dma16 = [](const void* src, unsigned lds_addr) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src));
+  };
+  const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
+  const char* zsrc = reinterpret_cast<const char*>(g_sr_zero_page);
+  // half hf (0 / 1) of padded row y -> ring slot y & (NSLOT - 1): lane l = 16-B chunk 64 hf + l (chunks past the row's end: the zero page)
+  auto dma_half = [&](int y, int hf) __attribute__((always_inline)) {
+    const int c = 64 * hf + lane;
+    const bool ok = y < p.hp && c < nchunk;
+    dma16(ok ? xbase + (long long)y * row_bytes + c * 16 : zsrc, ring_addr + (unsigned)(y & (NSLOT - 1)) * SLOT + hf * 1024);
+  };
+
+  // ---- weights: all 64 channels x 7 filter rows, resident in registers.  Fragment row li of channel tile ni <-> channel
+  // (ni >> 1)*32 + (li >> 2)*8 + (ni & 1)*4 + (li & 3): a lane's accumulator registers of tiles 2j, 2j + 1 are 8 CONSECUTIVE channels --------
+  uint4 wf[7][4];
+#pragma unroll
+  for (int r = 0; r < 7; ++r)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int ch = (ni >> 1) * 32 + (li >> 2) * 8 + (ni & 1) * 4 + (li & 3);
+      wf[r][ni] = *reinterpret_cast<const uint4*>(p.w + ch * 256 + r * 32 + g * 8);
+    }
+
+  // ---- prologue: rows 0 .. 2 D + 4 (steps 0 .. D - 1), two half-row instructions each, over the 7 waves; waited for in full --------------
+  for (int k = wave; k < 2 * (2 * D + 5); k += 7) dma_half(k >> 1, k & 1);
+  // everything the prologue requested (filter fragments, rows) is waited for HERE, with the builtin: a load the compiler still counts as
+  // pending on the loop's entry path would make its waitcnt pass drain the whole queue in every iteration (see conv_1x1.hip on vmcnt)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
+
+  const int px = wave * 16 + li;                 // this lane's output pixel (wo) of every row
+  const int a_off = 16 * (px + g);               // byte offset of its 8 k-elements in a ring row
+  float s1[2][8], s2[2][8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[j][e] = s2[j][e] = 0.f;
+  bf16_t* yrow = p.y + ((long long)img * p.ho * p.wo + px) * 64 + g * 8;
+
+  for (int ho = 0; ho < p.ho; ++ho) {
+    // loader waves 0-3, in issue order: ... DMA(ho-D) [rows of this step], 2 stores(ho-D), then per later step one DMA + 2 stores:
+    // vector-memory operations retire in order, so <= 3 D - 1 outstanding means this step's rows have landed (the other waves have
+    // only stores in flight)
+    if (ho >= D) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * D - 1) : "memory");
+    else asm volatile("s_barrier" ::: "memory");
+    // rows 2 (ho + D) + 5, + 6 (the last rows of step ho + D) -> slots outside the windows of steps ho .. ho + D - 1 (2 D + 7 <= 32 rows)
+    if (wave < 4) dma_half(2 * (ho + D) + 5 + (wave >> 1), wave & 1);
+    f32x4 acc[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 fa[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) fa[r] = *reinterpret_cast<const uint4*>(ring + ((2 * ho + r) & (NSLOT - 1)) * SLOT + a_off);
+#pragma unroll
+    for (int r = 0; r < 7; ++r)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[ni] = sh_mfma16(wf[r][ni], fa[r], acc[ni]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 lo = acc[2 * j], hi = acc[2 * j + 1];
+      const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      uint4 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      o.z = pack_bf16x2(v[4], v[5]);
+      o.w = pack_bf16x2(v[6], v[7]);
+      *reinterpret_cast<uint4*>(yrow + j * 32) = o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[j][e] += v[e];
+        s2[j][e] += v[e] * v[e];
+      }
+    }
+    yrow += (long long)p.wo * 64;
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  if (p.partial != nullptr) {
+    float* red = reinterpret_cast<float*>(ring);  // [7 waves][2][64]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t1 = row16_sum_sr(s1[j][e]), t2 = row16_sum_sr(s2[j][e]);
+        if (li == 0) {
+          red[(wave * 2 + 0) * 64 + j * 32 + g * 8 + e] = t1;
+          red[(wave * 2 + 1) * 64 + j * 32 + g * 8 + e] = t2;
+        }
+      }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      float t = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 7; ++wv) t += red[(wv * 2 + which) * 64 + c];
+      p.partial[((long long)img * 2 + which) * 64 + c] = t;
+    }
+  }
+}
+
+static hook_t g_stem_ring{-1};  // -1 = env SIMHAND_STEM_RING (default on), 0 / 1 forced
+void stem_ring_enable(int on) { g_stem_ring = on < 0 ? -1 : (on ? 1 : 0); }
+
+bool stem_ring_ok(int n, int hp, int wp, int ho, int wo) {
+  static const int env = getenv("SIMHAND_STEM_RING") ? atoi(getenv("SIMHAND_STEM_RING")) : 1;
+  const int h = g_stem_ring;
+  // the 224 x 224 geometry: one 16-pixel m-tile per wave of the 448-thread block, a padded row inside a 2-KB ring slot
+  return (h >= 0 ? h : env) && wo == 112 && wp * 8 <= 2048 && hp >= 2 * ho + 5 && n >= 1;
+}
+
+int launch_stem_ring(const void* xp, const void* w, void* y, float* partial, int n, int hp, int wp, int ho, int wo, hipStream_t s) {
+  StemRingArgs a;
+  a.xp = (const bf16_t*)xp; a.w = (const bf16_t*)w; a.y = (bf16_t*)y; a.partial = partial;
+  a.hp = hp; a.wp = wp; a.ho = ho; a.wo = wo;
+  stem_ring_fwd_kernel<<<n, 448, 0, s>>>(a);
+  return 0;
+}
+
+}  // namespace sh
