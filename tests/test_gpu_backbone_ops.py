@@ -145,10 +145,11 @@ def test_stem_im2col_conv(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("n,h,w", [(3, 36, 36), (2, 64, 48), (5, 31, 45), (1, 224, 224)])
+@pytest.mark.parametrize("n,h,w", [(3, 36, 36), (2, 64, 48), (5, 31, 45), (1, 224, 224), (3, 224, 224)])
 def test_stem_direct_conv(dtype, n, h, w):
     """7x7/2 stem read straight from the zero-padded NHWC4 input (no im2col matrix): forward, fused BN partial sums and
-    weight gradient against ATen; odd sizes exercise the ragged last tile and the bottom/right halo."""
+    weight gradient against ATen; odd sizes exercise the ragged last tile and the bottom/right halo; the 224 x 224 cases run the
+    one-block-per-image LDS-ring kernel (stem_ring.hip) and compare it bit for bit with the tile kernel."""
     from simhand_amd import ops
 
     g = torch.Generator().manual_seed(12)
