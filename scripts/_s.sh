@@ -1,2 +1,2 @@
-timeout 900 python -m pytest tests/test_gpu_backbone_ops.py tests/test_gpu_fullsize.py -q -x -k 'stem' 2>&1 | tail -2
-for i in 1 2; do for v in 0 1; do echo "STEM_RING=$v: $(SIMHAND_STEM_RING=$v python bench.py --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); k=d["kernel_ms_per_step"]; print(round(d["ms_per_step"],2), round(k["conv_fwd"],2), d["config"]["loss"])')"; done; done
+timeout 500 python scripts/race_probe.py 400 1 4 2>&1 | tail -8
+timeout 300 python scripts/race_probe.py 300 0 4 2>&1 | tail -5

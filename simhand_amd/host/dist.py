@@ -182,7 +182,16 @@ class OverlappedGradReducer:
             work = torch.cuda.Event()
             work.record(side)
         else:
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            # gloo runs its collectives on worker THREADS: with synchronised BatchNorm on, an asynchronous bucket and the BatchNorm sums
+            # of the block below would be in flight at the same time.  Ranks that share one GPU over gloo (the test arrangement) showed
+            # a corrupted tensor in ~2 % of such runs under GPU oversubscription (never with one collective at a time), so that
+            # combination issues its buckets synchronously; RCCL (the product path) orders every collective on its stream anyway.
+            from .. import ops
+
+            serial = ops.bn_sync_active() and dist.get_backend(self.group) == "gloo"
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=not serial)
+            if serial:
+                work = None
         self._pending.append((work, flat, self._bucket))
         self._bucket, self._size = [], 0
 

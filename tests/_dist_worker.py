@@ -21,6 +21,10 @@ from simhand_amd.host import dist as shdist  # noqa: E402
 from tests.test_gpu_step import _product  # noqa: E402
 
 rank, local, world = shdist.init_from_env()
+if os.environ.get("SIMHAND_POISON_WORKER"):  # torch.empty returns NaN patterns (tests/_poison.py)
+    from tests._poison import poison
+
+    poison(float(os.environ["SIMHAND_POISON_WORKER"]))
 if world > 1:
     assert dist.get_backend() == BACKEND, dist.get_backend()
 dev = torch.device("cuda", torch.cuda.current_device())

@@ -19,6 +19,10 @@ from simhand_amd.host import dist as shdist  # noqa: E402
 from tests.test_gpu_step import _product  # noqa: E402
 
 rank, local, world = shdist.init_from_env()
+if os.environ.get("SIMHAND_POISON_WORKER"):  # torch.empty returns NaN patterns (tests/_poison.py)
+    from tests._poison import poison
+
+    poison(float(os.environ["SIMHAND_POISON_WORKER"]))
 dev = torch.device("cuda", torch.cuda.current_device())
 AUG = ["color_jitter", "crop", "random_crop", "resize", "rotate"]
 wcfg = dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg")
@@ -37,8 +41,9 @@ shdist.broadcast_module_state(model)
 assert shdist.enable_sync_bn() == (world > 1) and ops.bn_sync_active() == (world > 1)
 off, b = shdist.shard_pairs(B, rank, world)
 shard = {k: v[off:off + b].to(dev) for k, v in batch.items()}
-reducer = shdist.OverlappedGradReducer(bucket_bytes=1 << 20)
-model.encoder.engine.grad_reducer = reducer
+reducer = shdist.OverlappedGradReducer(bucket_bytes=int(os.environ.get("SIMHAND_TEST_BUCKET", 1 << 20)))
+if not os.environ.get("SIMHAND_TEST_NO_REDUCER"):
+    model.encoder.engine.grad_reducer = reducer
 loss = model.training_step(shard, 0)["loss"]
 loss.backward()
 shdist.allreduce_gradients(model.parameters(), bucket_bytes=1 << 20, skip=reducer.reduced)
@@ -64,8 +69,9 @@ if rank == 0:
         errs.append(named[k])
     errs.sort()
     worst = sorted(named.items(), key=lambda kv: -kv[1])[:6]
-    assert errs[len(errs) // 2] <= 1e-2 and errs[-1] <= 6e-2, (errs[len(errs) // 2], errs[-1], worst,
-                                                                 [k for k, p in model.named_parameters() if not bool(torch.isfinite(p.grad).all())][:6])
+    bad = [(k, round(v, 4)) for k, v in named.items() if not v <= 6e-2]
+    nonfinite = [k for k, p in model.named_parameters() if p.grad is not None and not bool(torch.isfinite(p.grad).all())]
+    assert errs[len(errs) // 2] <= 1e-2 and errs[-1] <= 6e-2, (errs[len(errs) // 2], errs[-1], worst, len(bad), len(named), bad[:40], nonfinite[:10])
     ob = dict(om.named_buffers())
     worst = 0.0
     for k, buf in model.named_buffers():

@@ -25,6 +25,17 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _poison_uninitialised_memory():
+    """SIMHAND_POISON=<GiB>: every torch.empty of the session returns NaN patterns (tests/_poison.py); the worker processes of the
+    multi-rank tests do the same with SIMHAND_POISON_WORKER GiB each."""
+    if os.environ.get("SIMHAND_POISON"):
+        from tests._poison import poison
+
+        poison()
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
