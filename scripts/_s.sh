@@ -1,2 +1,2 @@
-timeout 500 python scripts/race_probe.py 400 1 4 2>&1 | tail -8
-timeout 300 python scripts/race_probe.py 300 0 4 2>&1 | tail -5
+F='amdgpu.ids|socket.cpp|Gloo'
+SIMHAND_GLOO_ASYNC_BUCKETS=1 PROBE_COLD=1 timeout 400 python scripts/syncbn_repeat_probe.py 300 2>&1 | grep -Ev "$F" | tail -14

@@ -17,7 +17,8 @@ from tests.test_gpu_step import _product  # noqa: E402
 
 reps, sync = int(sys.argv[1]), int(sys.argv[2])
 ncomp = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-LOAD = "import torch,time\nx=torch.randn(8192,8192,device='cuda',dtype=torch.bfloat16)\nwhile True:\n    y=x@x; torch.cuda.synchronize()\n"
+LOAD = ("import torch,time\nx=torch.randn(8192,8192,device='cuda',dtype=torch.bfloat16)\nwhile True:\n"
+        "    for _ in range(50): y=x@x\n    torch.cuda.synchronize(); time.sleep(0.05)\n")
 comps = [subprocess.Popen([sys.executable, "-c", LOAD]) for _ in range(ncomp)]
 try:
     AUG = ["color_jitter", "crop", "random_crop", "resize", "rotate"]
@@ -46,6 +47,8 @@ try:
             continue
         diff = [(k, ((cur[k] - first[k]).norm() / (first[k].norm() + 1e-30)).item()) for k in cur if not torch.equal(cur[k], first[k])]
         big = [(k, round(e, 5)) for k, e in diff if e > 1e-3]
+        if it % 50 == 0:
+            print(f"rep {it}: loss {loss.item():.6f}, {len(diff)} tensors not bit-equal to the first repetition", flush=True)
         if big:
             bad += 1
             print(f"rep {it}: loss {loss.item():.6f}; {len(big)} tensors differ by > 1e-3 (of {len(diff)} not bit-equal): {big[:8]}", flush=True)

@@ -188,7 +188,7 @@ class OverlappedGradReducer:
             # combination issues its buckets synchronously; RCCL (the product path) orders every collective on its stream anyway.
             from .. import ops
 
-            serial = ops.bn_sync_active() and dist.get_backend(self.group) == "gloo"
+            serial = ops.bn_sync_active() and dist.get_backend(self.group) == "gloo" and not os.environ.get("SIMHAND_GLOO_ASYNC_BUCKETS")
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=not serial)
             if serial:
                 work = None
