@@ -56,6 +56,7 @@ struct Gemm1x1Args {
   // output resolution, merged here instead of by a scatter-add pass over out.  sub null = off
   const bf16_t* sub = nullptr;
   int sub_h = 0, sub_w = 0;
+  int lt = 0;  // linear output stores through a wave-private LDS transpose (set by launch_gemm1x1: env SIMHAND_G1_LT, default on)
 };
 
 bool gemm1x1_supported(int k, int n);

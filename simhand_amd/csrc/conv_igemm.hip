@@ -1581,7 +1581,7 @@ int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w
   const double bytes = 2.0 * ((double)d->n * d->h * d->w * d->cin + (double)a.Mg * d->cout * (residual ? 2 : 1) + (double)d->cout * d->cin * d->r * d->s);
   ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, flops, bytes);
   route_hit(SH_ROUTE_FWD_BNACT);
-  if (use_1x1(d, d->cin, d->cout)) {
+  if (use_1x1(d, d->cin, d->cout) && !(d->cin == 128 && d->cout > 1024)) {  // K = 128: the 1x1 kernel caches 1024 channels' coefficients
     Gemm1x1Args g;
     g.a = (const bf16_t*)x; g.w = (const bf16_t*)w; g.out = (bf16_t*)out; g.bn_partial = nullptr;
     g.M = a.Mg; g.N = d->cout; g.accumulate = 0; g.res_grad = nullptr; g.res_mask = nullptr;

@@ -40,9 +40,14 @@ struct StemRingArgs {
   int hp, wp, ho, wo;
 };
 
+// LT: the wave's 16 pixels x 128 B of an output row are 2 KB CONTIGUOUS in memory; with LT the packed chunks go through a wave-private
+// 2-KB LDS block (16-B chunks XOR-swizzled by the pixel, conflict-free both ways) and leave as two fully linear 1-KB store instructions
+// (lane l: bytes 16 l), the shape of the BatchNorm streaming passes, instead of 16 segments of 64 B per instruction.
+template <bool LT>
 __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
   constexpr int SLOT = 2048, NSLOT = 32, D = 2;  // D: steps between a row's request and its use
   __shared__ __attribute__((aligned(16))) char ring[NSLOT * SLOT];
+  __shared__ __attribute__((aligned(16))) char tbuf[LT ? 7 * 2048 : 16];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int img = blockIdx.x;
@@ -88,6 +93,11 @@ __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[j][e] = s2[j][e] = 0.f;
   bf16_t* yrow = p.y + ((long long)img * p.ho * p.wo + px) * 64 + g * 8;
+  // LT: write offsets of the lane's two chunks (pixel li, chunk j * 4 + g), read offset of linear position l (pixel l >> 3, chunk l & 7)
+  char* tw = tbuf + (LT ? wave * 2048 : 0);
+  const int tw0 = li * 128 + (((0 * 4 + g) ^ (li & 7)) * 16), tw1 = li * 128 + (((1 * 4 + g) ^ (li & 7)) * 16);
+  const int tr0 = (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);  // second kilobyte: pixels 8..15, same keys -> + 1024
+  char* ylin = reinterpret_cast<char*>(p.y + ((long long)img * p.ho * p.wo + wave * 16) * 64) + lane * 16;
 
   for (int ho = 0; ho < p.ho; ++ho) {
     // loader waves 0-3, in issue order: ... DMA(ho-D) [rows of this step], 2 stores(ho-D), then per later step one DMA + 2 stores:
@@ -117,12 +127,19 @@ __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
       o.y = pack_bf16x2(v[2], v[3]);
       o.z = pack_bf16x2(v[4], v[5]);
       o.w = pack_bf16x2(v[6], v[7]);
-      *reinterpret_cast<uint4*>(yrow + j * 32) = o;
+      if (LT) *reinterpret_cast<uint4*>(tw + (j == 0 ? tw0 : tw1)) = o;
+      else *reinterpret_cast<uint4*>(yrow + j * 32) = o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         s1[j][e] += v[e];
         s2[j][e] += v[e] * v[e];
       }
+    }
+    if (LT) {  // same wave, in-order LDS queue: the reads see the writes above; the next row's writes follow these reads
+      const uint4 r0 = *reinterpret_cast<const uint4*>(tw + tr0), r1 = *reinterpret_cast<const uint4*>(tw + tr0 + 1024);
+      *reinterpret_cast<uint4*>(ylin) = r0;
+      *reinterpret_cast<uint4*>(ylin + 1024) = r1;
+      ylin += (long long)p.wo * 128;
     }
     yrow += (long long)p.wo * 64;
   }
@@ -164,7 +181,9 @@ int launch_stem_ring(const void* xp, const void* w, void* y, float* partial, int
   StemRingArgs a;
   a.xp = (const bf16_t*)xp; a.w = (const bf16_t*)w; a.y = (bf16_t*)y; a.partial = partial;
   a.hp = hp; a.wp = wp; a.ho = ho; a.wo = wo;
-  stem_ring_fwd_kernel<<<n, 448, 0, s>>>(a);
+  static const int lt = getenv("SIMHAND_STEM_RING_LT") ? atoi(getenv("SIMHAND_STEM_RING_LT")) : 1;
+  if (lt) stem_ring_fwd_kernel<true><<<n, 448, 0, s>>>(a);
+  else stem_ring_fwd_kernel<false><<<n, 448, 0, s>>>(a);
   return 0;
 }
 
