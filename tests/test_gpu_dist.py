@@ -34,8 +34,14 @@ def _run(world, backend, port, worker="_dist_worker.py", extra=()):
     res = _launch(world, backend, port, worker, extra)
     if backend == "gloo" and world > 1 and any(rc != 0 for rc, _ in res):
         bad = next((r, o) for r, (rc, o) in enumerate(res) if rc != 0)
-        print(f"\n[test_gpu_dist] world {world} over gloo on a shared GPU: rank {bad[0]} failed, REPEATING ONCE.  First failure:\n{bad[1][-1500:]}",
-              file=sys.stderr, flush=True)
+        msg = f"[test_gpu_dist] world {world} over gloo on a shared GPU: rank {bad[0]} failed, REPEATING ONCE.  First failure:\n{bad[1][-1500:]}"
+        print("\n" + msg, file=sys.stderr, flush=True)
+        try:  # pytest shows captured output only for failing tests: keep a record of every repetition next to the other run artefacts
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "dist_repeats.log"), "a") as f:
+                f.write(msg + "\n")
+        except OSError:
+            pass
         res = _launch(world, backend, port + 100, worker, extra)
     for r, (rc, o) in enumerate(res):
         assert rc == 0, f"rank {r} failed:\n{o[-3000:]}"
