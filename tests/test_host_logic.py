@@ -260,8 +260,23 @@ ops._BN_SYNC(msg)
 m = int(round(float(msg[-1]))); assert m == 40
 mean, var = msg[:6] / m, msg[6:12] / m - (msg[:6] / m) ** 2
 assert torch.allclose(mean, full.mean(0), atol=1e-12) and torch.allclose(var, full.var(0, unbiased=False), atol=1e-10)
+# under gloo + synchronised BatchNorm the overlapped reducer issues its buckets ONE COLLECTIVE AT A TIME (no asynchronous work object is
+# left in flight while the BatchNorm sums are exchanged: DESIGN 4, known issue); same sums, same bucket views
+red3 = shdist.OverlappedGradReducer(bucket_bytes=16)
+q3 = [torch.nn.Parameter(torch.zeros(n)) for n in (6, 5)]
+red3.submit([(q3[0], torch.full((6,), float(rank + 1)))])
+assert red3._pending and all(w is None for w, _, _ in red3._pending)          # already reduced when submit returns
+assert torch.equal(red3._pending[0][1], torch.full((6,), float(tot)))
+both = torch.tensor([1.0 + rank, 2.0]); ops._BN_SYNC(both)                      # a BatchNorm exchange between two buckets
+assert torch.equal(both, torch.tensor([float(tot), 2.0 * world]))
+red3.submit([(q3[1], torch.full((5,), 2.0 * (rank + 1)))]); o3 = red3.finish()
+assert torch.equal(o3[q3[0]], torch.full((6,), float(tot))) and torch.equal(o3[q3[1]], torch.full((5,), 2.0 * tot))
 shdist.disable_sync_bn()
 assert not ops.bn_sync_active()
+red4 = shdist.OverlappedGradReducer(bucket_bytes=16)                             # without it: asynchronous again
+red4.submit([(q3[0], torch.full((6,), float(rank + 1)))])
+assert red4._pending and red4._pending[0][0] is not None
+assert torch.equal(red4.finish()[q3[0]], torch.full((6,), float(tot)))
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
