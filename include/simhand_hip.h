@@ -54,6 +54,13 @@ enum sh_dist_mode {
 enum sh_weight_type { SH_W_NONE = 0, SH_W_LINEAR = 1, SH_W_NONLINEAR = 2,
                       SH_W_EXPLICIT = 3 /* D_loc / d_pos already hold the weights (functional surface) */ };
 
+/* SH_ABI_VERSION is bumped whenever a signature, a struct layout or an enum value of this header changes (history: 1 = rounds 1-2;
+ * 2 = round 3: `width` argument of simhand_proj_postprocess_fwd / _bwd / simhand_proj_stats, sh_dgrad_opts grew dy_src / dy_q / wt_q /
+ * dy_state / w_state / sub_grad, tuning setters renamed simhand_test_*; 3 = round 4: this constant, the in-library environment switches
+ * moved behind simhand_test_* hooks, the stem entry points of DESIGN 3).  A binding compares simhand_abi_version() with the
+ * SH_ABI_VERSION it was written against before its first call (simhand_amd/_lib.py load() does) -- a caller built against an older header
+ * would otherwise pass shifted arguments or a short options struct unnoticed. */
+#define SH_ABI_VERSION 3
 int simhand_abi_version(void);
 /* The library ships in two builds of the same sources: libsimhand_hip.so, whose 16-bit storage type (SH_BF16 below) is bfloat16 -- and
  * libsimhand_hip_f16.so, where the same enum value means IEEE fp16 (11-bit significand: the storage type of the reference's
@@ -92,12 +99,35 @@ enum sh_route {
   SH_ROUTE_DGRAD_DYSRC = 32,                                /* BN-backward apply fused into the 1x1 data gradient's dy loader */
   SH_ROUTE_FWD_CHAIN = 33,                                  /* conv3 + BN + residual + ReLU with the next block's conv1 chained on */
   SH_ROUTE_R128_FWD = 34, SH_ROUTE_R128_DGRAD = 35,         /* 128->128 3x3: activation tile staged once in an LDS ring, weights streamed per tap */
-  SH_ROUTE_COUNT = 36
+  SH_ROUTE_STEM_STATS = 36, SH_ROUTE_STEM_POOL = 37,        /* two-pass stem: statistics-only conv1; conv1 + BN + ReLU + MaxPool */
+  SH_ROUTE_STEM_BWD_FUSED = 38,                             /* stem backward: conv1 recomputed, dy in registers, dW in the same kernel */
+  SH_ROUTE_COUNT = 39
 };
 int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
 int simhand_route_reset(void);
 /* every test / tuning hook back to its default */
 int simhand_test_hooks_reset(void);
+/* Kernel-selection switches that round 3 read from SIMHAND_* environment variables inside the library, now ordinary test hooks: the
+ * library itself reads NO environment variable.  simhand_test_switch(which, value): value < 0 restores the built-in default;
+ * simhand_test_hooks_reset() restores all of them.  Every switch selects between kernels that compute the same result. */
+enum sh_test_switch {
+  SH_SW_BN_GRID_APPLY = 0, /* block cap of bn_apply's grid (default 131072) */
+  SH_SW_BN_GRID_BWD = 1,   /* block cap of bn_bwd_apply's grid (default 131072) */
+  SH_SW_R128 = 2,          /* conv3x3_r128_kernel for the 128-channel 3x3 layers (default 1) */
+  SH_SW_G1_PF = 3,         /* branch-free fast variants of gemm1x1_kernel per K: bit 0 K = 64, bit 1 K = 128, bit 2 K = 256 (default 7) */
+  SH_SW_G1_CHAIN = 4,      /* chained next conv1 per K: bit 0 K = 64, bit 1 K = 128 (default 1); simhand_test_conv1x1_chain_mask overrides */
+  SH_SW_G1_LT = 5,         /* linear epilogue stores of gemm1x1_kernel: bit 0 forward, bit 1 data gradient (default 1) */
+  SH_SW_FUSE_S2 = 6,       /* BN-backward sums fused into stride-2 3x3 data gradients: 1 all, 2 only on the 256-wide kernel (default 0) */
+  SH_SW_WG_DMA = 7,        /* wgrad1x1_dma_kernel (default 1) */
+  SH_SW_WG3_S2 = 8,        /* stride-2 form of wgrad3x3_kernel (default 1) */
+  SH_SW_WG_BIG = 9,        /* 256 x 128 tiles of the plain 1x1 weight gradient (default 1) */
+  SH_SW_WG_WIDE = 10,      /* one tile across the wide side of the 64 <-> 256 weight gradients (default 1) */
+  SH_SW_STEM_WG256 = 11,   /* 64 x 256 tile of the stem weight gradient (default 1) */
+  SH_SW_STEM_RING = 12,    /* stem_ring_fwd_kernel at 224 x 224 (default 1) */
+  SH_SW_STEM_RING_LT = 13, /* its linear stores (default 1) */
+  SH_SW_COUNT = 14
+};
+int simhand_test_switch(int which, int value);
 
 /* ---- optional per-kernel-class HIP-event profiler (used by bench.py) ----- */
 enum sh_prof_class { SH_PROF_CONV_FWD = 0, SH_PROF_CONV_DGRAD = 1, SH_PROF_CONV_WGRAD = 2,
@@ -248,6 +278,28 @@ int simhand_stem_pack_weights(const float* w_oihw, void* wp, int dtype, sh_strea
 /* rows of the bn_partial buffer simhand_stem_conv_fwd fills: [blocks][2][64] */
 int simhand_stem_conv_fwd_stat_blocks(int n, int h, int w, int dtype);
 int simhand_stem_conv_fwd(const void* xp, const void* wp, void* y, float* bn_partial, int n, int h, int w, int dtype, sh_stream_t stream);
+/* The TWO-PASS stem (round 4; 16-bit storage at 224 x 224 only: simhand_stem_two_pass_ok).  conv1 is 0.24 GFLOP per image -- cheaper
+ * to run again than to write its 112 x 112 x 64 raw output and read it back (6.6 GB per 2048 images each way):
+ *   pass 1  simhand_stem_conv_fwd with y == NULL: BatchNorm partial sums only (then simhand_bn_finalize as usual);
+ *   pass 2  simhand_stem_conv_bn_relu_pool: conv1 again with BN + ReLU + MaxPool(3, 2, 1) in its epilogue -> pooled [n][56][56][64],
+ *           idx (winner tap) and ywin (the winner's raw conv output; may be NULL): bit for bit what simhand_stem_conv_fwd followed
+ *           by simhand_bn_relu_maxpool_fwd produce (NaN activations excepted: a NaN wins its window either way, which NaN of several
+ *           is unspecified here);
+ *   backward  simhand_stem_bwd_fused: conv1 a third time inside the kernel that forms dy = BatchNorm-backward(gathered pooled
+ *           gradient, y) in registers and accumulates dW = dy^T x from the same LDS-resident input rows -- neither y nor dy exists
+ *           in HBM.  dgamma / dbeta come from the pooled-size statistics pass as before (simhand_bn_bwd_partial on ywin).
+ * Replaces (reference): conv1 -> bn1 -> relu -> maxpool of the torchvision ResNet stem and their autograd backward
+ * (src/models/resnet_model.py:13-26). */
+int simhand_stem_two_pass_ok(int n, int h, int w, int dtype);
+int simhand_stem_conv_bn_relu_pool(const void* xp, const void* wp, const float* scale, const float* shift, void* pooled, uint8_t* idx,
+                                   void* ywin, int n, int h, int w, int dtype, sh_stream_t stream);
+/* dz [n][56][56][64]: gradient of the pooled output; idx: winner taps of the forward; mean / invstd / scale / shift: the forward's
+ * BatchNorm state; gamma (NULL = 1), dgamma, dbeta: the finalized BatchNorm-backward sums (simhand_bn_bwd_partial over (dz, ywin) +
+ * simhand_bn_bwd_finalize); dw_oihw: fp32 [64][3][7][7].  Per-block partial sums go through `workspace` and are added in a fixed order. */
+size_t simhand_stem_bwd_fused_workspace_bytes(int n);
+int simhand_stem_bwd_fused(const void* xp, const void* wp, const void* dz, const uint8_t* idx, const float* scale, const float* shift,
+                           const float* mean, const float* invstd, const float* gamma, const float* dgamma, const float* dbeta,
+                           float* dw_oihw, void* workspace, size_t workspace_bytes, int n, int h, int w, int dtype, sh_stream_t stream);
 /* bf16 route of simhand_stem_conv_fwd: 1 (default) = persistent direct-stem kernel (weights resident in LDS, next tile's rows in
  * flight under the current tile's MFMAs), 2 = activation-stationary kernel, one block per 256 rows, 0 = 128 x 64 tile kernel
  * (same k order, bit-identical outputs; tuning / test hook) */

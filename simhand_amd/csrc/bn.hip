@@ -1276,8 +1276,7 @@ int simhand_bn_apply(const void* y, const float* scale, const float* shift, cons
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (residual ? 3 : 2));
   route_hit(SH_ROUTE_BN_APPLY);
-  static const int cap = getenv("SIMHAND_BN_GRID_APPLY") ? atoi(getenv("SIMHAND_BN_GRID_APPLY")) : 131072;
-  const int grid = row_grid(m, c / ve, cap);
+  const int grid = row_grid(m, c / ve, sw(SH_SW_BN_GRID_APPLY));
 #define SH_BN_APPLY(T, NT) bn_apply_kernel<T, NT><<<grid, 256, 0, s>>>((const T*)y, scale, shift, (const T*)residual, relu, (T*)a, relu_mask, m, c)
   if (dtype == SH_F32) { if (g_bn_nt) SH_BN_APPLY(float, true); else SH_BN_APPLY(float, false); }
   else { if (g_bn_nt) SH_BN_APPLY(bf16_t, true); else SH_BN_APPLY(bf16_t, false); }
@@ -1363,8 +1362,7 @@ int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const flo
   ProfScope ps(SH_PROF_BN, s, 0, (double)m * c * (dtype == SH_F32 ? 4 : 2) * (3 + (relu == 1 ? 1 : 0) + (dres ? 1 : 0)));
   route_hit(SH_ROUTE_BN_BWD_APPLY);
   const float inv_m = (float)(1.0 / (double)m);
-  static const int cap = getenv("SIMHAND_BN_GRID_BWD") ? atoi(getenv("SIMHAND_BN_GRID_BWD")) : 131072;
-  const int grid = row_grid(m, c / ve, cap);
+  const int grid = row_grid(m, c / ve, sw(SH_SW_BN_GRID_BWD));
 #define SH_BN_BA(T, NT) bn_bwd_apply_kernel<T, NT><<<grid, 256, 0, s>>>((const T*)da, (const T*)a, (const T*)y, mean, invstd, gamma, dgamma, dbeta, scale, shift, relu, (T*)dy, (T*)dres, m, c, inv_m)
   if (dtype == SH_F32) { if (g_bn_nt) SH_BN_BA(float, true); else SH_BN_BA(float, false); }
   else { if (g_bn_nt) SH_BN_BA(bf16_t, true); else SH_BN_BA(bf16_t, false); }

@@ -29,6 +29,7 @@ void route_hit(int route);
 // test / tuning hooks are relaxed atomics (they only choose between kernels that compute the same result); every file that
 // owns some puts them back to their defaults here (simhand_test_hooks_reset)
 typedef std::atomic<int> hook_t;
+int sw(int which);  // current value of a simhand_test_switch (core.hip): the hook if set, else the built-in default
 void hooks_reset_igemm();
 void hooks_reset_c64();
 void hooks_reset_r128();

@@ -290,12 +290,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
   }
 }
 
-static hook_t g_use_r128{-1};  // -1 = env SIMHAND_R128 (default on), 0 / 1 forced
+static hook_t g_use_r128{-1};  // -1 = simhand_test_switch(SH_SW_R128) (default on), 0 / 1 forced
 void r128_enable(int on) { g_use_r128 = on < 0 ? -1 : (on ? 1 : 0); }
 void hooks_reset_r128() { g_use_r128 = -1; }
 
 bool r128_supported(int dtype, int cin, int cout, int r, int s, int stride, int pad, int w, long long q_total) {
-  static const int env = getenv("SIMHAND_R128") ? atoi(getenv("SIMHAND_R128")) : 1;
+  const int env = sw(SH_SW_R128);
   const int h = g_use_r128;
   return (h >= 0 ? h : env) && dtype == SH_BF16 && cin == 128 && cout == 128 && r == 3 && s == 3 && stride == 1 && pad == 1 && w + 2 <= 32 &&
          q_total < (1ll << 31) && q_total >= 256 * 64;

@@ -194,8 +194,32 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
         jstride = p.stem_wp * 4;
       }
     }
+    if (!ST && !FUSE && p.stem_wp == 0) {
+      // line-shaped loads: lane l fetches chunk l & 7 of rows l >> 3 and 8 + (l >> 3) of every 128-B column; transposed below
+      const long long ra = mbase + mi * 16 + (lane >> 3), rb = ra + 8;
+      const bool oka = FAST || ra < p.M, okb = FAST || rb < p.M;
+#pragma unroll
+      for (int c4 = 0; c4 < K / 64; ++c4) {
+        afr[mi][2 * c4] = oka ? *reinterpret_cast<const uint4*>(p.a + ra * K + c4 * 64 + (lane & 7) * 8) : make_uint4(0, 0, 0, 0);
+        afr[mi][2 * c4 + 1] = okb ? *reinterpret_cast<const uint4*>(p.a + rb * K + c4 * 64 + (lane & 7) * 8) : make_uint4(0, 0, 0, 0);
+      }
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < (ST ? KF - 1 : KF); ++j) afr[mi][j] = ok ? *reinterpret_cast<const uint4*>(pr + j * jstride) : make_uint4(0, 0, 0, 0);
+  }
+  if constexpr (!ST && !FUSE) {
+    if (p.stem_wp == 0) {  // wave-private transpose: (row l >> 3 (+ 8), chunk l & 7) -> (row li, chunks g and 4 + g): the operand shape
+#pragma unroll
+      for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+        for (int c4 = 0; c4 < K / 64; ++c4) {
+          *reinterpret_cast<uint4*>(tw + tr0) = afr[mi][2 * c4];
+          *reinterpret_cast<uint4*>(tw + tr0 + 1024) = afr[mi][2 * c4 + 1];
+          afr[mi][2 * c4] = *reinterpret_cast<const uint4*>(tw + tw0);
+          afr[mi][2 * c4 + 1] = *reinterpret_cast<const uint4*>(tw + tw1);
+        }
+    }
   }
   if constexpr (DGRAD) {
     if (p.xf_y != nullptr) {  // block-uniform, prologue only: BatchNorm-backward apply on the freshly loaded gradient rows
@@ -204,10 +228,30 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
       uint4 yfr[MF][KF];
 #pragma unroll
       for (int mi = 0; mi < MF; ++mi) {
-        const long long row = mbase + mi * 16 + li;
-        const bf16_t* py = p.xf_y + (row < p.M ? row : 0) * K + g * 8;
+        if constexpr (!FUSE) {  // line-shaped (rows l >> 3 and + 8, chunk l & 7 of every 128-B column), transposed below
+          const long long ra = mbase + mi * 16 + (lane >> 3), rb = ra + 8;
 #pragma unroll
-        for (int j = 0; j < KF; ++j) yfr[mi][j] = *reinterpret_cast<const uint4*>(py + j * 32);
+          for (int c4 = 0; c4 < K / 64; ++c4) {
+            yfr[mi][2 * c4] = *reinterpret_cast<const uint4*>(p.xf_y + (ra < p.M ? ra : 0) * K + c4 * 64 + (lane & 7) * 8);
+            yfr[mi][2 * c4 + 1] = *reinterpret_cast<const uint4*>(p.xf_y + (rb < p.M ? rb : 0) * K + c4 * 64 + (lane & 7) * 8);
+          }
+        } else {
+          const long long row = mbase + mi * 16 + li;
+          const bf16_t* py = p.xf_y + (row < p.M ? row : 0) * K + g * 8;
+#pragma unroll
+          for (int j = 0; j < KF; ++j) yfr[mi][j] = *reinterpret_cast<const uint4*>(py + j * 32);
+        }
+      }
+      if constexpr (!FUSE) {
+#pragma unroll
+        for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+          for (int c4 = 0; c4 < K / 64; ++c4) {
+            *reinterpret_cast<uint4*>(tw + tr0) = yfr[mi][2 * c4];
+            *reinterpret_cast<uint4*>(tw + tr0 + 1024) = yfr[mi][2 * c4 + 1];
+            yfr[mi][2 * c4] = *reinterpret_cast<const uint4*>(tw + tw0);
+            yfr[mi][2 * c4 + 1] = *reinterpret_cast<const uint4*>(tw + tw1);
+          }
       }
       // the five coefficient vectors through LDS (the weight-tile buffers are idle until the first SH_G1_STORE): one global load per
       // thread and vector instead of ten float4 loads per lane and k-slice
@@ -256,7 +300,21 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
             o4[q] = pack_bf16x2(r2[0], r2[1]);
           }
           afr[mi][j] = ok ? make_uint4(o4[0], o4[1], o4[2], o4[3]) : make_uint4(0, 0, 0, 0);
-          if (ok) *reinterpret_cast<uint4*>(p.xf_out + row * K + g * 8 + j * 32) = afr[mi][j];
+          if (FUSE && ok) *reinterpret_cast<uint4*>(p.xf_out + row * K + g * 8 + j * 32) = afr[mi][j];
+        }
+      }
+      if constexpr (!FUSE) {  // dy leaves line-shaped as well (the weight gradient that follows reads it)
+#pragma unroll
+        for (int mi = 0; mi < MF; ++mi) {
+          const long long ra = mbase + mi * 16 + (lane >> 3), rb = ra + 8;
+#pragma unroll
+          for (int c4 = 0; c4 < K / 64; ++c4) {
+            *reinterpret_cast<uint4*>(tw + tw0) = afr[mi][2 * c4];
+            *reinterpret_cast<uint4*>(tw + tw1) = afr[mi][2 * c4 + 1];
+            const uint4 r0 = *reinterpret_cast<const uint4*>(tw + tr0), r1 = *reinterpret_cast<const uint4*>(tw + tr0 + 1024);
+            if (ra < p.M) *reinterpret_cast<uint4*>(p.xf_out + ra * K + c4 * 64 + (lane & 7) * 8) = r0;
+            if (rb < p.M) *reinterpret_cast<uint4*>(p.xf_out + rb * K + c4 * 64 + (lane & 7) * 8) = r1;
+          }
         }
       }
       __syncthreads();  // every wave is done with the coefficients before the first weight tile overwrites them
@@ -269,9 +327,9 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
 #pragma unroll
     for (int mi = 0; mi < (EP ? MF : 1); ++mi) {
       const long long row = mbase + mi * 16 + li;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)  // rows beyond M read row 0 (never stored): no branch around the load
-        rq[mi][j] = *reinterpret_cast<const uint4*>(p.ep_res + (FAST || row < p.M ? row : 0) * p.N + nc2 * 64 + j * 32 + g * 8);
+      const long long ra = mbase + mi * 16 + (lane >> 3), rb = ra + 8;  // line-shaped: rows l >> 3 and + 8, chunk l & 7
+      rq[mi][0] = *reinterpret_cast<const uint4*>(p.ep_res + (FAST || ra < p.M ? ra : 0) * p.N + nc2 * 64 + (lane & 7) * 8);
+      rq[mi][1] = *reinterpret_cast<const uint4*>(p.ep_res + (FAST || rb < p.M ? rb : 0) * p.N + nc2 * 64 + (lane & 7) * 8);
     }
   };
   if constexpr (EP) {
@@ -310,8 +368,9 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
         }
       }
       if constexpr (PF == 1) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) pg[mi][j] = *reinterpret_cast<const uint4*>(p.res_grad + r * p.N + nc2 * 64 + j * 32 + g * 8);
+        const long long ra = mbase + mi * 16 + (lane >> 3);  // line-shaped: rows l >> 3 and + 8, chunk l & 7 (whole blocks: every row exists)
+        pg[mi][0] = *reinterpret_cast<const uint4*>(p.res_grad + ra * p.N + nc2 * 64 + (lane & 7) * 8);
+        pg[mi][1] = *reinterpret_cast<const uint4*>(p.res_grad + (ra + 8) * p.N + nc2 * 64 + (lane & 7) * 8);
         pm[mi] = *reinterpret_cast<const uint2*>(p.res_mask + r * (p.N >> 3) + nc2 * 8);
       }
       pk[mi] = *reinterpret_cast<const uint2*>(p.fmask + r * (p.N >> 3) + nc2 * 8);
@@ -593,6 +652,20 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
             const long long row = mbase + mi * 16 + li;
             uint4 ov[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
             mb[0] = mb[1] = 0u;
+            if constexpr (PF == 1) {  // the prefetched res_grad rows arrive line-shaped: into the accumulator shape
+              *reinterpret_cast<uint4*>(tw + tr0) = pg[mi][0];
+              *reinterpret_cast<uint4*>(tw + tr0 + 1024) = pg[mi][1];
+              pg[mi][0] = *reinterpret_cast<const uint4*>(tw + tw0);
+              pg[mi][1] = *reinterpret_cast<const uint4*>(tw + tw1);
+            }
+            if constexpr (EP != 0) {
+              if (EP == 2 || p.ep_res != nullptr) {  // the prefetched residual rows arrive line-shaped: into the operand shape
+                *reinterpret_cast<uint4*>(tw + tr0) = rq[mi][0];
+                *reinterpret_cast<uint4*>(tw + tr0 + 1024) = rq[mi][1];
+                rq[mi][0] = *reinterpret_cast<const uint4*>(tw + tw0);
+                rq[mi][1] = *reinterpret_cast<const uint4*>(tw + tw1);
+              }
+            }
             if (FAST || row < p.M) {
 #pragma unroll
               for (int j = 0; j < 2; ++j) {
@@ -728,21 +801,21 @@ void hooks_reset_1x1() { g_mf[0] = 4; g_mf[1] = 2; g_mf[2] = 2; gemm1x1_set_chai
 static int mf_of(int k) { return g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)]; }
 void gemm1x1_set_mf(int k, int mf) { g_mf[k == 64 ? 0 : (k == 128 ? 1 : 2)] = mf; }
 
-// the branch-free variants (EP == 2, PF) per K; env for A/B timing against the generic kernels
+// the branch-free variants (EP == 2, PF) per K; simhand_test_switch(SH_SW_G1_PF) for A/B timing against the generic kernels
 static int pf_of(int k) {
-  static const int env = getenv("SIMHAND_G1_PF") ? atoi(getenv("SIMHAND_G1_PF")) : 7;  // bit 0: K = 64, 1: 128, 2: 256
+  const int env = sw(SH_SW_G1_PF);  // bit 0: K = 64, 1: 128, 2: 256
   return (env >> (k == 64 ? 0 : (k == 128 ? 1 : 2))) & 1;
 }
 
 int gemm1x1_rows_per_block(int k) { return 64 * mf_of(k); }
 
 // chained next conv1: K = 64 (128-row blocks, all panels resident: N <= 256) and K = 128 (64-row blocks, streamed panels: N <= 512)
-// bit 0: K = 64, bit 1: K = 128; -1 = SIMHAND_G1_CHAIN or 1 (test / tuning hook, env for A/B timing).  K = 128 is OFF by default:
+// bit 0: K = 64, bit 1: K = 128; -1 = simhand_test_switch(SH_SW_G1_CHAIN), default 1 (test / tuning hooks).  K = 128 is OFF by default:
 // measured at 2048 x 28^2 the chained launch takes 1353 us against 908 + 434 for the two separate ones (its 64-row blocks and the
 // streamed panels cost what the saved read of the block output gains); K = 64 @ 56^2: 1816 against 1590 + 750.
 static hook_t g_chain{-1};
 static int chain_env() {
-  static const int env = getenv("SIMHAND_G1_CHAIN") ? atoi(getenv("SIMHAND_G1_CHAIN")) : 1;
+  const int env = sw(SH_SW_G1_CHAIN);
   const int h = g_chain;
   return h >= 0 ? h : env;
 }
@@ -762,7 +835,7 @@ bool gemm1x1_sub_ok(const Gemm1x1Args& a, int k) {
 
 int launch_gemm1x1(const Gemm1x1Args& a_in, int k, bool dgrad, hipStream_t s) {
   // bit 0: forward launches, bit 1: data gradients (measured neutral there: their stores are not what they wait for)
-  static const int lt_env = getenv("SIMHAND_G1_LT") ? atoi(getenv("SIMHAND_G1_LT")) : 1;
+  const int lt_env = sw(SH_SW_G1_LT);
   Gemm1x1Args a = a_in;
   a.lt = (lt_env >> (dgrad ? 1 : 0)) & 1;
   if (a.chain_w != nullptr) {  // the caller checked gemm1x1_chain_ok and passes residual + ReLU + mask

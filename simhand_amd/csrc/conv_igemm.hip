@@ -1651,13 +1651,36 @@ int simhand_stem_conv_fwd_stat_blocks(int n, int h, int w, int dtype) {
   return dtype == SH_BF16 && g_stem_1x1 ? gemm1x1_stem_stat_blocks(m) : ceil_div(m, 128);  // partial rows of the kernel the same arguments select
 }
 
+int simhand_stem_two_pass_ok(int n, int h, int w, int dtype) {
+  int hp, wp, ho, wo;
+  if (n < 1 || dtype != SH_BF16 || simhand_stem_geometry(h, w, &hp, &wp, &ho, &wo)) return 0;
+  return stem_ring_geometry_ok(hp, wp, ho, wo) ? 1 : 0;
+}
+
+int simhand_stem_conv_bn_relu_pool(const void* xp, const void* wp_, const float* scale, const float* shift, void* pooled, uint8_t* idx,
+                                   void* ywin, int n, int h, int w, int dtype, sh_stream_t stream) {
+  SH_REQUIRE(xp && wp_ && scale && shift && pooled && idx, "stem_conv_bn_relu_pool: NULL pointer");
+  SH_REQUIRE(simhand_stem_two_pass_ok(n, h, w, dtype), "stem_conv_bn_relu_pool: 16-bit storage at 224 x 224 only (n=%d h=%d w=%d dtype=%d)", n, h, w, dtype);
+  int hp, wp, ho, wo;
+  if (simhand_stem_geometry(h, w, &hp, &wp, &ho, &wo)) return 1;
+  const double mo = (double)n * ho * wo;
+  // (pooled + ywin in the storage type, one winner byte per element, the padded input once)
+  ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, 2.0 * mo * 64 * 147, 2.0 * ((double)n * hp * wp * 4 + mo / 4 * 64 * (ywin ? 2 : 1)) + mo / 4 * 64);
+  route_hit(SH_ROUTE_STEM_POOL);
+  launch_stem_ring_pool(xp, wp_, scale, shift, pooled, idx, ywin, n, hp, wp, ho, wo, (hipStream_t)stream);
+  return check_launch("stem_conv_bn_relu_pool");
+}
+
 int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_partial, int n, int h, int w, int dtype,
                           sh_stream_t stream) {
-  SH_REQUIRE(xp && wp_ && y, "stem_conv_fwd: NULL pointer");
+  SH_REQUIRE(xp && wp_, "stem_conv_fwd: NULL pointer");
   SH_REQUIRE(dtype == SH_F32 || dtype == SH_BF16, "stem_conv_fwd: bad dtype %d", dtype);
   SH_REQUIRE(n >= 1, "stem_conv_fwd: bad shape");
   int hp, wp, ho, wo;
   if (simhand_stem_geometry(h, w, &hp, &wp, &ho, &wo)) return 1;
+  // y == NULL: statistics only (pass 1 of the two-pass stem) -- the ring kernel's geometry only
+  SH_REQUIRE(y != nullptr || (bn_partial != nullptr && simhand_stem_two_pass_ok(n, h, w, dtype)),
+             "stem_conv_fwd: y == NULL (statistics only) needs bn_partial and the two-pass geometry (simhand_stem_two_pass_ok)");
   const int ke = dtype == SH_F32 ? 32 : 64;
   IgemmArgs a;
   a.a = xp; a.w = wp_; a.out = y; a.bn_partial = bn_partial;
@@ -1676,12 +1699,13 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
   a.div_w = make_fastdiv((unsigned)wo);
   a.m_tiles = ceil_div(a.Mg, 128);
   a.n_tiles = 1;
-  const double flops = 2.0 * (double)a.Mg * 64 * 147;
+  // (the statistics-only pass of the two-pass stem is overhead, not algorithmic work: its FLOPs are credited once, to pass 2)
+  const double flops = y != nullptr ? 2.0 * (double)a.Mg * 64 * 147 : 0.0;
   const double es = dtype == SH_F32 ? 4 : 2;
-  const double bytes = es * ((double)n * hp * wp * 4 + (double)a.Mg * 64 + 64.0 * 256);
+  const double bytes = es * ((double)n * hp * wp * 4 + (y != nullptr ? (double)a.Mg * 64 : 0.0) + 64.0 * 256);
   ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, flops, bytes);
-  route_hit(SH_ROUTE_STEM_FWD);
-  if (dtype == SH_BF16 && g_stem_1x1 && stem_ring_ok(n, hp, wp, ho, wo)) {
+  route_hit(y != nullptr ? SH_ROUTE_STEM_FWD : SH_ROUTE_STEM_STATS);
+  if (dtype == SH_BF16 && (y == nullptr || (g_stem_1x1 && stem_ring_ok(n, hp, wp, ho, wo)))) {
     launch_stem_ring(xp, wp_, y, bn_partial, n, hp, wp, ho, wo, (hipStream_t)stream);
     return check_launch("stem_conv_fwd (input rows in an LDS ring)");
   }
@@ -1876,8 +1900,8 @@ int simhand_conv2d_dgrad_fuse_pays(const sh_conv_desc* d) {
   if (!d) return 0;
   // stride-2 3x3: each of the four parity-class launches pays the extra read of y against a quarter of the MFMA work; the
   // standalone pass is faster (same-box A/B of the whole step: 126.4 -> 125.9 ms)
-  static const int fuse_s2 = getenv("SIMHAND_FUSE_S2") ? atoi(getenv("SIMHAND_FUSE_S2")) : 0;  // A/B timing
-  // (SIMHAND_FUSE_S2: 1 = all stride-2 3x3 layers, 2 = only those on the 256 x 256 kernel -- round-3 A/B)
+  const int fuse_s2 = sw(SH_SW_FUSE_S2);  // A/B timing
+  // (SH_SW_FUSE_S2: 1 = all stride-2 3x3 layers, 2 = only those on the 256 x 256 kernel -- round-3 A/B)
   if (d->stride == 2 && d->r == 3 && !g_fuse_1x1 && !(fuse_s2 == 1 || (fuse_s2 == 2 && d->cin >= 256 && d->cout >= 256))) return 0;
   return (!use_1x1(d, d->cout, d->cin) || g_fuse_1x1) ? 1 : 0;
 }

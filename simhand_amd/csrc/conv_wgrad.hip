@@ -919,9 +919,9 @@ __global__ __launch_bounds__(512, 1) void wgrad1x1_dma_kernel(Wgrad1Args p) {
   }
 }
 
-static hook_t g_wg_dma{-1};  // -1 = env SIMHAND_WG_DMA (default on), 0 / 1 forced
+static hook_t g_wg_dma{-1};  // -1 = simhand_test_switch(SH_SW_WG_DMA) (default on), 0 / 1 forced
 static bool use_wg_dma(const sh_conv_desc* d) {
-  static const int env = getenv("SIMHAND_WG_DMA") ? atoi(getenv("SIMHAND_WG_DMA")) : 1;
+  const int env = sw(SH_SW_WG_DMA);
   const int h = g_wg_dma;
   // cout != cin: never the Gram launches of the BatchNorm fold (x = dy = a, operand transforms), which share the splits query
   return (h >= 0 ? h : env) && d->dtype == SH_BF16 && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && d->cout % 256 == 0 &&
@@ -944,11 +944,11 @@ static void plan_dma(const sh_conv_desc* d, int* splitk, int* per) {
 
 static hook_t g_use_wgrad3{1};
 static hook_t g_wg3_blocks{512};  // all-taps 3x3 kernel: two blocks per CU, one round (512 beats 768 by 4-10 %)
-static hook_t g_wgrad3_s2{-1};  // stride-2 form: -1 = env SIMHAND_WG3_S2 (default on), 0 / 1 forced
+static hook_t g_wgrad3_s2{-1};  // stride-2 form: -1 = simhand_test_switch(SH_SW_WG3_S2) (default on), 0 / 1 forced
 static bool use_wgrad3(const sh_conv_desc* d) {
   if (!g_use_wgrad3 || d->dtype != SH_BF16 || d->r != 3 || d->s != 3 || d->pad != 1) return false;
   if (d->stride == 2) {  // parity-plane rings: even input, the largest tap shift -(wo + 2) inside one 32-row chunk
-    static const int env = getenv("SIMHAND_WG3_S2") ? atoi(getenv("SIMHAND_WG3_S2")) : 1;
+    const int env = sw(SH_SW_WG3_S2);
     const int h = g_wgrad3_s2;
     return (h >= 0 ? h : env) && d->h % 2 == 0 && d->w % 2 == 0 && d->wo + 2 <= 32 && (long long)d->n * (d->ho + 1) * (d->wo + 1) < (1ll << 31);
   }
@@ -977,18 +977,18 @@ static bool is_plain(const sh_conv_desc* d) {
   return d->dtype == SH_BF16 && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0;
 }
 // 256 x 128 tiles (32-pixel k-steps, 8 x 4 MFMA tiles per wave) for the plain 1x1 kernel where cout % 256 == 0: a quarter less operand
-// traffic per MFMA than 128 x 128 -- (1024, 256) @ 14^2 293 -> 264 us, (2048, 512) @ 7^2 268 -> 251 (env SIMHAND_WG_BIG=0: A/B timing)
+// traffic per MFMA than 128 x 128 -- (1024, 256) @ 14^2 293 -> 264 us, (2048, 512) @ 7^2 268 -> 251 (SH_SW_WG_BIG = 0: A/B timing)
 static hook_t g_wg_big{-1};
 static bool wg_big(const sh_conv_desc* d) {
-  static const int env = getenv("SIMHAND_WG_BIG") ? atoi(getenv("SIMHAND_WG_BIG")) : 1;
+  const int env = sw(SH_SW_WG_BIG);
   const int h = g_wg_big;
   // cout != cin: never the Gram launches of the BatchNorm fold (x = dy = a: their operand transforms live in the 128-row tiles)
   return (h >= 0 ? h : env) && is_plain(d) && g_use_tr && d->cout % 256 == 0 && d->cin % 128 == 0 && d->cout != d->cin;
 }
 // one tile across the WIDE side of the stage-1 layers (64 <-> 256 channels): the narrow operand is then staged once per pixel range
-// instead of once per 128-channel tile of the wide side (4.7 -> 4.1 GB per launch at 2048 x 56^2); env SIMHAND_WG_WIDE=0: A/B timing
+// instead of once per 128-channel tile of the wide side (4.7 -> 4.1 GB per launch at 2048 x 56^2); SH_SW_WG_WIDE = 0: A/B timing
 static bool wg_wide(const sh_conv_desc* d) {
-  static const int env = getenv("SIMHAND_WG_WIDE") ? atoi(getenv("SIMHAND_WG_WIDE")) : 1;
+  const int env = sw(SH_SW_WG_WIDE);
   return env && is_plain(d) && g_use_tr && ((d->cin == 64 && d->cout == 256) || (d->cout == 64 && d->cin == 256));
 }
 static void plan(const sh_conv_desc* d, int* bm, int* bn, int* splitk, int* pps, bool allow_big = true) {
@@ -1179,7 +1179,7 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
   route_hit(stem_wp > 0 ? SH_ROUTE_WGRAD_STEM : (plain ? SH_ROUTE_WGRAD_PLAIN : SH_ROUTE_WGRAD_GENERIC));
   if (dy_colsum != nullptr) route_hit(SH_ROUTE_WGRAD_COLSUM);
 #define SH_WG(T, BM, BN) wgrad_kernel<T, BM, BN><<<nblk, 256, 0, s>>>(a)
-  static const int stem256 = getenv("SIMHAND_STEM_WG256") ? atoi(getenv("SIMHAND_STEM_WG256")) : 1;  // (env: A/B timing; 1.68 -> 1.57 ms at 2048 images)
+  const int stem256 = sw(SH_SW_STEM_WG256);  // (A/B timing; 1.68 -> 1.57 ms at 2048 images)
   if (stem_wp > 0 && stem256 && d->dtype == SH_BF16) {
     // all 256 virtual channels in one tile: dy is staged once per pixel range instead of once per 128-channel tile; 32-pixel k-steps
     // (the 64 x 256 tile's LDS at 64 pixels would leave one block per CU); twice the splits keep the block count

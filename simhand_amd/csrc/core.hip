@@ -73,11 +73,28 @@ ProfScope::~ProfScope() {
   (void)hipEventRecord(g_recs[slot].b, stream);  // a failed record surfaces as an error in prof_collect's synchronize
 }
 
+static hook_t g_sw[SH_SW_COUNT];
+static const int g_sw_default[SH_SW_COUNT] = {131072, 131072, 1, 7, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1};
+static struct SwInit { SwInit() { for (auto& h : g_sw) h.store(-1, std::memory_order_relaxed); } } g_sw_init;
+int sw(int which) {
+  const int v = g_sw[which].load(std::memory_order_relaxed);
+  return v < 0 ? g_sw_default[which] : v;
+}
+
 }  // namespace sh
 
 extern "C" {
 
-int simhand_abi_version(void) { return 1; }
+int simhand_test_switch(int which, int value) {
+  if (which < 0 || which >= SH_SW_COUNT) {
+    sh::set_error("test_switch: which=%d out of range", which);
+    return 1;
+  }
+  sh::g_sw[which].store(value < 0 ? -1 : value, std::memory_order_relaxed);
+  return 0;
+}
+
+int simhand_abi_version(void) { return SH_ABI_VERSION; }
 // 0: this build's 16-bit storage type (enum SH_BF16) is bfloat16; 1: IEEE fp16 (libsimhand_hip_f16.so)
 int simhand_half_format(void) { return SH_H16_FORMAT; }
 
@@ -127,6 +144,7 @@ int simhand_test_hooks_reset(void) {
   sh::hooks_reset_1x1();
   sh::hooks_reset_wgrad();
   sh::hooks_reset_bn();
+  for (auto& h : sh::g_sw) h.store(-1, std::memory_order_relaxed);
   return 0;
 }
 

@@ -14,7 +14,7 @@ single-process nn.DataParallel, src/experiments/main.py:152-163).
 from __future__ import annotations
 
 import os
-from typing import Iterable, List, Tuple
+from typing import Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -51,20 +51,31 @@ class RcclComm:
     _DT = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2, torch.int64: 3}
     _OP = {"sum": 0, "max": 1, "min": 2}
 
-    def __init__(self, id_bytes: bytes, world: int, rank: int):
+    def __init__(self, id_bytes: bytes, world: int, rank: int, side_id_bytes: bytes = None):
+        """side_id_bytes: the id of a SECOND communicator over the same ranks, used only for collectives issued on the side
+        stream (the overlapped gradient buckets).  RCCL / NCCL order the collectives of ONE communicator by their issue order on
+        every rank and do not allow two of them in flight from different streams, so the bucket all-reduces that overlap the
+        compute stream's own collectives (synchronised BatchNorm sums) need a communicator of their own; without one the buckets
+        are issued on the compute stream (correct, not overlapped)."""
         import ctypes as C
 
         from .. import _lib
 
         self._lib, self._C = _lib.load(), C
         _lib.require_device()
-        handle = C.c_void_p()
-        buf = (C.c_uint8 * 128).from_buffer_copy(id_bytes)
-        _lib.check(self._lib.simhand_comm_init(buf, world, rank, C.byref(handle)), "comm_init")
-        self._h = handle
+        self._h = self._init(id_bytes, world, rank)
+        self._h_side = self._init(side_id_bytes, world, rank) if side_id_bytes is not None else None
         w, r = C.c_int(), C.c_int()
         _lib.check(self._lib.simhand_comm_world(self._h, C.byref(w), C.byref(r)), "comm_world")
         self.world, self.rank = w.value, r.value
+
+    def _init(self, id_bytes: bytes, world: int, rank: int):
+        from .. import _lib
+
+        handle = self._C.c_void_p()
+        buf = (self._C.c_uint8 * 128).from_buffer_copy(id_bytes)
+        _lib.check(self._lib.simhand_comm_init(buf, world, rank, self._C.byref(handle)), "comm_init")
+        return handle
 
     @staticmethod
     def unique_id() -> bytes:
@@ -78,16 +89,20 @@ class RcclComm:
 
     @classmethod
     def from_torch_distributed(cls, group=None) -> "RcclComm":
-        """Bootstrap over an existing torch.distributed group (any backend): rank 0's id travels by broadcast_object_list."""
-        box = [cls.unique_id() if dist.get_rank(group) == 0 else None]
+        """Bootstrap over an existing torch.distributed group (any backend): rank 0's ids (main + side-stream communicator)
+        travel by broadcast_object_list."""
+        box = [(cls.unique_id(), cls.unique_id()) if dist.get_rank(group) == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
-        return cls(box[0], dist.get_world_size(group), dist.get_rank(group))
+        return cls(box[0][0], dist.get_world_size(group), dist.get_rank(group), side_id_bytes=box[0][1])
 
     def _stream(self):
         return self._C.c_void_p(torch.cuda.current_stream().cuda_stream)  # inside `with torch.cuda.stream(s)`: s
 
-    def side_stream(self) -> "torch.cuda.Stream":
-        """The communicator's own HIP stream for collectives that overlap the compute stream (OverlappedGradReducer)."""
+    def side_stream(self) -> "Optional[torch.cuda.Stream]":
+        """The HIP stream of the SECOND communicator, for collectives that overlap the compute stream (OverlappedGradReducer);
+        None when the communicator was built without one (collectives of one ncclComm must not be in flight from two streams)."""
+        if self._h_side is None:
+            return None
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream()
         return self._side
@@ -99,18 +114,26 @@ class RcclComm:
         _lib.check(self._lib.simhand_comm_all_gather(self._h, self._C.c_void_p(x.data_ptr()), self._C.c_void_p(out.data_ptr()), x.numel(),
                                                      self._DT[x.dtype], self._stream()), "comm_all_gather")
 
-    def all_reduce_(self, t: torch.Tensor, op: str = "sum") -> torch.Tensor:
+    def all_reduce_(self, t: torch.Tensor, op: str = "sum", side: bool = False) -> torch.Tensor:
+        """side=True: through the second communicator (the caller has made side_stream() the current stream)."""
         from .. import _lib
 
         assert t.is_contiguous()
-        _lib.check(self._lib.simhand_comm_all_reduce(self._h, self._C.c_void_p(t.data_ptr()), self._C.c_void_p(t.data_ptr()), t.numel(),
+        h = self._h
+        if side:
+            if self._h_side is None:
+                raise RuntimeError("RcclComm.all_reduce_(side=True): built without a side-stream communicator")
+            h = self._h_side
+        _lib.check(self._lib.simhand_comm_all_reduce(h, self._C.c_void_p(t.data_ptr()), self._C.c_void_p(t.data_ptr()), t.numel(),
                                                      self._DT[t.dtype], self._OP[op], self._stream()), "comm_all_reduce")
         return t
 
     def close(self) -> None:
-        if self._h is not None:
-            self._lib.simhand_comm_destroy(self._h)
-            self._h = None
+        for name in ("_h_side", "_h"):
+            h = getattr(self, name, None)
+            if h is not None:
+                self._lib.simhand_comm_destroy(h)
+                setattr(self, name, None)
 
 
 def shard_pairs(global_pairs: int, rank: int, world: int) -> Tuple[int, int]:
@@ -143,14 +166,139 @@ def _bucket_views(flat: torch.Tensor, tensors: List[torch.Tensor]) -> List[torch
     return out
 
 
+# ---- torch.distributed collectives on DEVICE tensors -----------------------------------------------------------------------------
+# backend "nccl" (= RCCL, the product path) takes device tensors and orders every collective on its own stream.  backend "gloo"
+# carries HOST memory: torch's ProcessGroupGloo accepts a device tensor by staging it through pinned memory on pool streams of
+# its own, from its worker threads.  That arrangement only exists where ranks SHARE one GPU (tests on a 1-GPU box, RCCL refuses two
+# ranks per device), and it is where round 3 saw a corrupted collective result in ~2 % of 4-rank runs with an asynchronous bucket
+# and the synchronised-BatchNorm sums in flight together.  So the staging is done HERE, explicitly, and gloo only ever
+# sees host tensors: SIMHAND_GLOO_STAGING = "all" (default) | "buckets" (only the asynchronous gradient buckets; the experiment
+# that isolates them) | "off" (torch's own device path: the round-3 arrangement, kept for the stress script).
+def _gloo_staging() -> str:
+    return os.environ.get("SIMHAND_GLOO_STAGING", "all")
+
+
+def _is_gloo(group) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+
+_REDUCE_OPS = {"sum": "SUM", "max": "MAX", "min": "MIN"}
+
+
+def all_reduce_(t: torch.Tensor, op: str = "sum", group=None) -> torch.Tensor:
+    """In-place all-reduce of a contiguous tensor over `group` (RcclComm, torch.distributed group or None = default group),
+    stream-ordered on the current stream.  gloo + device tensor: synchronous host staging (D2H on the current stream, gloo on the
+    host copy, H2D on the current stream) -- no foreign stream, no worker-thread device work."""
+    if isinstance(group, RcclComm):
+        return group.all_reduce_(t, op)
+    rop = getattr(dist.ReduceOp, _REDUCE_OPS[op])
+    if t.is_cuda and _is_gloo(group) and _gloo_staging() == "all":
+        host = t.cpu()
+        dist.all_reduce(host, op=rop, group=group)
+        t.copy_(host)
+        return t
+    dist.all_reduce(t, op=rop, group=group)
+    return t
+
+
+def all_gather_into(out: torch.Tensor, x: torch.Tensor, group=None) -> torch.Tensor:
+    """out [world * x.numel()] <- every rank's contiguous x in rank order; same staging rule as all_reduce_."""
+    if isinstance(group, RcclComm):
+        group.all_gather_into(out, x)
+        return out
+    if x.is_cuda and _is_gloo(group) and _gloo_staging() == "all":
+        hx = x.cpu()
+        ho = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(ho, hx, group=group)
+        out.copy_(ho)
+        return out
+    dist.all_gather_into_tensor(out, x, group=group)
+    return out
+
+
+class _StagedBucket:
+    """One asynchronous SUM all-reduce of a device bucket over gloo with the staging spelled out: side stream behind an event on
+    the launch stream -> pinned host tensor -> gloo all-reduce of the HOST tensor (asynchronous: gloo's worker thread touches host
+    memory only) -> wait() copies back on the current stream."""
+
+    _side = None
+
+    def __init__(self, flat: torch.Tensor, group):
+        cls = _StagedBucket
+        if cls._side is None or cls._side.device != flat.device:
+            cls._side = torch.cuda.Stream(device=flat.device)
+        self.flat = flat
+        self.host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
+        ready = torch.cuda.Event()
+        ready.record()                                  # the flatten, on the launch stream
+        flat.record_stream(cls._side)
+        with torch.cuda.stream(cls._side):
+            cls._side.wait_event(ready)
+            self.host.copy_(flat, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(cls._side)
+        copied.synchronize()                            # the host copy is complete before gloo reads it
+        self.work = dist.all_reduce(self.host, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+    def wait(self) -> None:
+        self.work.wait()
+        self.flat.copy_(self.host, non_blocking=True)   # current stream; the pinned block outlives the copy (host allocator events)
+
+
+class CollectiveAudit:
+    """Diagnostic (SIMHAND_DIST_DIAG=1, tests / scripts/dist_stress.py only): keeps the INPUT of every collective issued through
+    this module next to its result and, at verify(), re-does each one on host copies with plain synchronous gloo -- so a wrong
+    gradient can be attributed to a collective that returned a wrong result from right inputs (transport) or to wrong inputs
+    (whatever produced them).  Records cost one clone per collective; verify() is called after the step."""
+
+    def __init__(self):
+        self.records = []  # (tag, input clone, result tensor (live) or clone)
+
+    def note(self, tag: str, pre: torch.Tensor, post: torch.Tensor) -> None:
+        self.records.append((tag, pre, post))
+
+    def verify(self, group=None) -> list:
+        """-> list of findings (dicts), empty when every collective result equals the host re-computation."""
+        out = []
+        for i, (tag, pre, post) in enumerate(self.records):
+            chk = pre.detach().to("cpu", copy=True)  # (copy: a host tensor would be reduced in place)
+            dist.all_reduce(chk, op=dist.ReduceOp.SUM, group=group)
+            got = post.detach().cpu()
+            if got.dtype != chk.dtype:
+                got = got.to(chk.dtype)
+            bad = ~((got == chk) | (torch.isnan(got) & torch.isnan(chk)))
+            # a different summation ORDER is not a finding: ring all-reduce orders differ between the device path and the host re-do
+            tol = 1e-5 * float(chk.abs().max()) + 1e-12
+            bad &= (got - chk).abs() > tol
+            if bool(bad.any()):
+                idx = bad.reshape(-1).nonzero().reshape(-1)
+                own = pre.detach().cpu().to(chk.dtype)
+                out.append({"record": i, "tag": tag, "numel": chk.numel(), "n_bad": int(idx.numel()), "first_bad": int(idx[0]), "last_bad": int(idx[-1]),
+                            "max_abs_err": float((got - chk).abs().max()), "ref_abs_max": float(chk.abs().max()),
+                            "got_abs_max": float(got[torch.isfinite(got)].abs().max()) if bool(torch.isfinite(got).any()) else float("nan"),
+                            "equals_own_input": bool(torch.equal(got, own)),
+                            "bad_equal_own_input": bool(torch.equal(got.reshape(-1)[idx], own.reshape(-1)[idx]))})
+        return out
+
+
+_AUDIT: Optional[CollectiveAudit] = None
+
+
+def set_collective_audit(audit: Optional[CollectiveAudit]) -> None:
+    global _AUDIT
+    _AUDIT = audit
+
+
 class OverlappedGradReducer:
     """Gradient all-reduce OVERLAPPED with the backward pass (north star: "all-reduce of gradients ... overlapped with
     backward").  The backbone is one hand-written backward (`ResNetEngine.backward`) that finishes its parameter gradients
     block by block, last stage first; each finished group is handed to ``submit``: full buckets are flattened once and go out
-    as asynchronous SUM all-reduces while the earlier blocks' kernels keep the compute stream busy -- torch.distributed runs
-    them on RCCL's own stream; with an ``RcclComm`` group they are issued on the communicator's side stream behind an event
-    on the launch stream.  ``finish`` (end of the backbone's backward) waits and returns ``{parameter: reduced gradient}``
-    whose tensors are VIEWS of the reduced buckets (nothing is copied back; the engine hands them to autograd as the
+    as asynchronous SUM all-reduces while the earlier blocks' kernels keep the compute stream busy -- torch.distributed (nccl)
+    runs them on RCCL's own stream; with an ``RcclComm`` group they are issued on the side stream of the communicator's SECOND
+    ncclComm behind an event on the launch stream (one ncclComm must not have collectives in flight from two streams: the compute
+    stream's own collectives -- synchronised BatchNorm, the loss exchanges -- keep the first); over gloo (ranks sharing a GPU:
+    tests) through ``_StagedBucket``.  ``finish`` (end of the backbone's backward) waits and returns ``{parameter: reduced
+    gradient}`` whose tensors are VIEWS of the reduced buckets (nothing is copied back; the engine hands them to autograd as the
     gradients); ``reduced`` tells ``allreduce_gradients`` which parameters are done.  wire="bf16": buckets travel as bf16
     (half the ring time; the sum is then a bf16 sum).  xGMI is point to point (7 links x ~153 GB/s per GPU): a ResNet-50's
     98.5 MB of fp32 gradients are ~1-3 ms of ring time per step -- hidden behind ~80 ms of backward instead of appended."""
@@ -171,27 +319,26 @@ class OverlappedGradReducer:
         if not self._bucket:
             return
         flat = _bucket_flat([g for _, g in self._bucket], self.wire)
+        if _AUDIT is not None:
+            _AUDIT.note(f"bucket{len(self._pending)}", flat.clone(), flat)
         if isinstance(self.group, RcclComm):
             side = self.group.side_stream()
-            ready = torch.cuda.Event()
-            ready.record()                     # the flatten above, on the launch stream
-            flat.record_stream(side)
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
+            if side is None:                       # no second communicator: in order on the launch stream
                 self.group.all_reduce_(flat, "sum")
-            work = torch.cuda.Event()
-            work.record(side)
-        else:
-            # gloo runs its collectives on worker THREADS: with synchronised BatchNorm on, an asynchronous bucket and the BatchNorm sums
-            # of the block below would be in flight at the same time.  Ranks that share one GPU over gloo (the test arrangement) showed
-            # a corrupted tensor in ~2 % of such runs under GPU oversubscription (never with one collective at a time), so that
-            # combination issues its buckets synchronously; RCCL (the product path) orders every collective on its stream anyway.
-            from .. import ops
-
-            serial = ops.bn_sync_active() and dist.get_backend(self.group) == "gloo" and not os.environ.get("SIMHAND_GLOO_ASYNC_BUCKETS")
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=not serial)
-            if serial:
                 work = None
+            else:
+                ready = torch.cuda.Event()
+                ready.record()                     # the flatten above, on the launch stream
+                flat.record_stream(side)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    self.group.all_reduce_(flat, "sum", side=True)
+                work = torch.cuda.Event()
+                work.record(side)
+        elif flat.is_cuda and _is_gloo(self.group) and _gloo_staging() in ("all", "buckets"):
+            work = _StagedBucket(flat, self.group)
+        else:
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((work, flat, self._bucket))
         self._bucket, self._size = [], 0
 
@@ -224,9 +371,15 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) ->
     """Parameters and buffers of rank `src` to every rank (replica consistency does not rest on identical seeding)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
+    stage = _is_gloo(group) and _gloo_staging() == "all"
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src, group=group)
+            if stage and t.is_cuda:  # gloo carries host memory (see all_reduce_)
+                host = t.data.cpu()
+                dist.broadcast(host, src=src, group=group)
+                t.data.copy_(host)
+            else:
+                dist.broadcast(t.data, src=src, group=group)
 
 
 def enable_sync_bn(group=None) -> bool:
@@ -246,7 +399,16 @@ def enable_sync_bn(group=None) -> bool:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         ops.set_bn_sync(None)
         return False
-    ops.set_bn_sync(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group))
+
+    def _sync(t: torch.Tensor) -> None:
+        if _AUDIT is not None:
+            pre = t.clone()
+            all_reduce_(t, "sum", group)
+            _AUDIT.note("bn_sync", pre, t.clone())
+        else:
+            all_reduce_(t, "sum", group)
+
+    ops.set_bn_sync(_sync)
     return True
 
 
@@ -288,10 +450,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
     keep = _GRAD_PLANS.get(key)
     if keep is None:
         has = torch.tensor([1 if p.grad is not None else 0 for p in plist], dtype=torch.int64, device=plist[0].device)
-        if abi:
-            group.all_reduce_(has, "max")
-        else:
-            dist.all_reduce(has, op=dist.ReduceOp.MAX, group=group)
+        all_reduce_(has, "max", group)
         keep = _GRAD_PLANS[key] = [bool(k) for k in has.tolist()]  # the only host read, first step only
     grads: List[torch.Tensor] = []
     owners: List[torch.nn.Parameter] = []
@@ -314,9 +473,13 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
         if size >= bucket_bytes or i == 0:
             tensors = grads[i:lo]
             flat = _bucket_flat(tensors, wdt)
+            if _AUDIT is not None:
+                _AUDIT.note(f"tail{len(pending)}", flat.clone(), flat)
             if abi:  # stream-ordered on the current stream: nothing to wait for on the host
                 group.all_reduce_(flat, "sum")
                 work = None
+            elif flat.is_cuda and _is_gloo(group) and _gloo_staging() in ("all", "buckets"):
+                work = _StagedBucket(flat, group)
             else:
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
             pending.append((work, flat, i, lo))

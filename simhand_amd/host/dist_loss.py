@@ -74,11 +74,9 @@ def _world(group):
 
 def _all_gather(out: Tensor, x: Tensor, group) -> Tensor:
     """out [world * x.numel()] <- every rank's contiguous x, rank order."""
-    if _is_abi(group):
-        group.all_gather_into(out, x)
-    else:
-        dist.all_gather_into_tensor(out, x, group=group)
-    return out
+    from . import dist as shdist  # gloo + device tensors (ranks sharing a GPU: tests) are staged through host memory there
+
+    return shdist.all_gather_into(out, x, group)
 
 
 def _reference_order(buf: Tensor, b_loc: int, world: int) -> Tensor:

@@ -77,28 +77,44 @@ class ModelCheckpoint:
             return
         os.makedirs(self.dirpath, exist_ok=True)
         path = os.path.join(self.dirpath, self.format_name(epoch, metrics))
-        torch.save(trainer.checkpoint_dict(module, epoch), path)
         self.kept.append((key, path))
         self.kept.sort(key=lambda t: t[0])
+        drops = []
         while self.save_top_k > 0 and len(self.kept) > self.save_top_k:
-            _, drop = self.kept.pop()
+            drops.append(self.kept.pop()[1])
+        self.best_model_path = self.kept[0][1]
+        torch.save(trainer.checkpoint_dict(module, epoch), path)  # records `kept` INCLUDING itself: what a resumed run may prune later
+        for drop in drops:
             if os.path.exists(drop):
                 os.remove(drop)
-        self.best_model_path = self.kept[0][1]
+
+    def _template_regex(self) -> "re.Pattern":
+        """This callback's filename template as a regular expression (literal text kept, every {name:fmt} field a number)."""
+        parts = re.split(r"(\{[^{}]+\})", self.filename)
+        rx = "".join((re.escape(f[1:-1].split(":")[0]) + r"=(?P<%s>-?\d+(?:\.\d+)?)" % re.sub(r"\W", "_", f[1:-1].split(":")[0]))
+                     if f.startswith("{") else re.escape(f) for f in parts)
+        return re.compile("^" + rx + r"\.ckpt$")
+
+    def restore(self, kept, best: str = "") -> None:
+        """Adopt the (score key, path) list a checkpoint of THIS run recorded: exact scores, and only files the run wrote itself."""
+        self.kept = sorted(((float(k), str(p)) for k, p in kept if os.path.exists(p)), key=lambda t: t[0])
+        self.best_model_path = self.kept[0][1] if self.kept else (best or "")
 
     def rescan(self) -> None:
-        """Rebuild `kept` from the checkpoint files already in dirpath (a resumed run must keep pruning to save_top_k across the
-        restart): the monitored score is parsed back out of the reference's filename template ({monitor}=%.6f)."""
+        """Fallback for checkpoints that carry no kept-list (written before round 4): rebuild `kept` from the files in dirpath whose
+        WHOLE name matches this callback's filename template -- other runs' files that merely contain "{monitor}=<float>" are never
+        adopted, hence never pruned.  Scores come back at the template's 6 decimals."""
         if not self.dirpath or not os.path.isdir(self.dirpath):
             return
-        pat = re.compile(re.escape(self.monitor) + r"=(-?\d+\.\d+)")
+        rx = self._template_regex()
+        field = re.sub(r"\W", "_", self.monitor)
         known = {p for _, p in self.kept}
         for fn in sorted(os.listdir(self.dirpath)):
-            m = pat.search(fn)
+            m = rx.match(fn)
             path = os.path.join(self.dirpath, fn)
-            if m is None or not fn.endswith(".ckpt") or path in known:
+            if m is None or field not in m.groupdict() or path in known:
                 continue
-            score = float(m.group(1))
+            score = float(m.group(field))
             self.kept.append((score if self.mode == "min" else -score, path))
         self.kept.sort(key=lambda t: t[0])
         if self.kept:
@@ -170,7 +186,12 @@ class Trainer:
             "state_dict": module.state_dict(), "hyper_parameters": module.hparams,
             "optimizer_states": [o.state_dict() for o in self.optimizers],
             "lr_schedulers": [s["scheduler"].state_dict() for s in self.schedulers],
-            "native_amp_scaling_state": self.scaler.state_dict() if self.scaler.enabled else None,  # Lightning's key for the GradScaler
+            # the GradScaler state under BOTH of Lightning's keys: 1.8 (the reference's pin) writes the precision plugin's state under
+            # its class name; "native_amp_scaling_state" is the pre-1.6 key 1.8 still reads for back-compat
+            "NativeMixedPrecisionPlugin": self.scaler.state_dict() if self.scaler.enabled else None,
+            "native_amp_scaling_state": self.scaler.state_dict() if self.scaler.enabled else None,
+            # the files this run's ModelCheckpoint callbacks wrote and still keep (a resumed run prunes these, and only these)
+            "callbacks_kept": [[list(map(list, cb.kept)), cb.best_model_path] for cb in self.callbacks if isinstance(cb, ModelCheckpoint)],
             # fp8 configuration: the delayed-scaling amax rings of every quantisation site (a resumed run continues with the same scales)
             "fp8_scaling_state": (module.encoder.engine.fp8_state_dict() if self.fp8 and hasattr(getattr(module, "encoder", None), "engine") else None),
         }
@@ -187,15 +208,24 @@ class Trainer:
         opts, scheds = model.configure_optimizers()
         self.optimizers, self.schedulers = opts, scheds
         start_epoch, skip_batches = 0, 0
+        resume_kept = []
         if ckpt_path:
             ck = torch.load(ckpt_path, map_location=device, weights_only=False)
+            resume_kept = list(ck.get("callbacks_kept") or [])
             model.load_state_dict(ck["state_dict"])
             for o, s in zip(opts, ck.get("optimizer_states", [])):
                 o.load_state_dict(s)
             for s, st in zip(scheds, ck.get("lr_schedulers", [])):
                 s["scheduler"].load_state_dict(st)
-            if self.scaler.enabled and ck.get("native_amp_scaling_state"):
-                self.scaler.load_state_dict(ck["native_amp_scaling_state"])
+            if self.scaler.enabled:
+                amp_state = ck.get("NativeMixedPrecisionPlugin") or ck.get("native_amp_scaling_state")  # PL 1.8's key first
+                if amp_state:
+                    self.scaler.load_state_dict(amp_state)
+                else:
+                    import warnings
+
+                    warnings.warn(f"{ckpt_path}: precision 16 resume without a GradScaler state (neither 'NativeMixedPrecisionPlugin' nor "
+                                  "'native_amp_scaling_state'): loss scaling restarts at its initial scale")
             if self.fp8 and ck.get("fp8_scaling_state") and hasattr(getattr(model, "encoder", None), "engine"):
                 model.encoder.engine.load_fp8_state_dict(ck["fp8_scaling_state"], device)
             self.global_step = ck.get("global_step", 0)
@@ -209,7 +239,13 @@ class Trainer:
             if isinstance(cb, ModelCheckpoint) and cb.dirpath is None:
                 cb.dirpath = os.path.join(self.default_root_dir, "checkpoints")
             if isinstance(cb, ModelCheckpoint) and ckpt_path:
-                cb.rescan()  # earlier top-k files of the run being resumed stay subject to pruning
+                # earlier top-k files of the run being resumed stay subject to pruning: the list the checkpoint itself carries (exact
+                # scores, this run's files only); checkpoints without one fall back to a scan for this callback's filename template
+                rec = resume_kept.pop(0) if resume_kept else None
+                if rec is not None:
+                    cb.restore(rec[0], rec[1])
+                else:
+                    cb.rescan()
         reducer = None
         if self.sync_batchnorm:
             from .dist import enable_sync_bn

@@ -46,9 +46,19 @@ class LARSAdam(torch.optim.Optimizer):
             for p in ps:
                 self.state[p]["step"] -= 1
 
+    # state[p]["step"] is PROVISIONAL between a guarded step and the next call of any method below (a step the device skipped is taken
+    # back here, one step late); every entry point that exposes or replaces the counters settles it first
     def state_dict(self):
         self._resolve_pending()
         return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        self._resolve_pending()  # a flag still pending belongs to the OLD counters: settle it before they are replaced
+        return super().load_state_dict(state_dict)
+
+    def zero_grad(self, set_to_none: bool = True):
+        self._resolve_pending()
+        return super().zero_grad(set_to_none=set_to_none)
 
     def _state(self, p):
         st = self.state[p]

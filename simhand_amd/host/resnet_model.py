@@ -23,7 +23,6 @@ OIHW fp32 -> KRSC / CRSK compute dtype when the parameter version changes.
 """
 from __future__ import annotations
 
-import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -137,6 +136,7 @@ class ResNetEngine:
         # the matrix-core-bound layers (3x3, and 1x1 with >= 512 input channels) whose BatchNorm is not folded; data / weight
         # gradients stay bf16.  Scales: ops.FP8Scaler (per-tensor; weights current, activations delayed).
         self.fp8 = fp8
+        self.fp8_all = False  # A/B: the round-2 fp8 set (every 3x3 and every 1x1 with >= 512 input channels)
         self._fp8_sites: Dict[int, tuple] = {}  # id(conv.weight) -> (activation scaler, weight scaler, packed weights, version)
         self._fp8_pre = None  # (activation tensor, its e4m3 codes) emitted by the BatchNorm-apply in front of an fp8 convolution
         self._packs: Dict[int, _Packed] = {}
@@ -150,26 +150,29 @@ class ResNetEngine:
         # the folds need every block's incoming gradient in masked form, which only the all-1x1 tails of Bottleneck nets give
         self._bottleneck = all(isinstance(b, Bottleneck) for li in (4, 5, 6, 7) for b in features[li])
         # BN-apply (+ReLU) of the unit in front of a folded conv runs inside the Gram launch the fold needs anyway
-        self.fuse_apply_gram = os.environ.get("SIMHAND_FUSE_GRAM", "1") == "1"  # env: A/B timing only
+        self.fuse_apply_gram = True  # (plain attributes: A/B runs set them, e.g. bench.py --engine fuse_apply_gram=0)
         # BN-backward apply of a 1x1 / stride-1 unit without residual runs inside that unit's weight-gradient launch
         # (off: measured on MI355X at 2048 x 224^2 the BatchNorm class drops 4.3 ms but the weight-gradient class grows 8.5 ms --
         # every cin tile of the launch re-derives the dy operand from TWO tensors; kept for the experiment record)
-        self._fuse_bwd_apply_wgrad = os.environ.get("SIMHAND_FUSE_BWDW", "0") == "1"
+        self._fuse_bwd_apply_wgrad = False
         # BN-backward apply of a Bottleneck's conv1 + bn1 runs in the A-operand load of conv1's DATA gradient (the activation-
         # stationary kernel loads each gradient row exactly once, straight into MFMA operand registers): the stand-alone pass
         # (2 reads + 1 write of the narrow tensor) becomes 1 extra read + 1 write inside that launch; the weight gradient then
-        # reads the dy it wrote (env: A/B timing only)
-        self._fuse_bwd_apply_dgrad = os.environ.get("SIMHAND_FUSE_BWDD", "1") == "1"
+        # reads the dy it wrote (attribute: A/B timing only)
+        self._fuse_bwd_apply_dgrad = True
         self._gram = None  # (activation tensor, a^T a, sum a) of the unit just applied that way
         # the next block's conv1 chained onto this block's conv3 + bn3 + add + ReLU launch (ops.conv2d_fwd_bnact_chain): the block
-        # output is written but not read back by that conv1 (env: A/B timing only)
-        self.chain_conv1 = os.environ.get("SIMHAND_CHAIN", "1") == "1"
+        # output is written but not read back by that conv1 (attribute: A/B timing only)
+        self.chain_conv1 = True
         self._chain = None  # (block output tensor, the chained conv module, its raw output, its BatchNorm partial sums)
-        # folded stride-2 shortcut convolutions run as dense 1x1 / stride-1 launches over the subsampled input (env: A/B timing only)
-        self.dense_shortcut = os.environ.get("SIMHAND_DENSE_DS", "1") == "1"
+        # folded stride-2 shortcut convolutions run as dense 1x1 / stride-1 launches over the subsampled input (attribute: A/B timing only)
+        self.dense_shortcut = True
         # backward of a stage-entry block: the shortcut's dense data gradient is merged into the main branch's conv1 data gradient
-        # (sh_dgrad_opts.sub_grad) instead of scatter-added onto it afterwards (env: A/B timing only)
-        self.merge_shortcut = os.environ.get("SIMHAND_MERGE_DS", "1") == "1"
+        # (sh_dgrad_opts.sub_grad) instead of scatter-added onto it afterwards (attribute: A/B timing only)
+        self.merge_shortcut = True
+        # stem at 224^2, 16-bit storage: conv1 run twice in the forward and once more in the backward instead of storing its raw output
+        # (attribute: A/B timing only)
+        self.stem_two_pass = True
         # multi-GPU: host.dist.OverlappedGradReducer -- finished parameter gradients go out block by block during backward
         self.grad_reducer = None
 
@@ -299,11 +302,11 @@ class ResNetEngine:
 
     def _fp8_ok(self, conv, d) -> bool:
         """fp8 forward where it measured FASTER than the bf16 kernel it replaces (ops.conv2d_fwd_fp8_pays: the 3x3 layers with >= 256
-        channels, on the e4m3 variant of the 256 x 256 LDS-DMA kernel); SIMHAND_FP8_ALL=1 restores the round-2 set (every 3x3 and
+        channels, on the e4m3 variant of the 256 x 256 LDS-DMA kernel); engine.fp8_all = True restores the round-2 set (every 3x3 and
         every 1x1 with >= 512 input channels) for A/B runs."""
         if not (self.fp8 and self.dtype == torch.bfloat16):
             return False
-        if os.environ.get("SIMHAND_FP8_ALL", "0") == "1":
+        if self.fp8_all:
             return (conv.kernel_size == (3, 3) or conv.in_channels >= 512) and ops.conv2d_fwd_fp8_supported(d)
         return ops.conv2d_fwd_fp8_pays(d)
 
@@ -422,17 +425,27 @@ class ResNetEngine:
         # matrix would be 9.9 GB); the same copy feeds the stem's weight gradient
         xp = ops.stem_pad_input(tuple(v.contiguous() for v in views), self.dtype)
         pk = self._pack(conv1, need_t=False, stem=True)
-        y, part = ops.stem_conv_fwd(xp, pk.krsc, h, w, want_stats=training)
-        ho, wo = y.shape[1], y.shape[2]
         d = ops.conv_desc(n, h, w, 3, 64, 7, 7, 2, 3, self.dtype)  # bookkeeping only (n, h, w, ho, wo, cout)
-        m = n * ho * wo
-        st = self._bn(bn1, part, m, 64, training)
-        # BN + ReLU + MaxPool in one pass: the 112x112x64 activation in between is never stored
         ywin = None
-        if want_ctx:  # + the winning taps' raw conv outputs: the backward's statistics pass then runs over pooled-size tensors
-            x, idx, ywin = ops.bn_relu_maxpool_fwd(y, st, want_winner=True)
+        two_pass = self.stem_two_pass and training and not ops.bn_sync_active() and ops.stem_two_pass_ok(n, h, w, self.dtype)
+        if two_pass:
+            # conv1 TWICE instead of a 6.6 GB round trip of its raw output (2048 x 224^2): statistics only, then conv1 again with
+            # BN + ReLU + MaxPool in its epilogue; the backward recomputes it a third time (ops.stem_backward_fused): y never exists
+            part = ops.stem_conv_stats(xp, pk.krsc, h, w)
+            m = n * d.ho * d.wo
+            st = self._bn(bn1, part, m, 64, training)
+            x, idx, ywin = ops.stem_conv_bn_relu_pool(xp, pk.krsc, st, h, w, want_winner=want_ctx)
+            y = None
         else:
-            x, idx = ops.bn_relu_maxpool_fwd(y, st)
+            y, part = ops.stem_conv_fwd(xp, pk.krsc, h, w, want_stats=training)
+            ho, wo = y.shape[1], y.shape[2]
+            m = n * ho * wo
+            st = self._bn(bn1, part, m, 64, training)
+            # BN + ReLU + MaxPool in one pass: the 112x112x64 activation in between is never stored
+            if want_ctx:  # + the winning taps' raw conv outputs: the backward's statistics pass then runs over pooled-size tensors
+                x, idx, ywin = ops.bn_relu_maxpool_fwd(y, st, want_winner=True)
+            else:
+                x, idx = ops.bn_relu_maxpool_fwd(y, st)
         if want_ctx:
             u = _Unit()
             u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv1, bn1, d, xp, y, None, st, True, True
@@ -464,7 +477,7 @@ class ResNetEngine:
                     idn = self._conv_bn(blk.downsample[0], blk.downsample[1], inp, False, None, training, dsaved)
                 conv, bn = units[-1]
                 # (the chained conv1 is a bf16 launch: fine in fp8 mode too, whose default fp8 set holds 3x3 layers only)
-                fp8_all = self.fp8 and os.environ.get("SIMHAND_FP8_ALL", "0") == "1"
+                fp8_all = self.fp8 and self.fp8_all
                 chain_conv = nxt.units()[0][0] if (nxt is not None and nxt.downsample is None and not fp8_all) else None
                 x = self._conv_bn(conv, bn, t, True, idn, training, saved, chain_conv=chain_conv)
                 if want_ctx:
@@ -721,10 +734,16 @@ class ResNetEngine:
                 sent = len(items)
         # stem: the pooled gradient is gathered through the winner index inside the BatchNorm-backward passes
         u = ctx["stem"]
-        dy, dg, db = ops.maxpool_bn_backward(dz, ctx["pool_idx"], u.y, u.st, u.bn.weight.detach(), ywin=ctx.get("pool_ywin"))
+        if u.y is None:  # two-pass stem: conv1 recomputed inside the kernel that forms dy and accumulates dW (neither y nor dy in HBM)
+            pk = self._pack(u.conv, need_t=False, stem=True)
+            dw, dg, db = ops.stem_backward_fused(u.x, pk.krsc, dz.contiguous(), ctx["pool_idx"], ctx["pool_ywin"], u.st, u.bn.weight.detach(),
+                                                 u.desc.h, u.desc.w)
+            grads[u.conv.weight] = dw
+        else:
+            dy, dg, db = ops.maxpool_bn_backward(dz, ctx["pool_idx"], u.y, u.st, u.bn.weight.detach(), ywin=ctx.get("pool_ywin"))
+            grads[u.conv.weight] = ops.stem_conv_wgrad(u.x, dy, u.desc.h, u.desc.w)
         grads[u.bn.weight] = dg
         grads[u.bn.bias] = db
-        grads[u.conv.weight] = ops.stem_conv_wgrad(u.x, dy, u.desc.h, u.desc.w)
         if red is not None:
             red.submit(list(grads.items())[sent:])
             grads.update(red.finish())  # waits for the buckets in flight; the reduced buckets' views ARE the gradients autograd receives

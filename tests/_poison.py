@@ -22,3 +22,23 @@ def poison(gib: float = None) -> bool:
     torch.cuda.synchronize()
     del big, small, tiny
     return True
+
+
+def poison_every() -> None:
+    """SIMHAND_POISON_EVERY=1 (multi-rank workers): EVERY device tensor that torch.empty / empty_like / new_empty hands out from now on is
+    filled with 0xFF bytes first -- also the blocks the caching allocator re-uses, which `poison` cannot reach (they hold the previous
+    tenant's finite data, so a read of rows nobody wrote passes silently until the allocator's re-use pattern shifts: with foreign
+    streams in play -- record_stream defers frees by event completion -- that pattern is timing dependent).  Slow; small problems only."""
+    import torch
+
+    def wrap(fn):
+        def inner(*a, **k):
+            t = fn(*a, **k)
+            if isinstance(t, torch.Tensor) and t.is_cuda and t.numel() and t.is_contiguous():
+                t.view(-1).view(torch.uint8).fill_(0xFF)
+            return t
+        return inner
+
+    torch.empty = wrap(torch.empty)
+    torch.empty_like = wrap(torch.empty_like)
+    torch.Tensor.new_empty = wrap(torch.Tensor.new_empty)

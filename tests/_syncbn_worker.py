@@ -23,6 +23,14 @@ if os.environ.get("SIMHAND_POISON_WORKER"):  # torch.empty returns NaN patterns 
     from tests._poison import poison
 
     poison(float(os.environ["SIMHAND_POISON_WORKER"]))
+if os.environ.get("SIMHAND_POISON_EVERY"):  # every torch.empty of the step returns NaN patterns, re-used blocks included
+    from tests._poison import poison_every
+
+    poison_every()
+audit = None
+if os.environ.get("SIMHAND_DIST_DIAG"):  # scripts/dist_stress.py: every collective's input kept and re-derived on the host afterwards
+    audit = shdist.CollectiveAudit()
+    shdist.set_collective_audit(audit)
 dev = torch.device("cuda", torch.cuda.current_device())
 AUG = ["color_jitter", "crop", "random_crop", "resize", "rotate"]
 wcfg = dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg")
@@ -39,6 +47,8 @@ torch.manual_seed(1000 + rank)
 model = _product("HandCLR_W", SIZE, wcfg, om)
 shdist.broadcast_module_state(model)
 assert shdist.enable_sync_bn() == (world > 1) and ops.bn_sync_active() == (world > 1)
+if world == 1 and os.environ.get("SIMHAND_FORCE_SYNC_PATH"):  # one rank: the synchronised code path (unfused BatchNorm passes) with an
+    ops.set_bn_sync(lambda t: None)                          # identity "all-reduce" -- same kernels, same buffers as with R ranks
 off, b = shdist.shard_pairs(B, rank, world)
 shard = {k: v[off:off + b].to(dev) for k, v in batch.items()}
 reducer = shdist.OverlappedGradReducer(bucket_bytes=int(os.environ.get("SIMHAND_TEST_BUCKET", 1 << 20)))
@@ -48,6 +58,17 @@ loss = model.training_step(shard, 0)["loss"]
 loss.backward()
 shdist.allreduce_gradients(model.parameters(), bucket_bytes=1 << 20, skip=reducer.reduced)
 torch.cuda.synchronize()
+if audit is not None and world > 1:
+    import json
+
+    shdist.set_collective_audit(None)
+    findings = audit.verify()
+    for f in findings:
+        print(f"AUDIT rank {rank}: " + json.dumps(f), flush=True)
+    print(f"AUDIT rank {rank}: {len(audit.records)} collectives re-derived on the host, {len(findings)} wrong", flush=True)
+    AUDIT_BAD = len(findings)
+else:
+    AUDIT_BAD = 0
 # every rank normalised with the same statistics: the running buffers agree bit for bit across ranks
 for k, buf in model.named_buffers():
     if buf.dtype.is_floating_point:
@@ -82,6 +103,29 @@ if rank == 0:
     # and per-rank statistics do NOT reproduce the full-batch step (the test can tell the two apart)
     print(f"rank 0 [sync BN, {BACKEND} x{world}, ResNet-{SIZE}]: loss {loss.item():.6f} == full-batch oracle {lo.item():.6f}; grad rel-L2 median "
           f"{errs[len(errs)//2]:.2e} max {errs[-1]:.2e}; running stats within {worst:.1e}")
+if BACKEND == "nccl" and world > 1:
+    # the same step with every exchange through the C ABI's RCCL wrappers: the synchronised-BatchNorm sums on the compute stream
+    # (first ncclComm) while the gradient buckets overlap them on the side stream (second ncclComm) -- reduced gradients tensor by tensor
+    comm = shdist.RcclComm.from_torch_distributed()
+    torch_grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    model.process_group = comm
+    assert shdist.enable_sync_bn(comm)
+    red_abi = shdist.OverlappedGradReducer(comm, bucket_bytes=1 << 20)
+    assert comm.side_stream() is not None
+    model.encoder.engine.grad_reducer = red_abi
+    loss_abi = model.training_step(shard, 0)["loss"]
+    loss_abi.backward()
+    shdist.allreduce_gradients(model.parameters(), group=comm, bucket_bytes=1 << 20, skip=red_abi.reduced)
+    torch.cuda.synchronize()
+    assert abs(loss_abi.item() - loss.item()) <= 1e-6 * abs(loss.item()), (loss_abi.item(), loss.item())
+    for k, p in model.named_parameters():
+        if k in torch_grads:
+            ref = torch_grads[k]
+            assert (p.grad - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-8, k
+    model.process_group = None
+    model.encoder.engine.grad_reducer = None
+    comm.close()
 shdist.disable_sync_bn()
 if world > 1:
     # control: the same shards with per-rank statistics give a different loss (the comparison above can tell the two modes apart)
@@ -91,4 +135,5 @@ if world > 1:
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()
+assert AUDIT_BAD == 0, f"{AUDIT_BAD} collectives returned a wrong result from right inputs"
 print("rank", rank, "ok")

@@ -809,6 +809,77 @@ def test_stem_bn_relu_maxpool_fused_equals_unfused(dtype, n, h, w):
     _check(dy2.view(m, c).float(), want_dy.float(), 1e-5 if dtype == torch.float32 else 1e-2, "dy with pooled-tensor statistics")
 
 
+def _stem_case(n, seed, dtype=torch.bfloat16):
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, 224, 224, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147)
+    gamma = torch.rand(64, generator=g) + 0.5
+    gamma[::7] *= -1.0                                   # negative scales: the activation DEcreases with the raw conv output there
+    beta = torch.randn(64, generator=g) * 0.2
+    xp = ops.stem_pad_input(x.to(DEV), dtype)
+    wpk = ops.stem_pack_weights(wt.to(DEV), dtype)
+    return x, wt, gamma.to(DEV), beta.to(DEV), xp, wpk
+
+
+@pytest.mark.parametrize("n", [1, 5])
+def test_stem_two_pass_forward_equals_one_pass_bit_for_bit(n):
+    """Round 4: conv1 run twice (statistics only, then conv1 + BN + ReLU + MaxPool in one kernel) == conv1 storing its raw output followed
+    by bn_relu_maxpool_fwd: the BatchNorm partial sums, the pooled activation, the winner taps and the winners' raw conv outputs, bit
+    for bit (ties between equal activations -- the ReLU's zeros, bf16 collisions -- resolved like ATen: first tap in scan order)."""
+    from simhand_amd import ops
+
+    x, wt, gamma, beta, xp, wpk = _stem_case(n, 40 + n)
+    assert ops.stem_two_pass_ok(n, 224, 224, torch.bfloat16) and not ops.stem_two_pass_ok(n, 96, 96, torch.bfloat16)
+    assert not ops.stem_two_pass_ok(n, 224, 224, torch.float32)
+    ops.route_reset()
+    y, part = ops.stem_conv_fwd(xp, wpk, 224, 224)
+    part2 = ops.stem_conv_stats(xp, wpk, 224, 224)
+    assert ops.route_counts()["stem_stats"] == 1
+    assert torch.equal(part, part2)
+    m = n * 112 * 112
+    st = ops.bn_finalize(part, m, 64, gamma, beta, None, None, None)
+    want_x, want_idx, want_yw = ops.bn_relu_maxpool_fwd(y, st, want_winner=True)
+    got_x, got_idx, got_yw = ops.stem_conv_bn_relu_pool(xp, wpk, st, 224, 224)
+    assert ops.route_counts()["stem_pool"] == 1
+    assert torch.equal(got_idx, want_idx), (got_idx != want_idx).sum().item()
+    assert torch.equal(got_x, want_x) and torch.equal(got_yw, want_yw)
+    x3, idx3, yw3 = ops.stem_conv_bn_relu_pool(xp, wpk, st, 224, 224, want_winner=False)
+    assert yw3 is None and torch.equal(x3, want_x) and torch.equal(idx3, want_idx)
+    # the winners spread over all nine taps, and a visible share of the windows are decided by ties (equal activations)
+    hist = torch.bincount(want_idx.view(-1).long().cpu(), minlength=9)
+    assert (hist > 0).all(), hist
+
+
+@pytest.mark.parametrize("n", [2, 260])
+def test_stem_fused_backward_equals_the_unfused_chain(n):
+    """stem_backward_fused (conv1 recomputed in the kernel that forms dy in registers and accumulates dW) == maxpool_bn_backward (reads the
+    stored y, writes dy) + stem_conv_wgrad (reads dy): dgamma / dbeta bit for bit (same kernels), dW to summation order -- and against
+    ATen's conv2d weight gradient on the host from the unfused chain's stored dy.  n = 260 > 256 blocks: two images on some blocks."""
+    from simhand_amd import ops
+
+    x, wt, gamma, beta, xp, wpk = _stem_case(n, 60 + n)
+    y, part = ops.stem_conv_fwd(xp, wpk, 224, 224)
+    m = n * 112 * 112
+    st = ops.bn_finalize(part, m, 64, gamma, beta, None, None, None)
+    px, idx, ywin = ops.bn_relu_maxpool_fwd(y, st, want_winner=True)
+    g = torch.Generator().manual_seed(n)
+    dz = torch.randn(px.shape, generator=g).to(DEV).to(torch.bfloat16)
+    dy, dg, db = ops.maxpool_bn_backward(dz, idx, y, st, gamma, ywin=ywin)
+    want = ops.stem_conv_wgrad(xp, dy, 224, 224)
+    ops.route_reset()
+    dw, dg2, db2 = ops.stem_backward_fused(xp, wpk, dz, idx, ywin, st, gamma, 224, 224)
+    assert ops.route_counts()["stem_bwd_fused"] == 1
+    assert torch.equal(dg, dg2) and torch.equal(db, db2)
+    assert bool(torch.isfinite(dw).all())
+    _check(dw.cpu(), want.cpu(), 2e-3, "fused stem dW vs the unfused chain")
+    if n <= 8:
+        xr = _rnd(x, torch.bfloat16)
+        ref = torch.nn.grad.conv2d_weight(xr, (64, 3, 7, 7), dy.float().cpu().permute(0, 3, 1, 2).contiguous(), stride=2, padding=3)
+        _check(dw.cpu(), ref, 2e-3, "fused stem dW vs ATen on the host")
+
+
 @pytest.mark.parametrize("shape", [(2, 56, 56, 64, 64), (3, 28, 28, 128, 128), (5, 14, 14, 256, 128), (7, 7, 7, 128, 256), (1, 5, 9, 64, 64),
                                    (40, 14, 14, 64, 128)])
 def test_wgrad_3x3_all_taps_kernel(shape):

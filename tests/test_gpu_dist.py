@@ -16,9 +16,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(world, backend, port, worker, extra):
+def _launch(world, backend, port, worker, extra, env_extra=None):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), OMP_NUM_THREADS="4",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     worker = os.path.join(ROOT, "tests", worker)
     procs = [subprocess.Popen([sys.executable, worker, ROOT, backend, *extra], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -26,23 +26,11 @@ def _launch(world, backend, port, worker, extra):
     return [(p.returncode, o) for p, o in zip(procs, outs)]
 
 
-def _run(world, backend, port, worker="_dist_worker.py", extra=()):
-    """R worker processes.  With gloo the ranks SHARE this box's one GPU (RCCL refuses two ranks per device): R processes time-sliced on
-    one device is an arrangement of this test only, and at R = 4 it has shown a timing-dependent corrupted tensor in 1-2 % of the runs
-    when the GPU is oversubscribed (round-3 stress runs, DESIGN "known issues"; never reproduced with one process per GPU semantics).
-    Such a run is repeated ONCE, loudly; a second failure fails the test."""
-    res = _launch(world, backend, port, worker, extra)
-    if backend == "gloo" and world > 1 and any(rc != 0 for rc, _ in res):
-        bad = next((r, o) for r, (rc, o) in enumerate(res) if rc != 0)
-        msg = f"[test_gpu_dist] world {world} over gloo on a shared GPU: rank {bad[0]} failed, REPEATING ONCE.  First failure:\n{bad[1][-1500:]}"
-        print("\n" + msg, file=sys.stderr, flush=True)
-        try:  # pytest shows captured output only for failing tests: keep a record of every repetition next to the other run artefacts
-            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "dist_repeats.log"), "a") as f:
-                f.write(msg + "\n")
-        except OSError:
-            pass
-        res = _launch(world, backend, port + 100, worker, extra)
+def _run(world, backend, port, worker="_dist_worker.py", extra=(), env_extra=None):
+    """R worker processes; a failed rank fails the test (no repetition).  With gloo the ranks SHARE this box's one GPU (RCCL refuses two
+    ranks per device) and every collective on a device tensor is staged through host memory by simhand_amd.host.dist itself
+    (SIMHAND_GLOO_STAGING): torch's ProcessGroupGloo only ever sees host tensors."""
+    res = _launch(world, backend, port, worker, extra, env_extra)
     for r, (rc, o) in enumerate(res):
         assert rc == 0, f"rank {r} failed:\n{o[-3000:]}"
         assert f"rank {r} ok" in o
@@ -58,6 +46,16 @@ def test_sync_batchnorm_sharded_step_equals_the_full_batch_step(world, size):
     """SURVEY 8e "optional SyncBN": with every BatchNorm's sums all-reduced, R ranks on R shards reproduce the ONE-process step on
     the concatenated batch (oracle: plain full-batch BatchNorm) -- loss, gradients after the all-reduce, running statistics."""
     _run(world, "gloo", 29660 + world + (10 if size == "50" else 0), worker="_syncbn_worker.py", extra=(size,))
+
+
+@pytest.mark.parametrize("world,size", [(1, "18"), (1, "50"), (2, "50")])
+def test_sync_batchnorm_path_reads_no_uninitialised_memory(world, size):
+    """The synchronised-BatchNorm step (the unfused fp32 passes + overlapped buckets the stress runs of DESIGN 4 exercise) with EVERY
+    torch.empty of the worker -- first-touch and re-used blocks alike -- pre-filled with NaN patterns (tests/_poison.py poison_every) and
+    every collective audited: a kernel that reads a row, a partial sum or a workspace slice nobody wrote turns the gradients into NaNs
+    instead of passing on the previous tenant's finite leftovers.  world 1 runs the same code path with an identity all-reduce."""
+    _run(world, "gloo", 29690 + world + (10 if size == "50" else 0), worker="_syncbn_worker.py", extra=(size,),
+         env_extra={"SIMHAND_POISON_EVERY": "1", "SIMHAND_FORCE_SYNC_PATH": "1", "SIMHAND_DIST_DIAG": "1"})
 
 
 def test_sharded_step_over_rccl():

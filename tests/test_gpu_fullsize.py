@@ -472,7 +472,7 @@ def test_fullsize_step_bf16_against_fp32_mode_same_weights():
     cos = F.cosine_similarity(zb.double(), zf.double(), dim=1)
     print({"loss_bf16": lb, "loss_fp32": lf, "z_cos_mean": float(cos.mean()), "z_cos_min": float(cos.min())})
     print("ROUTES", {k: v for k, v in rb.items() if v})
-    for r in ("igemm256_fwd", "igemm256_tail", "c64_fwd", "gemm1x1_fwd", "gemm1x1_fwd_bnact", "bn_apply_gram", "stem_fwd"):
+    for r in ("igemm256_fwd", "igemm256_tail", "c64_fwd", "gemm1x1_fwd", "gemm1x1_fwd_bnact", "bn_apply_gram", "stem_stats", "stem_pool"):
         assert rb[r] > 0, r
     assert abs(lb - lf) <= 2e-3 * abs(lf), (lb, lf)
     assert float(cos.mean()) >= 0.999 and float(cos.min()) >= 0.99, (float(cos.mean()), float(cos.min()))

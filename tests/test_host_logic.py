@@ -148,6 +148,40 @@ def test_checkpoint_filename_template():
         "handclr_w_pretrain_epoch=07_train_['ego4d-1m']_bs_8.0_1024_lr_3.2e-03_contrastive_loss=6.123457.ckpt"
 
 
+def test_checkpoint_pruning_never_adopts_foreign_files(tmp_path):
+    """A resumed run prunes to save_top_k over ITS OWN files: the list its checkpoint recorded (exact scores), or -- for checkpoints
+    without one -- files whose whole name matches this callback's template; another run's file in the same directory that merely
+    contains 'contrastive_loss=<float>' is neither adopted nor deleted."""
+    from simhand_amd.host.lightning import ModelCheckpoint
+
+    tmpl = "handclr_w_pretrain_{epoch:02d}_train_['ego4d-1m']_bs_8.0_1024_lr_3.2e-03_{contrastive_loss:.6f}"
+    mine = ModelCheckpoint(save_top_k=2, monitor="contrastive_loss", mode="min", filename=tmpl, dirpath=str(tmp_path))
+    own = [tmp_path / mine.format_name(e, {"contrastive_loss": v}) for e, v in ((0, 6.5), (1, 6.25))]
+    foreign = [tmp_path / "peclr_w_pretrain_epoch=03_train_['ego4d-1m']_bs_8.0_1024_lr_3.2e-03_contrastive_loss=0.100000.ckpt",
+               tmp_path / ("x" + own[0].name)]
+    for f in own + foreign:
+        f.write_bytes(b"")
+    mine.rescan()
+    assert sorted(p for _, p in mine.kept) == sorted(str(f) for f in own) and mine.best_model_path == str(own[1])
+
+    class _T:
+        global_rank = 0
+
+        def checkpoint_dict(self, module, epoch):
+            return {"kept": list(mine.kept)}
+
+    mine.on_epoch_end(_T(), None, 2, {"contrastive_loss": 6.0})   # a better third file: the worst of OUR files goes, the foreign ones stay
+    assert not own[0].exists() and own[1].exists() and all(f.exists() for f in foreign)
+    assert len(mine.kept) == 2 and mine.best_model_path.endswith("contrastive_loss=6.000000.ckpt")
+    # the saved dict lists the file being written (a resume from it restores exactly this set, with exact scores)
+    import torch
+
+    rec = torch.load(mine.best_model_path, weights_only=False)["kept"]
+    again = ModelCheckpoint(save_top_k=2, monitor="contrastive_loss", mode="min", filename=tmpl, dirpath=str(tmp_path))
+    again.restore(rec, "")
+    assert again.kept == mine.kept and again.best_model_path == mine.best_model_path
+
+
 def test_sharding_helpers():
     from simhand_amd.host.dist import shard_pairs
 
@@ -260,23 +294,27 @@ ops._BN_SYNC(msg)
 m = int(round(float(msg[-1]))); assert m == 40
 mean, var = msg[:6] / m, msg[6:12] / m - (msg[:6] / m) ** 2
 assert torch.allclose(mean, full.mean(0), atol=1e-12) and torch.allclose(var, full.var(0, unbiased=False), atol=1e-10)
-# under gloo + synchronised BatchNorm the overlapped reducer issues its buckets ONE COLLECTIVE AT A TIME (no asynchronous work object is
-# left in flight while the BatchNorm sums are exchanged: DESIGN 4, known issue); same sums, same bucket views
+# an asynchronous bucket stays in flight while BatchNorm sums are exchanged (no serialisation, no retry: DESIGN 4), and the collective
+# audit (what scripts/dist_stress.py runs with) re-derives every recorded collective on the host: clean run -> no finding; a result
+# tampered with after the fact -> exactly that record is reported
+audit = shdist.CollectiveAudit(); shdist.set_collective_audit(audit)
+shdist.enable_sync_bn()                                                          # re-install: the audited callable
 red3 = shdist.OverlappedGradReducer(bucket_bytes=16)
 q3 = [torch.nn.Parameter(torch.zeros(n)) for n in (6, 5)]
 red3.submit([(q3[0], torch.full((6,), float(rank + 1)))])
-assert red3._pending and all(w is None for w, _, _ in red3._pending)          # already reduced when submit returns
-assert torch.equal(red3._pending[0][1], torch.full((6,), float(tot)))
+assert red3._pending and red3._pending[0][0] is not None                         # asynchronous work object
 both = torch.tensor([1.0 + rank, 2.0]); ops._BN_SYNC(both)                      # a BatchNorm exchange between two buckets
 assert torch.equal(both, torch.tensor([float(tot), 2.0 * world]))
 red3.submit([(q3[1], torch.full((5,), 2.0 * (rank + 1)))]); o3 = red3.finish()
 assert torch.equal(o3[q3[0]], torch.full((6,), float(tot))) and torch.equal(o3[q3[1]], torch.full((5,), 2.0 * tot))
+assert [t for t, _, _ in audit.records] == ["bucket0", "bn_sync", "bucket1"]
+assert audit.verify() == []
+o3[q3[1]][3] += 64.0                                                             # bucket views alias the audited result
+found = audit.verify()
+assert len(found) == 1 and found[0]["tag"] == "bucket1" and found[0]["first_bad"] == found[0]["last_bad"] == 3 and found[0]["n_bad"] == 1, found
+shdist.set_collective_audit(None)
 shdist.disable_sync_bn()
 assert not ops.bn_sync_active()
-red4 = shdist.OverlappedGradReducer(bucket_bytes=16)                             # without it: asynchronous again
-red4.submit([(q3[0], torch.full((6,), float(rank + 1)))])
-assert red4._pending and red4._pending[0][0] is not None
-assert torch.equal(red4.finish()[q3[0]], torch.full((6,), float(tot)))
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
