@@ -69,7 +69,8 @@ __device__ __forceinline__ int sr_pos(int px) { return px ^ ((px >> 1) & 1); }
 template <int MODE, bool LT>
 __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
   constexpr int SLOT = 2048, NSLOT = MODE == 2 ? 16 : 32, D = 2;  // D: steps between a row's request and its use (2 D + 7 <= NSLOT rows)
-  constexpr int PROW = 112 * 128;                                  // one conv row of 112 pixels x 64 channels in the MODE 2 rings
+  constexpr int PROW = 113 * 128;                                  // one conv row of 112 pixels x 64 channels in the MODE 2 rings + one ZERO pixel
+                                                                   // (slot 112: what the pooling reads for column -1)
   __shared__ __attribute__((aligned(16))) char ring[NSLOT * SLOT];
   __shared__ __attribute__((aligned(16))) char tbuf[(LT && MODE == 0) ? 7 * 2048 : 16];
   __shared__ __attribute__((aligned(16))) char yring[MODE == 2 ? 4 * PROW : 16];  // raw conv rows (storage type), slot = row & 3
@@ -144,26 +145,39 @@ __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
   }
   const int pw = tid >> 3, cv = tid & 7;   // pooling role of this thread: pooled pixel, 8-channel chunk
   const int pho = p.ho >> 1, pwo = p.wo >> 1;
-  // pooled row q from conv rows 2 q - 1 .. 2 q + 1 of the rings (all complete and visible: the caller is behind a barrier that follows them)
+  // byte offsets (inside a ring row) of this thread's chunk of the three window columns 2 pw - 1 + kw; column -1 = the zero pixel
+  int pcol[3];
+  if (MODE == 2) {
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int col = 2 * pw - 1 + kw;
+      pcol[kw] = col < 0 ? 112 * 128 + cv * 16 : sr_pos(col) * 128 + ((cv ^ (col & 3)) * 16);
+    }
+    // zero for the block's life: the zero pixel of every ring row; ring slot 3 = "conv row -1" until conv row 3 overwrites it
+    for (int i = tid; i < 4 * 8; i += 448) {
+      *reinterpret_cast<uint4*>(aring + (i >> 3) * PROW + 112 * 128 + (i & 7) * 16) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(yring + (i >> 3) * PROW + 112 * 128 + (i & 7) * 16) = make_uint4(0, 0, 0, 0);
+    }
+    for (int i = tid; i < PROW / 16; i += 448) *reinterpret_cast<uint4*>(aring + 3 * PROW + i * 16) = make_uint4(0, 0, 0, 0);
+  }
+  // pooled row q from conv rows 2 q - 1 .. 2 q + 1 of the rings (all complete and visible: the caller is behind a barrier that follows them).
+  // key = (a_bits + 1) << 16 | (8 - tap): a >= 0, so keys order like (activation, earlier tap first): one v_max_u32 per tap and element; the
+  // zero pixel / zero row standing in for taps outside the image hold 0 < a_bits + 1 and never win
   auto pool_row = [&](int q) __attribute__((always_inline)) {
     unsigned key[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) key[e] = 0u;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
-      const int row = 2 * q - 1 + kh;
-      const char* ab = aring + (row & 3) * PROW;
+      const char* ab = aring + ((2 * q - 1 + kh) & 3) * PROW;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        const int col = 2 * pw - 1 + kw;
-        const bool ok = row >= 0 && col >= 0;            // (the bottom / right edges never leave the image: 2 * 55 + 1 = 111)
-        const int cc = col < 0 ? 0 : col;
-        const uint4 v = *reinterpret_cast<const uint4*>(ab + sr_pos(cc) * 128 + ((cv ^ (cc & 3)) * 16));
-        const unsigned m = ok ? 0xffffffffu : 0u, code = ok ? (unsigned)(8 - (kh * 3 + kw)) : 0u;
-        const unsigned w4[4] = {v.x & m, v.y & m, v.z & m, v.w & m};
+        const uint4 v = *reinterpret_cast<const uint4*>(ab + pcol[kw]);
+        const unsigned code = (unsigned)(8 - (kh * 3 + kw));
+        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const unsigned k0 = ((w4[i] & 0xffffu) << 8) | code, k1 = ((w4[i] >> 16) << 8) | code;
+          const unsigned k0 = (w4[i] << 16) | code, k1 = (w4[i] & 0xffff0000u) | code;
           key[2 * i] = k0 > key[2 * i] ? k0 : key[2 * i];              // first maximum wins: equal a -> the larger 8 - tap = the earlier tap
           key[2 * i + 1] = k1 > key[2 * i + 1] ? k1 : key[2 * i + 1];
         }
@@ -171,24 +185,23 @@ __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
     }
     const long long o = (((long long)img * pho + q) * pwo + pw) * 64 + cv * 8;
     uint4 po;
-    po.x = (key[0] >> 8) | ((key[1] >> 8) << 16);
-    po.y = (key[2] >> 8) | ((key[3] >> 8) << 16);
-    po.z = (key[4] >> 8) | ((key[5] >> 8) << 16);
-    po.w = (key[6] >> 8) | ((key[7] >> 8) << 16);
-    unsigned tap[8], lo = 0, hi = 0;
+    po.x = ((key[0] >> 16) | (key[1] & 0xffff0000u)) - 0x00010001u;   // (every window has a real tap: both halves >= 1, no borrow)
+    po.y = ((key[2] >> 16) | (key[3] & 0xffff0000u)) - 0x00010001u;
+    po.z = ((key[4] >> 16) | (key[5] & 0xffff0000u)) - 0x00010001u;
+    po.w = ((key[6] >> 16) | (key[7] & 0xffff0000u)) - 0x00010001u;
+    unsigned tap[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      tap[e] = 8u - (key[e] & 0xffu);
-      if (e < 4) lo |= tap[e] << (8 * e);
-      else hi |= tap[e] << (8 * (e - 4));
-    }
+    for (int e = 0; e < 8; ++e) tap[e] = 8u - (key[e] & 0xffu);
+    const unsigned lo = tap[0] | (tap[1] << 8) | (tap[2] << 16) | (tap[3] << 24), hi = tap[4] | (tap[5] << 8) | (tap[6] << 16) | (tap[7] << 24);
     unsigned yw[8];
     if (p.ywin != nullptr) {
+      const int rt0 = ((2 * q - 1) & 3) * PROW, rt1 = ((2 * q) & 3) * PROW, rt2 = ((2 * q + 1) & 3) * PROW;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {   // the winner's raw conv output: a 2-byte gather from the y ring
-        const int kh = (int)((tap[e] * 11u) >> 5), kw = (int)tap[e] - 3 * kh;
-        const int row = 2 * q - 1 + kh, col = 2 * pw - 1 + kw;   // a winner is always a valid tap
-        yw[e] = *reinterpret_cast<const unsigned short*>(yring + (row & 3) * PROW + sr_pos(col) * 128 + ((cv ^ (col & 3)) * 16) + e * 2);
+      for (int e = 0; e < 8; ++e) {   // the winner's raw conv output: a 2-byte gather from the y ring (a winner is always a real tap)
+        const unsigned kh = (tap[e] * 11u) >> 5, kw = tap[e] - 3u * kh;
+        const int ro = kh == 0 ? rt0 : (kh == 1 ? rt1 : rt2);
+        const int co = kw == 0 ? pcol[0] : (kw == 1 ? pcol[1] : pcol[2]);
+        yw[e] = *reinterpret_cast<const unsigned short*>(yring + ro + co + e * 2);
       }
     }
     *reinterpret_cast<uint4*>(p.pooled + o) = po;
@@ -265,6 +278,9 @@ __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
         oa.y = pack_bf16x2(av[2], av[3]);
         oa.z = pack_bf16x2(av[4], av[5]);
         oa.w = pack_bf16x2(av[6], av[7]);
+        // the ring holds a_bits + 1 (a >= 0: no carry into the sign): the all-zero stand-ins for taps outside the image then lose to
+        // EVERY real tap, a real tap whose activation is zero included (first-wins among real taps only, as ATen)
+        oa.x += 0x00010001u; oa.y += 0x00010001u; oa.z += 0x00010001u; oa.w += 0x00010001u;
         const int off = (ho & 3) * PROW + wr_off[j];
         *reinterpret_cast<uint4*>(yring + off) = o;
         *reinterpret_cast<uint4*>(aring + off) = oa;

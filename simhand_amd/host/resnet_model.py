@@ -171,8 +171,12 @@ class ResNetEngine:
         # (sh_dgrad_opts.sub_grad) instead of scatter-added onto it afterwards (attribute: A/B timing only)
         self.merge_shortcut = True
         # stem at 224^2, 16-bit storage: conv1 run twice in the forward and once more in the backward instead of storing its raw output
-        # (attribute: A/B timing only)
-        self.stem_two_pass = True
+        # (ops.stem_conv_stats / stem_conv_bn_relu_pool / stem_backward_fused).  Built, bit-exact against the one-pass chain and
+        # 13 GB / step lighter on HBM, but OFF by default: round 4 measured it neutral in isolation (forward 2.21 vs 2.30 ms, backward
+        # 3.22 vs 3.39 ms at 2048 images) and +0.4 .. +2 ms inside the step -- the one-pass kernels are HBM-bound, the fused ones
+        # VALU / MFMA-bound at one or two waves per SIMD, and under the step's power state core-bound kernels lose what they saved
+        # (DESIGN 3b).  bench.py --engine stem_two_pass=1 times it.
+        self.stem_two_pass = False
         # multi-GPU: host.dist.OverlappedGradReducer -- finished parameter gradients go out block by block during backward
         self.grad_reducer = None
 

@@ -192,9 +192,9 @@ def _check_bf16(res, loss_band, zcos_floor, gmed_floor, gp10_floor, flip_frac):
     assert res["flips"] <= flip_frac * res["mask_elems"], (res["flips"], res["mask_elems"])
 
 
-BF16_ROUTES_RN50 = ("stem_stats", "stem_pool", "stem_bwd_fused", "c64_fwd", "c64_dgrad", "gemm1x1_fwd", "gemm1x1_fwd_bnact", "gemm1x1_dgrad", "igemm128_fwd",
+BF16_ROUTES_RN50 = ("stem_fwd", "stem_bn_pool", "c64_fwd", "c64_dgrad", "gemm1x1_fwd", "gemm1x1_fwd_bnact", "gemm1x1_dgrad", "igemm128_fwd",
                     "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
-                    "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_colsum", "bn_apply_gram", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
+                    "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_apply_gram", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
                     "bn_bwd_apply", "ntxent_fwd", "ntxent_bwd", "fwd_chain", "dgrad_dysrc")
 
 
@@ -212,6 +212,38 @@ def test_config1_rn50_handclr_w_bf16_every_route_against_oracle():
     gp = res["grad_plain"]
     assert gp["median"] >= 0.93 and gp["p10"] >= 0.80, ("unconditioned gradient cosines", gp)
     assert res["z_min_cos_hip"] >= 0.995, res["z_min_cos_hip"]
+
+
+def test_two_pass_stem_step_equals_the_default_step():
+    """ResNetEngine.stem_two_pass (conv1 run twice in the forward, a third time inside the fused backward; opt-in) against the
+    default one-pass stem on the same weights and batch: the pooled activation is bit-identical given the same BatchNorm state, the
+    two statistics kernels agree to fp32 round-off, so the step's loss and the stem's gradients agree to round-off / summation order."""
+    from simhand_amd import ops
+
+    wcfg = dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg")
+    b = 6
+    batch = {k: v.to(DEV) for k, v in orc.synthetic_batch(b, size=224, seed=21).items()}
+    om = _oracle("simhand_w", "50", wcfg, 21, 0.1)
+    res = {}
+    for two_pass in (False, True):
+        model = _product("HandCLR_W", "50", wcfg, om, torch.bfloat16, b)
+        model.encoder.engine.stem_two_pass = two_pass
+        ops.route_reset()
+        out = model.training_step(batch, 0)
+        out["loss"].backward()
+        rc = ops.route_counts()
+        named = dict(model.named_parameters())
+        res[two_pass] = (float(out["loss"].detach()), {k: named[k].grad.detach().float().cpu().clone() for k in
+                                                       ("encoder.features.0.weight", "encoder.features.1.weight", "encoder.features.1.bias",
+                                                        "encoder.features.4.0.conv1.weight")}, rc)
+        del model
+    (l0, g0, r0), (l1, g1, r1) = res[False], res[True]
+    assert r0["stem_fwd"] == 1 and r0["stem_bn_pool"] >= 1 and r0["wgrad_stem"] == 1 and r0["stem_bwd_fused"] == 0
+    assert r1["stem_stats"] == 1 and r1["stem_pool"] == 1 and r1["stem_bwd_fused"] == 1 and r1["stem_fwd"] == 0 and r1["wgrad_stem"] == 0
+    assert abs(l0 - l1) <= 2e-5 * abs(l0), (l0, l1)
+    for k in g0:
+        err = (g0[k] - g1[k]).norm() / g0[k].norm()
+        assert float(err) <= 5e-3, (k, float(err))
 
 
 def test_config1_rn50_bf16_plain_random_init_tracks_the_twin():
