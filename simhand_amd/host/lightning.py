@@ -96,9 +96,13 @@ class ModelCheckpoint:
         return re.compile("^" + rx + r"\.ckpt$")
 
     def restore(self, kept, best: str = "") -> None:
-        """Adopt the (score key, path) list a checkpoint of THIS run recorded: exact scores, and only files the run wrote itself."""
-        self.kept = sorted(((float(k), str(p)) for k, p in kept if os.path.exists(p)), key=lambda t: t[0])
-        self.best_model_path = self.kept[0][1] if self.kept else (best or "")
+        """Adopt the (score key, path) list a checkpoint of THIS run recorded: exact scores, and only files the run wrote itself -- and
+        only those in THIS callback's directory (Lightning does the same: a resumed run with another dirpath starts its own top-k and
+        never prunes the run it was started from)."""
+        here = os.path.abspath(self.dirpath) if self.dirpath else None
+        self.kept = sorted(((float(k), str(p)) for k, p in kept
+                            if os.path.exists(p) and (here is None or os.path.abspath(os.path.dirname(p)) == here)), key=lambda t: t[0])
+        self.best_model_path = self.kept[0][1] if self.kept else ""
 
     def rescan(self) -> None:
         """Fallback for checkpoints that carry no kept-list (written before round 4): rebuild `kept` from the files in dirpath whose

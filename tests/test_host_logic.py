@@ -180,6 +180,12 @@ def test_checkpoint_pruning_never_adopts_foreign_files(tmp_path):
     again = ModelCheckpoint(save_top_k=2, monitor="contrastive_loss", mode="min", filename=tmpl, dirpath=str(tmp_path))
     again.restore(rec, "")
     assert again.kept == mine.kept and again.best_model_path == mine.best_model_path
+    # a resumed run writing to ANOTHER directory starts its own top-k: the run it was started from is never pruned (GPU test
+    # tests/test_gpu_main.py resumes from b/checkpoints into c/checkpoints and then exports the checkpoint it resumed from)
+    (tmp_path / "elsewhere").mkdir()
+    other = ModelCheckpoint(save_top_k=1, monitor="contrastive_loss", mode="min", filename=tmpl, dirpath=str(tmp_path / "elsewhere"))
+    other.restore(rec, "")
+    assert other.kept == [] and other.best_model_path == ""
 
 
 def test_sharding_helpers():
