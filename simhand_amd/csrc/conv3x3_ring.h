@@ -25,6 +25,9 @@ struct R128Args {
 bool r128_supported(int dtype, int cin, int cout, int r, int s, int stride, int pad, int w, long long q_total);
 int r128_blocks(long long q_total);
 int launch_r128(const R128Args& a, hipStream_t s);
+// stride-2 data gradient (128 -> 128, 3x3): a.x = dy [N][H][W][128], a.out = dx [N][2H][2W][128], a.w = CRSK; a.H, a.W, q_total, div_*: the dy grid
+bool r128_s2dgrad_supported(int dtype, int cin, int cout, int r, int s, int stride, int pad, int h, int w, int ho, int wo, long long q_total);
+int launch_r128_s2dgrad(const R128Args& a, hipStream_t s);
 void r128_enable(int on);
 
 }  // namespace sh

@@ -290,6 +290,198 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
   }
 }
 
+// ---- 3x3 / STRIDE 2 data gradient with 128 channels (the stage-2 entry block's conv2: dy 28 x 28 -> dx 56 x 56) on the same ring ------------
+// A stride-2 data gradient is four stride-1 problems over the OUTPUT (dy) grid, one per parity class (p, u) of the dx pixel
+// (2 a + p, 2 b + u): x row i = 2 o - 1 + r gives r = i + 1 - 2 o, so p = 0 takes filter row 1 at dy row a, p = 1 filter row 0 at dy row
+// a + 1 and filter row 2 at dy row a (columns alike): 1 + 2 + 2 + 4 = 9 tap visits with shifts 0 / +1 -- the MFMA work of the stride-1
+// layer one stage later (conv3x3_r128_kernel<2>, 496 us at 2048 x 28^2).  The parity-class launches of the tile kernel ran the same work in
+// 1039 us: 50 176 tiles with 2 - 8 k-steps each, two barriers per k-step, every tile re-staging its dy rows per tap.  Here a block owns 256
+// padded dy positions: the dy tile (+ halo) is staged ONCE, the four classes run back to back over it (2 + 4 + 4 + 8 = 18 k-steps of
+// [tap x 64 channels], weights streamed per k-step as in the stride-1 kernel), each class ends in its own store epilogue into its
+// parity plane of dx, issued two stores per k-step UNDER the next class's MFMAs (second accumulator set).  Stores go to a sink for pad
+// positions, so every wave issues exactly 8 per class and the counted vmcnt over the in-order queue (weights two steps ahead, the store
+// pairs of the last two steps allowed in flight) stays exact.
+__device__ uint4 g_r128_sink[64 * 8 * 8];   // [wave-lane][mi, j]: 16-B slots nobody reads
+
+struct R128S2Step { int t, h, dr, ds, last, cls; };
+__device__ constexpr R128S2Step kS2Steps[18] = {
+    // class 0 (p 0, u 0): tap (1, 1)
+    {4, 0, 0, 0, 0, 0}, {4, 1, 0, 0, 1, 0},
+    // class 1 (p 0, u 1): taps (1, 0) at column b + 1, (1, 2) at column b
+    {3, 0, 0, 1, 0, 1}, {5, 0, 0, 0, 0, 1}, {3, 1, 0, 1, 0, 1}, {5, 1, 0, 0, 1, 1},
+    // class 2 (p 1, u 0): taps (0, 1) at row a + 1, (2, 1) at row a
+    {1, 0, 1, 0, 0, 2}, {7, 0, 0, 0, 0, 2}, {1, 1, 1, 0, 0, 2}, {7, 1, 0, 0, 1, 2},
+    // class 3 (p 1, u 1): taps (0, 0), (0, 2), (2, 0), (2, 2)
+    {0, 0, 1, 1, 0, 3}, {2, 0, 1, 0, 0, 3}, {6, 0, 0, 1, 0, 3}, {8, 0, 0, 0, 0, 3},
+    {0, 1, 1, 1, 0, 3}, {2, 1, 1, 0, 0, 3}, {6, 1, 0, 1, 0, 3}, {8, 1, 0, 0, 1, 3}};
+
+__global__ __launch_bounds__(512, 1) void conv3x3_r128_s2dgrad_kernel(R128Args p) {
+  constexpr int BM = 256, BN = 128, MI = 4, NI = 4, HALO = 32;
+  constexpr int RROWS = BM + 2 * HALO;  // 320 ring rows: positions m0 - 32 .. m0 + 288
+  constexpr int HALF = RROWS * 128;
+  constexpr int A_BYTES = 2 * HALF;
+  constexpr int BST = BN * 128;
+  constexpr int NST = 3;
+  constexpr int NK = 18;
+  __shared__ __attribute__((aligned(16))) char smem[A_BYTES + NST * BST];
+
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int pl = (li & 4) == ((li & 8) >> 1) ? 2 * ((li & 3) + ((li >> 3) << 2)) : 2 * (li - 4) + 1;
+  const int WP = p.W + 1;   // p.H, p.W: the dy grid (the ring's grid); dx is 2 H x 2 W
+  int tile;
+  {
+    const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+  }
+  const long long m0 = (long long)tile * BM;
+
+  auto dma16 = [](const void* src, unsigned lds_addr) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src));
+  };
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int slot = lane & 7, r8l = lane >> 3;
+  const char* zsrc = reinterpret_cast<const char*>(g_r128_zero_page) + slot * 16;
+
+  auto fill_half = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int rb = wave + 8 * i;
+      const int j = rb * 8 + r8l;
+      const long long q = m0 - HALO + j;
+      const bool in = q >= 0 && q < p.q_total;
+      const unsigned qu = in ? (unsigned)q : 0u;
+      const unsigned img = fdiv(qu, p.div_pp);
+      const unsigned rem = qu - img * p.div_pp.d;
+      const unsigned hp = fdiv(rem, p.div_wp);
+      const unsigned wp = rem - hp * p.div_wp.d;
+      const bool ok = in && hp - 1u < (unsigned)p.H && wp - 1u < (unsigned)p.W;
+      const unsigned pix = (img * (unsigned)p.H + (hp - 1u)) * (unsigned)p.W + (wp - 1u);
+      const int chunk = slot ^ ((j >> 1) & 7);
+      const char* src = ok ? reinterpret_cast<const char*>(p.x + (unsigned long long)pix * 128 + h * 64 + chunk * 8) : zsrc;
+      dma16(src, smem_addr + h * HALF + rb * 8 * 128);
+    }
+  };
+  auto key_b = [](int row) __attribute__((always_inline)) -> int { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); };
+  const int lrow = wave * 8 + r8l;
+  const char* wb = reinterpret_cast<const char*>(p.w + (long long)lrow * (9 * 128) + (slot ^ key_b(lrow)) * 8);
+  // weight tile of k-step ks: rows lrow, lrow + 64 of [128 dx channels][64 dy channels] of tap t, half h (past the end: the zero page)
+  auto dma_w = [&](int ks, int t, int h) __attribute__((always_inline)) {
+    const bool live = ks < NK;
+    const unsigned dst = smem_addr + A_BYTES + (unsigned)(ks % NST) * BST + wave * 8 * 128;
+    const char* s0 = wb + (t * 128 + h * 64) * 2;
+    dma16(live ? s0 : zsrc, dst);
+    dma16(live ? s0 + 64ll * (9 * 128) * 2 : zsrc, dst + 64 * 128);
+  };
+
+  // prologue: BOTH halves of the dy tile (class 0 needs the second one in its second k-step), then the weights of steps 0 and 1
+  fill_half(0);
+  fill_half(1);
+  dma_w(0, kS2Steps[0].t, kS2Steps[0].h);
+  dma_w(1, kS2Steps[1].t, kS2Steps[1].h);
+
+  const int a_base = (wm * 64) * 128;
+  const int rowb0 = wn * 64 + (li >> 2) * 8 + (li & 3);
+  const int fbo = rowb0 * 128 + ((g ^ key_b(rowb0)) * 16);
+
+  // positions -> dx pixels of class (0, 0) for this lane's output rows (pad positions: the sink)
+  unsigned pix0[MI];
+  bool oks[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const long long q = m0 + wm * 64 + mi * 16 + pl;
+    const bool in = q < p.q_total;
+    const unsigned qu = in ? (unsigned)q : 0u;
+    const unsigned img = fdiv(qu, p.div_pp);
+    const unsigned rem = qu - img * p.div_pp.d;
+    const unsigned hp = fdiv(rem, p.div_wp);
+    const unsigned wp = rem - hp * p.div_wp.d;
+    oks[mi] = in && hp - 1u < (unsigned)p.H && wp - 1u < (unsigned)p.W;
+    pix0[mi] = (img * (unsigned)(2 * p.H) + 2u * (hp - 1u)) * (unsigned)(2 * p.W) + 2u * (wp - 1u);
+  }
+  const int ch0 = wn * 64 + g * 8;
+  char* sink = reinterpret_cast<char*>(g_r128_sink) + (size_t)lane * 8 * 16;
+
+  // TWO accumulator sets: class c accumulates into set c & 1 while the finished class c - 1 leaves set (c - 1) & 1 two stores per k-step
+  // (a store instruction of 64 x 16 B occupies the CU's memory pipeline ~70 cycles: eight of them back to back per wave stalled every
+  // class end for ~2 us with the matrix pipes idle -- 770 us per launch in that first form)
+  f32x4 acc[2][MI][NI];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[b][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // store n (0..7) of finished class cls: output row mi = n >> 1, channel group j = n & 1; pad positions -> the sink (exact store counts)
+  auto store_one = [&](int cls, int n) __attribute__((always_inline)) {
+    const int b = cls & 1, mi = n >> 1, j = n & 1;
+    const unsigned poff = (unsigned)((cls >> 1) * (2 * p.W) + (cls & 1));
+    const f32x4 lo = acc[b][mi][2 * j], hi = acc[b][mi][2 * j + 1];
+    uint4 o;
+    o.x = pack_bf16x2(lo[0], lo[1]);
+    o.y = pack_bf16x2(lo[2], lo[3]);
+    o.z = pack_bf16x2(hi[0], hi[1]);
+    o.w = pack_bf16x2(hi[2], hi[3]);
+    char* dst = oks[mi] ? reinterpret_cast<char*>(p.out + (unsigned long long)(pix0[mi] + poff) * 128 + ch0 + 32 * j) : sink + (mi * 2 + j) * 16;
+    *reinterpret_cast<uint4*>(dst) = o;
+    acc[b][mi][2 * j] = (f32x4){0.f, 0.f, 0.f, 0.f};       // the set is clean again when class cls + 2 takes it
+    acc[b][mi][2 * j + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    const R128S2Step st = kS2Steps[ks];
+    const int cur = st.cls & 1;
+    // the class that finished before this one leaves in steps first + 0 .. first + 3 of this class, two stores per step (n = 2 i, 2 i + 1)
+    const int first = st.cls == 1 ? 2 : (st.cls == 2 ? 6 : 10);
+    const int si = st.cls >= 1 && ks - first >= 0 && ks - first < 4 ? ks - first : -1;   // this step's store pair, or none
+    // vector-memory operations retire in order.  Behind the weights of step ks the queue may hold: the weights of step ks + 1 (2) and the
+    // store pairs of steps ks - 1 and ks - 2 (steps 2 .. 13 carry one)
+    const int allow = 2 + (ks - 1 >= 2 && ks - 1 <= 13 ? 2 : 0) + (ks - 2 >= 2 && ks - 2 <= 13 ? 2 : 0);
+    if (allow == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    else if (allow == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    {
+      const int kn = ks + 2 < NK ? ks + 2 : 0;
+      dma_w(ks + 2, kS2Steps[kn].t, kS2Steps[kn].h);
+    }
+    const char* sa = smem + st.h * HALF + a_base;
+    const int ob = A_BYTES + (ks % NST) * BST + fbo;
+    uint4 fb[2][NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int on = ob + ((ni >> 1) * 32 + (ni & 1) * 4) * 128;
+      fb[0][ni] = *reinterpret_cast<const uint4*>(smem + on);
+      fb[1][ni] = *reinterpret_cast<const uint4*>(smem + (on ^ 64));
+    }
+    const int trow = HALO + pl + st.dr * WP + st.ds;
+    const int ra = trow * 128 + ((g ^ ((trow >> 1) & 7)) * 16);
+    uint4 fa[2][2];
+    fa[0][0] = *reinterpret_cast<const uint4*>(sa + ra);
+    fa[0][1] = *reinterpret_cast<const uint4*>(sa + (ra ^ 64));
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      if (mi + 1 < MI) {
+        fa[(mi + 1) & 1][0] = *reinterpret_cast<const uint4*>(sa + (mi + 1) * 16 * 128 + ra);
+        fa[(mi + 1) & 1][1] = *reinterpret_cast<const uint4*>(sa + (mi + 1) * 16 * 128 + (ra ^ 64));
+      }
+      if (si >= 0 && (mi == 1 || mi == 3)) store_one(st.cls - 1, 2 * si + (mi >> 1));   // under the MFMAs of this row group
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[cur][mi][ni] = sh_mfma16(fb[0][ni], fa[mi & 1][0], acc[cur][mi][ni]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[cur][mi][ni] = sh_mfma16(fb[1][ni], fa[mi & 1][1], acc[cur][mi][ni]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // the last class (3) leaves at the end; its stores drain under the next block's prologue
+#pragma unroll
+  for (int n = 0; n < 8; ++n) store_one(3, n);
+}
+
 static hook_t g_use_r128{-1};  // -1 = simhand_test_switch(SH_SW_R128) (default on), 0 / 1 forced
 void r128_enable(int on) { g_use_r128 = on < 0 ? -1 : (on ? 1 : 0); }
 void hooks_reset_r128() { g_use_r128 = -1; }
@@ -302,6 +494,22 @@ bool r128_supported(int dtype, int cin, int cout, int r, int s, int stride, int 
 }
 
 int r128_blocks(long long q_total) { return (int)((q_total + 255) / 256); }
+
+// the stride-2 data gradient: dy grid H x W (a0.H, a0.W), dx 2 H x 2 W
+bool r128_s2dgrad_supported(int dtype, int cin, int cout, int r, int s, int stride, int pad, int h, int w, int ho, int wo, long long q_total) {
+  const int env = sw(SH_SW_R128);
+  const int hk = g_use_r128;
+  return (hk >= 0 ? hk : env) && dtype == SH_BF16 && cin == 128 && cout == 128 && r == 3 && s == 3 && stride == 2 && pad == 1 && h == 2 * ho &&
+         w == 2 * wo && wo + 2 <= 32 && q_total < (1ll << 31) && q_total >= 256 * 64 && (long long)q_total * 4 < (1ll << 31);
+}
+
+int launch_r128_s2dgrad(const R128Args& a0, hipStream_t s) {
+  R128Args a = a0;
+  a.tiles = r128_blocks(a.q_total);
+  route_hit(SH_ROUTE_R128_DGRAD);
+  conv3x3_r128_s2dgrad_kernel<<<a.tiles, 512, 0, s>>>(a);
+  return 0;
+}
 
 int launch_r128(const R128Args& a0, hipStream_t s) {
   R128Args a = a0;

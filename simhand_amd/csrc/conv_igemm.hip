@@ -1859,6 +1859,22 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   if (sub == nullptr && use_r128_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr && x2 == nullptr &&
       src == nullptr && f8 == nullptr)
     return launch_r128_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream);
+  // 128 -> 128 3x3 / stride 2 (the stage-2 entry block's conv2), plain store: the four parity classes over ONE staged dy tile (conv3x3_ring.hip)
+  if (sub == nullptr && fuse == nullptr && accumulate == 0 && bias == nullptr && res_grad == nullptr && x2 == nullptr && src == nullptr &&
+      f8 == nullptr &&
+      r128_s2dgrad_supported(d->dtype, d->cin, d->cout, d->r, d->s, d->stride, d->pad, d->h, d->w, d->ho, d->wo,
+                             (long long)d->n * (d->ho + 1) * (d->wo + 1))) {
+    R128Args c;
+    c.x = (const bf16_t*)dy; c.w = (const bf16_t*)wt; c.out = (bf16_t*)dx; c.partial = nullptr;
+    c.fy = nullptr; c.fscale = c.fshift = nullptr; c.relu = 0;
+    c.N = d->n; c.H = d->ho; c.W = d->wo; c.dgrad = 1;
+    c.q_total = (long long)d->n * (d->ho + 1) * (d->wo + 1);
+    c.tiles = 0;
+    c.div_pp = make_fastdiv((unsigned)((d->ho + 1) * (d->wo + 1)));
+    c.div_wp = make_fastdiv((unsigned)(d->wo + 1));
+    launch_r128_s2dgrad(c, (hipStream_t)stream);   // (SH_ROUTE_DGRAD_PARITY was counted above: still four parity classes, one launch)
+    return check_launch("conv2d_dgrad (3x3 / stride 2 ring)");
+  }
   if (f8 != nullptr) {
     a.x_state = f8->dy_state;
     a.w_state = f8->w_state;

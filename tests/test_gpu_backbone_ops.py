@@ -536,6 +536,46 @@ def test_c64_conv3x3_fwd_dgrad(shape):
     _check(part.sum(0).cpu(), part_ref.sum(0).cpu(), 1e-5, "partials vs tile kernel")
 
 
+R128_S2_SHAPES = [(24, 56, 56), (40, 40, 60), (72, 34, 30), (96, 18, 46)]  # n, h, w of dx (even; wo + 2 <= 32; >= 16384 padded dy positions)
+
+
+@pytest.mark.parametrize("shape", R128_S2_SHAPES)
+def test_r128_conv3x3_stride2_dgrad(shape):
+    """Round 4: the 128 -> 128 3x3 / STRIDE-2 data gradient on the ring kernel (four parity classes over one staged dy tile, one store
+    epilogue per class) against fp32 torch, and against the parity-class launches of the tile kernel it replaces (another summation
+    order of the same bf16 products).  Every dx pixel is written exactly once: the output starts as NaN."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    n, h, w = shape
+    lib = ops._lib_dev()
+    g = torch.Generator().manual_seed(n * 100 + h)
+    x = _rnd(torch.randn(n, 128, h, w, generator=g), dtype).requires_grad_(True)
+    wt = _rnd(torch.randn(128, 128, 3, 3, generator=g) / 34.0, dtype)
+    y = F.conv2d(x, wt, stride=2, padding=1)
+    dy = _rnd(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    d = ops.conv_desc(n, h, w, 128, 128, 3, 3, 2, 1, dtype)
+    wtd = ops.pack_crsk(wt.detach().to(DEV), dtype)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    dx = torch.full((n, h, w, 128), float("nan"), dtype=dtype, device=DEV)
+    ops.route_reset()
+    ops.conv2d_dgrad(d, dyd, wtd, dx=dx)
+    rc = ops.route_counts()
+    assert rc["r128_dgrad"] == 1 and rc["dgrad_parity"] == 1 and rc["igemm128_dgrad"] == 0, rc
+    assert bool(torch.isfinite(dx.float()).all())
+    _check(dx.float().cpu().permute(0, 3, 1, 2), x.grad, _tol(dtype), "stride-2 dgrad (ring)")
+    lib.simhand_test_conv3x3_r128_enable(0)
+    try:
+        ops.route_reset()
+        dx_ref = ops.conv2d_dgrad(d, dyd, wtd)
+        assert ops.route_counts()["r128_dgrad"] == 0
+    finally:
+        lib.simhand_test_conv3x3_r128_enable(-1)
+    assert (dx.float() - dx_ref.float()).abs().max().item() <= 2.0 ** -7 * dx_ref.float().abs().max().item()
+    assert (dx != dx_ref).float().mean().item() < 0.05
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # 128 -> 128 channel 3x3: activation tile staged once in an LDS ring, weights streamed per tap (conv3x3_ring.hip)
 # ---------------------------------------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@ SHAPES = {
     (64, 256, 1, 1, 56): ("gemm1x1_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (256, 64, 1, 1, 56): ("gemm1x1_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (256, 128, 1, 1, 56): ("gemm1x1_fwd", "gemm1x1_dgrad", "wgrad_plain"),
-    (128, 128, 3, 2, 56): ("igemm128_fwd", "igemm128_dgrad", "wgrad3x3"),
+    (128, 128, 3, 2, 56): ("igemm128_fwd", "r128_dgrad", "wgrad3x3"),   # round 4: the four parity classes on the LDS-ring kernel
     (128, 512, 1, 1, 28): ("gemm1x1_fwd", "igemm128_dgrad", "wgrad_plain"),
     (256, 512, 1, 2, 56): ("igemm256_fwd", "igemm128_dgrad", "wgrad_generic"),
     (512, 128, 1, 1, 28): ("igemm128_fwd", "gemm1x1_dgrad", "wgrad_plain"),
