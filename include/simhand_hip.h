@@ -125,7 +125,8 @@ enum sh_test_switch {
   SH_SW_STEM_WG256 = 11,   /* 64 x 256 tile of the stem weight gradient (default 1) */
   SH_SW_STEM_RING = 12,    /* stem_ring_fwd_kernel at 224 x 224 (default 1) */
   SH_SW_STEM_RING_LT = 13, /* its linear stores (default 1) */
-  SH_SW_COUNT = 14
+  SH_SW_STEM_WG_RING = 14, /* stem weight gradient with both operands in LDS rings (stem_wgrad_ring_kernel) at 224 x 224 (default 1) */
+  SH_SW_COUNT = 15
 };
 int simhand_test_switch(int which, int value);
 

@@ -19,6 +19,7 @@
 // by a second deterministic pass (no float atomics).  Blocks of one pixel range are adjacent
 // in the logical block order and mapped to one XCD so dy / x tiles are shared in its L2.
 #include "common.h"
+#include "conv_1x1.h"
 
 #include <stdlib.h>
 
@@ -1296,10 +1297,19 @@ static void stem_wgrad_desc(sh_conv_desc* d, int n, int h, int w, int dtype) {
   d->cin = 256; d->cout = 64; d->r = d->s = 1; d->stride = 1; d->pad = 0; d->dtype = dtype;
 }
 
+// 224 x 224, 16-bit storage: both operands in LDS rings, one pass over dy and the padded input (stem_bwd.hip stem_wgrad_ring_kernel)
+static bool stem_wgrad_ring_ok(int n, int h, int w, int dtype) {
+  int hp, wp, ho, wo;
+  if (n < 1 || dtype != SH_BF16 || !sw(SH_SW_STEM_WG_RING) || simhand_stem_geometry(h, w, &hp, &wp, &ho, &wo)) return false;
+  return stem_ring_geometry_ok(hp, wp, ho, wo);
+}
+
 size_t simhand_stem_conv_wgrad_workspace_bytes(int n, int h, int w, int dtype) {
   sh_conv_desc d;
   stem_wgrad_desc(&d, n, h, w, dtype);
-  return 2 * simhand_conv2d_wgrad_workspace_bytes(&d) + 4096;  // (the single-tile form runs twice the splits)
+  const size_t tile = 2 * simhand_conv2d_wgrad_workspace_bytes(&d) + 4096;  // (the single-tile form runs twice the splits)
+  const size_t ring = n >= 1 ? (size_t)stem_wgrad_ring_blocks(n) * 64 * 224 * sizeof(float) : 0;  // per-block partials of the ring kernel
+  return tile > ring ? tile : ring;   // (independent of the test switch: either kernel may take the call)
 }
 
 int simhand_stem_conv_wgrad(const void* xp, const void* dy, float* dw_oihw, void* workspace, size_t workspace_bytes, int n, int h,
@@ -1308,6 +1318,15 @@ int simhand_stem_conv_wgrad(const void* xp, const void* dy, float* dw_oihw, void
   sh_conv_desc d;
   stem_wgrad_desc(&d, n, h, w, dtype);
   const int hp = h + 8, wp = (w + 8 + 7) / 8 * 8;
+  if (stem_wgrad_ring_ok(n, h, w, dtype)) {
+    SH_REQUIRE(xp && dy && dw_oihw && workspace, "stem_conv_wgrad: NULL pointer");
+    SH_REQUIRE(workspace_bytes >= (size_t)stem_wgrad_ring_blocks(n) * 64 * 224 * sizeof(float), "stem_conv_wgrad: workspace too small");
+    const double mo = (double)n * 112 * 112;
+    ProfScope ps(SH_PROF_CONV_WGRAD, (hipStream_t)stream, 2.0 * mo * 64 * 147, 2.0 * (mo * 64 + (double)n * hp * wp * 4));
+    route_hit(SH_ROUTE_WGRAD_STEM);
+    launch_stem_wgrad_ring(xp, dy, dw_oihw, (float*)workspace, n, hp, wp, (hipStream_t)stream);
+    return check_launch("stem_conv_wgrad (LDS rings)");
+  }
   return wgrad_impl(&d, xp, dy, dw_oihw, -1, workspace, workspace_bytes, stream, hp, wp);
 }
 

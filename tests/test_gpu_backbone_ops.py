@@ -893,6 +893,30 @@ def test_stem_two_pass_forward_equals_one_pass_bit_for_bit(n):
     assert (hist > 0).all(), hist
 
 
+@pytest.mark.parametrize("n", [3, 515])
+def test_stem_weight_gradient_ring_kernel(n):
+    """Round 4: the stem's weight gradient with BOTH operands in LDS rings (stem_wgrad_ring_kernel: dy rows and padded input rows cross
+    HBM -> LDS once) against the tile kernel it replaces at 224 x 224 (another summation order) and, for the small batch, ATen on the
+    host.  n = 515 > 512 blocks: some blocks take two images."""
+    from simhand_amd import ops
+
+    x, wt, gamma, beta, xp, wpk = _stem_case(n, 80 + n)
+    g = torch.Generator(device=DEV).manual_seed(n)
+    dy = torch.randn(n, 112, 112, 64, device=DEV, generator=g).to(torch.bfloat16)
+    ops.route_reset()
+    dw = ops.stem_conv_wgrad(xp, dy, 224, 224)
+    assert ops.route_counts()["wgrad_stem"] == 1 and bool(torch.isfinite(dw).all())
+    ops.test_switch("STEM_WG_RING", 0)
+    try:
+        want = ops.stem_conv_wgrad(xp, dy, 224, 224)
+    finally:
+        ops.test_switch("STEM_WG_RING", -1)
+    _check(dw.cpu(), want.cpu(), 1e-3, "ring vs tile kernel")
+    if n <= 8:
+        ref = torch.nn.grad.conv2d_weight(_rnd(x, torch.bfloat16), (64, 3, 7, 7), dy.float().cpu().permute(0, 3, 1, 2).contiguous(), stride=2, padding=3)
+        _check(dw.cpu(), ref, 2e-3, "ring kernel vs ATen")
+
+
 @pytest.mark.parametrize("n", [2, 260])
 def test_stem_fused_backward_equals_the_unfused_chain(n):
     """stem_backward_fused (conv1 recomputed in the kernel that forms dy in registers and accumulates dW) == maxpool_bn_backward (reads the
