@@ -52,6 +52,9 @@ __device__ __forceinline__ unsigned add_bf16x2_g1(unsigned a, unsigned b) {
 // every chunk would expose a global-load latency (measured 1.6x the HBM-bound time).
 // EP == 2: the same with residual, ReLU and bit mask all present and M a multiple of the block's rows (the conv3 of every
 // identity block): no conditional anywhere near a global load or store, see the note on vmcnt below.
+// EP == 3: BatchNorm scale / shift ONLY (no residual, no ReLU, no mask: the stage-entry shortcuts), whole blocks, branch-free: the generic
+// EP == 1 form took 2.1 ms for 64 -> 256 @ 56^2 (4.1 GB: 0.75 ms of HBM time) -- its conditional residual fetch inside the loop made the
+// waitcnt pass drain the queue once per chunk (see "vmcnt" below) although no residual exists on this layer.
 // PF == 2: the same without a residual gradient (first block of a stage: masked store only, accumulate 0).
 // PF == 3: PF == 2 + the stride-2 shortcut's dense data gradient (Gemm1x1Args::sub) added at the even pixels before the mask: each row's
 // pixel is decoded once, its 16-B chunks ride with the chunk's mask bytes (odd pixels fetch a zero page: no branch near a load).
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
   constexpr int NBL = 64 * CPR / 256;     // staged chunks per thread and step
   constexpr int ROWB = KC * 2;            // bytes per weight-tile row
   constexpr int BT = 64 * ROWB;           // bytes per weight tile
-  constexpr bool FAST = EP == 2 || PF != 0;
+  constexpr bool FAST = EP == 2 || EP == 3 || PF != 0;
   static_assert(!CH || (EP == 2 && (K == 64 || (K == 128 && MF == 1))), "the chained conv1 exists for the K = 64 / 128 fast forward variants");
   constexpr int CT = K / 16;              // chained conv1: 16-channel output tiles
   constexpr int PB = K * 128;             // bytes of one chain panel [K][64]
@@ -459,9 +462,9 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
         if (ks == 0) {
 #ifndef SH_ABL_R
           if constexpr (EP == 2) load_res(nc);
-          else load_pf(nc);
+          else if constexpr (PF != 0) load_pf(nc);
 #else   // ablation (garbage results): the epilogue rows are fetched once, by chunk 0 only
-          if (nc == 0) { if constexpr (EP == 2) load_res(0); else load_pf(0); }
+          if (nc == 0) { if constexpr (EP == 2) load_res(0); else if constexpr (PF != 0) load_pf(0); }
 #endif
         }
         if constexpr (CH && K == 128) panel_load(nc + 1 < nch ? nc + 1 : 0);  // lands under this chunk's MFMAs (last: panel 0 again, unused)
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
             const float4 h0 = *reinterpret_cast<const float4*>(s_ep + EPN + ch), h1 = *reinterpret_cast<const float4*>(s_ep + EPN + ch + 4);
             float o[8] = {lo[0] * s0.x + h0.x, lo[1] * s0.y + h0.y, lo[2] * s0.z + h0.z, lo[3] * s0.w + h0.w,
                           hi[0] * s1.x + h1.x, hi[1] * s1.y + h1.y, hi[2] * s1.z + h1.z, hi[3] * s1.w + h1.w};
-            if (EP == 2 || p.ep_res != nullptr) {
+            if (EP == 2 || (EP == 1 && p.ep_res != nullptr)) {
               const unsigned w4[4] = {rq[mi][j].x, rq[mi][j].y, rq[mi][j].z, rq[mi][j].w};  // prefetched a chunk ago
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
                 o[2 * i + 1] += h16_hi(w4[i]);
               }
             }
-            if (EP == 2 || p.ep_relu) {
+            if (EP == 2 || (EP == 1 && p.ep_relu)) {
               unsigned bits = 0;
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
@@ -659,7 +662,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
               pg[mi][1] = *reinterpret_cast<const uint4*>(tw + tw1);
             }
             if constexpr (EP != 0) {
-              if (EP == 2 || p.ep_res != nullptr) {  // the prefetched residual rows arrive line-shaped: into the operand shape
+              if (EP == 2 || (EP == 1 && p.ep_res != nullptr)) {  // the prefetched residual rows arrive line-shaped: into the operand shape
                 *reinterpret_cast<uint4*>(tw + tr0) = rq[mi][0];
                 *reinterpret_cast<uint4*>(tw + tr0 + 1024) = rq[mi][1];
                 rq[mi][0] = *reinterpret_cast<const uint4*>(tw + tw0);
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
                 if (FAST || rowa < p.M) *reinterpret_cast<uint4*>(da) = r0;
                 if (FAST || rowa + 8 < p.M) *reinterpret_cast<uint4*>(da + 8ll * p.N) = r1;
                 if constexpr (EP != 0) {
-                  if (EP == 2 || (p.ep_relu && p.ep_mask != nullptr)) {
+                  if (EP == 2 || (EP == 1 && p.ep_relu && p.ep_mask != nullptr)) {
                     // the pixel's eight mask bytes (chunks g and 4 + g of the four lanes li + 16 g) meet in one lane: one 8-B store per
                     // pixel instead of 128 one-byte stores per 16 pixels
                     unsigned mlo = mb[0] << (8 * g), mhi = mb[1] << (8 * g);
@@ -850,6 +853,9 @@ int launch_gemm1x1(const Gemm1x1Args& a_in, int k, bool dgrad, hipStream_t s) {
   // more resident blocks hide what the 32 MFMAs of a chunk cannot; measured 1.53 ms against 2.05 with 256 rows, 1.64 generic)
   if (!dgrad && k == 64 && mf == 4 && a.ep_scale != nullptr && a.ep_res != nullptr && a.ep_relu && a.ep_mask != nullptr && a.M % 128 == 0 && pf_of(64))
     mf = 2;
+  // the scale / shift-only fast variant (EP == 3) at K = 64: 128-row blocks as well (the 256-row form spills at three blocks per CU)
+  if (!dgrad && k == 64 && mf == 4 && a.ep_scale != nullptr && a.ep_res == nullptr && !a.ep_relu && a.ep_mask == nullptr && a.M % 128 == 0 && pf_of(64))
+    mf = 2;
   const int nblk = ceil_div(a.M, 64 * mf);
   const bool full = a.M % (64 * mf) == 0;
   route_hit(dgrad ? SH_ROUTE_GEMM1X1_DGRAD : (a.ep_scale != nullptr ? SH_ROUTE_GEMM1X1_FWD_BNACT : SH_ROUTE_GEMM1X1_FWD));
@@ -865,6 +871,8 @@ int launch_gemm1x1(const Gemm1x1Args& a_in, int k, bool dgrad, hipStream_t s) {
     else if (dgrad) gemm1x1_kernel<KV, MFV, true><<<nblk, 256, 0, s>>>(a);                      \
     else if (a.ep_scale != nullptr && a.ep_res != nullptr && a.ep_relu && a.ep_mask != nullptr && full && pf_of(KV))  \
       gemm1x1_kernel<KV, MFV, false, false, 2><<<nblk, 256, 0, s>>>(a);                         \
+    else if (a.ep_scale != nullptr && a.ep_res == nullptr && !a.ep_relu && a.ep_mask == nullptr && full && pf_of(KV))  \
+      gemm1x1_kernel<KV, MFV, false, false, 3><<<nblk, 256, 0, s>>>(a);                         \
     else if (a.ep_scale != nullptr) gemm1x1_kernel<KV, MFV, false, false, 1><<<nblk, 256, 0, s>>>(a);  \
     else gemm1x1_kernel<KV, MFV, false><<<nblk, 256, 0, s>>>(a);                                \
   } while (0)

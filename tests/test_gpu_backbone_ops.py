@@ -1082,6 +1082,37 @@ def test_conv_fwd_bnact_epilogue_and_gram_statistics(shape, with_res):
     assert torch.allclose(t2, xs.sum(0), rtol=1e-4, atol=1e-2) and torch.allclose(s2, xs.t() @ xs, rtol=1e-3, atol=1e-2)
 
 
+@pytest.mark.parametrize("shape", [(4, 16, 16, 64, 256), (2, 16, 16, 128, 512), (2, 16, 16, 256, 512), (6, 16, 16, 64, 64)])
+def test_conv_fwd_bn_only_epilogue_fast_variant(shape):
+    """Round 4: the scale / shift-only epilogue of the activation-stationary 1x1 kernel (the stage-entry shortcuts: BatchNorm, no residual,
+    no ReLU) has a branch-free variant for whole blocks (EP == 3).  Bit-identical to the generic epilogue form it replaces, and equal to
+    conv -> bn_apply to one bf16 ulp."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = _rnd(torch.randn(n, h, w, cin, generator=g).relu(), dtype).to(DEV).to(dtype)
+    wt = _rnd(torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin), dtype).to(DEV)
+    d = ops.conv_desc(n, h, w, cin, cout, 1, 1, 1, 0, dtype)
+    wk = ops.pack_krsc(wt, dtype)
+    y, part = ops.conv2d_fwd(d, x, wk, want_stats=True)
+    m = n * h * w
+    st = ops.bn_finalize(part, m, cout, (torch.rand(cout, generator=g) + 0.5).to(DEV), (torch.randn(cout, generator=g) * 0.3).to(DEV), None, None, None)
+    ops.route_reset()
+    got = ops.conv2d_fwd_bnact(d, x, wk, st, False, None)
+    assert ops.route_counts()["gemm1x1_fwd_bnact"] == 1
+    ops.test_switch("G1_PF", 0)   # the generic kernels (conditional epilogue)
+    try:
+        ref = ops.conv2d_fwd_bnact(d, x, wk, st, False, None)
+    finally:
+        ops.test_switch("G1_PF", -1)
+    assert torch.equal(got, ref)
+    want = ops.bn_apply(y.view(m, cout), st, m, cout, False, None)
+    err = (got.float().view(m, cout) - want.float()).abs().max().item()
+    assert err <= 2e-2 * want.float().abs().max().item() + 1e-3, err
+
+
 @pytest.mark.parametrize("n,h,c,relu", [(3, 13, 64, True), (2, 20, 128, True), (5, 9, 256, True), (2, 7, 512, False), (1, 5, 64, True)])
 def test_bn_apply_fused_into_the_gram_launch(n, h, c, relu):
     """simhand_bn_apply_gram: a = act(y*scale + shift), a^T a and sum a in one launch of the 1x1 weight-gradient kernel ==
