@@ -346,17 +346,22 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
   // ---- PF: residual gradient + masks of chunk 0
   uint4 pg[PF ? MF : 1][2];
   uint2 pm[PF ? MF : 1], pk[PF ? MF : 1];
-  const bf16_t* sp[PF == 3 ? MF : 1];  // PF == 3: this lane's row in `sub` (+ its 8-channel offset), or the zero page for an odd pixel
+  // PF == 3: the shortcut gradient `sub` lives on the EVEN pixels.  A 16-pixel group starts on an even column (M, W even), so its eight even
+  // pixels are eight rows of `sub` -- fetched LINE-shaped by one instruction per chunk (lane l: even pixel l >> 3 of the group, 16-B chunk
+  // l & 7 of the 64-channel chunk; pixels on odd image rows: the zero page) and turned into the accumulator shape through the wave-private
+  // LDS block in the epilogue.  (First form: two accumulator-shaped loads per chunk with three lanes in four on the zero page -- the merged
+  // launch took as long as the unmerged one plus its scatter-add pass.)
+  const bf16_t* sp[PF == 3 ? MF : 1];
   if constexpr (PF == 3) {
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi) {
-      const unsigned ru = (unsigned)(mbase + mi * 16 + li);  // M < 2^31; full blocks
+      const unsigned ru = (unsigned)(mbase + mi * 16 + 2 * (lane >> 3));  // M < 2^31; full blocks; an even pixel of the row grid
       const unsigned img = fdiv(ru, p.div_hw);
       const unsigned rem = ru - img * p.div_hw.d;
       const unsigned hh = fdiv(rem, p.div_w);
       const unsigned ww = rem - hh * p.div_w.d;
       const unsigned srow = (img * (unsigned)(p.sub_h >> 1) + (hh >> 1)) * (unsigned)(p.sub_w >> 1) + (ww >> 1);
-      sp[mi] = ((hh | ww) & 1u) == 0 ? p.sub + (unsigned long long)srow * p.N + g * 8 : nullptr;
+      sp[mi] = (hh & 1u) == 0 ? p.sub + (unsigned long long)srow * p.N + (lane & 7) * 8 : nullptr;
     }
   }
   auto load_pf = [&](int nc2) __attribute__((always_inline)) {
@@ -364,11 +369,8 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
     for (int mi = 0; mi < (PF ? MF : 1); ++mi) {
       const long long r = mbase + mi * 16 + li;
       if constexpr (PF == 3) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const bf16_t* q = sp[mi] != nullptr ? sp[mi] + nc2 * 64 + j * 32 : reinterpret_cast<const bf16_t*>(g_g1_zero_page);
-          pg[mi][j] = *reinterpret_cast<const uint4*>(q);
-        }
+        const bf16_t* q = sp[mi] != nullptr ? sp[mi] + nc2 * 64 : reinterpret_cast<const bf16_t*>(g_g1_zero_page);
+        pg[mi][0] = *reinterpret_cast<const uint4*>(q);
       }
       if constexpr (PF == 1) {
         const long long ra = mbase + mi * 16 + (lane >> 3);  // line-shaped: rows l >> 3 and + 8, chunk l & 7 (whole blocks: every row exists)
@@ -660,6 +662,15 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
               *reinterpret_cast<uint4*>(tw + tr0 + 1024) = pg[mi][1];
               pg[mi][0] = *reinterpret_cast<const uint4*>(tw + tw0);
               pg[mi][1] = *reinterpret_cast<const uint4*>(tw + tw1);
+            }
+            if constexpr (PF == 3) {  // the eight even pixels' `sub` rows arrive line-shaped (1 KB): pixel li = 2 s takes chunks g and 4 + g of row s
+              const int ss = lane >> 3, sr = li >> 1;
+              *reinterpret_cast<uint4*>(tw + ss * 128 + (((lane & 7) ^ ss) * 16)) = pg[mi][0];
+              const uint4 e0 = *reinterpret_cast<const uint4*>(tw + sr * 128 + (((0 * 4 + g) ^ sr) * 16));
+              const uint4 e1 = *reinterpret_cast<const uint4*>(tw + sr * 128 + (((1 * 4 + g) ^ sr) * 16));
+              const bool ev = (li & 1) == 0;   // odd pixels carry no shortcut gradient
+              pg[mi][0] = ev ? e0 : make_uint4(0, 0, 0, 0);
+              pg[mi][1] = ev ? e1 : make_uint4(0, 0, 0, 0);
             }
             if constexpr (EP != 0) {
               if (EP == 2 || (EP == 1 && p.ep_res != nullptr)) {  // the prefetched residual rows arrive line-shaped: into the operand shape
