@@ -585,6 +585,9 @@ int simhand_subsample2(const void* x, void* y, int n, int h, int w, int c, int d
 int simhand_scatter2_add(const void* src, void* dx, const uint8_t* mask, int n, int h, int w, int c, int dtype, sh_stream_t stream);
 int simhand_avgpool_fwd(const void* x, void* y, int n, int hw, int c, int dtype, sh_stream_t stream);
 int simhand_avgpool_bwd(const void* dy, void* dx, int n, int hw, int c, int dtype, sh_stream_t stream);
+/* the same with the gradient gated by the ReLU bit mask [n * hw][c / VE] of the pooled tensor (NULL = no gate): avgpool_bwd followed by
+ * simhand_apply_relu_bitmask in one pass, bit for bit */
+int simhand_avgpool_bwd_masked(const void* dy, const uint8_t* mask, void* dx, int n, int hw, int c, int dtype, sh_stream_t stream);
 
 /* column sums of [M][C] (Linear bias gradient); partial: (2*simhand_bn_stat_blocks(m,c) + 1) * c floats */
 int simhand_colsum(const void* x, int64_t m, int c, int dtype, float* partial, float* out, sh_stream_t stream);

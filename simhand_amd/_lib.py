@@ -196,6 +196,7 @@ SIGNATURES = {
     "simhand_subsample2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "simhand_scatter2_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "simhand_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "simhand_avgpool_bwd_masked": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "simhand_colsum": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "simhand_sumsq_partial": (_I, [_P, _L, _P, _I, _P]),
     "simhand_opt_chunk_elems": (_I, []),

@@ -170,8 +170,11 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// mask (optional): ReLU bit mask [n * hw][c / VE] of the tensor the pooled map came from -- the gradient leaves already gated (what the
+// folded BatchNorm backward of the last block wants: avgpool_bwd + apply_bitmask in one pass, same bits)
 template <typename T>
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int n, int hw, int c) {
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ mask, T* __restrict__ dx, int n,
+                                                          int hw, int c) {
   constexpr int VE = Vec16<T>::N;
   const int cvecs = c / VE;
   const int64_t total = (int64_t)n * hw * cvecs;
@@ -180,8 +183,12 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ 
     const int img = (int)(i / ((int64_t)hw * cvecs));
     float g[VE];
     Vec16<T>::load(dy + ((int64_t)img * cvecs + cv) * VE, g);
+    const unsigned bits = mask != nullptr ? mask[i] : 0xffu;
 #pragma unroll
-    for (int e = 0; e < VE; ++e) g[e] /= (float)hw;
+    for (int e = 0; e < VE; ++e) {
+      g[e] /= (float)hw;
+      g[e] = (bits >> e) & 1u ? g[e] : 0.f;   // (the store rounds: the same bits apply_bitmask would have kept)
+    }
     Vec16<T>::store(dx + i * VE, g);
   }
 }
@@ -511,14 +518,18 @@ int simhand_avgpool_fwd(const void* x, void* y, int n, int hw, int c, int dtype,
 }
 
 int simhand_avgpool_bwd(const void* dy, void* dx, int n, int hw, int c, int dtype, sh_stream_t stream) {
+  return simhand_avgpool_bwd_masked(dy, nullptr, dx, n, hw, c, dtype, stream);
+}
+
+int simhand_avgpool_bwd_masked(const void* dy, const uint8_t* mask, void* dx, int n, int hw, int c, int dtype, sh_stream_t stream) {
   SH_REQUIRE(dy && dx, "avgpool_bwd: NULL pointer");
   if (vec_ok(c, dtype, "avgpool_bwd")) return 1;
   const int ve = dtype == SH_F32 ? 4 : 8;
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_POOL, s, 0, (double)n * hw * c * (dtype == SH_F32 ? 4 : 2));
   const int64_t total = (int64_t)n * hw * (c / ve);
-  SH_DISPATCH(dtype, (avgpool_bwd_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)dy, (float*)dx, n, hw, c)),
-              (avgpool_bwd_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)dy, (bf16_t*)dx, n, hw, c)));
+  SH_DISPATCH(dtype, (avgpool_bwd_kernel<float><<<stream_grid(total), 256, 0, s>>>((const float*)dy, mask, (float*)dx, n, hw, c)),
+              (avgpool_bwd_kernel<bf16_t><<<stream_grid(total), 256, 0, s>>>((const bf16_t*)dy, mask, (bf16_t*)dx, n, hw, c)));
   return check_launch("avgpool_bwd");
 }
 

@@ -682,13 +682,11 @@ class ResNetEngine:
         red = self.grad_reducer if (self.grad_reducer is not None and self.grad_reducer.active()) else None
         sent = 0  # gradients of `grads` (insertion order) already handed to the reducer
         g = d_enc.contiguous() if d_enc.dtype == self.dtype else ops.cast(d_enc.contiguous(), self.dtype)
-        dz = ops.avgpool_bwd(g, ctx["last_shape"])
         blocks = ctx["blocks"]
         top = blocks[-1][0][-1] if blocks else None
         top_fold = self.fold_bn3 and self._foldable(top)
-        if top_fold:  # the last block's bn3 folds as well: gate its incoming gradient by the output ReLU mask
-            n_, h_, w_, c_ = dz.shape
-            dz = ops.apply_relu_bitmask(dz, top.mask)
+        # the last block's bn3 folds as well: its incoming gradient leaves the pooling backward already gated by the output ReLU mask
+        dz = ops.avgpool_bwd(g, ctx["last_shape"], mask=top.mask if top_fold else None)
         dz_part = None  # per-tile sums for the current block's last unit, when the next block's dgrad produced them
         dz_masked = top_fold  # dz is stored already gated by this block's output ReLU mask
         for bi in range(len(blocks) - 1, -1, -1):

@@ -846,11 +846,12 @@ def avgpool_fwd(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def avgpool_bwd(dy: torch.Tensor, in_shape) -> torch.Tensor:
+def avgpool_bwd(dy: torch.Tensor, in_shape, mask=None) -> torch.Tensor:
+    """mask: ReLU bit mask of the pooled tensor -- the gradient leaves already gated (== apply_relu_bitmask(avgpool_bwd(dy), mask))."""
     lib = _lib_dev()
     n, h, w, c = in_shape
     dx = torch.empty(n, h, w, c, dtype=dy.dtype, device=dy.device)
-    check(lib.simhand_avgpool_bwd(_ptr(dy), _ptr(dx), n, h * w, c, dt(dy.dtype), _stream()), "avgpool_bwd")
+    check(lib.simhand_avgpool_bwd_masked(_ptr(dy), _ptr(mask), _ptr(dx), n, h * w, c, dt(dy.dtype), _stream()), "avgpool_bwd")
     return dx
 
 

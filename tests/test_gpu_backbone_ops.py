@@ -893,6 +893,21 @@ def test_stem_two_pass_forward_equals_one_pass_bit_for_bit(n):
     assert (hist > 0).all(), hist
 
 
+def test_avgpool_backward_with_the_relu_gate_equals_two_passes():
+    """avgpool_bwd(mask=...) == apply_relu_bitmask(avgpool_bwd(...)), bit for bit (the gate of the last block's folded bn3 backward)."""
+    from simhand_amd import ops
+
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for dtype in (torch.bfloat16, torch.float32):
+        ve = 8 if dtype == torch.bfloat16 else 4
+        n, h, w, c = 6, 7, 7, 2048
+        dy = torch.randn(n, c, device=DEV, generator=g).to(dtype)
+        mask = torch.randint(0, 256, (n * h * w, c // ve), device=DEV, generator=g, dtype=torch.uint8)
+        want = ops.apply_relu_bitmask(ops.avgpool_bwd(dy, (n, h, w, c)), mask)
+        got = ops.avgpool_bwd(dy, (n, h, w, c), mask=mask)
+        assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("n", [3, 515])
 def test_stem_weight_gradient_ring_kernel(n):
     """Round 4: the stem's weight gradient with BOTH operands in LDS rings (stem_wgrad_ring_kernel: dy rows and padded input rows cross
