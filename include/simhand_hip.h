@@ -140,6 +140,9 @@ int simhand_prof_enable(int on);
 int simhand_prof_set_classes(uint32_t mask);
 /* blocks until recorded events completed; out_ms/out_flops/out_bytes/out_count are host arrays of SH_PROF_NCLASS */
 int simhand_prof_collect(double* out_ms, double* out_flops, double* out_bytes, int64_t* out_count);
+/* the individual records since the last collect / reset, in issue order (class, elapsed ms, algorithmic FLOPs and bytes of each launch);
+ * does not clear them.  Diagnostic: scripts/launch_outliers.py lists the launches furthest above the time their own work allows. */
+int simhand_prof_records(int max_records, int* cls, double* ms, double* flops, double* bytes, int* n_out);
 int simhand_prof_reset(void);
 
 /* ===========================================================================

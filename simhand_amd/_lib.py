@@ -105,6 +105,7 @@ SIGNATURES = {
     "simhand_prof_enable": (_I, [_I]),
     "simhand_prof_set_classes": (_I, [C.c_uint32]),
     "simhand_prof_collect": (_I, [_P, _P, _P, _P]),
+    "simhand_prof_records": (_I, [_I, _P, _P, _P, _P, _P]),
     "simhand_prof_reset": (_I, []),
     "simhand_pos_dist": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "simhand_neg_dist_workspace_bytes": (_S, [_I, _I]),

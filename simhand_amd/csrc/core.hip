@@ -170,6 +170,33 @@ int simhand_prof_reset(void) {
   return 0;
 }
 
+// per-launch records in issue order (diagnostic: which launch sits furthest above the time its own algorithmic bytes / FLOPs allow);
+// does NOT clear the records (simhand_prof_collect / simhand_prof_reset do)
+int simhand_prof_records(int max_records, int* cls, double* ms, double* flops, double* bytes, int* n_out) {
+  std::lock_guard<std::mutex> lk(sh::g_prof_mu);
+  if (!cls || !ms || !flops || !bytes || !n_out || max_records < 0) {
+    sh::set_error("prof_records: bad arguments");
+    return 1;
+  }
+  int n = 0;
+  for (auto& r : sh::g_recs) {
+    if (n >= max_records) break;
+    if (hipEventSynchronize(r.b) != hipSuccess) {
+      sh::set_error("hipEventSynchronize failed in prof_records");
+      return 1;
+    }
+    float t = 0;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) {
+      sh::set_error("hipEventElapsedTime failed in prof_records");
+      return 1;
+    }
+    cls[n] = r.cls; ms[n] = t; flops[n] = r.flops; bytes[n] = r.bytes;
+    ++n;
+  }
+  *n_out = n;
+  return 0;
+}
+
 int simhand_prof_collect(double* out_ms, double* out_flops, double* out_bytes, int64_t* out_count) {
   std::lock_guard<std::mutex> lk(sh::g_prof_mu);
   for (int i = 0; i < SH_PROF_NCLASS; ++i) {

@@ -1172,6 +1172,18 @@ def prof_reset() -> None:
     _lib.load().simhand_prof_reset()
 
 
+def prof_records(max_records: int = 4096) -> list:
+    """[(class name, ms, algorithmic FLOPs, algorithmic bytes)] of every launch recorded since the last collect / reset, in issue order."""
+    lib = _lib.load()
+    cls = (C.c_int * max_records)()
+    ms = (C.c_double * max_records)()
+    fl = (C.c_double * max_records)()
+    by = (C.c_double * max_records)()
+    n = C.c_int()
+    check(lib.simhand_prof_records(max_records, cls, ms, fl, by, C.byref(n)), "prof_records")
+    return [(_lib.PROF_CLASSES[cls[i]], ms[i], fl[i], by[i]) for i in range(n.value)]
+
+
 def prof_collect() -> dict:
     lib = _lib.load()
     n = len(_lib.PROF_CLASSES)
