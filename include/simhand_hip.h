@@ -101,7 +101,8 @@ enum sh_route {
   SH_ROUTE_R128_FWD = 34, SH_ROUTE_R128_DGRAD = 35,         /* 128->128 3x3: activation tile staged once in an LDS ring, weights streamed per tap */
   SH_ROUTE_STEM_STATS = 36, SH_ROUTE_STEM_POOL = 37,        /* two-pass stem: statistics-only conv1; conv1 + BN + ReLU + MaxPool */
   SH_ROUTE_STEM_BWD_FUSED = 38,                             /* stem backward: conv1 recomputed, dy in registers, dW in the same kernel */
-  SH_ROUTE_COUNT = 39
+  SH_ROUTE_FWD_BNIN = 39,                                   /* 3x3 forward with the previous unit's BatchNorm + ReLU applied in its LDS ring */
+  SH_ROUTE_COUNT = 40
 };
 int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
 int simhand_route_reset(void);
@@ -270,6 +271,16 @@ int simhand_test_conv3x3_r128_enable(int on);
 /* tuning / test hook of the short-K (cin or cout in {64,128,256}) bf16 stride-1 1x1 kernel: rows per block = 64*mf */
 int simhand_test_conv1x1_set_rows(int k, int mf);
 int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void* y, float* bn_partial, sh_stream_t stream);
+/* simhand_bn_apply (ReLU, no residual) + simhand_conv2d_fwd in ONE launch, for the 3x3 layers whose kernel keeps its activation rows in an
+ * LDS ring (simhand_conv2d_fwd_bnin_ok(d): the 64 -> 64 layers at 56 x 56): y_in is the previous unit's RAW conv output [n][h][w][cin], the ring
+ * rows are rewritten in place as a = relu(y_in * in_scale + in_shift) before any tap reads them (pad positions fetch NaNs, which the ReLU
+ * turns into the exact zeros the padding needs), and a leaves as a by-product (a_out, same shape: the weight gradient's operand).  The
+ * stand-alone pass -- one read and one write of the tensor -- disappears.  y, bn_partial as simhand_conv2d_fwd(d, a, ...); a_out, y and
+ * bn_partial are bit-identical to the two-launch sequence.  Replaces (reference): bn1 + relu + conv2 of torchvision's Bottleneck.forward
+ * (src/models/resnet_model.py:13-58). */
+int simhand_conv2d_fwd_bnin_ok(const sh_conv_desc* d);
+int simhand_conv2d_fwd_bnin(const sh_conv_desc* d, const void* y_in, const float* in_scale, const float* in_shift, const void* w, void* a_out,
+                            void* y, float* bn_partial, sh_stream_t stream);
 /* Direct 7x7 / stride 2 / pad 3 / 3 -> 64 stem (torchvision ResNet conv1, src/models/resnet_model.py:13-26) without an
  * im2col matrix.  simhand_stem_pad_input repacks the NCHW fp32 image batch to zero-padded NHWC4
  * xp [n][hp][wp][4] (dtype elements; geometry from simhand_stem_geometry: hp = h + 8, wp = roundup8(w + 8),

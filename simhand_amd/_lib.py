@@ -34,8 +34,8 @@ ROUTES = ("igemm128_fwd", "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "i
           "gemm1x1_dgrad", "c64_fwd", "c64_dgrad", "stem_fwd", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
           "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
           "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram", "wgrad_bnbwd", "ntxent_fused_dist",
-          "dgrad_dysrc", "fwd_chain", "r128_fwd", "r128_dgrad", "stem_stats", "stem_pool", "stem_bwd_fused")
-ROUTE_COUNT = 39
+          "dgrad_dysrc", "fwd_chain", "r128_fwd", "r128_dgrad", "stem_stats", "stem_pool", "stem_bwd_fused", "fwd_bnin")
+ROUTE_COUNT = 40
 
 
 class SimhandHipError(RuntimeError):
@@ -121,6 +121,8 @@ SIGNATURES = {
     "simhand_proj_stats": (_I, [_P, _I, _I, _P, _P, _P]),
     "simhand_conv2d_fwd_stat_blocks": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "simhand_conv2d_fwd_bnin_ok": (_I, [C.POINTER(ConvDesc)]),
+    "simhand_conv2d_fwd_bnin": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "simhand_conv2d_dgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),
     "simhand_conv2d_dgrad_masked_residual": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "simhand_conv2d_wgrad_workspace_bytes": (_S, [C.POINTER(ConvDesc)]),

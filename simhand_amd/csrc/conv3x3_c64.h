@@ -14,6 +14,12 @@ struct C64Args {
   const float* fscale;  // ... y * fscale + fshift > 0
   const float* fshift;
   int relu;             // dgrad + partial: 1 = gate by the recomputed ReLU mask, 0 = no ReLU
+  // forward with the PREVIOUS unit's BatchNorm + ReLU applied on the way in (in_scale != null): x is that unit's raw conv output, the ring rows
+  // are rewritten in place as relu(x * in_scale + in_shift) before any tap reads them, and the activation leaves as a by-product (a_out: the
+  // weight gradient's operand) -- the stand-alone bn_apply pass (one read, one write of the tensor) disappears
+  const float* in_scale;
+  const float* in_shift;
+  bf16_t* a_out;
   int N, H, W;
   int dgrad;            // 1: tap offsets are mirrored
   long long q_total;    // N * (H+2) * (W+2)

@@ -24,6 +24,18 @@ __device__ uint4 g_c64_zero_page[8];
 // results at pad positions are stored here: every wave then issues exactly two stores per step, which the counted
 // s_waitcnt of the DMA ring relies on (a skipped store would shift the count)
 __device__ uint4 g_c64_sink[64 * 64];
+// BNIN: pad positions fetch NaNs instead of zeros -- NaN * scale + shift is NaN and the ReLU (v > 0 ? v : 0) turns it into the exact zero a
+// pad position has to hold after the activation, whatever the channel's scale and shift are
+#ifdef SH_H16_FP16
+#define SH_C64_NAN2 0x7e007e00u
+#else
+#define SH_C64_NAN2 0x7fc07fc0u
+#endif
+__device__ uint4 g_c64_nan_page[8] = {
+    {SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2}, {SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2},
+    {SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2}, {SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2},
+    {SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2}, {SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2},
+    {SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2}, {SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2, SH_C64_NAN2}};
 
 typedef __attribute__((ext_vector_type(8))) __bf16 c64_frag_t;
 
@@ -36,8 +48,12 @@ __device__ __forceinline__ float row16_sum_c64(float v) {
 }
 
 // MODE 0: store only; 1: forward + BN partial statistics; 2: data gradient + BN-backward sums of the previous unit
-template <int MODE>
+// BNIN (forward): x is the previous unit's RAW conv output; every wave rewrites the ring rows it fetched itself as relu(x * in_scale + in_shift)
+// (its own s_waitcnt is all the synchronisation that takes: the rewrite of chunk j + 2 runs at the end of step j, one barrier before its first
+// reader) and stores them to a_out on the way
+template <int MODE, bool BNIN = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
+  static_assert(!BNIN || MODE != 2, "BNIN is a forward form");
   constexpr int RING = 512;  // ring rows (8 chunks of 64)
   constexpr int D = 2;       // DMA distance in steps
   __shared__ __attribute__((aligned(16))) char ring[RING * 128];
@@ -82,8 +98,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
   };
   const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
   const int slot = lane & 7;
-  const char* zsrc = reinterpret_cast<const char*>(g_c64_zero_page) + slot * 16;
-  auto dma_chunk = [&](int c) __attribute__((always_inline)) {
+  const char* zsrc = reinterpret_cast<const char*>(BNIN ? g_c64_nan_page : g_c64_zero_page) + slot * 16;
+  // off[h] (BNIN): element offset of the 16 bytes the lane fetched (a_out gets the rewritten ones at the same place), ~0 for a pad position
+  auto dma_chunk = [&](int c, unsigned (&off)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int row = wave * 16 + h * 8 + (lane >> 3);          // row inside the 64-row chunk
@@ -99,6 +116,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
       const int chunk = slot ^ ((row >> 1) & 7);                // ring row = 64 (c + 1) + row: same key
       const char* src = ok ? reinterpret_cast<const char*>(p.x + (unsigned long long)pix * 64 + chunk * 8) : zsrc;
       dma16(src, ring_addr + ((((c + 1) * 64) & (RING - 1)) + wave * 16 + h * 8) * 128);
+      if constexpr (BNIN) off[h] = ok ? pix * 64u + (unsigned)chunk * 8u : 0xffffffffu;  // < 2^32 elements (q_total < 2^31 / 64 checked on the host)
+    }
+  };
+  // BNIN: rewrite the lane's own 2 x 16 bytes of chunk c in place; own = the chunk belongs to this block's range (else a neighbour stores it)
+  auto bn_chunk = [&](int c, const unsigned (&off)[2], bool own) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = wave * 16 + h * 8 + (lane >> 3);
+      const int chunk = slot ^ ((row >> 1) & 7);
+      char* at = ring + ((((c + 1) * 64) & (RING - 1)) + row) * 128 + slot * 16;
+      const uint4 v = *reinterpret_cast<const uint4*>(at);
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+      float sc[8], sh[8], o[8];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 a = *reinterpret_cast<const float4*>(&s_coef[0][chunk * 8 + 4 * i]);
+        const float4 b = *reinterpret_cast<const float4*>(&s_coef[1][chunk * 8 + 4 * i]);
+        sc[4 * i] = a.x; sc[4 * i + 1] = a.y; sc[4 * i + 2] = a.z; sc[4 * i + 3] = a.w;
+        sh[4 * i] = b.x; sh[4 * i + 1] = b.y; sh[4 * i + 2] = b.z; sh[4 * i + 3] = b.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // the arithmetic of bn_apply_kernel (bn.hip), bit for bit
+        o[2 * i] = h16_lo(w4[i]) * sc[2 * i] + sh[2 * i];
+        o[2 * i + 1] = h16_hi(w4[i]) * sc[2 * i + 1] + sh[2 * i + 1];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+      uint4 r;
+      r.x = pack_bf16x2(o[0], o[1]);
+      r.y = pack_bf16x2(o[2], o[3]);
+      r.z = pack_bf16x2(o[4], o[5]);
+      r.w = pack_bf16x2(o[6], o[7]);
+      *reinterpret_cast<uint4*>(at) = r;
+      uint4* dst = own && off[h] != 0xffffffffu ? reinterpret_cast<uint4*>(p.a_out + off[h]) : &g_c64_sink[(blockIdx.x & 63) * 64 + lane];
+      *dst = r;  // always one store: the counted waits below rely on it
     }
   };
 
@@ -139,17 +191,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
   };
 
   // prologue: chunks -1 .. 2 in the order the counted waits assume
+  unsigned off_cur[2] = {0u, 0u};
+  if constexpr (BNIN) {
+    if (tid < 64) {
+      s_coef[0][tid] = p.in_scale[tid];
+      s_coef[1][tid] = p.in_shift[tid];
+    }
+    __syncthreads();
+    unsigned o0[2], o1[2], o2[2];
+    dma_chunk(-1, o0);
+    dma_chunk(0, o1);
+    dma_chunk(1, o2);
+    dma_chunk(2, off_cur);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // the lane's own rows of chunks -1 .. 1 have landed
+    bn_chunk(-1, o0, false);
+    bn_chunk(0, o1, nsteps > 0);
+    bn_chunk(1, o2, nsteps > 1);
+  } else {
 #pragma unroll
-  for (int c = -1; c <= D; ++c) dma_chunk(c);
+    for (int c = -1; c <= D; ++c) dma_chunk(c, off_cur);
+  }
 
   for (int j = 0; j < nsteps; ++j) {
+    unsigned off_new[2];
+    if constexpr (BNIN) {
+      // chunk j + 1 was fetched AND rewritten by its owners before they arrived here (end of step j - 1 / prologue): the barrier only needs their
+      // LDS writes to be done
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      dma_chunk(j + 1 + D, off_new);
+    } else {
     // outstanding, in issue order: DMA chunk j + 1 (2 per wave), stores of step j - 2 (2), DMA chunk j + 2 (2), stores of step
     // j - 1 (2); vector-memory operations retire in order, so <= 6 outstanding means chunk j + 1 has landed.  After the
     // barrier it is visible to every wave and every wave is done with step j - 1
     // (steps 0 and 1 have no older stores in the queue yet: the stricter count is the safe one there)
     if (j < 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-    dma_chunk(j + 1 + D);  // ring slot (j + 4) & 7: outside the window (chunks j - 1 .. j + 1) and the chunk in flight (j + 2)
+    dma_chunk(j + 1 + D, off_new);  // ring slot (j + 4) & 7: outside the window (chunks j - 1 .. j + 1) and the chunk in flight (j + 2)
+    }
 
     // MODE 2: this step's rows of the previous unit's conv output are fetched now and consumed in the epilogue
     unsigned pixe[2];
@@ -222,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
         for (int e = 0; e < 8; ++e) {
           const float ve = valid ? v[e] : 0.f;
           s1[e] += ve;
-          s2[e] += ve * ve;
+          s2[e] = __builtin_fmaf(ve, ve, s2[e]);  // spelled out: left to the compiler, the two forward instantiations contracted it differently
         }
       }
       if constexpr (MODE == 2) {
@@ -255,6 +333,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
             }
         }
       }
+    }
+    if constexpr (BNIN) {
+      // issued after the DMAs of chunk j + 2 (top of step j - 1, or the prologue): stores of step j - 1 (2), rewritten rows of chunk j + 1 (2), DMAs of
+      // chunk j + 3 (2), stores of step j (2) -- in-order retirement: <= 8 outstanding means the lane's rows of chunk j + 2 are in LDS
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      bn_chunk(j + 2, off_cur, j + 2 < nsteps);
+      off_cur[0] = off_new[0];
+      off_cur[1] = off_new[1];
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -305,7 +391,11 @@ int launch_c64(const C64Args& a0, hipStream_t s) {
   const int b = c64_blocks(a.q_total);
   a.steps_per_block = (int)((steps + b - 1) / b);
   route_hit(a.dgrad ? SH_ROUTE_C64_DGRAD : SH_ROUTE_C64_FWD);
-  if (a.partial == nullptr) conv3x3_c64_kernel<0><<<b, 256, 0, s>>>(a);
+  if (a.in_scale != nullptr) {
+    route_hit(SH_ROUTE_FWD_BNIN);
+    if (a.partial == nullptr) conv3x3_c64_kernel<0, true><<<b, 256, 0, s>>>(a);
+    else conv3x3_c64_kernel<1, true><<<b, 256, 0, s>>>(a);
+  } else if (a.partial == nullptr) conv3x3_c64_kernel<0><<<b, 256, 0, s>>>(a);
   else if (!a.dgrad) conv3x3_c64_kernel<1><<<b, 256, 0, s>>>(a);
   else conv3x3_c64_kernel<2><<<b, 256, 0, s>>>(a);
   return 0;

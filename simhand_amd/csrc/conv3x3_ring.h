@@ -15,6 +15,11 @@ struct R128Args {
   const float* fscale;  // ... y * fscale + fshift > 0
   const float* fshift;
   int relu;             // dgrad + partial: 1 = gate by the recomputed ReLU mask, 0 = no ReLU
+  // forward with the PREVIOUS unit's BatchNorm + ReLU applied on the way in (in_scale != null; see C64Args): x is that unit's raw conv output,
+  // the staged tile is rewritten in place as relu(x * in_scale + in_shift), the activation leaves as a by-product (a_out)
+  const float* in_scale;
+  const float* in_shift;
+  bf16_t* a_out;
   int N, H, W;
   int dgrad;            // 1: tap offsets are mirrored
   long long q_total;    // N * (H+1) * (W+1): padded grid with shared pad rows / columns

@@ -33,6 +33,18 @@
 namespace sh {
 
 __device__ uint4 g_r128_zero_page[8];
+// BNIN: pad positions fetch NaNs; NaN * scale + shift is NaN and the ReLU (v > 0 ? v : 0) makes it the exact zero the padding needs
+#ifdef SH_H16_FP16
+#define SH_R128_NAN2 0x7e007e00u
+#else
+#define SH_R128_NAN2 0x7fc07fc0u
+#endif
+__device__ uint4 g_r128_nan_page[8] = {
+    {SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2}, {SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2},
+    {SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2}, {SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2},
+    {SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2}, {SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2},
+    {SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2}, {SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2, SH_R128_NAN2}};
+__device__ uint4 g_r128_bn_sink[512];  // the by-product's stores of halo / pad rows (a neighbour tile owns them / nobody does)
 
 __device__ __forceinline__ float row16_sum_r128(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
@@ -43,8 +55,12 @@ __device__ __forceinline__ float row16_sum_r128(float v) {
 }
 
 // MODE 0: store only; 1: forward + BN partial statistics; 2: data gradient + BN-backward sums of the previous unit
-template <int MODE>
+// BNIN (forward): x is the previous unit's RAW conv output; every lane rewrites the 2 x 5 ring pieces it fetched itself as
+// relu(x * in_scale + in_shift) (its own s_waitcnt is the only synchronisation that needs) and stores the ones of the tile's own 256 positions
+// to a_out -- the bn_apply pass disappears
+template <int MODE, bool BNIN = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
+  static_assert(!BNIN || MODE != 2, "BNIN is a forward form");
   constexpr int BM = 256, BN = 128, MI = 4, NI = 4, HALO = 32;
   constexpr int RROWS = BM + 2 * HALO;  // 320 ring rows: positions m0 - 32 .. m0 + 288
   constexpr int HALF = RROWS * 128;     // one 64-channel half of the ring
@@ -74,6 +90,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
   const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int slot = lane & 7, r8l = lane >> 3;
   const char* zsrc = reinterpret_cast<const char*>(g_r128_zero_page) + slot * 16;
+  const char* nsrc = reinterpret_cast<const char*>(BNIN ? g_r128_nan_page : g_r128_zero_page) + slot * 16;
+  // BNIN: the lane's 16-B slot holds the same 8 channels in all five rows it fetches per half (the rows' swizzle keys agree): coefficients in
+  // registers for the prologue; the loads go out first, ahead of every DMA in the in-order queue
+  const int bn_chunk = slot ^ (((wave & 1) * 4 + (r8l >> 1)) & 7);
+  float bsc[BNIN ? 2 : 1][8], bsh[BNIN ? 2 : 1][8];
+  unsigned boff[BNIN ? 2 : 1][5];
+  if constexpr (BNIN) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 a = *reinterpret_cast<const float4*>(p.in_scale + h * 64 + bn_chunk * 8 + 4 * i);
+        const float4 b = *reinterpret_cast<const float4*>(p.in_shift + h * 64 + bn_chunk * 8 + 4 * i);
+        bsc[h][4 * i] = a.x; bsc[h][4 * i + 1] = a.y; bsc[h][4 * i + 2] = a.z; bsc[h][4 * i + 3] = a.w;
+        bsh[h][4 * i] = b.x; bsh[h][4 * i + 1] = b.y; bsh[h][4 * i + 2] = b.z; bsh[h][4 * i + 3] = b.w;
+      }
+  }
 
   // ---- ring fill: half h = 40 instructions of 8 rows, instruction n of the half by wave n % 8 (5 per wave); lane l = row 8 rb + (l >> 3),
   // 16-B slot l & 7, source chunk slot ^ key(row) --------------------------------------------------------------------------------
@@ -92,8 +125,36 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
       const bool ok = in && hp - 1u < (unsigned)p.H && wp - 1u < (unsigned)p.W;
       const unsigned pix = (img * (unsigned)p.H + (hp - 1u)) * (unsigned)p.W + (wp - 1u);
       const int chunk = slot ^ ((j >> 1) & 7);
-      const char* src = ok ? reinterpret_cast<const char*>(p.x + (unsigned long long)pix * 128 + h * 64 + chunk * 8) : zsrc;
+      const char* src = ok ? reinterpret_cast<const char*>(p.x + (unsigned long long)pix * 128 + h * 64 + chunk * 8) : nsrc;
       dma16(src, smem_addr + h * HALF + rb * 8 * 128);
+      if constexpr (BNIN)  // where the rewritten 16 bytes go: own positions (ring rows 32 .. 287) that are real pixels; < 2^32 (checked on the host)
+        boff[h][i] = ok && j >= HALO && j < HALO + BM ? pix * 128u + (unsigned)(h * 64 + chunk * 8) : 0xffffffffu;
+    }
+  };
+  auto bn_half = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int rb = wave + 8 * i;
+      char* at = smem + h * HALF + (rb * 8 + r8l) * 128 + slot * 16;
+      const uint4 v = *reinterpret_cast<const uint4*>(at);
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // the arithmetic of bn_apply_kernel (bn.hip), bit for bit
+        o[2 * e] = h16_lo(w4[e]) * bsc[BNIN ? h : 0][2 * e] + bsh[BNIN ? h : 0][2 * e];
+        o[2 * e + 1] = h16_hi(w4[e]) * bsc[BNIN ? h : 0][2 * e + 1] + bsh[BNIN ? h : 0][2 * e + 1];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+      uint4 r;
+      r.x = pack_bf16x2(o[0], o[1]);
+      r.y = pack_bf16x2(o[2], o[3]);
+      r.z = pack_bf16x2(o[4], o[5]);
+      r.w = pack_bf16x2(o[6], o[7]);
+      *reinterpret_cast<uint4*>(at) = r;
+      const unsigned bo = boff[BNIN ? h : 0][i];
+      uint4* dst = bo != 0xffffffffu ? reinterpret_cast<uint4*>(p.a_out + bo) : &g_r128_bn_sink[tid];
+      *dst = r;
     }
   };
   // ---- weight tile of k-step ks (half h = ks / 9, tap t = ks % 9): rows lrow, lrow + 64 of [128][64 k], chunk slot ^ key_b(row) ----
@@ -114,6 +175,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
   dma_w(0);
   dma_w(1);
   fill_half(1);
+  if constexpr (BNIN) {
+    // in-order retirement: <= 9 outstanding = the lane's rows of half 0 are in LDS; then its 5 stores may fly while half 1 is waited for.  The
+    // loop's counted waits only look at what is younger than the weight tiles of steps >= 2: everything issued here is older
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    bn_half(0);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    bn_half(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rewritten rows are in LDS before the loop's first barrier
+  }
 
   // ---- fragment addressing ----------------------------------------------------------------------------------------------------
   int trow[9], tcol[9];
@@ -248,7 +318,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
         for (int e = 0; e < 8; ++e) {
           const float ve = oks[mi] ? v[e] : 0.f;
           s1[j][e] += ve;
-          s2[j][e] += ve * ve;
+          s2[j][e] = __builtin_fmaf(ve, ve, s2[j][e]);  // spelled out: the instantiations must agree bit for bit
         }
       }
       if constexpr (MODE == 2) {  // BN-backward sums of the previous unit: g = stored gradient * relu'(y), sums of g and g * y
@@ -515,7 +585,11 @@ int launch_r128(const R128Args& a0, hipStream_t s) {
   R128Args a = a0;
   a.tiles = r128_blocks(a.q_total);
   route_hit(a.dgrad ? SH_ROUTE_R128_DGRAD : SH_ROUTE_R128_FWD);
-  if (a.partial == nullptr) conv3x3_r128_kernel<0><<<a.tiles, 512, 0, s>>>(a);
+  if (a.in_scale != nullptr) {
+    route_hit(SH_ROUTE_FWD_BNIN);
+    if (a.partial == nullptr) conv3x3_r128_kernel<0, true><<<a.tiles, 512, 0, s>>>(a);
+    else conv3x3_r128_kernel<1, true><<<a.tiles, 512, 0, s>>>(a);
+  } else if (a.partial == nullptr) conv3x3_r128_kernel<0><<<a.tiles, 512, 0, s>>>(a);
   else if (!a.dgrad) conv3x3_r128_kernel<1><<<a.tiles, 512, 0, s>>>(a);
   else conv3x3_r128_kernel<2><<<a.tiles, 512, 0, s>>>(a);
   return 0;

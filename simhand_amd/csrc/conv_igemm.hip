@@ -1454,10 +1454,18 @@ static bool use_c64(const sh_conv_desc* d) {
 static bool use_c64_dgrad(const sh_conv_desc* d, int accumulate, int relu_mode, bool has_bias) {
   return use_c64(d) && accumulate == 0 && !has_bias && (relu_mode < 0 || relu_mode == 0 || relu_mode == 2);
 }
+struct BnIn {  // the previous unit's BatchNorm + ReLU applied inside the ring (simhand_conv2d_fwd_bnin)
+  const float* scale;
+  const float* shift;
+  void* a_out;
+};
 static int launch_c64_conv(const sh_conv_desc* d, const void* x, const void* w, void* out, float* partial, bool dgrad,
-                           const sh_bn_bwd_fuse* fuse, hipStream_t s) {
+                           const sh_bn_bwd_fuse* fuse, hipStream_t s, const BnIn* bnin = nullptr) {
   C64Args c;
   c.x = (const bf16_t*)x; c.w = (const bf16_t*)w; c.out = (bf16_t*)out; c.partial = partial;
+  c.in_scale = bnin ? bnin->scale : nullptr;
+  c.in_shift = bnin ? bnin->shift : nullptr;
+  c.a_out = bnin ? (bf16_t*)bnin->a_out : nullptr;
   c.fy = fuse ? (const bf16_t*)fuse->y : nullptr;
   c.fscale = fuse ? fuse->scale : nullptr;
   c.fshift = fuse ? fuse->shift : nullptr;
@@ -1485,9 +1493,12 @@ static bool use_r128_dgrad(const sh_conv_desc* d, int accumulate, int relu_mode,
   return use_r128(d) && accumulate == 0 && !has_bias && (relu_mode < 0 || relu_mode == 0 || relu_mode == 2);
 }
 static int launch_r128_conv(const sh_conv_desc* d, const void* x, const void* w, void* out, float* partial, bool dgrad,
-                            const sh_bn_bwd_fuse* fuse, hipStream_t s) {
+                            const sh_bn_bwd_fuse* fuse, hipStream_t s, const BnIn* bnin = nullptr) {
   R128Args c;
   c.x = (const bf16_t*)x; c.w = (const bf16_t*)w; c.out = (bf16_t*)out; c.partial = partial;
+  c.in_scale = bnin ? bnin->scale : nullptr;
+  c.in_shift = bnin ? bnin->shift : nullptr;
+  c.a_out = bnin ? (bf16_t*)bnin->a_out : nullptr;
   c.fy = fuse ? (const bf16_t*)fuse->y : nullptr;
   c.fscale = fuse ? fuse->scale : nullptr;
   c.fshift = fuse ? fuse->shift : nullptr;
@@ -1552,6 +1563,26 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
   if (use_r128(d)) return launch_r128_conv(d, x, w, y, bn_partial, false, nullptr, (hipStream_t)stream);
   if (use_256_fwd(d, a.Mg)) return launch_igemm256<false>(a, (hipStream_t)stream);
   return d->dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
+}
+
+int simhand_conv2d_fwd_bnin_ok(const sh_conv_desc* d) {
+  if (d == nullptr || d->dtype != SH_BF16) return 0;
+  // the by-product's element offsets are 32-bit in the kernel
+  return (use_c64(d) || use_r128(d)) && (long long)d->n * d->h * d->w * d->cin < (1ll << 32) ? 1 : 0;
+}
+
+int simhand_conv2d_fwd_bnin(const sh_conv_desc* d, const void* y_in, const float* in_scale, const float* in_shift, const void* w, void* a_out,
+                            void* y, float* bn_partial, sh_stream_t stream) {
+  if (check_desc(d, "conv2d_fwd_bnin")) return 1;
+  SH_REQUIRE(y_in && in_scale && in_shift && w && a_out && y, "conv2d_fwd_bnin: NULL pointer");
+  SH_REQUIRE(simhand_conv2d_fwd_bnin_ok(d), "conv2d_fwd_bnin: no ring kernel for this layer (simhand_conv2d_fwd_bnin_ok)");
+  const double mg = (double)d->n * d->ho * d->wo;
+  const double flops = 2.0 * mg * d->cout * d->cin * d->r * d->s;
+  const double bytes = 2.0 * (2.0 * (double)d->n * d->h * d->w * d->cin + mg * d->cout + (double)d->cout * d->cin * d->r * d->s);
+  ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, flops, bytes);
+  const BnIn b = {in_scale, in_shift, a_out};
+  if (use_r128(d)) return launch_r128_conv(d, y_in, w, y, bn_partial, false, nullptr, (hipStream_t)stream, &b);
+  return launch_c64_conv(d, y_in, w, y, bn_partial, false, nullptr, (hipStream_t)stream, &b);
 }
 
 int simhand_conv2d_fwd_bnact(const sh_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
@@ -1867,6 +1898,7 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
     R128Args c;
     c.x = (const bf16_t*)dy; c.w = (const bf16_t*)wt; c.out = (bf16_t*)dx; c.partial = nullptr;
     c.fy = nullptr; c.fscale = c.fshift = nullptr; c.relu = 0;
+    c.in_scale = c.in_shift = nullptr; c.a_out = nullptr;
     c.N = d->n; c.H = d->ho; c.W = d->wo; c.dgrad = 1;
     c.q_total = (long long)d->n * (d->ho + 1) * (d->wo + 1);
     c.tiles = 0;

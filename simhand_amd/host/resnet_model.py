@@ -128,6 +128,19 @@ class _Unit:
     __slots__ = ("conv", "bn", "desc", "x", "y", "a", "st", "relu", "stem", "has_res", "mask", "x_in", "s2", "t2", "ws2")
 
 
+class _Pending:
+    """A unit whose BatchNorm + ReLU has not been applied yet: the next 3x3 convolution applies it inside its LDS ring
+    (ops.conv2d_fwd_bnin) and hands the activation back as a by-product."""
+    __slots__ = ("y", "st", "unit")
+
+    def __init__(self, y, st, unit):
+        self.y, self.st, self.unit = y, st, unit
+
+    @property
+    def shape(self):
+        return self.y.shape
+
+
 class ResNetEngine:
     def __init__(self, features: nn.Sequential, dtype: torch.dtype = torch.float32, fp8: bool = False):
         self.features = features
@@ -177,6 +190,9 @@ class ResNetEngine:
         # VALU / MFMA-bound at one or two waves per SIMD, and under the step's power state core-bound kernels lose what they saved
         # (DESIGN 3b).  bench.py --engine stem_two_pass=1 times it.
         self.stem_two_pass = False
+        # bn1 + ReLU of a Bottleneck applied inside conv2's launch where that 3x3 kernel keeps its activation rows in an LDS ring (the
+        # 64- and 128-channel stride-1 layers): the bn_apply pass of those units disappears (attribute: A/B timing only)
+        self.bn_on_load = True
         # multi-GPU: host.dist.OverlappedGradReducer -- finished parameter gradients go out block by block during backward
         self.grad_reducer = None
 
@@ -377,17 +393,23 @@ class ResNetEngine:
         return ops.conv2d_fwd_fp8(d, xq, site[2], site[0], site[1], want_stats=training)
 
     def _conv_bn(self, conv, bn, x, relu, residual, training, save: Optional[list], need_dgrad=True, gram_next=False, chain_conv=None,
-                 fp8_next=None):
+                 fp8_next=None, bnin_next=None):
         """gram_next: the activation feeds a folded 1x1 convolution (which needs a^T a and sum a): BatchNorm-apply + ReLU then
         run inside that Gram launch (ops.bn_apply_gram) instead of as a pass of their own."""
         if self._fold_fwd_ok(conv, relu, residual):
             return self._conv_bn_folded(conv, bn, x, relu, residual, training, save, chain_conv=chain_conv)
+        pend = x if isinstance(x, _Pending) else None
         n, h, w, cin = x.shape
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         d = ops.conv_desc(n, h, w, cin, conv.out_channels, k, k, s, p, self.dtype)
         pk = self._pack(conv, need_t=save is not None and need_dgrad)
         chained, self._chain = self._chain, None
-        if chained is not None and chained[0] is x and chained[1] is conv:
+        if pend is not None:
+            # the unit in front left its BatchNorm + ReLU to this launch; its activation comes back as a by-product
+            x, y, part = ops.conv2d_fwd_bnin(d, pend.y, pend.st, pk.krsc, want_stats=training)
+            if pend.unit is not None:
+                pend.unit.a = x
+        elif chained is not None and chained[0] is x and chained[1] is conv:
             y, part = chained[2], chained[3]  # computed by the previous block's conv3 launch from its output chunks
         elif self._fp8_ok(conv, d):
             y, part = self._conv_fwd_fp8(conv, d, x, training)
@@ -396,7 +418,14 @@ class ResNetEngine:
         m = n * d.ho * d.wo
         st = self._bn(bn, part, m, conv.out_channels, training)
         mask = None
-        if save is not None and residual is not None and relu:
+        defer = False
+        if bnin_next is not None and self.bn_on_load and relu and residual is None and not gram_next and self.dtype in _H16:
+            k2, s2, p2 = bnin_next.kernel_size[0], bnin_next.stride[0], bnin_next.padding[0]
+            d2 = ops.conv_desc(n, d.ho, d.wo, conv.out_channels, bnin_next.out_channels, k2, k2, s2, p2, self.dtype)
+            defer = ops.conv2d_fwd_bnin_ok(d2) and not self._fp8_ok(bnin_next, d2)
+        if defer:
+            a = None  # filled in by the consumer (u.a, below)
+        elif save is not None and residual is not None and relu:
             a, mask = ops.bn_apply(y, st, m, conv.out_channels, relu, residual, want_mask=True)
         elif gram_next and training and residual is None and self.fuse_apply_gram and self.dtype in _H16:
             a, s2, t2 = ops.bn_apply_gram(y, st, relu)
@@ -414,6 +443,8 @@ class ResNetEngine:
             u.mask = mask
             u.x_in = u.s2 = u.t2 = u.ws2 = None
             save.append(u)
+        if defer:
+            return _Pending(y, st, save[-1] if save is not None else None)
         return a
 
     def forward(self, images, training: bool, want_ctx: bool):
@@ -474,7 +505,8 @@ class ResNetEngine:
                     # the unit in front of a folded stride-1 conv3: its BN-apply rides on the Gram launch
                     gram_next = (ui == len(units) - 2 and last_conv.stride == (1, 1) and self._fold_fwd_ok(last_conv, True, inp))
                     fp8_next = units[ui + 1][0] if (self.fp8 and ui + 1 < len(units) - 1) else None
-                    t = self._conv_bn(conv, bn, t, True, None, training, saved, gram_next=gram_next, fp8_next=fp8_next)
+                    bnin_next = units[ui + 1][0]  # the conv that reads this unit's activation
+                    t = self._conv_bn(conv, bn, t, True, None, training, saved, gram_next=gram_next, fp8_next=fp8_next, bnin_next=bnin_next)
                 idn = inp
                 dsaved: Optional[list] = [] if want_ctx else None
                 if blk.downsample is not None:

@@ -207,6 +207,25 @@ def conv2d_fwd(d: ConvDesc, x, w, want_stats: bool = True):
     return y, part
 
 
+def conv2d_fwd_bnin_ok(d: ConvDesc) -> bool:
+    return bool(_lib_dev().simhand_conv2d_fwd_bnin_ok(C.byref(d)))
+
+
+def conv2d_fwd_bnin(d: ConvDesc, y_in, st_in: "BNState", w, want_stats: bool = True):
+    """a = relu(y_in * st_in.scale + st_in.shift); y = conv(a, w) in one launch: the BatchNorm + ReLU of the unit in front is applied inside
+    the 3x3 kernel's LDS ring and a leaves as a by-product.  Returns (a, y, partial sums or None); bit-identical to bn_apply + conv2d_fwd."""
+    lib = _lib_dev()
+    a = torch.empty_like(y_in)
+    y = torch.empty(d.n, d.ho, d.wo, d.cout, dtype=y_in.dtype, device=y_in.device)
+    part = None
+    if want_stats:
+        nblk = lib.simhand_conv2d_fwd_stat_blocks(C.byref(d))
+        part = torch.empty(nblk, 2, d.cout, dtype=torch.float32, device=y_in.device)
+    check(lib.simhand_conv2d_fwd_bnin(C.byref(d), _ptr(y_in), _ptr(st_in.scale), _ptr(st_in.shift), _ptr(w), _ptr(a), _ptr(y), _ptr(part),
+                                      _stream()), "conv2d_fwd_bnin")
+    return a, y, part
+
+
 def conv2d_fwd_bnact(d: ConvDesc, x, w, st: "BNState", relu: bool, residual=None, want_mask: bool = False):
     """out = act(conv(x) * st.scale + st.shift (+ residual)) with the BN / residual / ReLU tail in the conv epilogue
     (bf16; the raw conv output is never stored).  Returns out or (out, ReLU bit mask)."""

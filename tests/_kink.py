@@ -54,6 +54,14 @@ def record_hip_relu_masks(store: list):
             store.append((res[0] > 0).cpu())
         return res
 
+    orig_bnin = ops.conv2d_fwd_bnin
+
+    def conv2d_fwd_bnin(d, y_in, st_in, w, want_stats=True):
+        res = orig_bnin(d, y_in, st_in, w, want_stats)  # (activation of the unit in front, conv output, partial sums): ReLU is implied
+        store.append((res[0] > 0).cpu())
+        return res
+
+    ops.conv2d_fwd_bnin = conv2d_fwd_bnin
     ops.bn_apply_gram = bn_apply_gram
     ops.bn_apply = bn_apply
     ops.bn_relu_maxpool_fwd = bn_relu_maxpool_fwd
@@ -67,6 +75,7 @@ def record_hip_relu_masks(store: list):
         ops.conv2d_fwd_bnact = orig_fused
         ops.conv2d_fwd_bnact_chain = orig_chain
         ops.bn_apply_gram = orig_gram
+        ops.conv2d_fwd_bnin = orig_bnin
 
 
 @contextlib.contextmanager

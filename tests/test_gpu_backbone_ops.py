@@ -1128,6 +1128,45 @@ def test_conv_fwd_bn_only_epilogue_fast_variant(shape):
     assert err <= 2e-2 * want.float().abs().max().item() + 1e-3, err
 
 
+@pytest.mark.parametrize("n,h,w,c", [(3, 56, 56, 64), (5, 20, 33, 64), (70, 7, 7, 64), (2, 56, 61, 64), (24, 28, 28, 128), (40, 14, 30, 128),
+                                     (300, 7, 7, 128)])
+def test_conv3x3_forward_with_the_previous_batchnorm_applied_in_its_ring(n, h, w, c):
+    """Round 4: simhand_conv2d_fwd_bnin -- bn_apply (ReLU) + the 3x3 convolution in one launch: the ring rows are rewritten in LDS, pad
+    positions fetch NaNs that the ReLU turns into zeros, the activation leaves as a by-product.  a, y and the BatchNorm partial sums are
+    bit-identical to the two launches; scales of either sign, a zero scale with a positive shift (the case no finite pad value could serve)."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + w)
+    d = ops.conv_desc(n, h, w, c, c, 3, 3, 1, 1, dtype)
+    if not ops.conv2d_fwd_bnin_ok(d):
+        pytest.skip("no ring kernel for this shape")
+    y_in = (torch.randn(n, h, w, c, generator=g) * 2.0 + 0.3).to(DEV).to(dtype)
+    wt = _rnd(torch.randn(c, c, 3, 3, generator=g) / math.sqrt(9 * c), dtype).to(DEV)
+    wk = ops.pack_krsc(wt, dtype)
+    st = ops.BNState(c, DEV)
+    st.scale.copy_((torch.randn(c, generator=g) * 0.8).to(DEV))
+    st.shift.copy_((torch.randn(c, generator=g) * 0.5).to(DEV))
+    st.scale[c - 2] = 0.0
+    st.shift[c - 2] = 0.4
+    st.scale[3] = 0.0
+    st.shift[3] = 0.7   # every pad position would read 0.7 here if the padding were applied before the activation
+    st.scale[5] = 0.0
+    st.shift[5] = -0.2
+    m = n * h * w
+    a_ref = ops.bn_apply(y_in.view(m, c), st, m, c, True, None).view(n, h, w, c)
+    y_ref, p_ref = ops.conv2d_fwd(d, a_ref, wk, want_stats=True)
+    ops.route_reset()
+    a, y, part = ops.conv2d_fwd_bnin(d, y_in, st, wk, want_stats=True)
+    rc = ops.route_counts()
+    assert rc["fwd_bnin"] == 1 and rc["c64_fwd" if c == 64 else "r128_fwd"] == 1
+    assert torch.equal(a, a_ref)
+    assert torch.equal(y, y_ref)
+    assert torch.equal(part, p_ref)
+    _, y0, none = ops.conv2d_fwd_bnin(d, y_in, st, wk, want_stats=False)
+    assert none is None and torch.equal(y0, y_ref)
+
+
 @pytest.mark.parametrize("n,h,c,relu", [(3, 13, 64, True), (2, 20, 128, True), (5, 9, 256, True), (2, 7, 512, False), (1, 5, 64, True)])
 def test_bn_apply_fused_into_the_gram_launch(n, h, c, relu):
     """simhand_bn_apply_gram: a = act(y*scale + shift), a^T a and sum a in one launch of the 1x1 weight-gradient kernel ==

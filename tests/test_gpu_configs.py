@@ -195,7 +195,7 @@ def _check_bf16(res, loss_band, zcos_floor, gmed_floor, gp10_floor, flip_frac):
 BF16_ROUTES_RN50 = ("stem_fwd", "stem_bn_pool", "c64_fwd", "c64_dgrad", "gemm1x1_fwd", "gemm1x1_fwd_bnact", "gemm1x1_dgrad", "igemm128_fwd",
                     "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
                     "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_apply_gram", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
-                    "bn_bwd_apply", "ntxent_fwd", "ntxent_bwd", "fwd_chain", "dgrad_dysrc")
+                    "bn_bwd_apply", "ntxent_fwd", "ntxent_bwd", "fwd_chain", "dgrad_dysrc", "fwd_bnin")
 
 
 def test_config1_rn50_handclr_w_bf16_every_route_against_oracle():
@@ -244,6 +244,37 @@ def test_two_pass_stem_step_equals_the_default_step():
     for k in g0:
         err = (g0[k] - g1[k]).norm() / g0[k].norm()
         assert float(err) <= 5e-3, (k, float(err))
+
+
+def test_bn_on_load_step_is_bit_identical_to_the_separate_bn_apply_pass():
+    """ResNetEngine.bn_on_load (bn1 + ReLU of the 64- and 128-channel Bottlenecks applied inside conv2's LDS ring, the activation a
+    by-product of that launch) against the stand-alone bn_apply pass, same weights and batch: the activation, the convolution output and
+    its BatchNorm sums are bit-identical, so the whole step is -- loss and every gradient compared with torch.equal.  12 pairs = 24 images:
+    both ring kernels run (3 stage-1 units on conv3x3_c64, 3 stage-2 units on conv3x3_r128)."""
+    from simhand_amd import ops
+
+    wcfg = dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg")
+    b = 12
+    batch = {k: v.to(DEV) for k, v in orc.synthetic_batch(b, size=224, seed=23).items()}
+    om = _oracle("simhand_w", "50", wcfg, 23, 0.1)
+    res = {}
+    for on in (False, True):
+        model = _product("HandCLR_W", "50", wcfg, om, torch.bfloat16, b)
+        model.encoder.engine.bn_on_load = on
+        ops.route_reset()
+        out = model.training_step(batch, 0)
+        out["loss"].backward()
+        rc = ops.route_counts()
+        res[on] = (out["loss"].detach().float().cpu().clone(), {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()
+                                                                 if p.grad is not None}, rc)
+        del model
+    (l0, g0, r0), (l1, g1, r1) = res[False], res[True]
+    assert r0["fwd_bnin"] == 0 and r1["fwd_bnin"] == 6, (r0["fwd_bnin"], r1["fwd_bnin"])
+    assert r0["bn_apply"] - r1["bn_apply"] == 6, (r0["bn_apply"], r1["bn_apply"])
+    assert torch.equal(l0, l1), (l0, l1)
+    assert g0.keys() == g1.keys() and len(g0) > 100
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
 
 
 def test_config1_rn50_bf16_plain_random_init_tracks_the_twin():
