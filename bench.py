@@ -80,7 +80,7 @@ def parse():
                          "e.g. --switch R128=0.  The library reads no environment variable; the default run sets none of these")
     ap.add_argument("--engine", action="append", default=[], metavar="ATTR=V",
                     help="A/B timing only: an engine-level fusion attribute of host/resnet_model.py ResNetEngine (chain_conv1, dense_shortcut, "
-                         "merge_shortcut, fuse_apply_gram, fuse_bwd_apply_dgrad, fuse_bwd_apply_wgrad, fp8_all, bn_on_load, stem_two_pass), e.g. --engine chain_conv1=0")
+                         "merge_shortcut, fuse_apply_gram, fuse_bwd_apply_dgrad, fuse_bwd_apply_wgrad, fp8_all, bn_on_load, bwd_apply_in_ring, stem_two_pass), e.g. --engine chain_conv1=0")
     ap.add_argument("--no-loss-scaling", action="store_true", help="--precision 16 without the GradScaler (timing split only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=32,

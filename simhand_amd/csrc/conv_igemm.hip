@@ -1492,10 +1492,20 @@ static bool use_r128(const sh_conv_desc* d) {
 static bool use_r128_dgrad(const sh_conv_desc* d, int accumulate, int relu_mode, bool has_bias) {
   return use_r128(d) && accumulate == 0 && !has_bias && (relu_mode < 0 || relu_mode == 0 || relu_mode == 2);
 }
+// sh_dy_src on the ring kernel (the by-product's element offsets are 32-bit there)
+static bool dysrc_r128_ok(const sh_conv_desc* d) { return use_r128(d) && (long long)d->n * d->ho * d->wo * d->cout < (1ll << 32); }
+static void r128_dy_src(R128Args& c, const sh_dy_src* src) {
+  c.dy_y = src ? (const bf16_t*)src->y : nullptr;
+  c.dy_s = src ? src->scale : nullptr; c.dy_h = src ? src->shift : nullptr;
+  c.dy_a = src ? src->coef_a : nullptr; c.dy_b = src ? src->coef_b : nullptr; c.dy_c = src ? src->coef_c : nullptr;
+  c.dy_relu = src ? src->relu : 0;
+  c.dy_out = src ? (bf16_t*)src->dy_out : nullptr;
+}
 static int launch_r128_conv(const sh_conv_desc* d, const void* x, const void* w, void* out, float* partial, bool dgrad,
-                            const sh_bn_bwd_fuse* fuse, hipStream_t s, const BnIn* bnin = nullptr) {
+                            const sh_bn_bwd_fuse* fuse, hipStream_t s, const BnIn* bnin = nullptr, const sh_dy_src* src = nullptr) {
   R128Args c;
   c.x = (const bf16_t*)x; c.w = (const bf16_t*)w; c.out = (bf16_t*)out; c.partial = partial;
+  r128_dy_src(c, src);
   c.in_scale = bnin ? bnin->scale : nullptr;
   c.in_shift = bnin ? bnin->shift : nullptr;
   c.a_out = bnin ? (bf16_t*)bnin->a_out : nullptr;
@@ -1794,8 +1804,11 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   if (src != nullptr) {
     SH_REQUIRE(src->da && src->y && src->scale && src->shift && src->coef_a && src->coef_b && src->coef_c && src->dy_out,
                "conv2d_dgrad_ex: dy_src has a NULL member");
-    SH_REQUIRE(x2 == nullptr && use_1x1(d, d->cout, d->cin),
-               "conv2d_dgrad_ex: dy_src needs a layer simhand_conv2d_dgrad_dysrc_ok accepts and a single reduction segment");
+    const bool ring = dysrc_r128_ok(d) && use_r128_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr &&
+                      f8 == nullptr && (f8sub == nullptr || f8sub->sub_grad == nullptr);
+    SH_REQUIRE(x2 == nullptr && (use_1x1(d, d->cout, d->cin) || ring),
+               "conv2d_dgrad_ex: dy_src needs a layer simhand_conv2d_dgrad_dysrc_ok accepts, a single reduction segment and (3x3 ring kernel) "
+               "the store-only or fused-sums form");
     dy = src->da;
   }
   SH_REQUIRE(dy && wt && dx, "conv2d_dgrad: NULL pointer");
@@ -1888,8 +1901,8 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   if (sub == nullptr && use_c64_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr)
     return launch_c64_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream);
   if (sub == nullptr && use_r128_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr && x2 == nullptr &&
-      src == nullptr && f8 == nullptr)
-    return launch_r128_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream);
+      f8 == nullptr && (src == nullptr || dysrc_r128_ok(d)))
+    return launch_r128_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream, nullptr, src);
   // 128 -> 128 3x3 / stride 2 (the stage-2 entry block's conv2), plain store: the four parity classes over ONE staged dy tile (conv3x3_ring.hip)
   if (sub == nullptr && fuse == nullptr && accumulate == 0 && bias == nullptr && res_grad == nullptr && x2 == nullptr && src == nullptr &&
       f8 == nullptr &&
@@ -1899,6 +1912,7 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
     c.x = (const bf16_t*)dy; c.w = (const bf16_t*)wt; c.out = (bf16_t*)dx; c.partial = nullptr;
     c.fy = nullptr; c.fscale = c.fshift = nullptr; c.relu = 0;
     c.in_scale = c.in_shift = nullptr; c.a_out = nullptr;
+    r128_dy_src(c, nullptr);
     c.N = d->n; c.H = d->ho; c.W = d->wo; c.dgrad = 1;
     c.q_total = (long long)d->n * (d->ho + 1) * (d->wo + 1);
     c.tiles = 0;
@@ -1973,7 +1987,8 @@ int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* w
   return dgrad_impl(d, dy, wt, dx, o->accumulate, o->res_grad, o->res_mask, stream, o->fuse, o->bias, o->x2, o->wt2, o->c2, o->dy_src, o);
 }
 
-int simhand_conv2d_dgrad_dysrc_ok(const sh_conv_desc* d) { return d != nullptr && use_1x1(d, d->cout, d->cin) ? 1 : 0; }
+// the 1x1 layers of the activation-stationary kernel; the 128 -> 128 3x3 / stride-1 layers of the ring kernel (store-only and fused-sums forms)
+int simhand_conv2d_dgrad_dysrc_ok(const sh_conv_desc* d) { return d != nullptr && (use_1x1(d, d->cout, d->cin) || dysrc_r128_ok(d)) ? 1 : 0; }
 
 int simhand_conv2d_dgrad_concat_ok(const sh_conv_desc* d, int c2) {
   if (!d) return 0;

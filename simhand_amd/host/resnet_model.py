@@ -193,6 +193,12 @@ class ResNetEngine:
         # bn1 + ReLU of a Bottleneck applied inside conv2's launch where that 3x3 kernel keeps its activation rows in an LDS ring (the
         # 64- and 128-channel stride-1 layers): the bn_apply pass of those units disappears (attribute: A/B timing only)
         self.bn_on_load = True
+        # bn2's backward apply done inside conv2's data-gradient ring (sh_dy_src on conv3x3_r128; with fuse_bwd_apply_dgrad): the
+        # bn_bwd_apply pass of those units disappears.  Built and tested, OFF by default: round 4 measured 752 us against 548 (data gradient)
+        # + ~200 (the pass) at 2048 images and no change of the step (102.09 / 102.08 vs 102.03 / 102.15 ms, same box) -- two operands and
+        # five coefficient vectors per element are ~90 VALU instructions per 16 bytes, which every wave of the tile issues at the same
+        # time, so nothing hides them (the forward twin, bn_on_load, needs ~30 and pays).  bench.py --engine bwd_apply_in_ring=1 times it.
+        self.bwd_apply_in_ring = False
         # multi-GPU: host.dist.OverlappedGradReducer -- finished parameter gradients go out block by block during backward
         self.grad_reducer = None
 
@@ -654,6 +660,13 @@ class ResNetEngine:
         fuse_dg = (self.fuse_bwd_apply_dgrad and not fuse_apply and self.dtype in _H16 and not u.stem and relu_mask is None
                    and not u.has_res and need_dx and prev is not None and prev_masked_store and u.conv.kernel_size == (1, 1)
                    and u.conv.stride == (1, 1) and u.conv.padding == (0, 0) and ops.conv2d_dgrad_dysrc_ok(d))
+        # 3x3 units whose data gradient keeps its operand rows in an LDS ring (conv3x3_r128): the same fusion inside that ring, with the
+        # previous unit's BatchNorm-backward sums still in the epilogue
+        fuse_dg3 = (self.fuse_bwd_apply_dgrad and self.bwd_apply_in_ring and not fuse_apply and not fuse_dg and self.dtype in _H16
+                    and not u.stem and relu_mask is None and not u.has_res and need_dx and prev is not None and not prev_masked_store
+                    and u.conv.kernel_size == (3, 3) and res_grad is None and dx_into is None and sub_grad is None and not prev.has_res
+                    and self.fuse_bn_bwd and not (self.fp8 and ops.conv2d_dgrad_fp8_pays(d)) and ops.conv2d_dgrad_fuse_pays(d)
+                    and ops.conv2d_dgrad_dysrc_ok(d))
         # fp8 configuration: the data gradient of the 3x3 layers with >= 256 channels runs on e4m3 operands; dy's codes leave the
         # BatchNorm-backward apply pass (delayed scaling), the CRSK weights are re-quantised per parameter version
         f8 = None
@@ -662,7 +675,7 @@ class ResNetEngine:
             f8 = self._fp8_site_bwd(u.conv, da.device)
         bw = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, False,
                              mask_from_y=u.relu and not u.has_res, relu_mask=relu_mask, raw_partial=raw_partial,
-                             apply=not (fuse_apply or fuse_dg), fp8_scaler=f8[0] if f8 is not None else None)
+                             apply=not (fuse_apply or fuse_dg or fuse_dg3), fp8_scaler=f8[0] if f8 is not None else None)
         dy, _, dg, db = bw[:4]
         dyq = bw[4] if len(bw) > 4 else None
         grads[u.bn.weight] = dg
@@ -677,6 +690,14 @@ class ResNetEngine:
                                          dy_src=(da.contiguous(), u.y, u.st, coefs, u.relu, dy), sub_grad=sub_grad)
             grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))
             return dxm, None
+        if fuse_dg3:
+            coefs = ops.bn_bwd_coefs(u.st, u.bn.weight.detach(), dg, db, m)
+            pk = self._pack(u.conv, need_t=True)
+            dy = torch.empty_like(u.y)
+            dx, part = ops.conv2d_dgrad_ex(d, None, pk.crsk, fuse_mode=2 if prev.relu else 0, prev_y=prev.y, prev_st=prev.st if prev.relu else None,
+                                           dy_src=(da.contiguous(), u.y, u.st, coefs, u.relu, dy))
+            grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))
+            return dx, part
         if fuse_apply:
             coefs = ops.bn_bwd_coefs(u.st, u.bn.weight.detach(), dg, db, m)
             grads[w], dy = ops.conv2d_wgrad_bnbwd(d, u.x, da, u.y, u.st, coefs, u.relu, tuple(w.shape))

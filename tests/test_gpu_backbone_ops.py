@@ -1167,6 +1167,52 @@ def test_conv3x3_forward_with_the_previous_batchnorm_applied_in_its_ring(n, h, w
     assert none is None and torch.equal(y0, y_ref)
 
 
+@pytest.mark.parametrize("n,h,w,relu,sums", [(24, 28, 28, True, True), (40, 14, 30, True, False), (300, 7, 7, False, True), (64, 17, 15, True, True)])
+def test_conv3x3_data_gradient_with_its_batchnorm_backward_applied_in_the_ring(n, h, w, relu, sums):
+    """Round 4: sh_dy_src on the 128 -> 128 3x3 ring kernel -- the data gradient takes the gradient w.r.t. the unit's ACTIVATION, rewrites its
+    staged tile as dy = A gate(da) - B y + C (pad positions forced to zero, y pieces loaded next to the DMAs) and emits dy as a by-product.
+    dy against the fp32 expression (one bf16 ulp: the compiler may contract differently); dx and the previous unit's fused BatchNorm-backward
+    sums BIT-identical to the plain kernel run on that dy."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    c = 128
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + w)
+    d = ops.conv_desc(n, h, w, c, c, 3, 3, 1, 1, dtype)
+    if not ops.conv2d_dgrad_dysrc_ok(d):
+        pytest.skip("no ring kernel for this shape")
+    da = (torch.randn(n, h, w, c, generator=g) * 1.3).to(DEV).to(dtype)
+    y = (torch.randn(n, h, w, c, generator=g) * 1.5 + 0.2).to(DEV).to(dtype)
+    wt = _rnd(torch.randn(c, c, 3, 3, generator=g) / math.sqrt(9 * c), dtype).to(DEV)
+    wtd = ops.pack_crsk(wt, dtype)
+    st = ops.BNState(c, DEV)
+    st.scale.copy_((torch.randn(c, generator=g) * 0.8).to(DEV))
+    st.shift.copy_((torch.randn(c, generator=g) * 0.5).to(DEV))
+    coefs = tuple((torch.randn(c, generator=g) * s_).to(DEV) for s_ in (0.9, 0.2, 0.3))
+    prev_y = (torch.randn(n, h, w, c, generator=g)).to(DEV).to(dtype)
+    pst = ops.BNState(c, DEV)
+    pst.scale.copy_((torch.randn(c, generator=g) * 0.8).to(DEV))
+    pst.shift.copy_((torch.randn(c, generator=g) * 0.5).to(DEV))
+    dy = torch.full((n, h, w, c), float("nan"), dtype=dtype, device=DEV)
+    ops.route_reset()
+    dx, part = ops.conv2d_dgrad_ex(d, None, wtd, fuse_mode=2 if sums else None, prev_y=prev_y if sums else None, prev_st=pst if sums else None,
+                                   dy_src=(da, y, st, coefs, relu, dy))
+    rc = ops.route_counts()
+    assert rc["r128_dgrad"] == 1 and rc["dgrad_dysrc"] == 1, rc
+    gate = (y.float() * st.scale + st.shift > 0) if relu else torch.ones_like(y, dtype=torch.bool)
+    want = coefs[0] * torch.where(gate, da.float(), torch.zeros_like(da, dtype=torch.float32)) - coefs[1] * y.float() + coefs[2]
+    assert bool(torch.isfinite(dy.float()).all())   # every pixel of the by-product was written exactly by its owner tile
+    err = (dy.float() - want).abs()
+    assert bool((err <= 2.0 ** -7 * want.abs() + 1e-6).all()), float(err.max())
+    if sums:
+        dx_ref, part_ref = ops.conv2d_dgrad_fused(d, dy, wtd, prev_y, pst, None)
+        assert torch.equal(part, part_ref)
+    else:
+        dx_ref = ops.conv2d_dgrad(d, dy, wtd)
+        assert part is None
+    assert torch.equal(dx, dx_ref)
+
+
 @pytest.mark.parametrize("n,h,c,relu", [(3, 13, 64, True), (2, 20, 128, True), (5, 9, 256, True), (2, 7, 512, False), (1, 5, 64, True)])
 def test_bn_apply_fused_into_the_gram_launch(n, h, c, relu):
     """simhand_bn_apply_gram: a = act(y*scale + shift), a^T a and sum a in one launch of the 1x1 weight-gradient kernel ==

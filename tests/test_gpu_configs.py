@@ -277,6 +277,37 @@ def test_bn_on_load_step_is_bit_identical_to_the_separate_bn_apply_pass():
         assert torch.equal(g0[k], g1[k]), k
 
 
+def test_bn_backward_apply_in_the_data_gradient_ring_tracks_the_separate_pass():
+    """ResNetEngine.bwd_apply_in_ring (bn2's backward apply inside conv2's data-gradient ring on the 128-channel stride-1 units, dy a
+    by-product) against the stand-alone bn_bwd_apply pass: same loss (the forward is untouched); dy = A g - B y + C is another rounding of
+    the pass's A (g - k2) - (y - mu) is k3, so gradients agree to bf16 round-off, not bit for bit."""
+    from simhand_amd import ops
+
+    wcfg = dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg")
+    b = 12
+    batch = {k: v.to(DEV) for k, v in orc.synthetic_batch(b, size=224, seed=29).items()}
+    om = _oracle("simhand_w", "50", wcfg, 29, 0.1)
+    res = {}
+    for on in (False, True):
+        model = _product("HandCLR_W", "50", wcfg, om, torch.bfloat16, b)
+        model.encoder.engine.bwd_apply_in_ring = on
+        ops.route_reset()
+        out = model.training_step(batch, 0)
+        out["loss"].backward()
+        rc = ops.route_counts()
+        res[on] = (out["loss"].detach().float().cpu().clone(), {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()
+                                                                 if p.grad is not None}, rc)
+        del model
+    (l0, g0, r0), (l1, g1, r1) = res[False], res[True]
+    assert r1["dgrad_dysrc"] - r0["dgrad_dysrc"] == 3 and r0["bn_bwd_apply"] - r1["bn_bwd_apply"] == 3, (r0, r1)
+    assert torch.equal(l0, l1)
+    cos = []
+    for k in g0:
+        cos.append(float((g0[k] * g1[k]).sum() / (g0[k].norm() * g1[k].norm() + 1e-30)))
+    cos.sort()
+    assert cos[0] >= 0.995 and cos[len(cos) // 2] >= 0.9995, (cos[0], cos[len(cos) // 2])
+
+
 def test_config1_rn50_bf16_plain_random_init_tracks_the_twin():
     """Same step at plain random init (the chaotic regime, see the module docstring): no absolute band is meaningful --
     the HIP path must stay as close to the fp32 oracle as the oracle's bf16-storage twin does."""
