@@ -605,6 +605,41 @@ def test_fullsize_bn_apply_gram_launch(c, h):
     _close(t2.double(), wt2, 1e-4, "sum a")
 
 
+@pytest.mark.parametrize("c,h,route", [(64, 56, "c64_fwd"), (128, 28, "r128_fwd")])
+def test_fullsize_bn_on_load_forward(c, h, route):
+    """Round 4: bn1 + ReLU applied inside conv2's LDS ring (simhand_conv2d_fwd_bnin) at 2048 images -- the persistent block ranges / the
+    6 728 tiles with their halos, the by-product written exactly once per pixel.  Activation against torch's expression (one bf16 ulp) and
+    bit for bit against the stand-alone pass; the convolution on 16 sampled images against ATen CPU; y and the BatchNorm sums bit for bit
+    against the plain kernel on that activation."""
+    from simhand_amd import ops
+
+    o = _operands((c, c, 3, 1, h), need=("x", "w"))
+    d, y_in = o["d"], o["x"]
+    wk = ops.pack_krsc(o["w"], DT)
+    g = torch.Generator(device=DEV).manual_seed(c + h)
+    st = ops.BNState(c, DEV)
+    st.scale.copy_(torch.randn(c, device=DEV, generator=g) * 0.8)
+    st.shift.copy_(torch.randn(c, device=DEV, generator=g) * 0.3)
+    st.scale[1] = 0.0
+    st.shift[1] = 0.5   # a pad position read after the activation would show up here
+    ops.hooks_reset()
+    ops.route_reset()
+    a, y, part = ops.conv2d_fwd_bnin(d, y_in, st, wk, want_stats=True)
+    torch.cuda.synchronize()
+    rc = ops.route_counts()
+    assert rc["fwd_bnin"] == 1 and rc[route] == 1, rc
+    m = N * h * h
+    want_a = ops.bn_apply(y_in.view(m, c), st, m, c, True)
+    assert torch.equal(a.view(m, c), want_a)
+    ref_a = (y_in.view(m, c).float() * st.scale + st.shift).clamp_min(0)
+    assert ((a.view(m, c).float() - ref_a).abs() <= ref_a.abs() * 2.0 ** -7 + 1e-6).all()
+    idx = torch.tensor(SAMPLE, device=DEV)
+    want = F.conv2d(_nchw(a, idx), o["w"].cpu(), stride=1, padding=1)
+    _close(_nchw(y, idx), want, 1e-2, "fwd through the ring rewrite")
+    y2, part2 = ops.conv2d_fwd(d, a, wk, want_stats=True)
+    assert torch.equal(y, y2) and torch.equal(part, part2)
+
+
 def test_fullsize_chained_conv1_stage1():
     """conv3 + bn3 + residual + ReLU of a stage-1 block with the next block's conv1 chained on, at 2048 x 56^2."""
     from simhand_amd import ops
