@@ -70,6 +70,34 @@ def test_conv_fwd_dgrad_wgrad_fp16_storage(shape):
     _check(ops.conv2d_wgrad_oihw(d, xd, dyd, (cout, cin, k, k)).cpu(), wt.grad, 1e-3, "wgrad")
 
 
+@pytest.mark.parametrize("n,h,c,route", [(3, 56, 64, "c64_fwd"), (24, 28, 128, "r128_fwd")])
+def test_bn_on_load_forward_fp16_storage(n, h, c, route):
+    """simhand_conv2d_fwd_bnin in the fp16 build: the pad page holds fp16 NaNs (0x7e00) there -- a bf16 NaN pattern read as fp16 would be a
+    finite number and leak scale * x + shift into the padding.  Bit-identical to bn_apply + conv2d_fwd, zero scale / positive shift included."""
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(n + h + c)
+    d = ops.conv_desc(n, h, h, c, c, 3, 3, 1, 1, H)
+    assert ops.conv2d_fwd_bnin_ok(d)
+    y_in = (torch.randn(n, h, h, c, generator=g) * 2.0 + 0.3).to(DEV).to(H)
+    wt = _rnd(torch.randn(c, c, 3, 3, generator=g) / math.sqrt(9 * c)).to(DEV)
+    wk = ops.pack_krsc(wt, H)
+    st = ops.BNState(c, DEV)
+    st.scale.copy_((torch.randn(c, generator=g) * 0.8).to(DEV))
+    st.shift.copy_((torch.randn(c, generator=g) * 0.5).to(DEV))
+    st.scale[3] = 0.0
+    st.shift[3] = 0.7
+    m = n * h * h
+    a_ref = ops.bn_apply(y_in.view(m, c), st, m, c, True, None).view(n, h, h, c)
+    y_ref, p_ref = ops.conv2d_fwd(d, a_ref, wk, want_stats=True)
+    ops.route_reset()
+    a, y, part = ops.conv2d_fwd_bnin(d, y_in, st, wk, want_stats=True)
+    rc = ops.route_counts()
+    assert rc["fwd_bnin"] == 1 and rc[route] == 1
+    assert torch.equal(a, a_ref) and torch.equal(y, y_ref) and torch.equal(part, p_ref)
+    assert bool(torch.isfinite(y.float()).all())
+
+
 def test_a_bf16_tensor_is_refused_by_the_fp16_build():
     from simhand_amd import _lib, ops
 
