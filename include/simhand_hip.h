@@ -102,7 +102,8 @@ enum sh_route {
   SH_ROUTE_STEM_STATS = 36, SH_ROUTE_STEM_POOL = 37,        /* two-pass stem: statistics-only conv1; conv1 + BN + ReLU + MaxPool */
   SH_ROUTE_STEM_BWD_FUSED = 38,                             /* stem backward: conv1 recomputed, dy in registers, dW in the same kernel */
   SH_ROUTE_FWD_BNIN = 39,                                   /* 3x3 forward with the previous unit's BatchNorm + ReLU applied in its LDS ring */
-  SH_ROUTE_COUNT = 40
+  SH_ROUTE_N128_FWD = 40, SH_ROUTE_N128_DGRAD = 41,         /* 1x1 with 128 destination channels behind a long reduction: 128 x 128 LDS-DMA tiles, two blocks per CU */
+  SH_ROUTE_COUNT = 42
 };
 int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
 int simhand_route_reset(void);
@@ -127,7 +128,8 @@ enum sh_test_switch {
   SH_SW_STEM_RING = 12,    /* stem_ring_fwd_kernel at 224 x 224 (default 1) */
   SH_SW_STEM_RING_LT = 13, /* its linear stores (default 1) */
   SH_SW_STEM_WG_RING = 14, /* stem weight gradient with both operands in LDS rings (stem_wgrad_ring_kernel) at 224 x 224 (default 1) */
-  SH_SW_COUNT = 15
+  SH_SW_N128 = 15,         /* gemm_n128_kernel for the 1x1 layers with 128 destination channels and >= 256 of reduction (default 1) */
+  SH_SW_COUNT = 16
 };
 int simhand_test_switch(int which, int value);
 

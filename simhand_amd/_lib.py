@@ -34,8 +34,8 @@ ROUTES = ("igemm128_fwd", "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "i
           "gemm1x1_dgrad", "c64_fwd", "c64_dgrad", "stem_fwd", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
           "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
           "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram", "wgrad_bnbwd", "ntxent_fused_dist",
-          "dgrad_dysrc", "fwd_chain", "r128_fwd", "r128_dgrad", "stem_stats", "stem_pool", "stem_bwd_fused", "fwd_bnin")
-ROUTE_COUNT = 40
+          "dgrad_dysrc", "fwd_chain", "r128_fwd", "r128_dgrad", "stem_stats", "stem_pool", "stem_bwd_fused", "fwd_bnin", "n128_fwd", "n128_dgrad")
+ROUTE_COUNT = 42
 
 
 class SimhandHipError(RuntimeError):

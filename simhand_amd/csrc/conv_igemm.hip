@@ -1216,6 +1216,231 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   }
 }
 
+// ======================================================================================================================
+// 1x1 / stride-1 GEMM with exactly 128 destination channels and a long reduction (bf16): out [M][128] = a [M][K1] w^T (+ a2 [M][K2] w2^T).
+// Replaces (reference): conv3's input gradient / conv1's forward of torchvision's stage-2 Bottlenecks (src/models/resnet_model.py:13-58;
+// cuDNN there): 512 -> 128 @ 28^2 forward, and the folded 128 <- 512 (+ 128) data gradient with bias and the previous unit's BatchNorm-
+// backward sums.  The register-staged 128 x 128 kernel runs these as a serial chain (loads, barrier, 32 MFMAs, barrier: 650 us in the
+// step for 2.47 GB = 0.45 ms of HBM time + 0.26 ms of matrix time, which add up); the 256-wide LDS-DMA kernel needs 256 channels.
+// Here: the 128 x 128 x 64 tile of igemm_kernel with the operand delivery of igemm256_kernel -- both operands global -> LDS by
+// LDS-DMA (inline asm), activation rows two k-steps ahead (three 16-KB stages), weights one (two stages), counted vmcnt, ONE barrier per
+// k-step, 4 waves as 2 (pixels) x 2 (channels) of 64 x 64 each (64 accumulator registers), and TWO blocks per CU: one block's epilogue (stores, the y rows of the fused sums) runs under the other's k-loop.
+// LDS image, swizzles (applied on the DMA source side), weight-row permutation and fragment addressing are igemm256_kernel's.
+template <bool DGRAD>
+__global__ __launch_bounds__(256, 2) void gemm_n128_kernel(IgemmArgs p) {
+  typedef bf16_t T;
+  constexpr int BM = 128, BN = 128, MI = 4, NI = 4, VE = 8;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, NSA = 3, B_BASE = NSA * A_BYTES;
+  // THREE activation stages (that operand comes from HBM: two k-steps ahead) and two weight stages (L2-resident: one step ahead):
+  // 80 KB per block, two blocks = the CU's 160 KB
+  __shared__ __attribute__((aligned(16))) char smem[NSA * A_BYTES + 2 * B_BYTES];
+  auto dma16 = [](const void* src, unsigned lds_addr) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src));
+  };
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m_tile = xcd_remap(blockIdx.x, gridDim.x);
+  const long long m0 = (long long)m_tile * BM;
+
+  // ---- DMA map: instruction i of wave w fills tile rows 32 i + 8 w .. + 8; lane l = row (l >> 3), 16-B slot l & 7 ----
+  const int slot = lane & 7;
+  const int lrow = wave * 8 + (lane >> 3);  // 0..31; rows lrow + 32 i share their swizzle keys
+  auto key_b = [](int row) __attribute__((always_inline)) -> int { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); };
+  auto chan_of = [](int ni, int m) __attribute__((always_inline)) -> int { return (ni >> 1) * 32 + (m >> 2) * 8 + (ni & 1) * 4 + (m & 3); };
+  const int chunk_a = slot ^ ((lrow >> 1) & 7);
+  const int chunk_b = slot ^ key_b(lrow);
+  const char* zsrc = reinterpret_cast<const char*>(g_zero_page) + slot * 16;
+  const int lda = p.lda;           // channels per row of a and of w (first segment)
+  const int cs1 = lda / 64;        // its k-steps
+  const int nk = p.Ca / 64;        // all k-steps (Ca = lda + Ca2)
+  const T* __restrict__ a1 = reinterpret_cast<const T*>(p.a);
+  const T* __restrict__ w1 = reinterpret_cast<const T*>(p.w);
+  const T* __restrict__ a2 = reinterpret_cast<const T*>(p.a2);
+  const T* __restrict__ w2 = reinterpret_cast<const T*>(p.w2);
+  bool rok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rok[i] = m0 + lrow + 32 * i < p.Mg;
+  // past the end: the zero page (the counted waits below see four instructions per operand and step)
+  auto issue_a = [&](int kt) __attribute__((always_inline)) {
+    const bool live = kt < nk, seg2 = kt >= cs1;
+    const T* ab = seg2 ? a2 : a1;
+    const long long ld = seg2 ? p.Ca2 : lda;
+    const int k0 = (seg2 ? kt - cs1 : kt) * 64;
+    const unsigned dst = smem_addr + (kt % NSA) * A_BYTES + wave * 8 * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* src = live && rok[i] ? reinterpret_cast<const char*>(ab + (m0 + lrow + 32 * i) * ld + k0 + chunk_a * VE) : zsrc;
+      dma16(src, dst + i * 32 * 128);
+    }
+  };
+  auto issue_b = [&](int kt) __attribute__((always_inline)) {
+    const bool live = kt < nk, seg2 = kt >= cs1;
+    const T* wb = seg2 ? w2 : w1;
+    const long long ld = seg2 ? p.Ca2 : lda;
+    const int k0 = (seg2 ? kt - cs1 : kt) * 64;
+    const unsigned dst = smem_addr + B_BASE + (kt & 1) * B_BYTES + wave * 8 * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      dma16(live ? reinterpret_cast<const char*>(wb + (long long)(lrow + 32 * i) * ld + k0 + chunk_b * VE) : zsrc, dst + i * 32 * 128);
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fkey = (li >> 1) & 7;
+  const int fo0 = (g ^ fkey) * 16;
+  const int fa_base = (wm * 64 + li) * 128;
+  const int rowb0 = wn * 64 + chan_of(0, li);
+  const int fbo = B_BASE + rowb0 * 128 + ((g ^ key_b(rowb0)) * 16);
+
+  // in-order queue: A0, B0, A1 | step kt issues B(kt+1) then A(kt+2): at the top of step kt everything but A(kt+1) (4 instructions) has landed
+  issue_a(0);
+  issue_b(0);
+  issue_a(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... and every wave is past step kt - 1's stages
+    issue_b(kt + 1);   // weight stage (kt + 1) & 1 = the one step kt - 1 read
+    issue_a(kt + 2);   // activation stage (kt + 2) % 3 = the one step kt - 1 read
+    const char* sta = smem + (kt % NSA) * A_BYTES;
+    const char* stb = smem + (kt & 1) * B_BYTES;
+    uint4 fb[2][NI], fa[2][2];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      fb[0][ni] = *reinterpret_cast<const uint4*>(stb + fbo + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
+      fb[1][ni] = *reinterpret_cast<const uint4*>(stb + (fbo ^ 64) + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
+    }
+    fa[0][0] = *reinterpret_cast<const uint4*>(sta + fa_base + fo0);
+    fa[0][1] = *reinterpret_cast<const uint4*>(sta + fa_base + (fo0 ^ 64));
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      if (mi + 1 < MI) {  // the next row group's fragments are read while this one's MFMAs run
+        fa[(mi + 1) & 1][0] = *reinterpret_cast<const uint4*>(sta + fa_base + (mi + 1) * 16 * 128 + fo0);
+        fa[(mi + 1) & 1][1] = *reinterpret_cast<const uint4*>(sta + fa_base + (mi + 1) * 16 * 128 + (fo0 ^ 64));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = sh_mfma16(fb[0][ni], fa[mi & 1][0], acc[mi][ni]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = sh_mfma16(fb[1][ni], fa[mi & 1][1], acc[mi][ni]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS is reused by the reductions below
+
+  // ---- epilogue: lane holds pixel m0 + wm*64 + mi*16 + li, channels wn*64 + g*8 + 32 j .. + 7 (j = 0, 1) ----
+  T* __restrict__ out = reinterpret_cast<T*>(p.out);
+  const int ch0 = wn * 64 + g * VE;
+  float* red = reinterpret_cast<float*>(smem);  // [2 (wm)][2][BN]
+  const bool sums = DGRAD ? p.fpartial != nullptr : p.bn_partial != nullptr;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ch = ch0 + j * 32;
+    float s1[VE], s2[VE], sc[VE], sh[VE], bb[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s1[e] = s2[e] = sc[e] = bb[e] = 0.f, sh[e] = 1.f;  // (no ReLU: the gate y * 0 + 1 > 0 is open)
+    uint4 yq[MI];
+    if constexpr (DGRAD) {
+      if (p.bias != nullptr) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ch), b1 = *reinterpret_cast<const float4*>(p.bias + ch + 4);
+        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+      }
+      if (sums) {
+        if (p.fmode == 2) {
+#pragma unroll
+          for (int e = 0; e < VE; e += 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(p.fscale + ch + e), b4 = *reinterpret_cast<const float4*>(p.fshift + ch + e);
+            sc[e] = a4.x; sc[e + 1] = a4.y; sc[e + 2] = a4.z; sc[e + 3] = a4.w;
+            sh[e] = b4.x; sh[e + 1] = b4.y; sh[e + 2] = b4.z; sh[e + 3] = b4.w;
+          }
+        }
+        // all y rows of this 32-channel group are requested before the first is used (rows past the range read row 0, branch-free)
+        const T* __restrict__ fy = reinterpret_cast<const T*>(p.fy);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const long long pix = m0 + wm * 64 + mi * 16 + li;
+          yq[mi] = *reinterpret_cast<const uint4*>(fy + (pix < p.Mg ? pix : 0) * BN + ch);
+        }
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const long long pix = m0 + wm * 64 + mi * 16 + li;
+      const bool ok = pix < p.Mg;
+      const f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if constexpr (DGRAD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bb[e];
+      }
+      uint4 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      o.z = pack_bf16x2(v[4], v[5]);
+      o.w = pack_bf16x2(v[6], v[7]);
+      if (ok) *reinterpret_cast<uint4*>(out + pix * BN + ch) = o;
+      if (sums) {
+        if constexpr (DGRAD) {  // sums of the STORED gradient (as igemm_kernel): g = bf16(result) gated by the recomputed ReLU mask
+          const unsigned w4[4] = {o.x, o.y, o.z, o.w};
+          const unsigned y4[4] = {yq[mi].x, yq[mi].y, yq[mi].z, yq[mi].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int e = 2 * i + h;
+              const float gq = h == 0 ? h16_lo(w4[i]) : h16_hi(w4[i]);
+              const float yy = h == 0 ? h16_lo(y4[i]) : h16_hi(y4[i]);
+              const bool on = ok && yy * sc[e] + sh[e] > 0.f;
+              const float gv = on ? gq : 0.f;
+              s1[e] += gv;
+              s2[e] += gv * yy;
+            }
+        } else {  // forward: BatchNorm partial statistics of the fp32 results
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float ve = ok ? v[e] : 0.f;
+            s1[e] += ve;
+            s2[e] += ve * ve;
+          }
+        }
+      }
+    }
+    if (sums) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const float t1 = row16_sum(s1[e]), t2 = row16_sum(s2[e]);
+        if (li == 0) {
+          red[(wm * 2 + 0) * BN + ch + e] = t1;
+          red[(wm * 2 + 1) * BN + ch + e] = t2;
+        }
+      }
+    }
+  }
+  if (sums) {
+    __syncthreads();
+    const int which = tid >> 7, c = tid & 127;
+    const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c];
+    float* dstp = DGRAD ? p.fpartial : p.bn_partial;
+    dstp[((long long)m_tile * 2 + which) * BN + c] = v;
+  }
+}
+
+// 128 destination channels, 1x1 / stride 1, reduction segments in multiples of 64 and >= 256 long, at least 64 tiles
+static bool use_n128(const sh_conv_desc* d, int Ng, int K1, int K2, long long Mg) {
+  return sw(SH_SW_N128) && d->dtype == SH_BF16 && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && Ng == 128 && K1 % 64 == 0 &&
+         K2 % 64 == 0 && K1 + K2 >= 256 && Mg >= 128 * 64;
+}
+template <bool DGRAD>
+static int launch_n128(IgemmArgs a, hipStream_t s) {
+  if (a.lda == 0) a.lda = a.Ca;
+  route_hit(DGRAD ? SH_ROUTE_N128_DGRAD : SH_ROUTE_N128_FWD);
+  gemm_n128_kernel<DGRAD><<<ceil_div(a.Mg, 128), 256, 0, s>>>(a);
+  return check_launch(DGRAD ? "conv2d_dgrad (1x1, 128 channels)" : "conv2d_fwd (1x1, 128 channels)");
+}
+
 // the 256 x 256 kernel takes the bf16 layers with >= 256 destination channels in multiples of 256 and a reduction long
 // enough (>= 8 k-steps of 64) to amortise its one-block-per-CU prologue / epilogue
 static hook_t g_use_256{1};
@@ -1572,6 +1797,7 @@ int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void
   if (use_c64(d)) return launch_c64_conv(d, x, w, y, bn_partial, false, nullptr, (hipStream_t)stream);
   if (use_r128(d)) return launch_r128_conv(d, x, w, y, bn_partial, false, nullptr, (hipStream_t)stream);
   if (use_256_fwd(d, a.Mg)) return launch_igemm256<false>(a, (hipStream_t)stream);
+  if (use_n128(d, d->cout, d->cin, 0, a.Mg)) return launch_n128<false>(a, (hipStream_t)stream);
   return d->dtype == SH_F32 ? launch_igemm<float, false>(a, (hipStream_t)stream) : launch_igemm<bf16_t, false>(a, (hipStream_t)stream);
 }
 
@@ -1898,6 +2124,11 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
     if (check_launch("conv2d_dgrad (1x1)")) return 1;
     return sub != nullptr && !merged ? sub_fallback() : 0;
   }
+  // 128 destination channels behind a long reduction (conv3 of the stage-2 Bottlenecks, with the folded second segment): LDS-DMA tiles, two blocks per CU
+  if (sub == nullptr && src == nullptr && f8 == nullptr && accumulate == 0 && res_grad == nullptr &&
+      (fuse == nullptr || ((fuse->relu_mode == 0 || fuse->relu_mode == 2) && fuse->partial != nullptr)) &&
+      use_n128(d, d->cin, d->cout, x2 != nullptr ? c2 : 0, a.Mg))
+    return launch_n128<true>(a, (hipStream_t)stream);
   if (sub == nullptr && use_c64_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr)
     return launch_c64_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream);
   if (sub == nullptr && use_r128_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr && x2 == nullptr &&

@@ -1163,7 +1163,7 @@ def route_counts() -> dict:
 
 # include/simhand_hip.h enum sh_test_switch (the kernel-selection switches that were SIMHAND_* environment variables in round 3)
 TEST_SWITCHES = {"BN_GRID_APPLY": 0, "BN_GRID_BWD": 1, "R128": 2, "G1_PF": 3, "G1_CHAIN": 4, "G1_LT": 5, "FUSE_S2": 6, "WG_DMA": 7,
-                 "WG3_S2": 8, "WG_BIG": 9, "WG_WIDE": 10, "STEM_WG256": 11, "STEM_RING": 12, "STEM_RING_LT": 13, "STEM_WG_RING": 14}
+                 "WG3_S2": 8, "WG_BIG": 9, "WG_WIDE": 10, "STEM_WG256": 11, "STEM_RING": 12, "STEM_RING_LT": 13, "STEM_WG_RING": 14, "N128": 15}
 
 
 def test_switch(name: str, value: int) -> None:

@@ -1213,6 +1213,66 @@ def test_conv3x3_data_gradient_with_its_batchnorm_backward_applied_in_the_ring(n
     assert torch.equal(dx, dx_ref)
 
 
+@pytest.mark.parametrize("n,h,w,k1,k2,mode", [(11, 28, 28, 512, 128, 2), (17, 23, 21, 512, 0, 0), (9, 31, 30, 256, 64, None), (12, 28, 28, 1024, 0, 2)])
+def test_gemm_n128_data_gradient_and_forward(n, h, w, k1, k2, mode):
+    """Round 4: gemm_n128_kernel (1x1, 128 destination channels, long reduction: 128 x 128 LDS-DMA tiles, two blocks per CU) against the
+    128-row register-staged tile kernel it replaces (switch N128 = 0; same k order and MFMA chain: results compared exactly) and fp32 torch:
+    the data gradient with a second reduction segment, fp32 bias and the previous unit's BatchNorm-backward sums; the forward with its
+    BatchNorm partial statistics; ragged row counts."""
+    from simhand_amd import ops
+
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(n * 100 + k1 + k2)
+    c = 128
+    d = ops.conv_desc(n, h, w, c, k1, 1, 1, 1, 0, dtype)   # conv c -> k1; its data gradient reduces over k1 (+ k2)
+    dy = _rnd(torch.randn(n, h, w, k1, generator=g), dtype).to(DEV).to(dtype)
+    wt = _rnd(torch.randn(k1, c, 1, 1, generator=g) / math.sqrt(k1), dtype).to(DEV)
+    wtd = ops.pack_crsk(wt, dtype)
+    kw = {}
+    if k2:
+        x2 = _rnd(torch.randn(n, h, w, k2, generator=g), dtype).to(DEV).to(dtype)
+        w2 = _rnd(torch.randn(c, k2, generator=g) / math.sqrt(k2), dtype).to(DEV).to(dtype)
+        kw.update(x2=x2, wt2=w2, bias=torch.randn(c, generator=g).to(DEV))
+    if mode is not None:
+        py = _rnd(torch.randn(n, h, w, c, generator=g), dtype).to(DEV).to(dtype)
+        pst = ops.BNState(c, DEV)
+        pst.scale.copy_((torch.randn(c, generator=g) * 0.8).to(DEV))
+        pst.shift.copy_((torch.randn(c, generator=g) * 0.5).to(DEV))
+        kw.update(fuse_mode=mode, prev_y=py, prev_st=pst if mode == 2 else None)
+    ops.route_reset()
+    dx, part = ops.conv2d_dgrad_ex(d, dy, wtd, **kw)
+    assert ops.route_counts()["n128_dgrad"] == 1
+    ops.test_switch("N128", 0)
+    try:
+        ops.route_reset()
+        dx_ref, part_ref = ops.conv2d_dgrad_ex(d, dy, wtd, **kw)
+        assert ops.route_counts()["n128_dgrad"] == 0
+    finally:
+        ops.test_switch("N128", -1)
+    assert torch.equal(dx, dx_ref)
+    if mode is not None:
+        assert torch.allclose(part.sum(0), part_ref.sum(0), rtol=1e-4, atol=1e-2)
+    want = dy.float().view(-1, k1) @ wt.view(k1, c)
+    if k2:
+        want = want + x2.float().view(-1, k2) @ w2.float().t() + kw["bias"]
+    _check(dx.float().view(-1, c).cpu(), want.cpu(), _tol(dtype), "n128 data gradient")
+    # forward of the mirrored layer (k1 -> 128) with BatchNorm partial sums
+    df = ops.conv_desc(n, h, w, k1, c, 1, 1, 1, 0, dtype)
+    wf = _rnd(torch.randn(c, k1, 1, 1, generator=g) / math.sqrt(k1), dtype).to(DEV)
+    wk = ops.pack_krsc(wf, dtype)
+    ops.route_reset()
+    y, ps = ops.conv2d_fwd(df, dy, wk, want_stats=True)
+    assert ops.route_counts()["n128_fwd"] == (1 if k1 > 256 else 0)   # K <= 256: the activation-stationary kernel keeps the layer
+    ops.test_switch("N128", 0)
+    try:
+        y_ref, ps_ref = ops.conv2d_fwd(df, dy, wk, want_stats=True)
+    finally:
+        ops.test_switch("N128", -1)
+    assert torch.equal(y, y_ref)
+    assert torch.allclose(ps.sum(0), ps_ref.sum(0), rtol=1e-4, atol=1e-2)
+    _check(y.float().view(-1, c).cpu(), (dy.float().view(-1, k1) @ wf.view(c, k1).t()).cpu(), _tol(dtype), "n128 forward")
+
+
 @pytest.mark.parametrize("n,h,c,relu", [(3, 13, 64, True), (2, 20, 128, True), (5, 9, 256, True), (2, 7, 512, False), (1, 5, 64, True)])
 def test_bn_apply_fused_into_the_gram_launch(n, h, c, relu):
     """simhand_bn_apply_gram: a = act(y*scale + shift), a^T a and sum a in one launch of the 1x1 weight-gradient kernel ==

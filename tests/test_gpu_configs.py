@@ -195,7 +195,7 @@ def _check_bf16(res, loss_band, zcos_floor, gmed_floor, gp10_floor, flip_frac):
 BF16_ROUTES_RN50 = ("stem_fwd", "stem_bn_pool", "c64_fwd", "c64_dgrad", "gemm1x1_fwd", "gemm1x1_fwd_bnact", "gemm1x1_dgrad", "igemm128_fwd",
                     "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
                     "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_apply_gram", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
-                    "bn_bwd_apply", "ntxent_fwd", "ntxent_bwd", "fwd_chain", "dgrad_dysrc", "fwd_bnin")
+                    "bn_bwd_apply", "ntxent_fwd", "ntxent_bwd", "fwd_chain", "dgrad_dysrc", "fwd_bnin", "n128_fwd", "n128_dgrad")
 
 
 def test_config1_rn50_handclr_w_bf16_every_route_against_oracle():

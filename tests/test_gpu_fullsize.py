@@ -32,9 +32,9 @@ SHAPES = {
     (256, 64, 1, 1, 56): ("gemm1x1_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (256, 128, 1, 1, 56): ("gemm1x1_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (128, 128, 3, 2, 56): ("igemm128_fwd", "r128_dgrad", "wgrad3x3"),   # round 4: the four parity classes on the LDS-ring kernel
-    (128, 512, 1, 1, 28): ("gemm1x1_fwd", "igemm128_dgrad", "wgrad_plain"),
+    (128, 512, 1, 1, 28): ("gemm1x1_fwd", "n128_dgrad", "wgrad_plain"),   # round 4: 128 x 128 LDS-DMA tiles, two blocks per CU
     (256, 512, 1, 2, 56): ("igemm256_fwd", "igemm128_dgrad", "wgrad_generic"),
-    (512, 128, 1, 1, 28): ("igemm128_fwd", "gemm1x1_dgrad", "wgrad_plain"),
+    (512, 128, 1, 1, 28): ("n128_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (128, 128, 3, 1, 28): ("r128_fwd", "r128_dgrad", "wgrad3x3"),
     (512, 256, 1, 1, 28): ("igemm256_fwd", "gemm1x1_dgrad", "wgrad_plain"),
     (256, 256, 3, 2, 28): ("igemm256_fwd", "igemm256_dgrad", "wgrad3x3"),
@@ -505,6 +505,7 @@ def test_fullsize_folded_dgrad_two_segments_bias_and_fused_sums(cw, cc, h):
     torch.cuda.synchronize()
     rc = ops.route_counts()
     assert rc["dgrad_concat"] == 1 and rc["dgrad_fused_sums"] == 1, rc
+    assert rc["n128_dgrad"] == (1 if cw == 128 else 0), rc   # round 4: the 128-channel layer on gemm_n128_kernel
     idx = torch.tensor(SAMPLE, device=DEV)
     want = (gy[idx].float().cpu().reshape(-1, cc) @ wa.float().cpu().t() + a2[idx].float().cpu().reshape(-1, cw) @ wm.float().cpu().t()
             + bias.cpu())
