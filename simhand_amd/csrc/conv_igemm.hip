@@ -1812,6 +1812,8 @@ int simhand_conv2d_fwd_bnin(const sh_conv_desc* d, const void* y_in, const float
   if (check_desc(d, "conv2d_fwd_bnin")) return 1;
   SH_REQUIRE(y_in && in_scale && in_shift && w && a_out && y, "conv2d_fwd_bnin: NULL pointer");
   SH_REQUIRE(simhand_conv2d_fwd_bnin_ok(d), "conv2d_fwd_bnin: no ring kernel for this layer (simhand_conv2d_fwd_bnin_ok)");
+  // a tile re-reads its neighbours' halo rows: in place, some of them would already hold the activation
+  SH_REQUIRE(a_out != y_in && a_out != y && y != y_in, "conv2d_fwd_bnin: y_in, a_out and y must be three distinct tensors");
   const double mg = (double)d->n * d->ho * d->wo;
   const double flops = 2.0 * mg * d->cout * d->cin * d->r * d->s;
   const double bytes = 2.0 * (2.0 * (double)d->n * d->h * d->w * d->cin + mg * d->cout + (double)d->cout * d->cin * d->r * d->s);
@@ -2032,6 +2034,8 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
                "conv2d_dgrad_ex: dy_src has a NULL member");
     const bool ring = dysrc_r128_ok(d) && use_r128_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr &&
                       f8 == nullptr && (f8sub == nullptr || f8sub->sub_grad == nullptr);
+    SH_REQUIRE(!ring || (src->dy_out != src->da && src->dy_out != src->y && src->dy_out != dx),
+               "conv2d_dgrad_ex: dy_src on the ring kernel writes dy_out while neighbouring tiles still read da / y: they must be distinct tensors");
     SH_REQUIRE(x2 == nullptr && (use_1x1(d, d->cout, d->cin) || ring),
                "conv2d_dgrad_ex: dy_src needs a layer simhand_conv2d_dgrad_dysrc_ok accepts, a single reduction segment and (3x3 ring kernel) "
                "the store-only or fused-sums form");

@@ -1165,6 +1165,13 @@ def test_conv3x3_forward_with_the_previous_batchnorm_applied_in_its_ring(n, h, w
     assert torch.equal(part, p_ref)
     _, y0, none = ops.conv2d_fwd_bnin(d, y_in, st, wk, want_stats=False)
     assert none is None and torch.equal(y0, y_ref)
+    # in place is refused: a tile re-reads its neighbours' halo rows, some of which would already hold the activation
+    import ctypes as C
+    from simhand_amd import _lib
+    lib = _lib.load()
+    rc = lib.simhand_conv2d_fwd_bnin(C.byref(d), y_in.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), wk.data_ptr(), y_in.data_ptr(),
+                                     y0.data_ptr(), None, None)
+    assert rc != 0 and b"distinct" in lib.simhand_last_error()
 
 
 @pytest.mark.parametrize("n,h,w,relu,sums", [(24, 28, 28, True, True), (40, 14, 30, True, False), (300, 7, 7, False, True), (64, 17, 15, True, True)])
