@@ -31,7 +31,7 @@ cat "$out/${tag}_bench_b1024.json"
 # per-GPU batch of 2048 pairs = 4096 images), precision 16
 # (fp16 storage + GradScaler: the reference's policy), ResNet-18 / ResNet-152
 {
-  for cfg in "--experiment simclr" "--experiment simclr --precision fp8" "--experiment simclr --per-gpu-batch 2048" "--experiment simclr --precision fp8 --per-gpu-batch 2048" "--precision 16" "--resnet 18" "--resnet 152 --experiment peclr_w --per-gpu-batch 512" "--engine stem_two_pass=1" "--engine bn_on_load=0" "--engine bwd_apply_in_ring=1"; do
+  for cfg in "--experiment simclr" "--experiment simclr --precision fp8" "--experiment simclr --per-gpu-batch 2048" "--experiment simclr --precision fp8 --per-gpu-batch 2048" "--precision 16" "--resnet 18" "--resnet 152 --experiment peclr_w --per-gpu-batch 512"; do
     python bench.py --steps 8 --warmup 3 --no-cpu-baseline $cfg 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.readlines()[-1]); print('| bench.py $cfg |', round(d['ms_per_step'], 2), 'ms/step |', round(d['value']), 'pairs/s |', d['dtype'], '|')"
   done
 } > "$out/${tag}_other_configs.md"
