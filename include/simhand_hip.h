@@ -274,7 +274,8 @@ int simhand_test_conv3x3_r128_enable(int on);
 int simhand_test_conv1x1_set_rows(int k, int mf);
 int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void* y, float* bn_partial, sh_stream_t stream);
 /* simhand_bn_apply (ReLU, no residual) + simhand_conv2d_fwd in ONE launch, for the 3x3 layers whose kernel keeps its activation rows in an
- * LDS ring (simhand_conv2d_fwd_bnin_ok(d): the 64 -> 64 layers at 56 x 56): y_in is the previous unit's RAW conv output [n][h][w][cin], the ring
+ * LDS ring (simhand_conv2d_fwd_bnin_ok(d): the 64 -> 64 ring kernel, e.g. 56 x 56, AND the 128 -> 128 ring kernel, e.g. 28 x 28, as long as
+ * n*h*w*cin < 2^32 -- the by-product's element offsets are 32-bit in the kernels): y_in is the previous unit's RAW conv output [n][h][w][cin], the ring
  * rows are rewritten in place as a = relu(y_in * in_scale + in_shift) before any tap reads them (pad positions fetch NaNs, which the ReLU
  * turns into the exact zeros the padding needs), and a leaves as a by-product (a_out, same shape: the weight gradient's operand).  The
  * stand-alone pass -- one read and one write of the tensor -- disappears.  y, bn_partial as simhand_conv2d_fwd(d, a, ...); a_out, y and

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
       const int chunk = slot ^ ((row >> 1) & 7);                // ring row = 64 (c + 1) + row: same key
       const char* src = ok ? reinterpret_cast<const char*>(p.x + (unsigned long long)pix * 64 + chunk * 8) : zsrc;
       dma16(src, ring_addr + ((((c + 1) * 64) & (RING - 1)) + wave * 16 + h * 8) * 128);
-      if constexpr (BNIN) off[h] = ok ? pix * 64u + (unsigned)chunk * 8u : 0xffffffffu;  // < 2^32 elements (q_total < 2^31 / 64 checked on the host)
+      if constexpr (BNIN) off[h] = ok ? pix * 64u + (unsigned)chunk * 8u : 0xffffffffu;  // 32-bit element offset: n*h*w*cin < 2^32 (simhand_conv2d_fwd_bnin_ok, re-checked in launch_c64_conv)
     }
   };
   // BNIN: rewrite the lane's own 2 x 16 bytes of chunk c in place; own = the chunk belongs to this block's range (else a neighbour stores it)

@@ -706,8 +706,8 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   typedef bf16_t T;                                                             // stored results (and bf16 operands)
   typedef typename std::conditional<FP8, unsigned char, bf16_t>::type IT;     // operand element
   constexpr int KE = FP8 ? 128 : 64, VE = 8, IVE = FP8 ? 16 : 8, BM = MI * 32, BN = 256, NI = 4, WR = MI * 16;  // WR: rows per wave
-  constexpr int A_BYTES = 256 * 128, STAGE = A_BYTES + BN * 128;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  constexpr int A_BYTES = 256 * 128, B_BYTES = BN * 128, NSA = 3, NSB = 2, B_BASE = NSA * A_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[NSA * A_BYTES + NSB * B_BYTES];  // 160 KB: the CU's whole LDS
   // LDS-DMA as inline asm: hipcc's waitcnt pass makes every ds_read wait for ALL outstanding builtin LDS-DMAs
   // (s_waitcnt vmcnt(0) right after the barrier), which would drain the prefetch; the asm form is invisible to it and
   // the loop counts vmcnt by hand.  m0 = LDS byte address of the wave's 1-KB destination.
@@ -796,64 +796,86 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   const int cs1 = p.lda / KE;  // k-steps of the first K segment (== csteps without a second one)
   const int dma_row0 = wave * 8 * 128;  // + i * 64 * 128: wave-uniform LDS offset of this wave's 8 rows
 
-  // DMA state of the NEXT k-step (wave-uniform): tap walk, element offsets, destination stage
-  int l_cs = 0, l_tr = 0, l_ts = 0;
+  // DMA state (wave-uniform).  TWO walkers over the same k order: the activation walker runs two k-steps ahead of the MFMAs (three
+  // 32-KB stages), the weight walker one (two stages) -- 160 KB, the whole LDS of the CU.  k order: taps INNERMOST (a 64-channel
+  // slice of the activation rows visits its taps back to back: the re-reads of a slice are at most nts * ntr k-steps apart and stay
+  // in L2 whatever cin is; tap-major order measured 5-10 % slower from cin = 512 on, scripts/tile_overhead.py).
+  struct Walk { int cs, tr, ts; };
+  Walk wa = {0, 0, 0}, wb = {0, 0, 0};
   int n_hoff = 0, n_woff = 0, n_aoff = 0, n_boff = 0;
-  unsigned n_dA = 0;
-  bool n_live = true;  // false on the last k-step: its (branch-free) DMAs fetch the zero page into the idle stage
-  auto next_step = [&](int stage) __attribute__((always_inline)) {
-    if constexpr (DGRAD) if (p.a2 != nullptr && l_cs == cs1) {
-      // second K segment (1x1 / stride 1: pixel index == m): re-base the row and weight pointers so that the same
-      // l_cs * KE offsets walk a2 / w2; dead rows keep their h0 = -2^20
+  unsigned n_dA = 0, n_dB = 0;
+  bool a_live = true, b_live = true;  // false past the last k-step: the (branch-free) DMAs then fetch the zero page into an idle stage
+  auto advance = [&](Walk& w) __attribute__((always_inline)) {
+    if (++w.ts == nts) {
+      w.ts = 0;
+      if (++w.tr == ntr) {
+        w.tr = 0;
+        ++w.cs;
+      }
+    }
+  };
+  auto next_a = [&](int stage) __attribute__((always_inline)) {
+    if constexpr (DGRAD) if (p.a2 != nullptr && wa.cs == cs1) {
+      // second K segment (1x1 / stride 1: pixel index == m): re-base the row pointers so that the same cs * KE offsets walk a2;
+      // dead rows keep their h0 = -2^20
       const IT* a2 = reinterpret_cast<const IT*>(p.a2);
       const long long back = -(long long)cs1 * KE;
       pa0 = a2 + (long long)(m0 + lrow) * p.Ca2 + chunk_a * VE + back;
       pa1 = a2 + (long long)(m0 + lrow + 64) * p.Ca2 + chunk_a * VE + back;
       pa2 = a2 + (long long)(m0 + lrow + 128) * p.Ca2 + chunk_a * VE + back;
       pa3 = a2 + (long long)(m0 + lrow + 192) * p.Ca2 + chunk_a * VE + back;
-      pb0 = reinterpret_cast<const IT*>(p.w2) + (long long)(n0 + lrow) * p.Ca2 + chunk_b * VE + back;
+    }
+    n_hoff = dh * wa.tr;
+    n_woff = dh * wa.ts;
+    n_aoff = (n_hoff * p.Ws + n_woff) * p.lda + wa.cs * KE;
+    n_dA = smem_addr + stage * A_BYTES + dma_row0;
+    advance(wa);
+  };
+  auto next_b = [&](int stage) __attribute__((always_inline)) {
+    if constexpr (DGRAD) if (p.a2 != nullptr && wb.cs == cs1) {  // second K segment: w2 [Ng][Ca2]
+      pb0 = reinterpret_cast<const IT*>(p.w2) + (long long)(n0 + lrow) * p.Ca2 + chunk_b * VE - (long long)cs1 * KE;
       wrow64 = 64ll * p.Ca2;
     }
-    n_hoff = dh * l_tr;
-    n_woff = dh * l_ts;
-    n_aoff = (n_hoff * p.Ws + n_woff) * p.lda + l_cs * KE;
-    n_boff = ((r0 + rstep * l_tr) * p.S + (s0 + rstep * l_ts)) * p.lda + l_cs * KE;
-    n_dA = smem_addr + stage * STAGE + dma_row0;
-    if (++l_cs == csteps) {  // tap-major k order (taps innermost measured the same: the re-reads are not the limiter)
-      l_cs = 0;
-      if (++l_ts == nts) {
-        l_ts = 0;
-        ++l_tr;
-      }
-    }
+    n_boff = ((r0 + rstep * wb.tr) * p.S + (s0 + rstep * wb.ts)) * p.lda + wb.cs * KE;
+    n_dB = smem_addr + B_BASE + stage * B_BYTES + dma_row0;
+    advance(wb);
   };
-  // part q of the 8 DMA instructions of a k-step: 0-3 = A rows lrow + 64 q, 4-7 = weight rows lrow + 64 (q - 4)
-  auto dma_part = [&](int q) __attribute__((always_inline)) {
-    auto dma_a = [&](const IT* pa, int h0, int w0, int i) __attribute__((always_inline)) {
-      const bool ok = n_live && (unsigned)(h0 + n_hoff) < (unsigned)p.Hs && (unsigned)(w0 + n_woff) < (unsigned)p.Ws;
-      const char* src = ok ? reinterpret_cast<const char*>(pa + n_aoff) : zsrc;
-      dma16(src, n_dA + i * 64 * 128);
-    };
 #ifndef SH_ABL256
 #define SH_ABL256 0
 #endif
-    // SH_ABL256 (scripts/igemm256_ablate.sh; garbage results): 1 = A from the zero page, 2 = no A DMAs, 3 = no B DMAs, 4 = none
-#if SH_ABL256 == 1
-    if (q < 4) { dma16(zsrc, n_dA + q * 64 * 128); return; }
-#elif SH_ABL256 == 2
-    if (q < 4) return;
-#elif SH_ABL256 == 3
-    if (q >= 4) return;
-#elif SH_ABL256 == 4
-    return;
+  // SH_ABL256 (ablation builds, garbage results; scripts/diag_r05*.sh): 1 = activations from the zero page, 9 = weights from the zero
+  // page, 8 = both (issue slots and LDS writes stay, L2 traffic goes), 2 / 3 / 4 = no activation / no weight / no DMAs at all
+  // part i (0..3) of a k-step's activation DMAs: tile rows lrow + 64 i (MI = 7: rows 224.. fetch the zero page -- every wave issues the
+  // same number of DMAs, the counted waits below depend on it)
+  auto dma_a_part = [&](int i) __attribute__((always_inline)) {
+    auto dma_a = [&](const IT* pa, int h0, int w0) __attribute__((always_inline)) {
+      const bool ok = a_live && (unsigned)(h0 + n_hoff) < (unsigned)p.Hs && (unsigned)(w0 + n_woff) < (unsigned)p.Ws;
+      const char* src = ok ? reinterpret_cast<const char*>(pa + n_aoff) : zsrc;
+#if SH_ABL256 == 1 || SH_ABL256 == 8
+      src = zsrc;
 #endif
-    if (q == 0) dma_a(pa0, h00, w00, 0);
-    else if (q == 1) dma_a(pa1, h01, w01, 1);
-    else if (q == 2) dma_a(pa2, h02, w02, 2);
-    else if (q == 3) {
-      if (MI == 8 || wave < 4) dma_a(pa3, h03, w03, 3);  // wave-uniform: rows 192 + 8 wave .. of a 224-row tile exist for waves 0-3 only
-    }
-    else dma16(n_live ? reinterpret_cast<const char*>(pb0 + (q - 4) * wrow64 + n_boff) : zsrc, n_dA + A_BYTES + (q - 4) * 64 * 128);
+#if SH_ABL256 != 2 && SH_ABL256 != 4
+      dma16(src, n_dA + i * 64 * 128);
+#endif
+    };
+    if (i == 0) dma_a(pa0, h00, w00);
+    else if (i == 1) dma_a(pa1, h01, w01);
+    else if (i == 2) dma_a(pa2, h02, w02);
+    else dma_a(pa3, h03, w03);
+  };
+  auto dma_b_part = [&](int i) __attribute__((always_inline)) {
+    const char* src = b_live ? reinterpret_cast<const char*>(pb0 + i * wrow64 + n_boff) : zsrc;
+#if SH_ABL256 == 9 || SH_ABL256 == 8
+    src = zsrc;
+#endif
+#if SH_ABL256 != 3 && SH_ABL256 != 4
+    dma16(src, n_dB + i * 64 * 128);
+#endif
+  };
+  // the 8 DMA instructions a wave issues per k-step, in queue order: 0-3 = weights of step kt + 1, 4-7 = activations of step kt + 2
+  auto dma_part = [&](int q) __attribute__((always_inline)) {
+    if (q < 4) dma_b_part(q);
+    else dma_a_part(q - 4);
   };
 
   f32x4 acc[MI][NI];
@@ -866,31 +888,48 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   const int fo0 = (g ^ fkey) * 16;
   const int fa_base = (wm * WR + li) * 128;
   const int rowb0 = wn * 64 + chan_of(0, li);
-  const int fbo = A_BYTES + rowb0 * 128 + ((g ^ key_b(rowb0)) * 16);
+  const int fbo = rowb0 * 128 + ((g ^ key_b(rowb0)) * 16);
 
-  // ---- main loop: ONE barrier per k-step.  Before it every wave has (a) waited for its own DMAs of step kt and (b)
-  // finished reading the other stage (step kt - 1); after it the DMAs of step kt + 1 go out into that other stage, one
-  // after every 8 MFMAs, and have the whole step to land.  The fragments of MFMA group grp + 1 are read before the
-  // MFMAs of group grp are issued.  (Measured alternatives, both slower: two barriers per step with all DMAs up front;
-  // two wave groups ping-ponging load / compute segments across 8 barriers per step -- s_barrier costs ~250 cycles.)
+  // ---- main loop: ONE barrier per k-step and a COUNTED wait -- the vector-memory queue never drains.  The CU's L1 holds a bounded
+  // number of L2 requests in flight (measured: ~40 lines at ~270 cycles of L2 latency = 19 B/clk, against the 30 B/clk the MFMAs could
+  // consume; with every DMA served from L1 the same loop runs at the MFMA rate -- profiles/r05_igemm256_ablation.txt), so what the loop
+  // must do is keep that queue non-empty ALL the time: one DMA instruction after every MFMA group, weights of step kt + 1 first (they
+  // have the rest of the step to land), then the activations of step kt + 2 (a whole further step).  In-order retirement: at the top
+  // of step kt the queue ends with [W(kt) x 4, A(kt + 1) x 4]; vmcnt(4) leaves exactly A(kt + 1) in flight.  The barrier that follows
+  // orders (a) every wave's landed DMAs of step kt before anybody's fragment reads and (b) everybody's reads of step kt - 1 before
+  // the DMAs into its stages (A stage (kt + 2) % 3 == (kt - 1) % 3, W stage (kt + 1) & 1).  The fragments of MFMA group grp + 1 are
+  // read before the MFMAs of group grp are issued.  (Measured alternatives, all slower: two 64-KB stages with the DMAs in the first half
+  // of the step and vmcnt(0) -- the round 1-4 form; two barriers per step; ping-pong wave groups: s_barrier costs ~250 cycles.)
   if (nk > 0) {
-    next_step(0);
+    next_a(0);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) dma_part(q);
+    for (int i = 0; i < 4; ++i) dma_a_part(i);
+    next_b(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_b_part(i);
+    a_live = 1 < nk;
+    next_a(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_a_part(i);
   }
+  int sa = 0;  // kt % 3
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    n_live = kt + 1 < nk;  // last step: the (branch-free) DMAs fetch the zero page into the idle stage
-    next_step((kt + 1) & 1);
-    const char* st = smem + (kt & 1) * STAGE;
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    b_live = kt + 1 < nk;
+    next_b((kt + 1) & 1);
+    a_live = kt + 2 < nk;
+    next_a(sa == 0 ? 2 : sa - 1);  // (kt + 2) % 3
+    const char* st = smem + sa * A_BYTES;                      // activation stage of this step
+    const char* stb = smem + B_BASE + (kt & 1) * B_BYTES;      // weight stage
+    sa = sa == 2 ? 0 : sa + 1;
     if constexpr (FP8) {
       // one scaled MFMA per 16 x 16 tile pair and k-step: operand = the lane's chunks g (k 0..63 half) and g + 4 of its tile row
       typedef __attribute__((ext_vector_type(8))) int i32x8;
       uint4 fbl[NI], fbh[NI], fal[2][2], fah[2][2];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        fbl[ni] = *reinterpret_cast<const uint4*>(st + fbo + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
-        fbh[ni] = *reinterpret_cast<const uint4*>(st + (fbo ^ 64) + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
+        fbl[ni] = *reinterpret_cast<const uint4*>(stb + fbo + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
+        fbh[ni] = *reinterpret_cast<const uint4*>(stb + (fbo ^ 64) + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
       }
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
@@ -928,7 +967,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     } else {
     uint4 fb[2][NI], fa[2][2];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) fb[0][ni] = *reinterpret_cast<const uint4*>(st + fbo + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
+    for (int ni = 0; ni < NI; ++ni) fb[0][ni] = *reinterpret_cast<const uint4*>(stb + fbo + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
     fa[0][0] = *reinterpret_cast<const uint4*>(st + fa_base + fo0);
     fa[0][1] = *reinterpret_cast<const uint4*>(st + fa_base + 16 * 128 + fo0);
 #pragma unroll
@@ -940,10 +979,18 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         if (grp == 3) {
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            fb[1][ni] = *reinterpret_cast<const uint4*>(st + (fbo ^ 64) + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
+            fb[1][ni] = *reinterpret_cast<const uint4*>(stb + (fbo ^ 64) + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
         }
+#if SH_ABL256 == 6  // ablation (garbage results): half of the A fragment reads
+        if ((grp & 1) == 0) { fa[1][0] = fa[0][0]; fa[1][1] = fa[0][1]; } else {
+#elif SH_ABL256 == 7  // ablation: no A fragment reads after the first group of a k-step
+        if (true) { fa[(grp + 1) & 1][0] = fa[grp & 1][0]; fa[(grp + 1) & 1][1] = fa[grp & 1][1]; } else {
+#else
+        {
+#endif
         fa[(grp + 1) & 1][0] = *reinterpret_cast<const uint4*>(st + fa_base + (2 * nq) * 16 * 128 + fo);
         if (2 * nq + 1 < MI) fa[(grp + 1) & 1][1] = *reinterpret_cast<const uint4*>(st + fa_base + (2 * nq + 1) * 16 * 128 + fo);
+        }
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[2 * q][ni] = Mma<T>::run(fb[kk][ni], fa[grp & 1][0], acc[2 * q][ni]);
@@ -951,12 +998,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[2 * q + 1][ni] = Mma<T>::run(fb[kk][ni], fa[grp & 1][1], acc[2 * q + 1][ni]);
       }
-      // next step's DMAs: two per group in the FIRST half of the step, so that the last one has half a step to land before the
-      // vmcnt(0) at the top of the loop (one per group over the whole step measured 3-7 % slower on the 3x3 layers)
-      if (grp < 4) {
-        dma_part(2 * grp);
-        dma_part(2 * grp + 1);
-      }
+      dma_part(grp);  // one DMA instruction per MFMA group: the L1's request queue stays fed through the whole step
     }
       }
   }
@@ -1697,6 +1739,9 @@ static int launch_c64_conv(const sh_conv_desc* d, const void* x, const void* w, 
   c.relu = fuse && fuse->relu_mode == 2 ? 1 : 0;
   c.N = d->n; c.H = d->h; c.W = d->w; c.dgrad = dgrad ? 1 : 0;
   c.q_total = c64_q_total(d);
+  // the kernels' pixel / element arithmetic is 32-bit: padded positions (boff, q) and, for the BatchNorm-on-load by-product, off[]
+  SH_REQUIRE(c.q_total < (1ll << 31), "conv3x3 c64: padded pixel grid exceeds 2^31 positions");
+  SH_REQUIRE(bnin == nullptr || (long long)d->n * d->h * d->w * 64 < (1ll << 32), "conv3x3 c64 (bnin): n*h*w*64 exceeds the 32-bit element offsets");
   c.steps_per_block = 0;
   c.div_pp = make_fastdiv((unsigned)((d->h + 1) * (d->w + 1)));
   c.div_wp = make_fastdiv((unsigned)(d->w + 1));
@@ -1740,6 +1785,9 @@ static int launch_r128_conv(const sh_conv_desc* d, const void* x, const void* w,
   c.relu = fuse && fuse->relu_mode == 2 ? 1 : 0;
   c.N = d->n; c.H = d->h; c.W = d->w; c.dgrad = dgrad ? 1 : 0;
   c.q_total = c64_q_total(d);
+  SH_REQUIRE(c.q_total < (1ll << 31), "conv3x3 r128: padded pixel grid exceeds 2^31 positions");
+  SH_REQUIRE((bnin == nullptr && src == nullptr) || (long long)d->n * d->h * d->w * 128 < (1ll << 32),
+             "conv3x3 r128 (bnin / dy_src): n*h*w*128 exceeds the 32-bit element offsets");
   c.tiles = 0;
   c.div_pp = make_fastdiv((unsigned)((d->h + 1) * (d->w + 1)));
   c.div_wp = make_fastdiv((unsigned)(d->w + 1));

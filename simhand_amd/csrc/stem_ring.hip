@@ -28,7 +28,8 @@
 //           tap (uint8, scan order kh then kw, first maximum wins: ATen's rule) and the winner's RAW conv output -- the three tensors
 //           bn_relu_maxpool_fwd_kernel (bn.hip) produces from the stored y, bit for bit (tests/test_gpu_backbone_ops.py).
 //           a >= 0, so its bit patterns order like unsigned integers: window maximum and first-wins argmax are ONE v_max_u32 per tap
-//           on keys (a_bits << 8 | 8 - tap).
+//           on keys ((a_bits + 1) << 16 | 8 - tap): the + 1 bias is load-bearing -- the all-zero stand-ins for taps outside the image
+//           hold key 0 < (a_bits + 1) << 16 and therefore never win, whatever a is.
 #include "conv_1x1.h"
 
 #include <stdlib.h>

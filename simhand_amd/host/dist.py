@@ -104,7 +104,9 @@ class RcclComm:
         if self._h_side is None:
             return None
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream()
+            # HIGH priority: the second communicator's kernels must become resident next to long one-block-per-CU compute kernels,
+            # otherwise a peer's side-communicator kernel can wait on ours while ours waits behind the compute stream
+            self._side = torch.cuda.Stream(priority=-1)
         return self._side
 
     def all_gather_into(self, out: torch.Tensor, x: torch.Tensor) -> None:
@@ -322,7 +324,13 @@ class OverlappedGradReducer:
         if _AUDIT is not None:
             _AUDIT.note(f"bucket{len(self._pending)}", flat.clone(), flat)
         if isinstance(self.group, RcclComm):
-            side = self.group.side_stream()
+            from .. import ops
+
+            # Under synchronised BatchNorm the compute stream issues collectives of the FIRST communicator all through the backward;
+            # two communicators with kernels in flight at once are only deadlock-free if both can be resident on every rank, which
+            # nothing guarantees next to one-block-per-CU compute kernels, and the combination has no multi-GPU run behind it
+            # (open issue): buckets then go out in order on the launch stream (correct, not overlapped).
+            side = None if ops.bn_sync_active() else self.group.side_stream()
             if side is None:                       # no second communicator: in order on the launch stream
                 self.group.all_reduce_(flat, "sum")
                 work = None

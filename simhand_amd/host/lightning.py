@@ -77,6 +77,9 @@ class ModelCheckpoint:
             return
         os.makedirs(self.dirpath, exist_ok=True)
         path = os.path.join(self.dirpath, self.format_name(epoch, metrics))
+        # a resumed run may rewrite a file it already lists (default template '{epoch:02d}', or a mid-epoch resume that re-runs the
+        # epoch): ONE entry per path, the new score replaces the old one
+        self.kept = [(k, p) for k, p in self.kept if p != path]
         self.kept.append((key, path))
         self.kept.sort(key=lambda t: t[0])
         drops = []
@@ -84,8 +87,9 @@ class ModelCheckpoint:
             drops.append(self.kept.pop()[1])
         self.best_model_path = self.kept[0][1]
         torch.save(trainer.checkpoint_dict(module, epoch), path)  # records `kept` INCLUDING itself: what a resumed run may prune later
+        live = {p for _, p in self.kept}
         for drop in drops:
-            if os.path.exists(drop):
+            if drop not in live and os.path.exists(drop):  # never remove a file an entry (or best_model_path) still points to
                 os.remove(drop)
 
     def _template_regex(self) -> "re.Pattern":

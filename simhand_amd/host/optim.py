@@ -36,10 +36,12 @@ class LARSAdam(torch.optim.Optimizer):
 
     accepts_found_inf = True
 
-    def _resolve_pending(self) -> None:
+    def _resolve_pending(self, block: bool = True) -> None:
         if self._pending is None:
             return
         host, ev, ps = self._pending
+        if not block and not ev.query():
+            return  # the flag is still on its way: the next step() settles it
         self._pending = None
         ev.synchronize()
         if float(host[0]) != 0.0:  # that step was skipped on the device: take its count back
@@ -57,7 +59,9 @@ class LARSAdam(torch.optim.Optimizer):
         return super().load_state_dict(state_dict)
 
     def zero_grad(self, set_to_none: bool = True):
-        self._resolve_pending()
+        # called at the top of every step, BEFORE the next forward / backward are enqueued: never block here (a blocking read would idle
+        # the GPU once per iteration under precision 16); zero_grad neither exposes nor replaces the counters
+        self._resolve_pending(block=False)
         return super().zero_grad(set_to_none=set_to_none)
 
     def _state(self, p):

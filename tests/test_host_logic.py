@@ -188,6 +188,32 @@ def test_checkpoint_pruning_never_adopts_foreign_files(tmp_path):
     assert other.kept == [] and other.best_model_path == ""
 
 
+def test_checkpoint_rewritten_file_keeps_one_entry_and_is_never_pruned_under_its_better_score(tmp_path):
+    """A resumed run that re-runs an epoch rewrites a filename its restored kept-list already holds (default template '{epoch:02d}').
+    There must be ONE entry per path afterwards, and pruning the worse entry must not delete the file the better one names."""
+    import torch
+    from simhand_amd.host.lightning import ModelCheckpoint
+
+    class _T:
+        global_rank = 0
+
+        def checkpoint_dict(self, module, epoch):
+            return {"epoch": epoch}
+
+    ck = ModelCheckpoint(save_top_k=2, monitor="contrastive_loss", mode="min", dirpath=str(tmp_path))
+    ck.on_epoch_end(_T(), None, 0, {"contrastive_loss": 6.5})
+    ck.on_epoch_end(_T(), None, 1, {"contrastive_loss": 6.4})
+    resumed = ModelCheckpoint(save_top_k=2, monitor="contrastive_loss", mode="min", dirpath=str(tmp_path))
+    resumed.restore(list(ck.kept), ck.best_model_path)
+    resumed.on_epoch_end(_T(), None, 1, {"contrastive_loss": 6.0})   # epoch 1 again, better: same file name 'epoch=01.ckpt'
+    paths = [p for _, p in resumed.kept]
+    assert len(paths) == len(set(paths)) == 2
+    assert resumed.best_model_path.endswith("epoch=01.ckpt") and resumed.kept[0][0] == 6.0
+    resumed.on_epoch_end(_T(), None, 2, {"contrastive_loss": 6.2})   # pushes out epoch 0, must not touch epoch 1's file
+    assert (tmp_path / "epoch=01.ckpt").exists() and not (tmp_path / "epoch=00.ckpt").exists()
+    assert torch.load(resumed.best_model_path, weights_only=False)["epoch"] == 1
+
+
 def test_sharding_helpers():
     from simhand_amd.host.dist import shard_pairs
 
