@@ -999,6 +999,14 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         for (int ni = 0; ni < NI; ++ni) acc[2 * q + 1][ni] = Mma<T>::run(fb[kk][ni], fa[grp & 1][1], acc[2 * q + 1][ni]);
       }
       dma_part(grp);  // one DMA instruction per MFMA group: the L1's request queue stays fed through the whole step
+#ifdef SH_ABL_VALU  // experiment: SH_ABL_VALU extra (dependent-free) VALU instructions per MFMA group
+      {
+        int t = lane;
+#pragma unroll
+        for (int e = 0; e < SH_ABL_VALU; ++e) asm volatile("v_add_u32 %0, %0, %1" : "+v"(t) : "v"(lane));
+        asm volatile("" ::"v"(t));
+      }
+#endif
     }
       }
   }

@@ -457,12 +457,17 @@ def test_big_tile_conv_fwd_dgrad(shape, force_big_tile):
     yf = y.detach().permute(0, 2, 3, 1).reshape(m, cout)
     _check(part[:, 0].sum(0).cpu() / m, yf.mean(0), 1e-2, "stat mean")
     _check(part[:, 1].sum(0).cpu() / m, (yf * yf).mean(0), 1e-2, "stat sumsq")
-    # bit-for-bit the 128x128 kernel's result: same k order, same fp32 MFMA accumulation
+    # against the 128x128 kernel: 1x1 layers bit for bit (same k order, same fp32 MFMA accumulation); 3x3 layers walk k with the taps
+    # innermost since round 5 (the 128-row kernel tap-major): another fp32 summation order, equal to one bf16 rounding step
     lib = ops._lib_dev()
     lib.simhand_test_igemm256_enable(0)
     y_ref, _ = ops.conv2d_fwd(d, xd, wd, want_stats=True)
     lib.simhand_test_igemm256_enable(2)
-    assert torch.equal(yd, y_ref)
+    if k == 1:
+        assert torch.equal(yd, y_ref)
+    else:
+        err = (yd.float() - y_ref.float()).abs()
+        assert float(err.max()) <= 2.0 ** -7 * float(y_ref.float().abs().max()) and float((err > 0).float().mean()) < 0.2
 
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
     dxd = ops.conv2d_dgrad(d, dyd, wtd)

@@ -477,6 +477,116 @@ def test_fullsize_step_backward_operands_captured_against_aten():
     assert checked == 4
 
 
+def test_fullsize_step_backward_data_gradients_captured_against_aten():
+    """The DATA path of the full-size backward, checked independently: during a real bf16 ResNet-50 step at
+    1024 pairs (production dispatch) four data-gradient launches are captured with the operands the engine handed them, and ATen on the
+    host recomputes dx on the 16 sampled images: (A) a stage-1 folded two-segment gradient g (A W) + a2 (-W^T B W) + C W, (B) a stage-entry
+    conv1 gradient with the stride-2 shortcut's dense gradient merged at the even pixels (`sub_grad`) and stored through the consumer's
+    mask, (C) an identity block's conv1 gradient whose dy operand is DERIVED on load (`dy_src`: dy = A gate(da) - B y + C, also checked)
+    with the masked-residual merge, (D) a 3x3 / stride-2 gradient."""
+    from oracle import step as orc
+    from simhand_amd import ops
+    from tests.test_gpu_configs import _product
+
+    b = 1024
+    wcfg = dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg")
+    batch = {k: v.to(DEV) for k, v in orc.synthetic_batch(b, size=224, seed=7).items()}
+    torch.manual_seed(7)
+    om = orc.StepOracle("simhand_w", "50", ["color_jitter", "crop", "random_crop", "resize", "rotate"], **wcfg).train()
+    with torch.no_grad():
+        for k, p in om.named_parameters():
+            if k.endswith("bn3.weight"):
+                p.fill_(0.1)
+    ops.hooks_reset()
+    model = _product("HandCLR_W", "50", wcfg, om, DT, b)
+    idx = torch.tensor(SAMPLE, device=DEV)
+    cap = {}
+    real_ex, real_fused = ops.conv2d_dgrad_ex, ops.conv2d_dgrad_fused
+
+    def pick(t):
+        return None if t is None else t[idx].float().cpu()
+
+    def spy_ex(d, dy, wt, dx=None, accumulate=False, res_grad=None, res_mask=None, bias=None, fuse_mode=None, prev_y=None, prev_st=None,
+               prev_mask=None, want_sums=True, x2=None, wt2=None, dy_src=None, fp8=None, sub_grad=None):
+        out = real_ex(d, dy, wt, dx=dx, accumulate=accumulate, res_grad=res_grad, res_mask=res_mask, bias=bias, fuse_mode=fuse_mode,
+                      prev_y=prev_y, prev_st=prev_st, prev_mask=prev_mask, want_sums=want_sums, x2=x2, wt2=wt2, dy_src=dy_src, fp8=fp8,
+                      sub_grad=sub_grad)
+        kind = None
+        if x2 is not None and d.cin == 64 and fuse_mode == 2 and not accumulate:
+            kind = "A"
+        elif sub_grad is not None:
+            kind = "B"
+        elif dy_src is not None and res_grad is not None and sub_grad is None and not accumulate:
+            kind = "C"
+        if kind is not None and kind not in cap:
+            rec = dict(d=d, dx=pick(out[0]), wt=wt.float().cpu(), bias=None if bias is None else bias.float().cpu(), fuse_mode=fuse_mode,
+                       dy=pick(dy), x2=pick(x2), wt2=None if wt2 is None else wt2.float().cpu(), res_grad=pick(res_grad),
+                       res_mask=None if res_mask is None else res_mask.view(d.n, -1)[idx].cpu(),
+                       prev_mask=None if prev_mask is None else prev_mask.view(d.n, -1)[idx].cpu(),
+                       sub=None if sub_grad is None else sub_grad[idx].float().cpu())
+            if dy_src is not None:
+                da, ysrc, st_, coefs, relu_, dy_out = dy_src
+                rec.update(da=pick(da), y=pick(ysrc), scale=st_.scale.cpu(), shift=st_.shift.cpu(), coefs=[c.cpu() for c in coefs],
+                           relu=bool(relu_), dy_out=pick(dy_out))
+            cap[kind] = rec
+        return out
+
+    def spy_fused(d, dy, wt, prev_y, prev_st, prev_mask, dx=None, accumulate=False, res_grad=None, res_mask=None):
+        out = real_fused(d, dy, wt, prev_y, prev_st, prev_mask, dx=dx, accumulate=accumulate, res_grad=res_grad, res_mask=res_mask)
+        if d.stride == 2 and d.r == 3 and "D" not in cap and not accumulate and res_grad is None:
+            cap["D"] = dict(d=d, dx=pick(out[0]), dy=pick(dy), wt=wt.float().cpu())
+        return out
+
+    ops.conv2d_dgrad_ex, ops.conv2d_dgrad_fused = spy_ex, spy_fused
+    try:
+        out = model.training_step(batch, 0)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.conv2d_dgrad_ex, ops.conv2d_dgrad_fused = real_ex, real_fused
+    assert sorted(cap) == ["A", "B", "C", "D"], sorted(cap)
+
+    def unmask(mb, c):
+        """uint8 [imgs][pixels * c / 8] -> {0, 1} fp32 [imgs][pixels][c] (bit e of byte j = channel 8 j + e)."""
+        m8 = mb.view(mb.shape[0], -1, c // 8).to(torch.int32)
+        return torch.stack([(m8 >> e) & 1 for e in range(8)], dim=-1).reshape(mb.shape[0], -1, c).float()
+
+    # (A) two-segment folded gradient, bias in fp32, plain store
+    r = cap["A"]
+    d = r["d"]
+    ns = len(SAMPLE)
+    want = r["dy"].reshape(-1, d.cout) @ r["wt"].t() + r["x2"].reshape(-1, d.cin) @ r["wt2"].t() + r["bias"]
+    _close(r["dx"].reshape(-1, d.cin), want, 1e-2, "A: stage-1 two-segment folded data gradient of the step")
+    # (B) stage-entry conv1: dy . W + shortcut's dense gradient at the even pixels, stored through the consumer's mask
+    r = cap["B"]
+    d = r["d"]
+    dyb = r["dy_out"] if "dy_out" in r else r["dy"]
+    want = (dyb.reshape(-1, d.cout) @ r["wt"].t()).view(ns, d.h, d.w, d.cin)
+    want[:, ::2, ::2, :] += r["sub"]
+    if r["fuse_mode"] == 4:
+        want = want * unmask(r["prev_mask"], d.cin).view(ns, d.h, d.w, d.cin)
+    _close(r["dx"], want, 1e-2, "B: stage-entry conv1 data gradient with the merged shortcut gradient")
+    assert float(r["sub"].abs().max()) > 0 and float(r["dx"].abs().max()) > 0
+    # (C) identity block conv1: dy derived on load, masked-residual merge, masked store
+    r = cap["C"]
+    d = r["d"]
+    ca, cb, cc = r["coefs"]
+    gate = ((r["y"] * r["scale"] + r["shift"]) > 0).float() if r["relu"] else 1.0
+    dy_want = ca * (r["da"] * gate) - cb * r["y"] + cc
+    _close(r["dy_out"], dy_want, 1e-2, "C: dy derived on load (BatchNorm-backward apply)")
+    want = (r["dy_out"].reshape(-1, d.cout) @ r["wt"].t()).view(ns, -1, d.cin)
+    want = want + r["res_grad"].reshape(ns, -1, d.cin) * unmask(r["res_mask"], d.cin)
+    if r["fuse_mode"] == 4:
+        want = want * unmask(r["prev_mask"], d.cin)
+    _close(r["dx"].reshape(ns, -1, d.cin), want, 1e-2, "C: identity-block conv1 data gradient (dy_src + masked residual)")
+    # (D) 3x3 / stride 2 (CRSK weights [cin][r][s][cout] -> OIHW)
+    r = cap["D"]
+    d = r["d"]
+    w_oihw = r["wt"].view(d.cin, 3, 3, d.cout).permute(3, 0, 1, 2).contiguous()
+    want = torch.nn.grad.conv2d_input((ns, d.cin, d.h, d.w), w_oihw, r["dy"].permute(0, 3, 1, 2).contiguous(), stride=2, padding=1)
+    _close(r["dx"].permute(0, 3, 1, 2), want, 1e-2, "D: 3x3 / stride-2 data gradient of the step")
+
+
 FOLD_SHAPES = [(64, 256, 56), (128, 512, 28), (256, 1024, 14), (512, 2048, 7)]  # (w, 4w, H) of conv3 + bn3 per stage
 
 
