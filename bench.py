@@ -80,7 +80,11 @@ def parse():
                          "e.g. --switch R128=0.  The library reads no environment variable; the default run sets none of these")
     ap.add_argument("--engine", action="append", default=[], metavar="ATTR=V",
                     help="A/B timing only: an engine-level fusion attribute of host/resnet_model.py ResNetEngine (chain_conv1, dense_shortcut, "
-                         "merge_shortcut, fuse_apply_gram, fuse_bwd_apply_dgrad, fuse_bwd_apply_wgrad, fp8_all, bn_on_load, bwd_apply_in_ring, stem_two_pass), e.g. --engine chain_conv1=0")
+                         "merge_shortcut, fuse_apply_gram, fuse_bwd_apply_dgrad, fuse_bwd_apply_wgrad, fp8_all, bn_on_load), e.g. --engine chain_conv1=0")
+    ap.add_argument("--emulate-world", type=int, default=1, metavar="R",
+                    help="ONE process runs the rank-local work of an R-rank step (BASELINE configs[2] at R = 8): its own pairs through the backbone, "
+                         "the loss row block 2 b_loc x 2 b_loc R against a synthetic gathered Z_all / J_all, gradient buckets flattened and cast as on "
+                         "the wire -- NO collective is executed (an upper bound on data-parallel efficiency where no multi-GPU node is available)")
     ap.add_argument("--no-loss-scaling", action="store_true", help="--precision 16 without the GradScaler (timing split only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=32,
@@ -130,6 +134,116 @@ def self_launch(args) -> int:
             return rc or 124
         time.sleep(0.05)
     return rc
+
+
+class DeviceStateSampler:
+    """Clock / power of the GPU WHILE the timed steps run, read from the amdgpu sysfs nodes by a host thread (no device work, outside
+    every kernel): hwmon freq1_input (gfx clock), power1_average / power1_input (socket power), gpu_busy_percent.  The matrix-bound kernels
+    of this step run at the clock the power limit leaves (1.7-2.0 GHz on random operands, 2.25 GHz on zeros: profiles/
+    r05_igemm256_clock_and_ring.txt), so a slow box and a regression are told apart by these numbers on the bench line."""
+
+    def __init__(self, device_index: int, period_s: float = 0.02):
+        import glob
+        import threading
+
+        self.period, self.samples, self._stop, self._thr = period_s, [], threading.Event(), None
+        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+        want = None
+        try:  # match the HIP device's PCI address when torch exposes it, else the index-th amdgpu card
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{getattr(pr, 'pci_domain_id'):04x}:{getattr(pr, 'pci_bus_id'):02x}:{getattr(pr, 'pci_device_id'):02x}"
+        except Exception:  # noqa: BLE001
+            want = None
+        pick = next((c for c in cards if want and os.path.basename(os.path.realpath(c)).startswith(want)), None)
+        if pick is None and cards:
+            pick = cards[min(device_index, len(cards) - 1)]
+        self.dir = pick
+        hw = sorted(glob.glob(os.path.join(pick, "hwmon", "hwmon*"))) if pick else []
+        self.hw = hw[0] if hw else None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except Exception:  # noqa: BLE001
+            return None
+
+    def _sample(self):
+        clk = pw = busy = None
+        if self.hw:
+            v = self._read(os.path.join(self.hw, "freq1_input"))
+            clk = float(v) / 1e6 if v else None
+            v = self._read(os.path.join(self.hw, "power1_average")) or self._read(os.path.join(self.hw, "power1_input"))
+            pw = float(v) / 1e6 if v else None
+        if clk is None and self.dir:
+            v = self._read(os.path.join(self.dir, "pp_dpm_sclk")) or ""
+            cur = [ln for ln in v.splitlines() if ln.rstrip().endswith("*")]
+            if cur:
+                try:
+                    clk = float(cur[0].split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+                except Exception:  # noqa: BLE001
+                    clk = None
+        if self.dir:
+            v = self._read(os.path.join(self.dir, "gpu_busy_percent"))
+            busy = float(v) if v else None
+        return clk, pw, busy
+
+    def start(self):
+        import threading
+
+        if self.dir is None:
+            return self
+
+        def run():
+            while not self._stop.is_set():
+                self.samples.append(self._sample())
+                self._stop.wait(self.period)
+
+        self._thr = threading.Thread(target=run, daemon=True)
+        self._thr.start()
+        return self
+
+    def stop(self) -> dict:
+        self._stop.set()
+        if self._thr is not None:
+            self._thr.join(timeout=1.0)
+        if self.dir is None:
+            return {"available": False, "why": "no amdgpu sysfs node with pp_dpm_sclk readable by this user"}
+
+        def agg(i):
+            v = [s[i] for s in self.samples if s[i] is not None]
+            return None if not v else {"mean": sum(v) / len(v), "min": min(v), "max": max(v)}
+
+        return {"available": True, "samples": len(self.samples), "period_ms": self.period * 1e3, "sclk_mhz": agg(0), "socket_power_w": agg(1),
+                "gpu_busy_percent": agg(2), "source": f"{self.dir} (sysfs, host thread, during the timed steps)"}
+
+
+def make_emulated_comm(world: int):
+    """--emulate-world: a communicator whose collectives move NO data between devices.  all_gather_into fills every rank's slot with this
+    rank's own rows (a device-local copy of the size RCCL would deliver: the loss then runs its full 2 b_loc x N row block, N = world x
+    the local rows); all_reduce_ is a no-op (the buckets were already flattened / cast to the wire format by the caller)."""
+    from simhand_amd.host import dist as shdist
+
+    class EmulatedComm(shdist.RcclComm):
+        def __init__(self, world):  # no ncclComm is created
+            self.world, self.rank, self._side = world, 0, None
+
+        def side_stream(self):
+            if self._side is None:
+                self._side = torch.cuda.Stream(priority=-1)
+            return self._side
+
+        def all_gather_into(self, out, x):
+            out.view(self.world, -1).copy_(x.reshape(1, -1).expand(self.world, -1))
+
+        def all_reduce_(self, t, op="sum", side=False):
+            return t
+
+        def close(self):
+            pass
+
+    return EmulatedComm(world)
 
 
 def make_model(args, world):
@@ -249,9 +363,12 @@ def main():
     rank, local, world = shdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    emu = max(1, args.emulate_world)
+    if emu > 1 and world != 1:
+        raise SystemExit("--emulate-world runs in ONE process (--gpus 1)")
     _lib.require_device()
     device = torch.device("cuda", torch.cuda.current_device())  # = LOCAL_RANK (init_from_env set it)
-    model = make_model(args, world).to(device).train()
+    model = make_model(args, world * emu).to(device).train()
     for kv in args.switch:   # A/B hooks (never set in the default run; recorded in the line's config)
         name, v = kv.split("=", 1)
         ops.test_switch(name, int(v))
@@ -271,6 +388,11 @@ def main():
     batch = device_batch(args.per_gpu_batch, args.image_size, 5 + rank, device)
     params = [p for p in model.parameters()]
     reducer, group = None, None
+    if emu > 1:  # the rank-local work of an `emu`-rank step, no collective executed
+        group = make_emulated_comm(emu)
+        model.process_group = group
+        reducer = shdist.OverlappedGradReducer(group, wire=args.grad_wire)
+        model.encoder.engine.grad_reducer = reducer
     if world > 1:  # backbone gradients go out block by block during the backward pass; the head's follow in allreduce_gradients
         if args.comm == "abi" and dist.get_backend() == "nccl":  # bootstrap over torch.distributed, data path on the ABI communicator
             group = shdist.RcclComm.from_torch_distributed()
@@ -322,12 +444,14 @@ def main():
         ops.prof_set_classes(None)
     ops.prof_reset()
     every = max(1, args.event_every)
+    sampler = DeviceStateSampler(torch.cuda.current_device()).start() if rank == 0 else None
     t0 = time.perf_counter()
     for i in range(args.steps):
         ops.prof_enable(i % every == 0)  # live HIP events on the dominant class's launches, in every `every`-th timed step
         loss = step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
+    device_state = sampler.stop() if sampler is not None else None
     ops.prof_enable(False)
     prof = ops.prof_collect()
     ops.prof_set_classes(None)
@@ -396,10 +520,32 @@ def main():
                          "all_conv_tflops": all_conv_flops / (all_conv_ms * 1e-3) / 1e12 if all_conv_ms > 0 else 0.0,
                          "step_tflops_per_gpu": TRAIN_GFLOP_PER_PAIR.get(args.resnet, 0.0) * (args.image_size / 224.0) ** 2
                                                 * args.per_gpu_batch * args.steps / elapsed / 1e3},
+            "device_state": device_state,
             "kernel_ms_per_step": {k: v["ms"] / bsteps for k, v in breakdown.items()},
             "kernel_ms_source": "last warm-up step (events on every launch)" if warm_prof is not None else "timed region",
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU reference is timed at N = 1 only (the other ranks would idle behind it)
+        if emu > 1:
+            # what the wire would add if NOTHING overlapped -- ring all-reduce of the gradient bytes over xGMI (per-link bound,
+            # 2 (R - 1) / R x bytes / 153 GB/s) + three latency-bound small all-gathers
+            nparam = sum(p.numel() for p in params if p.requires_grad)
+            gbytes = nparam * (2 if args.grad_wire == "bf16" else 4)
+            ring_ms = 2.0 * (emu - 1) / emu * gbytes / 153e9 * 1e3
+            t_emu = elapsed / args.steps * 1e3
+            res["emulation"] = {
+                "what": f"rank-local work of ONE rank of a {emu}-rank step in one process: {args.per_gpu_batch} pairs through the backbone, loss row "
+                        f"block {2 * args.per_gpu_batch} x {2 * args.per_gpu_batch * emu} against a gathered buffer filled by device-local copies, gradient "
+                        f"buckets flattened ({args.grad_wire} wire) -- NO collective executed, NO multi-GPU measurement",
+                "emulated_world": emu, "ms_per_step_rank_local": t_emu, "grad_bytes_on_wire": gbytes,
+                "ring_allreduce_ms_not_overlapped_estimate": ring_ms,
+                "small_collectives": "3 all-gathers of <= 1.4 MB per rank (latency-bound, ~0.1 ms together: estimate)",
+                "projected_pairs_per_s_upper_bound": args.per_gpu_batch * emu / (t_emu * 1e-3),
+                "projected_pairs_per_s_if_nothing_overlaps": args.per_gpu_batch * emu / ((t_emu + ring_ms + 0.1) * 1e-3),
+                "note": "compare ms_per_step_rank_local with the N = 1 line of the same box: the ratio is the UPPER bound on the data-parallel "
+                        "efficiency of the compute side (global-negatives loss + bucket handling); RCCL time and contention come on top",
+            }
+            res["config"]["parallelism"] = f"dp1 emulating rank 0 of dp{emu} (no collective executed)"
+            res["config"]["global_batch"] = args.per_gpu_batch  # what THIS process processed per step
+        if not args.no_cpu_baseline and world == 1 and emu == 1:  # the CPU reference is timed at N = 1 only (the other ranks would idle behind it)
             res["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(res), flush=True)
     if world > 1:

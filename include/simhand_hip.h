@@ -57,10 +57,11 @@ enum sh_weight_type { SH_W_NONE = 0, SH_W_LINEAR = 1, SH_W_NONLINEAR = 2,
 /* SH_ABI_VERSION is bumped whenever a signature, a struct layout or an enum value of this header changes (history: 1 = rounds 1-2;
  * 2 = round 3: `width` argument of simhand_proj_postprocess_fwd / _bwd / simhand_proj_stats, sh_dgrad_opts grew dy_src / dy_q / wt_q /
  * dy_state / w_state / sub_grad, tuning setters renamed simhand_test_*; 3 = round 4: this constant, the in-library environment switches
- * moved behind simhand_test_* hooks, the stem entry points of DESIGN 3).  A binding compares simhand_abi_version() with the
+ * moved behind simhand_test_* hooks, the stem entry points of DESIGN 3; 4 = round 5: the two-pass / fused-backward stem entry points and
+ * their route counters removed (sh_route renumbered from 36 on), SH_SW_COUNT unchanged).  A binding compares simhand_abi_version() with the
  * SH_ABI_VERSION it was written against before its first call (simhand_amd/_lib.py load() does) -- a caller built against an older header
  * would otherwise pass shifted arguments or a short options struct unnoticed. */
-#define SH_ABI_VERSION 3
+#define SH_ABI_VERSION 4
 int simhand_abi_version(void);
 /* The library ships in two builds of the same sources: libsimhand_hip.so, whose 16-bit storage type (SH_BF16 below) is bfloat16 -- and
  * libsimhand_hip_f16.so, where the same enum value means IEEE fp16 (11-bit significand: the storage type of the reference's
@@ -99,11 +100,9 @@ enum sh_route {
   SH_ROUTE_DGRAD_DYSRC = 32,                                /* BN-backward apply fused into the 1x1 data gradient's dy loader */
   SH_ROUTE_FWD_CHAIN = 33,                                  /* conv3 + BN + residual + ReLU with the next block's conv1 chained on */
   SH_ROUTE_R128_FWD = 34, SH_ROUTE_R128_DGRAD = 35,         /* 128->128 3x3: activation tile staged once in an LDS ring, weights streamed per tap */
-  SH_ROUTE_STEM_STATS = 36, SH_ROUTE_STEM_POOL = 37,        /* two-pass stem: statistics-only conv1; conv1 + BN + ReLU + MaxPool */
-  SH_ROUTE_STEM_BWD_FUSED = 38,                             /* stem backward: conv1 recomputed, dy in registers, dW in the same kernel */
-  SH_ROUTE_FWD_BNIN = 39,                                   /* 3x3 forward with the previous unit's BatchNorm + ReLU applied in its LDS ring */
-  SH_ROUTE_N128_FWD = 40, SH_ROUTE_N128_DGRAD = 41,         /* 1x1 with 128 destination channels behind a long reduction: 128 x 128 LDS-DMA tiles, two blocks per CU */
-  SH_ROUTE_COUNT = 42
+  SH_ROUTE_FWD_BNIN = 36,                                   /* 3x3 forward with the previous unit's BatchNorm + ReLU applied in its LDS ring */
+  SH_ROUTE_N128_FWD = 37, SH_ROUTE_N128_DGRAD = 38,         /* 1x1 with 128 destination channels behind a long reduction: 128 x 128 LDS-DMA tiles, two blocks per CU */
+  SH_ROUTE_COUNT = 39
 };
 int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
 int simhand_route_reset(void);
@@ -296,28 +295,6 @@ int simhand_stem_pack_weights(const float* w_oihw, void* wp, int dtype, sh_strea
 /* rows of the bn_partial buffer simhand_stem_conv_fwd fills: [blocks][2][64] */
 int simhand_stem_conv_fwd_stat_blocks(int n, int h, int w, int dtype);
 int simhand_stem_conv_fwd(const void* xp, const void* wp, void* y, float* bn_partial, int n, int h, int w, int dtype, sh_stream_t stream);
-/* The TWO-PASS stem (round 4; 16-bit storage at 224 x 224 only: simhand_stem_two_pass_ok).  conv1 is 0.24 GFLOP per image -- cheaper
- * to run again than to write its 112 x 112 x 64 raw output and read it back (6.6 GB per 2048 images each way):
- *   pass 1  simhand_stem_conv_fwd with y == NULL: BatchNorm partial sums only (then simhand_bn_finalize as usual);
- *   pass 2  simhand_stem_conv_bn_relu_pool: conv1 again with BN + ReLU + MaxPool(3, 2, 1) in its epilogue -> pooled [n][56][56][64],
- *           idx (winner tap) and ywin (the winner's raw conv output; may be NULL): bit for bit what simhand_stem_conv_fwd followed
- *           by simhand_bn_relu_maxpool_fwd produce (NaN activations excepted: a NaN wins its window either way, which NaN of several
- *           is unspecified here);
- *   backward  simhand_stem_bwd_fused: conv1 a third time inside the kernel that forms dy = BatchNorm-backward(gathered pooled
- *           gradient, y) in registers and accumulates dW = dy^T x from the same LDS-resident input rows -- neither y nor dy exists
- *           in HBM.  dgamma / dbeta come from the pooled-size statistics pass as before (simhand_bn_bwd_partial on ywin).
- * Replaces (reference): conv1 -> bn1 -> relu -> maxpool of the torchvision ResNet stem and their autograd backward
- * (src/models/resnet_model.py:13-26). */
-int simhand_stem_two_pass_ok(int n, int h, int w, int dtype);
-int simhand_stem_conv_bn_relu_pool(const void* xp, const void* wp, const float* scale, const float* shift, void* pooled, uint8_t* idx,
-                                   void* ywin, int n, int h, int w, int dtype, sh_stream_t stream);
-/* dz [n][56][56][64]: gradient of the pooled output; idx: winner taps of the forward; mean / invstd / scale / shift: the forward's
- * BatchNorm state; gamma (NULL = 1), dgamma, dbeta: the finalized BatchNorm-backward sums (simhand_bn_bwd_partial over (dz, ywin) +
- * simhand_bn_bwd_finalize); dw_oihw: fp32 [64][3][7][7].  Per-block partial sums go through `workspace` and are added in a fixed order. */
-size_t simhand_stem_bwd_fused_workspace_bytes(int n);
-int simhand_stem_bwd_fused(const void* xp, const void* wp, const void* dz, const uint8_t* idx, const float* scale, const float* shift,
-                           const float* mean, const float* invstd, const float* gamma, const float* dgamma, const float* dbeta,
-                           float* dw_oihw, void* workspace, size_t workspace_bytes, int n, int h, int w, int dtype, sh_stream_t stream);
 /* bf16 route of simhand_stem_conv_fwd: 1 (default) = persistent direct-stem kernel (weights resident in LDS, next tile's rows in
  * flight under the current tile's MFMAs), 2 = activation-stationary kernel, one block per 256 rows, 0 = 128 x 64 tile kernel
  * (same k order, bit-identical outputs; tuning / test hook) */

@@ -71,27 +71,41 @@ def run(precision):
     return losses, pmax, time.perf_counter() - t0
 
 
+def _sr_bf16(x):
+    """fp32 -> bf16 with STOCHASTIC rounding (uniform 16 random bits added to the magnitude before the truncation), back as fp32."""
+    bits = x.contiguous().view(torch.int32)
+    rnd = torch.randint(0, 1 << 16, x.shape, device=x.device, dtype=torch.int32)
+    return ((bits + rnd) & -65536).view(torch.float32)
+
+
 class _Round(torch.autograd.Function):
-    """x -> storage dtype -> fp32 in the forward (if fwd) and / or the same rounding of the gradient in the backward (if bwd)."""
+    """x -> storage dtype -> fp32 in the forward (if fwd) and / or the same rounding of the gradient in the backward (if bwd).
+    fwd_dt: another storage type for the forward value (mitigation twins); sr: stochastic instead of nearest-even rounding (bf16 forward)."""
 
     @staticmethod
-    def forward(ctx, x, dt, fwd, bwd):
+    def forward(ctx, x, dt, fwd, bwd, fwd_dt=None, sr=False):
         ctx.dt, ctx.bwd = dt, bwd
-        return x.to(dt).to(torch.float32) if fwd else x
+        if not fwd:
+            return x
+        if sr:
+            return _sr_bf16(x)
+        return x.to(fwd_dt or dt).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
-        return (g.to(ctx.dt).to(torch.float32) if ctx.bwd else g), None, None, None
+        return (g.to(ctx.dt).to(torch.float32) if ctx.bwd else g), None, None, None, None, None
 
 
-def run_oracle(storage=None, parts="wag", scaler=False):
+def run_oracle(storage=None, parts="wag", scaler=False, act_storage=None, act_sr=False):
     """The CHECKER's curve: oracle.StepOracle (plain torch ops) on the same device, same initial weights / data / optimizer / schedule.
     storage = torch.bfloat16 / torch.float16: its encoder convolutions see storage-rounded operands -- the numerics model of a 16-bit
     storage path with fp32 accumulators, independent of any HIP kernel.  parts: which tensors are rounded -- "w" the conv weights
     (forward only: the weight GRADIENT stays fp32, as in the HIP path), "a" the conv inputs / outputs in the forward, "g" the
     gradients crossing those same edges in the backward.  scaler: torch.cuda.amp.GradScaler semantics around the backward (the
     reference's precision=16 policy, src/experiments/main.py:158-159: scale 2^16, halve + skip the step on inf / nan, double every
-    2000 clean steps) -- needed for fp16's 5-bit exponent, pointless for bf16."""
+    2000 clean steps) -- needed for fp16's 5-bit exponent, pointless for bf16.  Mitigation twins: act_storage = another
+    storage type for the FORWARD activations only (fp16 activations next to bf16 weights / gradients); act_sr = stochastic rounding of
+    the forward activations' bf16 stores (the tensor the decomposition blames)."""
     import torch.nn as nn
     import torch.nn.functional as F
 
@@ -104,7 +118,7 @@ def run_oracle(storage=None, parts="wag", scaler=False):
     om.load_state_dict(prod.state_dict(), strict=True)
     om = om.to(dev).train()
     if storage is not None:
-        ra = lambda t: _Round.apply(t, storage, "a" in parts, "g" in parts)  # noqa: E731
+        ra = lambda t: _Round.apply(t, storage, "a" in parts, "g" in parts, act_storage, act_sr)  # noqa: E731
         rw = lambda t: _Round.apply(t, storage, "w" in parts, False)         # noqa: E731
         for m in om.encoder.modules():
             if isinstance(m, nn.Conv2d):
@@ -161,7 +175,10 @@ if os.environ.get("SIMHAND_STABILITY_ORACLE", "0") == "1":
     twins = {"fp16 storage + GradScaler (the reference's precision=16)": run_oracle(torch.float16, "wag", scaler=True),
              "bf16 weights only": run_oracle(torch.bfloat16, "w"),
              "bf16 forward activations only": run_oracle(torch.bfloat16, "a"),
-             "bf16 backward gradients only": run_oracle(torch.bfloat16, "g")}
+             "bf16 backward gradients only": run_oracle(torch.bfloat16, "g"),
+             # mitigations for the bf16 lag (it is the forward activations' 8-bit significand): do they close the gap to fp32?
+             "MITIGATION bf16 storage, forward activations rounded STOCHASTICALLY": run_oracle(torch.bfloat16, "wag", act_sr=True),
+             "MITIGATION fp16 forward activations, bf16 weights + gradients (no scaler)": run_oracle(torch.bfloat16, "wag", act_storage=torch.float16)}
 lines = [f"# {a.steps} training steps, ResNet-50 handclr_w, {a.batches} fixed batches of {a.pairs} pairs @ {a.size}^2 revisited every epoch, LARS + Adam, "
          "linear warm-up + cosine schedule; same initial weights", "",
          "| step | loss bf16 (bf16 storage, fp32 accumulate / statistics / loss / optimizer, no loss scaling) | loss fp32 parity mode | bf16 / fp32 |"

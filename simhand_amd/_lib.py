@@ -34,8 +34,8 @@ ROUTES = ("igemm128_fwd", "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "i
           "gemm1x1_dgrad", "c64_fwd", "c64_dgrad", "stem_fwd", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
           "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
           "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram", "wgrad_bnbwd", "ntxent_fused_dist",
-          "dgrad_dysrc", "fwd_chain", "r128_fwd", "r128_dgrad", "stem_stats", "stem_pool", "stem_bwd_fused", "fwd_bnin", "n128_fwd", "n128_dgrad")
-ROUTE_COUNT = 42
+          "dgrad_dysrc", "fwd_chain", "r128_fwd", "r128_dgrad", "fwd_bnin", "n128_fwd", "n128_dgrad")
+ROUTE_COUNT = 39
 
 
 class SimhandHipError(RuntimeError):
@@ -90,7 +90,7 @@ _L = C.c_int64
 _F = C.c_float
 _S = C.c_size_t
 
-ABI_VERSION = 3  # include/simhand_hip.h SH_ABI_VERSION this table was written against (checked in load())
+ABI_VERSION = 4  # include/simhand_hip.h SH_ABI_VERSION this table was written against (checked in load())
 
 # name -> (restype, argtypes); every symbol include/simhand_hip.h declares
 SIGNATURES = {
@@ -133,10 +133,6 @@ SIGNATURES = {
     "simhand_stem_pack_weights": (_I, [_P, _P, _I, _P]),
     "simhand_stem_conv_fwd_stat_blocks": (_I, [_I, _I, _I, _I]),
     "simhand_stem_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "simhand_stem_two_pass_ok": (_I, [_I, _I, _I, _I]),
-    "simhand_stem_conv_bn_relu_pool": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "simhand_stem_bwd_fused_workspace_bytes": (_S, [_I]),
-    "simhand_stem_bwd_fused": (_I, [_P] * 13 + [_S, _I, _I, _I, _I, _P]),
     "simhand_stem_conv_wgrad_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "simhand_stem_conv_wgrad": (_I, [_P, _P, _P, _P, _S, _I, _I, _I, _I, _P]),
     "simhand_conv2d_wgrad_splits": (_I, [C.POINTER(ConvDesc)]),

@@ -20,17 +20,6 @@ struct R128Args {
   const float* in_scale;
   const float* in_shift;
   bf16_t* a_out;
-  // data gradient with THIS unit's BatchNorm-backward apply done on the way in (dy_y != null; sh_dy_src): x is the gradient w.r.t. the unit's
-  // activation, the staged tile is rewritten in place as dy = dy_a * gate(x) - dy_b * y + dy_c (gate: y * dy_s + dy_h > 0 when dy_relu) and
-  // leaves as a by-product (dy_out: the weight gradient's operand) -- the stand-alone bn_bwd_apply pass disappears
-  const bf16_t* dy_y;
-  const float* dy_s;
-  const float* dy_h;
-  const float* dy_a;
-  const float* dy_b;
-  const float* dy_c;
-  int dy_relu;
-  bf16_t* dy_out;
   int N, H, W;
   int dgrad;            // 1: tap offsets are mirrored
   long long q_total;    // N * (H+1) * (W+1): padded grid with shared pad rows / columns

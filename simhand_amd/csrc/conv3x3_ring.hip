@@ -58,13 +58,11 @@ __device__ __forceinline__ float row16_sum_r128(float v) {
 // BNIN (forward): x is the previous unit's RAW conv output; every lane rewrites the 2 x 5 ring pieces it fetched itself as
 // relu(x * in_scale + in_shift) (its own s_waitcnt is the only synchronisation that needs) and stores the ones of the tile's own 256 positions
 // to a_out -- the bn_apply pass disappears
-// DYIN (data gradient): x is the gradient w.r.t. this unit's ACTIVATION; the lanes rewrite their ring pieces as the BatchNorm-backward apply
-// dy = a * gate(x) - b * y + c (y pieces by ordinary loads next to the DMAs; pad positions forced to zero) and store the tile's own rows to
-// dy_out -- the bn_bwd_apply pass disappears (the expression is the 1x1 kernels' dy-source prologue's, conv_1x1.hip)
-template <int MODE, bool BNIN = false, bool DYIN = false>
+// (The backward twin -- this unit's BatchNorm-backward apply rewritten into the data gradient's ring, round 4 -- was exact but VALU-bound:
+// ~90 VALU instructions per 16 bytes, 752 us against 548 + a 200-us pass, step unchanged; removed in round 5, see docs/lab-notes.md.)
+template <int MODE, bool BNIN = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
   static_assert(!BNIN || MODE != 2, "BNIN is a forward form");
-  static_assert(!(BNIN && DYIN), "one operand transform at a time");
   constexpr int BM = 256, BN = 128, MI = 4, NI = 4, HALO = 32;
   constexpr int RROWS = BM + 2 * HALO;  // 320 ring rows: positions m0 - 32 .. m0 + 288
   constexpr int HALF = RROWS * 128;     // one 64-channel half of the ring
@@ -99,10 +97,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
   // registers for the prologue; the loads go out first, ahead of every DMA in the in-order queue
   const int bn_chunk = slot ^ (((wave & 1) * 4 + (r8l >> 1)) & 7);
   float bsc[BNIN ? 2 : 1][8], bsh[BNIN ? 2 : 1][8];
-  unsigned boff[(BNIN || DYIN) ? 2 : 1][5];
-  uint4 dyy[DYIN ? 2 : 1][5];   // DYIN: the y pieces next to the lane's ring pieces
-  unsigned dok[DYIN ? 2 : 1];   // ... and which of them are real pixels (bit i)
-  if constexpr (DYIN) dok[0] = dok[1] = 0u;
+  unsigned boff[BNIN ? 2 : 1][5];
   if constexpr (BNIN) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -134,69 +129,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
       const int chunk = slot ^ ((j >> 1) & 7);
       const char* src = ok ? reinterpret_cast<const char*>(p.x + (unsigned long long)pix * 128 + h * 64 + chunk * 8) : nsrc;
       dma16(src, smem_addr + h * HALF + rb * 8 * 128);
-      if constexpr (BNIN || DYIN)  // where the rewritten 16 bytes go: own positions (ring rows 32 .. 287) that are real pixels; < 2^32 (checked on the host)
+      if constexpr (BNIN)  // where the rewritten 16 bytes go: own positions (ring rows 32 .. 287) that are real pixels; < 2^32 (checked on the host)
         boff[h][i] = ok && j >= HALO && j < HALO + BM ? pix * 128u + (unsigned)(h * 64 + chunk * 8) : 0xffffffffu;
-      if constexpr (DYIN) {
-        const void* ys = ok ? (const void*)(p.dy_y + (unsigned long long)pix * 128 + h * 64 + chunk * 8) : (const void*)zsrc;
-        dyy[h][i] = *reinterpret_cast<const uint4*>(ys);
-        dok[h] |= ok ? (1u << i) : 0u;
-      }
     }
-  };
-  // DYIN coefficients (gate scale / shift, A, B, C) per channel: in LDS (2.5 KB next to the 128 KB of tiles) -- registers are what the
-  // fused-sums form of this kernel has least of
-  __shared__ __attribute__((aligned(16))) float s_dyc[DYIN ? 5 : 1][DYIN ? 128 : 4];
-  if constexpr (DYIN) {
-    if (tid < 128) {
-      s_dyc[0][tid] = p.dy_relu ? p.dy_s[tid] : 0.f;
-      s_dyc[1][tid] = p.dy_relu ? p.dy_h[tid] : 1.f;  // no ReLU: the gate y * 0 + 1 > 0 is always open
-      s_dyc[2][tid] = p.dy_a[tid];
-      s_dyc[3][tid] = p.dy_b[tid];
-      s_dyc[4][tid] = p.dy_c[tid];
-    }
-    __syncthreads();
-  }
-  auto dy_piece = [&](int h, int i) __attribute__((always_inline)) {
-    constexpr int HH = DYIN ? 1 : 0;
-    const int rb = wave + 8 * i;
-    char* at = smem + h * HALF + (rb * 8 + r8l) * 128 + slot * 16;
-    const uint4 v = *reinterpret_cast<const uint4*>(at);
-    const unsigned g4[4] = {v.x, v.y, v.z, v.w};
-    const unsigned y4[4] = {dyy[HH * h][i].x, dyy[HH * h][i].y, dyy[HH * h][i].z, dyy[HH * h][i].w};
-    const bool real = (dok[HH * h] >> i) & 1u;
-    float dcs[8], dch[8], dca[8], dcb[8], dcc[8];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      int c0 = DYIN ? h * 64 + bn_chunk * 8 + 4 * k : 0;
-      asm volatile("" : "+v"(c0));  // opaque: the five pieces of a half share these addresses, and 40 registers held across k-steps 0 .. 4 spill
-      const float4 t0 = *reinterpret_cast<const float4*>(&s_dyc[0][c0]), t1 = *reinterpret_cast<const float4*>(&s_dyc[DYIN ? 1 : 0][c0]);
-      const float4 t2 = *reinterpret_cast<const float4*>(&s_dyc[DYIN ? 2 : 0][c0]), t3 = *reinterpret_cast<const float4*>(&s_dyc[DYIN ? 3 : 0][c0]);
-      const float4 t4 = *reinterpret_cast<const float4*>(&s_dyc[DYIN ? 4 : 0][c0]);
-      dcs[4 * k] = t0.x; dcs[4 * k + 1] = t0.y; dcs[4 * k + 2] = t0.z; dcs[4 * k + 3] = t0.w;
-      dch[4 * k] = t1.x; dch[4 * k + 1] = t1.y; dch[4 * k + 2] = t1.z; dch[4 * k + 3] = t1.w;
-      dca[4 * k] = t2.x; dca[4 * k + 1] = t2.y; dca[4 * k + 2] = t2.z; dca[4 * k + 3] = t2.w;
-      dcb[4 * k] = t3.x; dcb[4 * k + 1] = t3.y; dcb[4 * k + 2] = t3.z; dcb[4 * k + 3] = t3.w;
-      dcc[4 * k] = t4.x; dcc[4 * k + 1] = t4.y; dcc[4 * k + 2] = t4.z; dcc[4 * k + 3] = t4.w;
-    }
-    unsigned o4[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float r2[2];
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int e = 2 * q + hh;
-        const float gv = hh == 0 ? h16_lo(g4[q]) : h16_hi(g4[q]);
-        const float yy = hh == 0 ? h16_lo(y4[q]) : h16_hi(y4[q]);
-        const bool on = yy * dcs[e] + dch[e] > 0.f;
-        r2[hh] = dca[e] * (on ? gv : 0.f) - dcb[e] * yy + dcc[e];  // the expression of the 1x1 kernels' dy-source prologue
-      }
-      o4[q] = real ? pack_bf16x2(r2[0], r2[1]) : 0u;  // pad positions hold zeros
-    }
-    const uint4 r = make_uint4(o4[0], o4[1], o4[2], o4[3]);
-    *reinterpret_cast<uint4*>(at) = r;
-    const unsigned bo = boff[(BNIN || DYIN) ? h : 0][i];
-    uint4* dst = bo != 0xffffffffu ? reinterpret_cast<uint4*>(p.dy_out + bo) : &g_r128_bn_sink[tid];
-    *dst = r;
   };
   auto bn_piece = [&](int h, int i) __attribute__((always_inline)) {
     const int rb = wave + 8 * i;
@@ -239,15 +174,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
   dma_w(0);
   dma_w(1);
   fill_half(1);
-  if constexpr (BNIN || DYIN) {
+  if constexpr (BNIN) {
     // in-order retirement: <= 9 outstanding = the lane's rows of half 0 are in LDS (the compiler's own loads -- y pieces, coefficients -- may sit
     // anywhere in the queue: extra operations only make a counted wait stricter).  Half 1 is rewritten piece by piece under k-steps 0 .. 4.
     asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      if constexpr (BNIN) bn_piece(0, i);
-      else dy_piece(0, i);
-    }
+    for (int i = 0; i < 5; ++i) bn_piece(0, i);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rewritten rows are in LDS before the loop's first barrier
   }
 
@@ -307,7 +239,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
       // W(ks+1) (ks >= 2)
       // MODE 2: the 8 loads of the previous unit's y rows go out in step 15 (behind W17), so that their round trip is over when the
       // epilogue wants them: steps 16 and 17 then leave 2 + 8 operations in flight
-      if constexpr (BNIN || DYIN) {
+      if constexpr (BNIN) {
         // queue: half 0 (5), W0, W1 (2 + 2), half 1 (5), the 5 by-product stores of half 0, then per step k: piece k's store (k <= 4), W(k + 2) (2).
         // Step 0 needs W0 and half 1's first instruction (9 younger), step 1 W1 and the second (11), step k >= 2 W(k): piece k - 1's store and
         // W(k + 1) are younger (3; 2 from step 6 on)
@@ -317,10 +249,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
         else if (MODE == 2 && SH_R128_YPF && h == 1 && t >= 7) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
         if (t < 5) {
-          if (h == 0) {  // piece t of half 1, under this step's MFMAs of the other waves (first read in step 9: five barriers away)
-            if constexpr (BNIN) bn_piece(1, t);
-            else dy_piece(1, t);
-          }
+          if (h == 0) bn_piece(1, t);  // piece t of half 1, under this step's MFMAs of the other waves (first read in step 9: five barriers away)
         }
       } else {
       if (ks < 2) asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
@@ -360,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_r128_kernel(R128Args p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragment reads are done before the next barrier
     }
   };
-  if constexpr (BNIN || DYIN) {
+  if constexpr (BNIN) {
     // both halves unrolled: the registers of half 1's pending pieces (steps 0 .. 4 of h = 0) are then dead for the rest of the loop instead of
     // live around its back edge
 #pragma unroll
@@ -684,10 +613,6 @@ int launch_r128(const R128Args& a0, hipStream_t s) {
     route_hit(SH_ROUTE_FWD_BNIN);
     if (a.partial == nullptr) conv3x3_r128_kernel<0, true><<<a.tiles, 512, 0, s>>>(a);
     else conv3x3_r128_kernel<1, true><<<a.tiles, 512, 0, s>>>(a);
-  } else if (a.dy_y != nullptr) {
-    route_hit(SH_ROUTE_DGRAD_DYSRC);
-    if (a.partial == nullptr) conv3x3_r128_kernel<0, false, true><<<a.tiles, 512, 0, s>>>(a);
-    else conv3x3_r128_kernel<2, false, true><<<a.tiles, 512, 0, s>>>(a);
   } else if (a.partial == nullptr) conv3x3_r128_kernel<0><<<a.tiles, 512, 0, s>>>(a);
   else if (!a.dgrad) conv3x3_r128_kernel<1><<<a.tiles, 512, 0, s>>>(a);
   else conv3x3_r128_kernel<2><<<a.tiles, 512, 0, s>>>(a);

@@ -72,13 +72,11 @@ int gemm1x1_stem_stat_blocks(long long m);                      // rows of the B
 void gemm1x1_set_stem_persistent(int on);
 // stem_ring.hip: the 224 x 224 stem forward with the input rows staged in an LDS ring (one block per image, one partial row per image)
 bool stem_ring_ok(int n, int hp, int wp, int ho, int wo);
-bool stem_ring_geometry_ok(int hp, int wp, int ho, int wo);  // the geometry alone (no test hook): what the two-pass stem requires
+bool stem_ring_geometry_ok(int hp, int wp, int ho, int wo);  // the geometry alone (no test hook)
 int launch_stem_ring(const void* xp, const void* w, void* y, float* partial, int n, int hp, int wp, int ho, int wo, hipStream_t s);
 void stem_ring_enable(int on);
 // stem_bwd.hip: the stem's weight gradient with both operands in LDS rings (224 x 224, 16-bit storage); workspace = blocks x 64 x 224 floats
 int stem_wgrad_ring_blocks(int n);
 int launch_stem_wgrad_ring(const void* xp, const void* dy, float* dw_oihw, float* workspace, int n, int hp, int wp, hipStream_t s);
-int launch_stem_ring_pool(const void* xp, const void* w, const float* scale, const float* shift, void* pooled, unsigned char* idx, void* ywin,
-                          int n, int hp, int wp, int ho, int wo, hipStream_t s);
 
 }  // namespace sh

@@ -1770,20 +1770,10 @@ static bool use_r128(const sh_conv_desc* d) {
 static bool use_r128_dgrad(const sh_conv_desc* d, int accumulate, int relu_mode, bool has_bias) {
   return use_r128(d) && accumulate == 0 && !has_bias && (relu_mode < 0 || relu_mode == 0 || relu_mode == 2);
 }
-// sh_dy_src on the ring kernel (the by-product's element offsets are 32-bit there)
-static bool dysrc_r128_ok(const sh_conv_desc* d) { return use_r128(d) && (long long)d->n * d->ho * d->wo * d->cout < (1ll << 32); }
-static void r128_dy_src(R128Args& c, const sh_dy_src* src) {
-  c.dy_y = src ? (const bf16_t*)src->y : nullptr;
-  c.dy_s = src ? src->scale : nullptr; c.dy_h = src ? src->shift : nullptr;
-  c.dy_a = src ? src->coef_a : nullptr; c.dy_b = src ? src->coef_b : nullptr; c.dy_c = src ? src->coef_c : nullptr;
-  c.dy_relu = src ? src->relu : 0;
-  c.dy_out = src ? (bf16_t*)src->dy_out : nullptr;
-}
 static int launch_r128_conv(const sh_conv_desc* d, const void* x, const void* w, void* out, float* partial, bool dgrad,
-                            const sh_bn_bwd_fuse* fuse, hipStream_t s, const BnIn* bnin = nullptr, const sh_dy_src* src = nullptr) {
+                            const sh_bn_bwd_fuse* fuse, hipStream_t s, const BnIn* bnin = nullptr) {
   R128Args c;
   c.x = (const bf16_t*)x; c.w = (const bf16_t*)w; c.out = (bf16_t*)out; c.partial = partial;
-  r128_dy_src(c, src);
   c.in_scale = bnin ? bnin->scale : nullptr;
   c.in_shift = bnin ? bnin->shift : nullptr;
   c.a_out = bnin ? (bf16_t*)bnin->a_out : nullptr;
@@ -1794,8 +1784,7 @@ static int launch_r128_conv(const sh_conv_desc* d, const void* x, const void* w,
   c.N = d->n; c.H = d->h; c.W = d->w; c.dgrad = dgrad ? 1 : 0;
   c.q_total = c64_q_total(d);
   SH_REQUIRE(c.q_total < (1ll << 31), "conv3x3 r128: padded pixel grid exceeds 2^31 positions");
-  SH_REQUIRE((bnin == nullptr && src == nullptr) || (long long)d->n * d->h * d->w * 128 < (1ll << 32),
-             "conv3x3 r128 (bnin / dy_src): n*h*w*128 exceeds the 32-bit element offsets");
+  SH_REQUIRE(bnin == nullptr || (long long)d->n * d->h * d->w * 128 < (1ll << 32), "conv3x3 r128 (bnin): n*h*w*128 exceeds the 32-bit element offsets");
   c.tiles = 0;
   c.div_pp = make_fastdiv((unsigned)((d->h + 1) * (d->w + 1)));
   c.div_wp = make_fastdiv((unsigned)(d->w + 1));
@@ -1976,26 +1965,6 @@ int simhand_stem_conv_fwd_stat_blocks(int n, int h, int w, int dtype) {
   return dtype == SH_BF16 && g_stem_1x1 ? gemm1x1_stem_stat_blocks(m) : ceil_div(m, 128);  // partial rows of the kernel the same arguments select
 }
 
-int simhand_stem_two_pass_ok(int n, int h, int w, int dtype) {
-  int hp, wp, ho, wo;
-  if (n < 1 || dtype != SH_BF16 || simhand_stem_geometry(h, w, &hp, &wp, &ho, &wo)) return 0;
-  return stem_ring_geometry_ok(hp, wp, ho, wo) ? 1 : 0;
-}
-
-int simhand_stem_conv_bn_relu_pool(const void* xp, const void* wp_, const float* scale, const float* shift, void* pooled, uint8_t* idx,
-                                   void* ywin, int n, int h, int w, int dtype, sh_stream_t stream) {
-  SH_REQUIRE(xp && wp_ && scale && shift && pooled && idx, "stem_conv_bn_relu_pool: NULL pointer");
-  SH_REQUIRE(simhand_stem_two_pass_ok(n, h, w, dtype), "stem_conv_bn_relu_pool: 16-bit storage at 224 x 224 only (n=%d h=%d w=%d dtype=%d)", n, h, w, dtype);
-  int hp, wp, ho, wo;
-  if (simhand_stem_geometry(h, w, &hp, &wp, &ho, &wo)) return 1;
-  const double mo = (double)n * ho * wo;
-  // (pooled + ywin in the storage type, one winner byte per element, the padded input once)
-  ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, 2.0 * mo * 64 * 147, 2.0 * ((double)n * hp * wp * 4 + mo / 4 * 64 * (ywin ? 2 : 1)) + mo / 4 * 64);
-  route_hit(SH_ROUTE_STEM_POOL);
-  launch_stem_ring_pool(xp, wp_, scale, shift, pooled, idx, ywin, n, hp, wp, ho, wo, (hipStream_t)stream);
-  return check_launch("stem_conv_bn_relu_pool");
-}
-
 int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_partial, int n, int h, int w, int dtype,
                           sh_stream_t stream) {
   SH_REQUIRE(xp && wp_, "stem_conv_fwd: NULL pointer");
@@ -2003,9 +1972,7 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
   SH_REQUIRE(n >= 1, "stem_conv_fwd: bad shape");
   int hp, wp, ho, wo;
   if (simhand_stem_geometry(h, w, &hp, &wp, &ho, &wo)) return 1;
-  // y == NULL: statistics only (pass 1 of the two-pass stem) -- the ring kernel's geometry only
-  SH_REQUIRE(y != nullptr || (bn_partial != nullptr && simhand_stem_two_pass_ok(n, h, w, dtype)),
-             "stem_conv_fwd: y == NULL (statistics only) needs bn_partial and the two-pass geometry (simhand_stem_two_pass_ok)");
+  SH_REQUIRE(y != nullptr, "stem_conv_fwd: NULL pointer");
   const int ke = dtype == SH_F32 ? 32 : 64;
   IgemmArgs a;
   a.a = xp; a.w = wp_; a.out = y; a.bn_partial = bn_partial;
@@ -2024,13 +1991,12 @@ int simhand_stem_conv_fwd(const void* xp, const void* wp_, void* y, float* bn_pa
   a.div_w = make_fastdiv((unsigned)wo);
   a.m_tiles = ceil_div(a.Mg, 128);
   a.n_tiles = 1;
-  // (the statistics-only pass of the two-pass stem is overhead, not algorithmic work: its FLOPs are credited once, to pass 2)
-  const double flops = y != nullptr ? 2.0 * (double)a.Mg * 64 * 147 : 0.0;
+  const double flops = 2.0 * (double)a.Mg * 64 * 147;
   const double es = dtype == SH_F32 ? 4 : 2;
-  const double bytes = es * ((double)n * hp * wp * 4 + (y != nullptr ? (double)a.Mg * 64 : 0.0) + 64.0 * 256);
+  const double bytes = es * ((double)n * hp * wp * 4 + (double)a.Mg * 64 + 64.0 * 256);
   ProfScope ps(SH_PROF_CONV_FWD, (hipStream_t)stream, flops, bytes);
-  route_hit(y != nullptr ? SH_ROUTE_STEM_FWD : SH_ROUTE_STEM_STATS);
-  if (dtype == SH_BF16 && (y == nullptr || (g_stem_1x1 && stem_ring_ok(n, hp, wp, ho, wo)))) {
+  route_hit(SH_ROUTE_STEM_FWD);
+  if (dtype == SH_BF16 && g_stem_1x1 && stem_ring_ok(n, hp, wp, ho, wo)) {
     launch_stem_ring(xp, wp_, y, bn_partial, n, hp, wp, ho, wo, (hipStream_t)stream);
     return check_launch("stem_conv_fwd (input rows in an LDS ring)");
   }
@@ -2088,13 +2054,8 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   if (src != nullptr) {
     SH_REQUIRE(src->da && src->y && src->scale && src->shift && src->coef_a && src->coef_b && src->coef_c && src->dy_out,
                "conv2d_dgrad_ex: dy_src has a NULL member");
-    const bool ring = dysrc_r128_ok(d) && use_r128_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr &&
-                      f8 == nullptr && (f8sub == nullptr || f8sub->sub_grad == nullptr);
-    SH_REQUIRE(!ring || (src->dy_out != src->da && src->dy_out != src->y && src->dy_out != dx),
-               "conv2d_dgrad_ex: dy_src on the ring kernel writes dy_out while neighbouring tiles still read da / y: they must be distinct tensors");
-    SH_REQUIRE(x2 == nullptr && (use_1x1(d, d->cout, d->cin) || ring),
-               "conv2d_dgrad_ex: dy_src needs a layer simhand_conv2d_dgrad_dysrc_ok accepts, a single reduction segment and (3x3 ring kernel) "
-               "the store-only or fused-sums form");
+    SH_REQUIRE(x2 == nullptr && use_1x1(d, d->cout, d->cin),
+               "conv2d_dgrad_ex: dy_src needs a layer simhand_conv2d_dgrad_dysrc_ok accepts and a single reduction segment");
     dy = src->da;
   }
   SH_REQUIRE(dy && wt && dx, "conv2d_dgrad: NULL pointer");
@@ -2192,8 +2153,8 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
   if (sub == nullptr && use_c64_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr)
     return launch_c64_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream);
   if (sub == nullptr && use_r128_dgrad(d, accumulate, fuse ? fuse->relu_mode : -1, bias != nullptr) && res_grad == nullptr && x2 == nullptr &&
-      f8 == nullptr && (src == nullptr || dysrc_r128_ok(d)))
-    return launch_r128_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream, nullptr, src);
+      f8 == nullptr && src == nullptr)
+    return launch_r128_conv(d, dy, wt, dx, fuse ? fuse->partial : nullptr, true, fuse, (hipStream_t)stream);
   // 128 -> 128 3x3 / stride 2 (the stage-2 entry block's conv2), plain store: the four parity classes over ONE staged dy tile (conv3x3_ring.hip)
   if (sub == nullptr && fuse == nullptr && accumulate == 0 && bias == nullptr && res_grad == nullptr && x2 == nullptr && src == nullptr &&
       f8 == nullptr &&
@@ -2203,7 +2164,6 @@ static int dgrad_impl(const sh_conv_desc* d, const void* dy, const void* wt, voi
     c.x = (const bf16_t*)dy; c.w = (const bf16_t*)wt; c.out = (bf16_t*)dx; c.partial = nullptr;
     c.fy = nullptr; c.fscale = c.fshift = nullptr; c.relu = 0;
     c.in_scale = c.in_shift = nullptr; c.a_out = nullptr;
-    r128_dy_src(c, nullptr);
     c.N = d->n; c.H = d->ho; c.W = d->wo; c.dgrad = 1;
     c.q_total = (long long)d->n * (d->ho + 1) * (d->wo + 1);
     c.tiles = 0;
@@ -2279,7 +2239,7 @@ int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* w
 }
 
 // the 1x1 layers of the activation-stationary kernel; the 128 -> 128 3x3 / stride-1 layers of the ring kernel (store-only and fused-sums forms)
-int simhand_conv2d_dgrad_dysrc_ok(const sh_conv_desc* d) { return d != nullptr && (use_1x1(d, d->cout, d->cin) || dysrc_r128_ok(d)) ? 1 : 0; }
+int simhand_conv2d_dgrad_dysrc_ok(const sh_conv_desc* d) { return d != nullptr && use_1x1(d, d->cout, d->cin) ? 1 : 0; }
 
 int simhand_conv2d_dgrad_concat_ok(const sh_conv_desc* d, int c2) {
   if (!d) return 0;

@@ -17,19 +17,8 @@
 //   BatchNorm partial sums of the fp32 results ride in registers across the image: one [2][64] row per block (= per image).
 // Only for the 224 x 224 geometry (wo = 112); other sizes keep the activation-stationary kernel.
 //
-// Round 4 -- the TWO-PASS stem forward (MODE 1 + MODE 2).  Train-mode BatchNorm needs the whole batch's statistics before the first
-// activation can be formed, so the one-pass form writes the raw conv1 output (3.3 GB at 2048 x 224^2) and a second kernel reads it back
-// for BN + ReLU + MaxPool.  conv1 is 0.24 GFLOP per image -- cheaper to run TWICE than that 6.6 GB round trip:
-//   MODE 1  statistics only: the same row walk, no output stores (the [2][64] partial sums per image are all that leaves the block);
-//   MODE 2  conv1 again with BatchNorm + ReLU + MaxPool(3, 2, 1) as its epilogue: the lanes round their fp32 results to the storage
-//           type exactly as MODE 0 would have stored them, form a = round(relu(y * scale + shift)) and put both 128-B pixel rows in a
-//           4-row LDS ring; after every odd conv row the block's 448 threads (pooled pixel t >> 3, 8-channel chunk t & 7) take the 3 x 3
-//           window maximum of pooled row po from rows 2 po - 1 .. 2 po + 1 of that ring and write the pooled activation, the winner
-//           tap (uint8, scan order kh then kw, first maximum wins: ATen's rule) and the winner's RAW conv output -- the three tensors
-//           bn_relu_maxpool_fwd_kernel (bn.hip) produces from the stored y, bit for bit (tests/test_gpu_backbone_ops.py).
-//           a >= 0, so its bit patterns order like unsigned integers: window maximum and first-wins argmax are ONE v_max_u32 per tap
-//           on keys ((a_bits + 1) << 16 | 8 - tap): the + 1 bias is load-bearing -- the all-zero stand-ins for taps outside the image
-//           hold key 0 < (a_bits + 1) << 16 and therefore never win, whatever a is.
+// (Round 4 also carried a two-pass / recompute form of the stem -- statistics-only and BN + ReLU + MaxPool-epilogue variants of this
+// kernel plus a fused backward: built, bit-exact, +1.0 ms in the step; removed in round 5, see docs/lab-notes.md and git history.)
 #include "conv_1x1.h"
 
 #include <stdlib.h>
@@ -49,33 +38,19 @@ __device__ __forceinline__ float row16_sum_sr(float v) {
 struct StemRingArgs {
   const bf16_t* xp;   // [n][hp][wp][4] zero-padded input
   const bf16_t* w;    // [64][256]: column r*32 + tap*4 + c (stem_pack_weights)
-  bf16_t* y;          // [n][ho][wo][64] (MODE 0)
-  float* partial;     // [n][2][64] or null (MODE 0, 1)
+  bf16_t* y;          // [n][ho][wo][64]
+  float* partial;     // [n][2][64] or null
   int hp, wp, ho, wo;
-  // MODE 2
-  const float* scale; // [64] BatchNorm scale / shift of the finalized statistics
-  const float* shift;
-  bf16_t* pooled;     // [n][ho/2][wo/2][64]
-  unsigned char* idx; // [n][ho/2][wo/2][64] winner tap kh*3 + kw
-  bf16_t* ywin;       // [n][ho/2][wo/2][64] raw conv output of the winner, or null
 };
 
 // LT: the wave's 16 pixels x 128 B of an output row are 2 KB CONTIGUOUS in memory; with LT the packed chunks go through a wave-private
 // 2-KB LDS block (16-B chunks XOR-swizzled by the pixel, conflict-free both ways) and leave as two fully linear 1-KB store instructions
 // (lane l: bytes 16 l), the shape of the BatchNorm streaming passes, instead of 16 segments of 64 B per instruction.
-// physical 128-B slot of conv pixel px inside a row of the MODE 2 rings: pairs of pixels alternate between the two 128-B halves of the
-// 64 LDS banks, so the pooling reads of one tap (columns 2 pw + kw - 1 of consecutive pooled pixels: all of one parity) spread over both
-__device__ __forceinline__ int sr_pos(int px) { return px ^ ((px >> 1) & 1); }
-
-template <int MODE, bool LT>
+template <bool LT>
 __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
-  constexpr int SLOT = 2048, NSLOT = MODE == 2 ? 16 : 32, D = 2;  // D: steps between a row's request and its use (2 D + 7 <= NSLOT rows)
-  constexpr int PROW = 113 * 128;                                  // one conv row of 112 pixels x 64 channels in the MODE 2 rings + one ZERO pixel
-                                                                   // (slot 112: what the pooling reads for column -1)
+  constexpr int SLOT = 2048, NSLOT = 32, D = 2;  // D: steps between a row's request and its use (2 D + 7 <= NSLOT rows)
   __shared__ __attribute__((aligned(16))) char ring[NSLOT * SLOT];
-  __shared__ __attribute__((aligned(16))) char tbuf[(LT && MODE == 0) ? 7 * 2048 : 16];
-  __shared__ __attribute__((aligned(16))) char yring[MODE == 2 ? 4 * PROW : 16];  // raw conv rows (storage type), slot = row & 3
-  __shared__ __attribute__((aligned(16))) char aring[MODE == 2 ? 4 * PROW : 16];  // activation rows a = round(relu(bn(y)))
+  __shared__ __attribute__((aligned(16))) char tbuf[LT ? 7 * 2048 : 16];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int img = blockIdx.x;
@@ -122,127 +97,18 @@ __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
     for (int e = 0; e < 8; ++e) s1[j][e] = s2[j][e] = 0.f;
   bf16_t* yrow = p.y + ((long long)img * p.ho * p.wo + px) * 64 + g * 8;
   // LT: write offsets of the lane's two chunks (pixel li, chunk j * 4 + g), read offset of linear position l (pixel l >> 3, chunk l & 7)
-  char* tw = tbuf + ((LT && MODE == 0) ? wave * 2048 : 0);
+  char* tw = tbuf + (LT ? wave * 2048 : 0);
   const int tw0 = li * 128 + (((0 * 4 + g) ^ (li & 7)) * 16), tw1 = li * 128 + (((1 * 4 + g) ^ (li & 7)) * 16);
   const int tr0 = (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);  // second kilobyte: pixels 8..15, same keys -> + 1024
   char* ylin = reinterpret_cast<char*>(p.y + ((long long)img * p.ho * p.wo + wave * 16) * 64) + lane * 16;
 
-  // ---- MODE 2 state.  MFMA lane (li, g) holds channels j*32 + g*8 + 0..7 (j = 0, 1) of pixel px: chunk j*4 + g of the pixel's 128-B row,
-  // at 16-B unit (chunk ^ (px & 3)) of physical slot sr_pos(px) -- the pooling reads of one tap are then conflict-free (the four pixels
-  // of a ds_read_b128 lane group sit pairwise in different bank halves, and two pixels 4 columns apart share the key, so their low /
-  // high unit quartets stay disjoint); the row writes are 2-way (inside the 13-cycle issue time of ds_write_b128) --------------------------
-  float bsc[2][8], bsh[2][8];
-  int wr_off[2];
-  if (MODE == 2) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        bsc[j][e] = p.scale[j * 32 + g * 8 + e];
-        bsh[j][e] = p.shift[j * 32 + g * 8 + e];
-      }
-      wr_off[j] = sr_pos(px) * 128 + (((j * 4 + g) ^ (px & 3)) * 16);
-    }
-  }
-  const int pw = tid >> 3, cv = tid & 7;   // pooling role of this thread: pooled pixel, 8-channel chunk
-  const int pho = p.ho >> 1, pwo = p.wo >> 1;
-  // byte offsets (inside a ring row) of this thread's chunk of the three window columns 2 pw - 1 + kw; column -1 = the zero pixel
-  int pcol[3];
-  if (MODE == 2) {
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int col = 2 * pw - 1 + kw;
-      pcol[kw] = col < 0 ? 112 * 128 + cv * 16 : sr_pos(col) * 128 + ((cv ^ (col & 3)) * 16);
-    }
-    // zero for the block's life: the zero pixel of every ring row; ring slot 3 = "conv row -1" until conv row 3 overwrites it
-    for (int i = tid; i < 4 * 8; i += 448) {
-      *reinterpret_cast<uint4*>(aring + (i >> 3) * PROW + 112 * 128 + (i & 7) * 16) = make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4*>(yring + (i >> 3) * PROW + 112 * 128 + (i & 7) * 16) = make_uint4(0, 0, 0, 0);
-    }
-    for (int i = tid; i < PROW / 16; i += 448) *reinterpret_cast<uint4*>(aring + 3 * PROW + i * 16) = make_uint4(0, 0, 0, 0);
-  }
-  // pooled row q from conv rows 2 q - 1 .. 2 q + 1 of the rings (all complete and visible: the caller is behind a barrier that follows them).
-  // key = (a_bits + 1) << 16 | (8 - tap): a >= 0, so keys order like (activation, earlier tap first): one v_max_u32 per tap and element; the
-  // zero pixel / zero row standing in for taps outside the image hold 0 < a_bits + 1 and never win
-  auto pool_row = [&](int q) __attribute__((always_inline)) {
-    unsigned key[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) key[e] = 0u;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const char* ab = aring + ((2 * q - 1 + kh) & 3) * PROW;
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const uint4 v = *reinterpret_cast<const uint4*>(ab + pcol[kw]);
-        const unsigned code = (unsigned)(8 - (kh * 3 + kw));
-        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const unsigned k0 = (w4[i] << 16) | code, k1 = (w4[i] & 0xffff0000u) | code;
-          key[2 * i] = k0 > key[2 * i] ? k0 : key[2 * i];              // first maximum wins: equal a -> the larger 8 - tap = the earlier tap
-          key[2 * i + 1] = k1 > key[2 * i + 1] ? k1 : key[2 * i + 1];
-        }
-      }
-    }
-    const long long o = (((long long)img * pho + q) * pwo + pw) * 64 + cv * 8;
-    uint4 po;
-    po.x = ((key[0] >> 16) | (key[1] & 0xffff0000u)) - 0x00010001u;   // (every window has a real tap: both halves >= 1, no borrow)
-    po.y = ((key[2] >> 16) | (key[3] & 0xffff0000u)) - 0x00010001u;
-    po.z = ((key[4] >> 16) | (key[5] & 0xffff0000u)) - 0x00010001u;
-    po.w = ((key[6] >> 16) | (key[7] & 0xffff0000u)) - 0x00010001u;
-    unsigned tap[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) tap[e] = 8u - (key[e] & 0xffu);
-    const unsigned lo = tap[0] | (tap[1] << 8) | (tap[2] << 16) | (tap[3] << 24), hi = tap[4] | (tap[5] << 8) | (tap[6] << 16) | (tap[7] << 24);
-    unsigned yw[8];
-    if (p.ywin != nullptr) {
-      const int rt0 = ((2 * q - 1) & 3) * PROW, rt1 = ((2 * q) & 3) * PROW, rt2 = ((2 * q + 1) & 3) * PROW;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {   // the winner's raw conv output: a 2-byte gather from the y ring (a winner is always a real tap)
-        const unsigned kh = (tap[e] * 11u) >> 5, kw = tap[e] - 3u * kh;
-        const int ro = kh == 0 ? rt0 : (kh == 1 ? rt1 : rt2);
-        const int co = kw == 0 ? pcol[0] : (kw == 1 ? pcol[1] : pcol[2]);
-        yw[e] = *reinterpret_cast<const unsigned short*>(yring + ro + co + e * 2);
-      }
-    }
-    *reinterpret_cast<uint4*>(p.pooled + o) = po;
-    *reinterpret_cast<uint2*>(p.idx + o) = make_uint2(lo, hi);
-    if (p.ywin != nullptr) {
-      uint4 yo;
-      yo.x = yw[0] | (yw[1] << 16);
-      yo.y = yw[2] | (yw[3] << 16);
-      yo.z = yw[4] | (yw[5] << 16);
-      yo.w = yw[6] | (yw[7] << 16);
-      *reinterpret_cast<uint4*>(p.ywin + o) = yo;
-    }
-  };
-  const int nstore = p.ywin != nullptr ? 3 : 2;  // vector-memory stores per thread of one pool_row
-
   for (int ho = 0; ho < p.ho; ++ho) {
-    // loader waves 0-3, in issue order (vector-memory operations retire in order):
-    //   MODE 0: ... DMA(ho-D) [rows of this step], 2 stores(ho-D), then per later step one DMA + 2 stores: <= 3 D - 1 outstanding means
-    //           this step's rows have landed (the other waves have only stores in flight);
-    //   MODE 1: no stores: <= D - 1;
-    //   MODE 2 (D = 2): an even step issues its DMA and then the stores of one pooled row: before an odd step the queue behind this step's
-    //           rows holds [DMA, stores], before an even one [stores (older than) ... DMA] -- wait down to 1 + nstore / to 1.
-    //           lgkmcnt(0): this wave's ring writes of the previous row are in LDS before the barrier releases their readers.
-    if (MODE == 0) {
-      if (ho >= D) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * D - 1) : "memory");
-      else asm volatile("s_barrier" ::: "memory");
-    } else if (MODE == 1) {
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(D - 1) : "memory");
-    } else {
-      static_assert(D == 2, "the MODE 2 wait counts are written for D = 2");
-      if (ho & 1) {
-        if (nstore == 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      }
-    }
+    // loader waves 0-3, in issue order (vector-memory operations retire in order): ... DMA(ho-D) [rows of this step], 2 stores(ho-D), then per
+    // later step one DMA + 2 stores: <= 3 D - 1 outstanding means this step's rows have landed (the other waves have only stores in flight)
+    if (ho >= D) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * D - 1) : "memory");
+    else asm volatile("s_barrier" ::: "memory");
     // rows 2 (ho + D) + 5, + 6 (the last rows of step ho + D) -> slots outside the windows of steps ho .. ho + D - 1 (2 D + 7 <= NSLOT rows)
     if (wave < 4) dma_half(2 * (ho + D) + 5 + (wave >> 1), wave & 1);
-    if (MODE == 2 && !(ho & 1) && ho >= 2) pool_row((ho >> 1) - 1);   // rows ho - 3 .. ho - 1; this step writes slot ho & 3 = (ho - 4) & 3
     f32x4 acc[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -263,41 +129,15 @@ __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
       o.y = pack_bf16x2(v[2], v[3]);
       o.z = pack_bf16x2(v[4], v[5]);
       o.w = pack_bf16x2(v[6], v[7]);
-      if (MODE == 2) {
-        // the activation bn_relu_maxpool_fwd_kernel forms from the STORED y: a = round(relu(y_rounded * scale + shift))
-        const unsigned yw4[4] = {o.x, o.y, o.z, o.w};
-        float av[8];
+      if (LT) *reinterpret_cast<uint4*>(tw + (j == 0 ? tw0 : tw1)) = o;
+      else *reinterpret_cast<uint4*>(yrow + j * 32) = o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float y0 = h16_lo(yw4[i]), y1 = h16_hi(yw4[i]);
-          float a0 = y0 * bsc[j][2 * i] + bsh[j][2 * i], a1 = y1 * bsc[j][2 * i + 1] + bsh[j][2 * i + 1];
-          av[2 * i] = a0 > 0.f ? a0 : 0.f;
-          av[2 * i + 1] = a1 > 0.f ? a1 : 0.f;
-        }
-        uint4 oa;
-        oa.x = pack_bf16x2(av[0], av[1]);
-        oa.y = pack_bf16x2(av[2], av[3]);
-        oa.z = pack_bf16x2(av[4], av[5]);
-        oa.w = pack_bf16x2(av[6], av[7]);
-        // the ring holds a_bits + 1 (a >= 0: no carry into the sign): the all-zero stand-ins for taps outside the image then lose to
-        // EVERY real tap, a real tap whose activation is zero included (first-wins among real taps only, as ATen)
-        oa.x += 0x00010001u; oa.y += 0x00010001u; oa.z += 0x00010001u; oa.w += 0x00010001u;
-        const int off = (ho & 3) * PROW + wr_off[j];
-        *reinterpret_cast<uint4*>(yring + off) = o;
-        *reinterpret_cast<uint4*>(aring + off) = oa;
-      } else if (MODE == 0) {
-        if (LT) *reinterpret_cast<uint4*>(tw + (j == 0 ? tw0 : tw1)) = o;
-        else *reinterpret_cast<uint4*>(yrow + j * 32) = o;
-      }
-      if (MODE != 2) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          s1[j][e] += v[e];
-          s2[j][e] += v[e] * v[e];
-        }
+      for (int e = 0; e < 8; ++e) {
+        s1[j][e] += v[e];
+        s2[j][e] += v[e] * v[e];
       }
     }
-    if (LT && MODE == 0) {  // same wave, in-order LDS queue: the reads see the writes above; the next row's writes follow these reads
+    if (LT) {  // same wave, in-order LDS queue: the reads see the writes above; the next row's writes follow these reads
       const uint4 r0 = *reinterpret_cast<const uint4*>(tw + tr0), r1 = *reinterpret_cast<const uint4*>(tw + tr0 + 1024);
       *reinterpret_cast<uint4*>(ylin) = r0;
       *reinterpret_cast<uint4*>(ylin + 1024) = r1;
@@ -306,10 +146,6 @@ __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
     yrow += (long long)p.wo * 64;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  if (MODE == 2) {
-    pool_row(pho - 1);   // rows 109 .. 111
-    return;
-  }
   if (p.partial != nullptr) {
     float* red = reinterpret_cast<float*>(ring);  // [7 waves][2][64]
 #pragma unroll
@@ -349,24 +185,9 @@ int launch_stem_ring(const void* xp, const void* w, void* y, float* partial, int
   StemRingArgs a = {};
   a.xp = (const bf16_t*)xp; a.w = (const bf16_t*)w; a.y = (bf16_t*)y; a.partial = partial;
   a.hp = hp; a.wp = wp; a.ho = ho; a.wo = wo;
-  if (y == nullptr) {  // statistics only (pass 1 of the two-pass stem): nothing but the per-image partial sums leaves the block
-    stem_ring_fwd_kernel<1, false><<<n, 448, 0, s>>>(a);
-    return 0;
-  }
   const int lt = sw(SH_SW_STEM_RING_LT);
-  if (lt) stem_ring_fwd_kernel<0, true><<<n, 448, 0, s>>>(a);
-  else stem_ring_fwd_kernel<0, false><<<n, 448, 0, s>>>(a);
-  return 0;
-}
-
-// pass 2 of the two-pass stem: conv1 + BatchNorm + ReLU + MaxPool(3, 2, 1) -> pooled activation, winner tap, winner's raw conv output
-int launch_stem_ring_pool(const void* xp, const void* w, const float* scale, const float* shift, void* pooled, unsigned char* idx, void* ywin,
-                          int n, int hp, int wp, int ho, int wo, hipStream_t s) {
-  StemRingArgs a = {};
-  a.xp = (const bf16_t*)xp; a.w = (const bf16_t*)w;
-  a.hp = hp; a.wp = wp; a.ho = ho; a.wo = wo;
-  a.scale = scale; a.shift = shift; a.pooled = (bf16_t*)pooled; a.idx = idx; a.ywin = (bf16_t*)ywin;
-  stem_ring_fwd_kernel<2, false><<<n, 448, 0, s>>>(a);
+  if (lt) stem_ring_fwd_kernel<true><<<n, 448, 0, s>>>(a);
+  else stem_ring_fwd_kernel<false><<<n, 448, 0, s>>>(a);
   return 0;
 }
 

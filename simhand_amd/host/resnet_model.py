@@ -183,22 +183,9 @@ class ResNetEngine:
         # backward of a stage-entry block: the shortcut's dense data gradient is merged into the main branch's conv1 data gradient
         # (sh_dgrad_opts.sub_grad) instead of scatter-added onto it afterwards (attribute: A/B timing only)
         self.merge_shortcut = True
-        # stem at 224^2, 16-bit storage: conv1 run twice in the forward and once more in the backward instead of storing its raw output
-        # (ops.stem_conv_stats / stem_conv_bn_relu_pool / stem_backward_fused).  Built, bit-exact against the one-pass chain and
-        # 13 GB / step lighter on HBM, but OFF by default: round 4 measured it neutral in isolation (forward 2.21 vs 2.30 ms, backward
-        # 3.22 vs 3.39 ms at 2048 images) and +0.4 .. +2 ms inside the step -- the one-pass kernels are HBM-bound, the fused ones
-        # VALU / MFMA-bound at one or two waves per SIMD, and under the step's power state core-bound kernels lose what they saved
-        # (DESIGN 3b).  bench.py --engine stem_two_pass=1 times it.
-        self.stem_two_pass = False
         # bn1 + ReLU of a Bottleneck applied inside conv2's launch where that 3x3 kernel keeps its activation rows in an LDS ring (the
         # 64- and 128-channel stride-1 layers): the bn_apply pass of those units disappears (attribute: A/B timing only)
         self.bn_on_load = True
-        # bn2's backward apply done inside conv2's data-gradient ring (sh_dy_src on conv3x3_r128; with fuse_bwd_apply_dgrad): the
-        # bn_bwd_apply pass of those units disappears.  Built and tested, OFF by default: round 4 measured 752 us against 548 (data gradient)
-        # + ~200 (the pass) at 2048 images and no change of the step (102.09 / 102.08 vs 102.03 / 102.15 ms, same box) -- two operands and
-        # five coefficient vectors per element are ~90 VALU instructions per 16 bytes, which every wave of the tile issues at the same
-        # time, so nothing hides them (the forward twin, bn_on_load, needs ~30 and pays).  bench.py --engine bwd_apply_in_ring=1 times it.
-        self.bwd_apply_in_ring = False
         # multi-GPU: host.dist.OverlappedGradReducer -- finished parameter gradients go out block by block during backward
         self.grad_reducer = None
 
@@ -468,25 +455,15 @@ class ResNetEngine:
         pk = self._pack(conv1, need_t=False, stem=True)
         d = ops.conv_desc(n, h, w, 3, 64, 7, 7, 2, 3, self.dtype)  # bookkeeping only (n, h, w, ho, wo, cout)
         ywin = None
-        two_pass = self.stem_two_pass and training and not ops.bn_sync_active() and ops.stem_two_pass_ok(n, h, w, self.dtype)
-        if two_pass:
-            # conv1 TWICE instead of a 6.6 GB round trip of its raw output (2048 x 224^2): statistics only, then conv1 again with
-            # BN + ReLU + MaxPool in its epilogue; the backward recomputes it a third time (ops.stem_backward_fused): y never exists
-            part = ops.stem_conv_stats(xp, pk.krsc, h, w)
-            m = n * d.ho * d.wo
-            st = self._bn(bn1, part, m, 64, training)
-            x, idx, ywin = ops.stem_conv_bn_relu_pool(xp, pk.krsc, st, h, w, want_winner=want_ctx)
-            y = None
+        y, part = ops.stem_conv_fwd(xp, pk.krsc, h, w, want_stats=training)
+        ho, wo = y.shape[1], y.shape[2]
+        m = n * ho * wo
+        st = self._bn(bn1, part, m, 64, training)
+        # BN + ReLU + MaxPool in one pass: the 112x112x64 activation in between is never stored
+        if want_ctx:  # + the winning taps' raw conv outputs: the backward's statistics pass then runs over pooled-size tensors
+            x, idx, ywin = ops.bn_relu_maxpool_fwd(y, st, want_winner=True)
         else:
-            y, part = ops.stem_conv_fwd(xp, pk.krsc, h, w, want_stats=training)
-            ho, wo = y.shape[1], y.shape[2]
-            m = n * ho * wo
-            st = self._bn(bn1, part, m, 64, training)
-            # BN + ReLU + MaxPool in one pass: the 112x112x64 activation in between is never stored
-            if want_ctx:  # + the winning taps' raw conv outputs: the backward's statistics pass then runs over pooled-size tensors
-                x, idx, ywin = ops.bn_relu_maxpool_fwd(y, st, want_winner=True)
-            else:
-                x, idx = ops.bn_relu_maxpool_fwd(y, st)
+            x, idx = ops.bn_relu_maxpool_fwd(y, st)
         if want_ctx:
             u = _Unit()
             u.conv, u.bn, u.desc, u.x, u.y, u.a, u.st, u.relu, u.stem = conv1, bn1, d, xp, y, None, st, True, True
@@ -660,13 +637,6 @@ class ResNetEngine:
         fuse_dg = (self.fuse_bwd_apply_dgrad and not fuse_apply and self.dtype in _H16 and not u.stem and relu_mask is None
                    and not u.has_res and need_dx and prev is not None and prev_masked_store and u.conv.kernel_size == (1, 1)
                    and u.conv.stride == (1, 1) and u.conv.padding == (0, 0) and ops.conv2d_dgrad_dysrc_ok(d))
-        # 3x3 units whose data gradient keeps its operand rows in an LDS ring (conv3x3_r128): the same fusion inside that ring, with the
-        # previous unit's BatchNorm-backward sums still in the epilogue
-        fuse_dg3 = (self.fuse_bwd_apply_dgrad and self.bwd_apply_in_ring and not fuse_apply and not fuse_dg and self.dtype in _H16
-                    and not u.stem and relu_mask is None and not u.has_res and need_dx and prev is not None and not prev_masked_store
-                    and u.conv.kernel_size == (3, 3) and res_grad is None and dx_into is None and sub_grad is None and not prev.has_res
-                    and self.fuse_bn_bwd and not (self.fp8 and ops.conv2d_dgrad_fp8_pays(d)) and ops.conv2d_dgrad_fuse_pays(d)
-                    and ops.conv2d_dgrad_dysrc_ok(d))
         # fp8 configuration: the data gradient of the 3x3 layers with >= 256 channels runs on e4m3 operands; dy's codes leave the
         # BatchNorm-backward apply pass (delayed scaling), the CRSK weights are re-quantised per parameter version
         f8 = None
@@ -675,7 +645,7 @@ class ResNetEngine:
             f8 = self._fp8_site_bwd(u.conv, da.device)
         bw = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, False,
                              mask_from_y=u.relu and not u.has_res, relu_mask=relu_mask, raw_partial=raw_partial,
-                             apply=not (fuse_apply or fuse_dg or fuse_dg3), fp8_scaler=f8[0] if f8 is not None else None)
+                             apply=not (fuse_apply or fuse_dg), fp8_scaler=f8[0] if f8 is not None else None)
         dy, _, dg, db = bw[:4]
         dyq = bw[4] if len(bw) > 4 else None
         grads[u.bn.weight] = dg
@@ -690,14 +660,6 @@ class ResNetEngine:
                                          dy_src=(da.contiguous(), u.y, u.st, coefs, u.relu, dy), sub_grad=sub_grad)
             grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))
             return dxm, None
-        if fuse_dg3:
-            coefs = ops.bn_bwd_coefs(u.st, u.bn.weight.detach(), dg, db, m)
-            pk = self._pack(u.conv, need_t=True)
-            dy = torch.empty_like(u.y)
-            dx, part = ops.conv2d_dgrad_ex(d, None, pk.crsk, fuse_mode=2 if prev.relu else 0, prev_y=prev.y, prev_st=prev.st if prev.relu else None,
-                                           dy_src=(da.contiguous(), u.y, u.st, coefs, u.relu, dy))
-            grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))
-            return dx, part
         if fuse_apply:
             coefs = ops.bn_bwd_coefs(u.st, u.bn.weight.detach(), dg, db, m)
             grads[w], dy = ops.conv2d_wgrad_bnbwd(d, u.x, da, u.y, u.st, coefs, u.relu, tuple(w.shape))
@@ -789,14 +751,8 @@ class ResNetEngine:
                 sent = len(items)
         # stem: the pooled gradient is gathered through the winner index inside the BatchNorm-backward passes
         u = ctx["stem"]
-        if u.y is None:  # two-pass stem: conv1 recomputed inside the kernel that forms dy and accumulates dW (neither y nor dy in HBM)
-            pk = self._pack(u.conv, need_t=False, stem=True)
-            dw, dg, db = ops.stem_backward_fused(u.x, pk.krsc, dz.contiguous(), ctx["pool_idx"], ctx["pool_ywin"], u.st, u.bn.weight.detach(),
-                                                 u.desc.h, u.desc.w)
-            grads[u.conv.weight] = dw
-        else:
-            dy, dg, db = ops.maxpool_bn_backward(dz, ctx["pool_idx"], u.y, u.st, u.bn.weight.detach(), ywin=ctx.get("pool_ywin"))
-            grads[u.conv.weight] = ops.stem_conv_wgrad(u.x, dy, u.desc.h, u.desc.w)
+        dy, dg, db = ops.maxpool_bn_backward(dz, ctx["pool_idx"], u.y, u.st, u.bn.weight.detach(), ywin=ctx.get("pool_ywin"))
+        grads[u.conv.weight] = ops.stem_conv_wgrad(u.x, dy, u.desc.h, u.desc.w)
         grads[u.bn.weight] = dg
         grads[u.bn.bias] = db
         if red is not None:

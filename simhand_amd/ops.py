@@ -559,57 +559,6 @@ def stem_conv_fwd(xp: torch.Tensor, wp: torch.Tensor, h: int, w: int, want_stats
     return y, part
 
 
-def stem_two_pass_ok(n: int, h: int, w: int, dtype: torch.dtype) -> bool:
-    """The two-pass stem (statistics-only conv1, then conv1 + BN + ReLU + MaxPool; fused backward) exists for 16-bit storage at 224^2."""
-    return dtype != torch.float32 and bool(_lib_dev().simhand_stem_two_pass_ok(n, h, w, dt(dtype)))
-
-
-def stem_conv_stats(xp: torch.Tensor, wp: torch.Tensor, h: int, w: int) -> torch.Tensor:
-    """Pass 1 of the two-pass stem: the BatchNorm partial sums [n][2][64] of conv1's output -- which is not written."""
-    lib = _lib_dev()
-    n = xp.shape[0]
-    part = torch.empty(n, 2, 64, dtype=torch.float32, device=xp.device)
-    check(lib.simhand_stem_conv_fwd(_ptr(xp), _ptr(wp), None, _ptr(part), n, h, w, dt(xp.dtype), _stream()), "stem_conv_fwd (statistics)")
-    return part
-
-
-def stem_conv_bn_relu_pool(xp: torch.Tensor, wp: torch.Tensor, st: "BNState", h: int, w: int, want_winner: bool = True):
-    """Pass 2: MaxPool(3,2,1)(ReLU(BN(conv1(x)))) -> (pooled [n][56][56][64], winner taps uint8, raw conv output of the winners or None)."""
-    lib = _lib_dev()
-    n = xp.shape[0]
-    _, _, ho, wo = stem_geometry(h, w)
-    out = torch.empty(n, ho // 2, wo // 2, 64, dtype=xp.dtype, device=xp.device)
-    idx = torch.empty(n, ho // 2, wo // 2, 64, dtype=torch.uint8, device=xp.device)
-    ywin = torch.empty_like(out) if want_winner else None
-    check(lib.simhand_stem_conv_bn_relu_pool(_ptr(xp), _ptr(wp), _ptr(st.scale), _ptr(st.shift), _ptr(out), _ptr(idx), _ptr(ywin), n, h, w,
-                                             dt(xp.dtype), _stream()), "stem_conv_bn_relu_pool")
-    return out, idx, ywin
-
-
-def stem_backward_fused(xp: torch.Tensor, wp: torch.Tensor, dz: torch.Tensor, idx: torch.Tensor, ywin: torch.Tensor, st: "BNState", gamma,
-                        h: int, w: int):
-    """Backward of the two-pass stem: (dW fp32 [64,3,7,7], dgamma, dbeta).  The BatchNorm sums run over the pooled tensors (every
-    pooled gradient lands on exactly its winner); conv1 is recomputed inside the kernel that forms dy and accumulates dW."""
-    lib = _lib_dev()
-    n = xp.shape[0]
-    dev = xp.device
-    c = 64
-    mo = dz.numel() // c
-    nblk = lib.simhand_bn_stat_blocks(mo, c)
-    part = torch.empty(nblk, 2, c, dtype=torch.float32, device=dev)
-    check(lib.simhand_bn_bwd_partial(_ptr(dz), None, _ptr(ywin), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift), 2, mo, c,
-                                     dt(xp.dtype), _ptr(part), _stream()), "bn_bwd_partial (pooled)")
-    dg = torch.empty(c, dtype=torch.float32, device=dev)
-    db = torch.empty(c, dtype=torch.float32, device=dev)
-    check(lib.simhand_bn_bwd_finalize(_ptr(part), nblk, c, _ptr(dg), _ptr(db), _stream()), "bn_bwd_finalize")
-    nb = lib.simhand_stem_bwd_fused_workspace_bytes(n)
-    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-    dw = torch.empty(64, 3, 7, 7, dtype=torch.float32, device=dev)
-    check(lib.simhand_stem_bwd_fused(_ptr(xp), _ptr(wp), _ptr(dz), _ptr(idx), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.invstd),
-                                     _ptr(gamma), _ptr(dg), _ptr(db), _ptr(dw), _ptr(ws), nb, n, h, w, dt(xp.dtype), _stream()), "stem_bwd_fused")
-    return dw, dg, db
-
-
 def stem_conv_wgrad(xp: torch.Tensor, dy: torch.Tensor, h: int, w: int) -> torch.Tensor:
     """fp32 weight.grad [64,3,7,7] of the stem from the padded input and dy [n,ho,wo,64]."""
     lib = _lib_dev()

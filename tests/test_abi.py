@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/simhand_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.simhand_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.simhand_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_compute_fails_loudly_without_gpu():

@@ -868,36 +868,6 @@ def _stem_case(n, seed, dtype=torch.bfloat16):
     return x, wt, gamma.to(DEV), beta.to(DEV), xp, wpk
 
 
-@pytest.mark.parametrize("n", [1, 5])
-def test_stem_two_pass_forward_equals_one_pass_bit_for_bit(n):
-    """Round 4: conv1 run twice (statistics only, then conv1 + BN + ReLU + MaxPool in one kernel) == conv1 storing its raw output followed
-    by bn_relu_maxpool_fwd: the BatchNorm partial sums, the pooled activation, the winner taps and the winners' raw conv outputs, bit
-    for bit (ties between equal activations -- the ReLU's zeros, bf16 collisions -- resolved like ATen: first tap in scan order)."""
-    from simhand_amd import ops
-
-    x, wt, gamma, beta, xp, wpk = _stem_case(n, 40 + n)
-    assert ops.stem_two_pass_ok(n, 224, 224, torch.bfloat16) and not ops.stem_two_pass_ok(n, 96, 96, torch.bfloat16)
-    assert not ops.stem_two_pass_ok(n, 224, 224, torch.float32)
-    ops.route_reset()
-    y, part = ops.stem_conv_fwd(xp, wpk, 224, 224)
-    part2 = ops.stem_conv_stats(xp, wpk, 224, 224)
-    assert ops.route_counts()["stem_stats"] == 1
-    # (another instantiation of the kernel: the compiler may contract v * v + s differently -- the sums agree to fp32 round-off)
-    assert torch.allclose(part, part2, rtol=2e-6, atol=1e-3), (part - part2).abs().max().item()
-    m = n * 112 * 112
-    st = ops.bn_finalize(part, m, 64, gamma, beta, None, None, None)
-    want_x, want_idx, want_yw = ops.bn_relu_maxpool_fwd(y, st, want_winner=True)
-    got_x, got_idx, got_yw = ops.stem_conv_bn_relu_pool(xp, wpk, st, 224, 224)
-    assert ops.route_counts()["stem_pool"] == 1
-    assert torch.equal(got_idx, want_idx), (got_idx != want_idx).sum().item()
-    assert torch.equal(got_x, want_x) and torch.equal(got_yw, want_yw)
-    x3, idx3, yw3 = ops.stem_conv_bn_relu_pool(xp, wpk, st, 224, 224, want_winner=False)
-    assert yw3 is None and torch.equal(x3, want_x) and torch.equal(idx3, want_idx)
-    # the winners spread over all nine taps, and a visible share of the windows are decided by ties (equal activations)
-    hist = torch.bincount(want_idx.view(-1).long().cpu(), minlength=9)
-    assert (hist > 0).all(), hist
-
-
 def test_avgpool_backward_with_the_relu_gate_equals_two_passes():
     """avgpool_bwd(mask=...) == apply_relu_bitmask(avgpool_bwd(...)), bit for bit (the gate of the last block's folded bn3 backward)."""
     from simhand_amd import ops
@@ -935,34 +905,6 @@ def test_stem_weight_gradient_ring_kernel(n):
     if n <= 8:
         ref = torch.nn.grad.conv2d_weight(_rnd(x, torch.bfloat16), (64, 3, 7, 7), dy.float().cpu().permute(0, 3, 1, 2).contiguous(), stride=2, padding=3)
         _check(dw.cpu(), ref, 2e-3, "ring kernel vs ATen")
-
-
-@pytest.mark.parametrize("n", [2, 260])
-def test_stem_fused_backward_equals_the_unfused_chain(n):
-    """stem_backward_fused (conv1 recomputed in the kernel that forms dy in registers and accumulates dW) == maxpool_bn_backward (reads the
-    stored y, writes dy) + stem_conv_wgrad (reads dy): dgamma / dbeta bit for bit (same kernels), dW to summation order -- and against
-    ATen's conv2d weight gradient on the host from the unfused chain's stored dy.  n = 260 > 256 blocks: two images on some blocks."""
-    from simhand_amd import ops
-
-    x, wt, gamma, beta, xp, wpk = _stem_case(n, 60 + n)
-    y, part = ops.stem_conv_fwd(xp, wpk, 224, 224)
-    m = n * 112 * 112
-    st = ops.bn_finalize(part, m, 64, gamma, beta, None, None, None)
-    px, idx, ywin = ops.bn_relu_maxpool_fwd(y, st, want_winner=True)
-    g = torch.Generator().manual_seed(n)
-    dz = torch.randn(px.shape, generator=g).to(DEV).to(torch.bfloat16)
-    dy, dg, db = ops.maxpool_bn_backward(dz, idx, y, st, gamma, ywin=ywin)
-    want = ops.stem_conv_wgrad(xp, dy, 224, 224)
-    ops.route_reset()
-    dw, dg2, db2 = ops.stem_backward_fused(xp, wpk, dz, idx, ywin, st, gamma, 224, 224)
-    assert ops.route_counts()["stem_bwd_fused"] == 1
-    assert torch.equal(dg, dg2) and torch.equal(db, db2)
-    assert bool(torch.isfinite(dw).all())
-    _check(dw.cpu(), want.cpu(), 2e-3, "fused stem dW vs the unfused chain")
-    if n <= 8:
-        xr = _rnd(x, torch.bfloat16)
-        ref = torch.nn.grad.conv2d_weight(xr, (64, 3, 7, 7), dy.float().cpu().permute(0, 3, 1, 2).contiguous(), stride=2, padding=3)
-        _check(dw.cpu(), ref, 2e-3, "fused stem dW vs ATen on the host")
 
 
 @pytest.mark.parametrize("shape", [(2, 56, 56, 64, 64), (3, 28, 28, 128, 128), (5, 14, 14, 256, 128), (7, 7, 7, 128, 256), (1, 5, 9, 64, 64),
@@ -1177,52 +1119,6 @@ def test_conv3x3_forward_with_the_previous_batchnorm_applied_in_its_ring(n, h, w
     rc = lib.simhand_conv2d_fwd_bnin(C.byref(d), y_in.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), wk.data_ptr(), y_in.data_ptr(),
                                      y0.data_ptr(), None, None)
     assert rc != 0 and b"distinct" in lib.simhand_last_error()
-
-
-@pytest.mark.parametrize("n,h,w,relu,sums", [(24, 28, 28, True, True), (40, 14, 30, True, False), (300, 7, 7, False, True), (64, 17, 15, True, True)])
-def test_conv3x3_data_gradient_with_its_batchnorm_backward_applied_in_the_ring(n, h, w, relu, sums):
-    """Round 4: sh_dy_src on the 128 -> 128 3x3 ring kernel -- the data gradient takes the gradient w.r.t. the unit's ACTIVATION, rewrites its
-    staged tile as dy = A gate(da) - B y + C (pad positions forced to zero, y pieces loaded next to the DMAs) and emits dy as a by-product.
-    dy against the fp32 expression (one bf16 ulp: the compiler may contract differently); dx and the previous unit's fused BatchNorm-backward
-    sums BIT-identical to the plain kernel run on that dy."""
-    from simhand_amd import ops
-
-    dtype = torch.bfloat16
-    c = 128
-    g = torch.Generator().manual_seed(n * 1000 + h * 10 + w)
-    d = ops.conv_desc(n, h, w, c, c, 3, 3, 1, 1, dtype)
-    if not ops.conv2d_dgrad_dysrc_ok(d):
-        pytest.skip("no ring kernel for this shape")
-    da = (torch.randn(n, h, w, c, generator=g) * 1.3).to(DEV).to(dtype)
-    y = (torch.randn(n, h, w, c, generator=g) * 1.5 + 0.2).to(DEV).to(dtype)
-    wt = _rnd(torch.randn(c, c, 3, 3, generator=g) / math.sqrt(9 * c), dtype).to(DEV)
-    wtd = ops.pack_crsk(wt, dtype)
-    st = ops.BNState(c, DEV)
-    st.scale.copy_((torch.randn(c, generator=g) * 0.8).to(DEV))
-    st.shift.copy_((torch.randn(c, generator=g) * 0.5).to(DEV))
-    coefs = tuple((torch.randn(c, generator=g) * s_).to(DEV) for s_ in (0.9, 0.2, 0.3))
-    prev_y = (torch.randn(n, h, w, c, generator=g)).to(DEV).to(dtype)
-    pst = ops.BNState(c, DEV)
-    pst.scale.copy_((torch.randn(c, generator=g) * 0.8).to(DEV))
-    pst.shift.copy_((torch.randn(c, generator=g) * 0.5).to(DEV))
-    dy = torch.full((n, h, w, c), float("nan"), dtype=dtype, device=DEV)
-    ops.route_reset()
-    dx, part = ops.conv2d_dgrad_ex(d, None, wtd, fuse_mode=2 if sums else None, prev_y=prev_y if sums else None, prev_st=pst if sums else None,
-                                   dy_src=(da, y, st, coefs, relu, dy))
-    rc = ops.route_counts()
-    assert rc["r128_dgrad"] == 1 and rc["dgrad_dysrc"] == 1, rc
-    gate = (y.float() * st.scale + st.shift > 0) if relu else torch.ones_like(y, dtype=torch.bool)
-    want = coefs[0] * torch.where(gate, da.float(), torch.zeros_like(da, dtype=torch.float32)) - coefs[1] * y.float() + coefs[2]
-    assert bool(torch.isfinite(dy.float()).all())   # every pixel of the by-product was written exactly by its owner tile
-    err = (dy.float() - want).abs()
-    assert bool((err <= 2.0 ** -7 * want.abs() + 1e-6).all()), float(err.max())
-    if sums:
-        dx_ref, part_ref = ops.conv2d_dgrad_fused(d, dy, wtd, prev_y, pst, None)
-        assert torch.equal(part, part_ref)
-    else:
-        dx_ref = ops.conv2d_dgrad(d, dy, wtd)
-        assert part is None
-    assert torch.equal(dx, dx_ref)
 
 
 @pytest.mark.parametrize("n,h,w,k1,k2,mode", [(11, 28, 28, 512, 128, 2), (17, 23, 21, 512, 0, 0), (9, 31, 30, 256, 64, None), (12, 28, 28, 1024, 0, 2)])

@@ -537,13 +537,21 @@ def test_fullsize_step_backward_data_gradients_captured_against_aten():
             cap["D"] = dict(d=d, dx=pick(out[0]), dy=pick(dy), wt=wt.float().cpu())
         return out
 
-    ops.conv2d_dgrad_ex, ops.conv2d_dgrad_fused = spy_ex, spy_fused
+    real_plain = ops.conv2d_dgrad
+
+    def spy_plain(d, dy, wt, dx=None, accumulate=False):  # the stride-2 3x3 layers take the plain entry (no fused sums at stride 2)
+        out = real_plain(d, dy, wt, dx=dx, accumulate=accumulate)
+        if d.stride == 2 and d.r == 3 and "D" not in cap and not accumulate:
+            cap["D"] = dict(d=d, dx=pick(out), dy=pick(dy), wt=wt.float().cpu())
+        return out
+
+    ops.conv2d_dgrad_ex, ops.conv2d_dgrad_fused, ops.conv2d_dgrad = spy_ex, spy_fused, spy_plain
     try:
         out = model.training_step(batch, 0)
         out["loss"].backward()
         torch.cuda.synchronize()
     finally:
-        ops.conv2d_dgrad_ex, ops.conv2d_dgrad_fused = real_ex, real_fused
+        ops.conv2d_dgrad_ex, ops.conv2d_dgrad_fused, ops.conv2d_dgrad = real_ex, real_fused, real_plain
     assert sorted(cap) == ["A", "B", "C", "D"], sorted(cap)
 
     def unmask(mb, c):
