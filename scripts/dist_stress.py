@@ -17,7 +17,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser()
 ap.add_argument("--tag", required=True)
-ap.add_argument("--staging", default="all", choices=["all", "buckets", "off"])
+ap.add_argument("--staging", default="all", choices=["all", "buckets", "thread", "off"])
+ap.add_argument("--canary", action="store_true", help="guard tails behind every torch.empty of the worker, checked after the step (tests/_poison.py)")
 ap.add_argument("--minutes", type=float, default=8.0)
 ap.add_argument("--groups", type=int, default=3)
 ap.add_argument("--world", type=int, default=4)
@@ -53,6 +54,8 @@ def group(gi):
                    HSA_ENABLE_IPC_MODE_LEGACY="0", SIMHAND_GLOO_STAGING=args.staging)
         if args.diag:
             env["SIMHAND_DIST_DIAG"] = "1"
+        if args.canary:
+            env["SIMHAND_CANARY"] = "1"
         t0 = time.time()
         procs = [subprocess.Popen([sys.executable, worker, ROOT, "gloo", args.size], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(args.world)]
@@ -79,7 +82,7 @@ for t in threads:
     t.start()
 for t in threads:
     t.join()
-summary = (f"SUMMARY tag={args.tag} staging={args.staging} diag={int(args.diag)} world={args.world} resnet={args.size} groups={args.groups} "
+summary = (f"SUMMARY tag={args.tag} staging={args.staging} diag={int(args.diag)} canary={int(args.canary)} world={args.world} resnet={args.size} groups={args.groups} "
            f"minutes={args.minutes} reps={stats['reps']} failed={stats['failed']} audit_findings={stats['audit_findings']}")
 say(summary)
 print(summary)

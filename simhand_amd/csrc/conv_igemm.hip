@@ -701,6 +701,9 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
 // the swizzle do not change; a lane's two 16-B fragment chunks (g and g + 4) together are ONE operand of
 // v_mfma_scale_f32_16x16x128_f8f6f4 (twice the bf16 rate, K = 128 per instruction): 32 instead of 64 matrix instructions per k-step
 // for twice the reduction length -- and half the operand bytes per FLOP, which is what bounds this kernel's loop.
+#ifndef SH_PRIO256
+#define SH_PRIO256 0  // see the bf16 loop
+#endif
 template <bool DGRAD, int MI = 8, bool FP8 = false>
 __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   typedef bf16_t T;                                                             // stored results (and bf16 operands)
@@ -913,8 +916,23 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     for (int i = 0; i < 4; ++i) dma_a_part(i);
   }
   int sa = 0;  // kt % 3
+#if SH_ABL256 == 30  // diagnostic build: where a wave's cycles go at the top of a k-step (garbage output rows 0 .. 7 of the tile hold the stamps)
+  unsigned long long st_dma = 0, st_bar = 0, st_all = __builtin_amdgcn_s_memtime();
+#endif
+  {
   for (int kt = 0; kt < nk; ++kt) {
+#if SH_ABL256 == 30
+    const unsigned long long ta = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    const unsigned long long tb = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const unsigned long long tc = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    st_dma += tb - ta;
+    st_bar += tc - tb;
+#else
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     b_live = kt + 1 < nk;
     next_b((kt + 1) & 1);
     a_live = kt + 2 < nk;
@@ -963,6 +981,9 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         }
         dma_part(2 * q);
         dma_part(2 * q + 1);
+#if SH_PRIO256 == 3  // the younger wave of each SIMD is raised in every other group (see the bf16 loop)
+        if (wave >= 4) { if ((q & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
       }
     } else {
     uint4 fb[2][NI], fa[2][2];
@@ -973,6 +994,17 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
 #pragma unroll
     for (int grp = 0; grp < 8; ++grp) {
       const int kk = grp >> 2, q = grp & 3;
+      // SH_PRIO256 = 3: issue priority of the YOUNGER wave of each SIMD raised in every other MFMA group.  The block's waves w and w + 4 share
+      // a SIMD; at equal priority the arbiter favours the OLDER one in every slot, so waves 0-3 run ahead and sit ~880 cycles per k-step in the
+      // barrier while waves 4-7, alone on their SIMDs, cannot keep the matrix pipe busy (s_memtime stamps: profiles/
+      // r05_igemm256_barrier_stamps.txt).  Taking turns cuts the barrier wait 490 -> 143 cycles and the step 3105 -> 2895 cycles: +3-8 % per
+      // launch IN ISOLATION -- and NOTHING in the training step (three alternating same-box pairs 101.87 vs 102.05 ms, profiles/
+      // r05_power_wall.md): the step runs at the socket's power limit (1.31 kW sampled), the more efficient kernel draws more power and the
+      // clock gives the cycles back (sampled sclk 2203 -> 2162 MHz).  Off by default; kept as the measured example of that wall.  (Also
+      // measured: raised for the whole step -- the roles flip; first half only -- as good; s_setprio around every MFMA burst -- slower.)
+#if SH_PRIO256 == 3
+      if (wave >= 4) { if ((grp & 1) == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
       if (grp < 7) {
         const int nkk = (grp + 1) >> 2, nq = (grp + 1) & 3;
         const int fo = nkk == 0 ? fo0 : (fo0 ^ 64);
@@ -1009,6 +1041,10 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
 #endif
     }
       }
+  }
+#if SH_ABL256 == 30
+  st_all = __builtin_amdgcn_s_memtime() - st_all;
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS is reused by the epilogues
   if constexpr (FP8) {  // per-tensor scales: one multiply per accumulator, before the statistics and the stores
@@ -1264,6 +1300,13 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
       }
     }
   }
+#if SH_ABL256 == 30
+  __syncthreads();
+  if (lane == 0 && n_tile == 0) {
+    float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + ((long long)m0 + wave) * p.Ng * 2);
+    o[0] = (float)st_dma; o[1] = (float)st_bar; o[2] = (float)st_all; o[3] = (float)nk;
+  }
+#endif
 }
 
 // ======================================================================================================================

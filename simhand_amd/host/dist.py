@@ -175,7 +175,11 @@ def _bucket_views(flat: torch.Tensor, tensors: List[torch.Tensor]) -> List[torch
 # ranks per device), and it is where round 3 saw a corrupted collective result in ~2 % of 4-rank runs with an asynchronous bucket
 # and the synchronised-BatchNorm sums in flight together.  So the staging is done HERE, explicitly, and gloo only ever
 # sees host tensors: SIMHAND_GLOO_STAGING = "all" (default) | "buckets" (only the asynchronous gradient buckets; the experiment
-# that isolates them) | "off" (torch's own device path: the round-3 arrangement, kept for the stress script).
+# that isolates them) | "thread" (as "all", but a bucket's staging never blocks the issuing host thread: the pinned copy is ordered by
+# events on a side stream and a SECOND host thread waits for it and runs the gloo all-reduce -- the launch stream keeps being fed as with
+# "off"; the stress variant ADVICE r4 asked for) | "off" (torch's own device path: the round-3 arrangement, kept for the stress script).
+# OPEN ISSUE: with "off" 2 of 76 four-rank shared-GPU runs produced a wrong LOCAL gradient (all audited collectives exact);
+# "all" made the symptom disappear (0 of 333) without identifying the cause -- it also adds host synchronisations that change timing.
 def _gloo_staging() -> str:
     return os.environ.get("SIMHAND_GLOO_STAGING", "all")
 
@@ -194,7 +198,7 @@ def all_reduce_(t: torch.Tensor, op: str = "sum", group=None) -> torch.Tensor:
     if isinstance(group, RcclComm):
         return group.all_reduce_(t, op)
     rop = getattr(dist.ReduceOp, _REDUCE_OPS[op])
-    if t.is_cuda and _is_gloo(group) and _gloo_staging() == "all":
+    if t.is_cuda and _is_gloo(group) and _gloo_staging() in ("all", "thread"):
         host = t.cpu()
         dist.all_reduce(host, op=rop, group=group)
         t.copy_(host)
@@ -208,7 +212,7 @@ def all_gather_into(out: torch.Tensor, x: torch.Tensor, group=None) -> torch.Ten
     if isinstance(group, RcclComm):
         group.all_gather_into(out, x)
         return out
-    if x.is_cuda and _is_gloo(group) and _gloo_staging() == "all":
+    if x.is_cuda and _is_gloo(group) and _gloo_staging() in ("all", "thread"):
         hx = x.cpu()
         ho = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(ho, hx, group=group)
@@ -245,6 +249,48 @@ class _StagedBucket:
     def wait(self) -> None:
         self.work.wait()
         self.flat.copy_(self.host, non_blocking=True)   # current stream; the pinned block outlives the copy (host allocator events)
+
+
+class _ThreadedBucket(_StagedBucket):
+    """As _StagedBucket, but the issuing host thread never blocks: the D2H copy is enqueued on the side stream behind an event and a helper
+    thread waits for `copied` and runs the (synchronous) gloo all-reduce of the HOST tensor.  Buckets of one process go through ONE helper
+    thread in submission order, so every rank issues its collectives in the same order."""
+
+    _pool = None
+
+    def __init__(self, flat: torch.Tensor, group):  # noqa: super().__init__ intentionally not called (it blocks on `copied`)
+        from concurrent.futures import ThreadPoolExecutor
+
+        cls = _StagedBucket
+        if cls._side is None or cls._side.device != flat.device:
+            cls._side = torch.cuda.Stream(device=flat.device)
+        if _ThreadedBucket._pool is None:
+            _ThreadedBucket._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="simhand-gloo")
+        self.flat = flat
+        self.host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        flat.record_stream(cls._side)
+        with torch.cuda.stream(cls._side):
+            cls._side.wait_event(ready)
+            self.host.copy_(flat, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(cls._side)
+        host = self.host
+
+        def run():
+            copied.synchronize()  # in the helper thread: the launch stream's host thread goes on issuing kernels
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+
+        self.work = _ThreadedBucket._pool.submit(run)
+
+    def wait(self) -> None:
+        self.work.result()
+        self.flat.copy_(self.host, non_blocking=True)
+
+
+def _staged_bucket(flat: torch.Tensor, group):
+    return _ThreadedBucket(flat, group) if _gloo_staging() == "thread" else _StagedBucket(flat, group)
 
 
 class CollectiveAudit:
@@ -343,8 +389,8 @@ class OverlappedGradReducer:
                     self.group.all_reduce_(flat, "sum", side=True)
                 work = torch.cuda.Event()
                 work.record(side)
-        elif flat.is_cuda and _is_gloo(self.group) and _gloo_staging() in ("all", "buckets"):
-            work = _StagedBucket(flat, self.group)
+        elif flat.is_cuda and _is_gloo(self.group) and _gloo_staging() in ("all", "buckets", "thread"):
+            work = _staged_bucket(flat, self.group)
         else:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((work, flat, self._bucket))
@@ -379,7 +425,7 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) ->
     """Parameters and buffers of rank `src` to every rank (replica consistency does not rest on identical seeding)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    stage = _is_gloo(group) and _gloo_staging() == "all"
+    stage = _is_gloo(group) and _gloo_staging() in ("all", "thread")
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             if stage and t.is_cuda:  # gloo carries host memory (see all_reduce_)
@@ -486,8 +532,8 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
             if abi:  # stream-ordered on the current stream: nothing to wait for on the host
                 group.all_reduce_(flat, "sum")
                 work = None
-            elif flat.is_cuda and _is_gloo(group) and _gloo_staging() in ("all", "buckets"):
-                work = _StagedBucket(flat, group)
+            elif flat.is_cuda and _is_gloo(group) and _gloo_staging() in ("all", "buckets", "thread"):
+                work = _staged_bucket(flat, group)
             else:
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
             pending.append((work, flat, i, lo))

@@ -27,6 +27,10 @@ if os.environ.get("SIMHAND_POISON_EVERY"):  # every torch.empty of the step retu
     from tests._poison import poison_every
 
     poison_every()
+if os.environ.get("SIMHAND_CANARY"):  # every torch.empty of the step carries a guard tail (tests/_poison.py guard_every): wild writes show
+    from tests._poison import guard_every
+
+    guard_every()
 audit = None
 if os.environ.get("SIMHAND_DIST_DIAG"):  # scripts/dist_stress.py: every collective's input kept and re-derived on the host afterwards
     audit = shdist.CollectiveAudit()
@@ -58,6 +62,12 @@ loss = model.training_step(shard, 0)["loss"]
 loss.backward()
 shdist.allreduce_gradients(model.parameters(), bucket_bytes=1 << 20, skip=reducer.reduced)
 torch.cuda.synchronize()
+if os.environ.get("SIMHAND_CANARY"):
+    from tests._poison import check_guards
+
+    bad_guards, live_guards = check_guards()
+    print(f"CANARY rank {rank}: {live_guards} live guarded allocations, {len(bad_guards)} overwritten {bad_guards[:8]}", flush=True)
+    assert not bad_guards, bad_guards
 if audit is not None and world > 1:
     import json
 
