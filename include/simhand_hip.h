@@ -102,7 +102,8 @@ enum sh_route {
   SH_ROUTE_R128_FWD = 34, SH_ROUTE_R128_DGRAD = 35,         /* 128->128 3x3: activation tile staged once in an LDS ring, weights streamed per tap */
   SH_ROUTE_FWD_BNIN = 36,                                   /* 3x3 forward with the previous unit's BatchNorm + ReLU applied in its LDS ring */
   SH_ROUTE_N128_FWD = 37, SH_ROUTE_N128_DGRAD = 38,         /* 1x1 with 128 destination channels behind a long reduction: 128 x 128 LDS-DMA tiles, two blocks per CU */
-  SH_ROUTE_COUNT = 39
+  SH_ROUTE_FP8_WGRAD = 39,                                  /* e4m3 3x3 weight gradient (reduction over pixels on the scaled K = 128 MFMA) */
+  SH_ROUTE_COUNT = 40
 };
 int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
 int simhand_route_reset(void);
@@ -398,6 +399,17 @@ typedef struct sh_dgrad_opts {
   const void* sub_grad;
 } sh_dgrad_opts;
 int simhand_conv2d_dgrad_fp8_pays(const sh_conv_desc* d);
+/* e4m3 WEIGHT gradient (BASELINE configs[4]; round 5): dW [cout][cin][3][3] fp32 (the reference's nn.Conv2d.weight.grad layout) = sum over
+ * pixels of dy^T x with BOTH operands as e4m3 codes -- x_q [n][h][w][cin] (the codes the BatchNorm-apply in front of the fp8 forward
+ * emitted, state x_state) and dy_q [n][h][w][cout] (the codes the BatchNorm-backward apply emitted for the fp8 data gradient, state
+ * dy_state) -- on v_mfma_scale_f32_16x16x128_f8f6f4 with the reduction running over 128 pixels per instruction; result = acc / (scale_x
+ * scale_dy).  Only where simhand_conv2d_wgrad_fp8_pays(d): 3x3 / stride 1 / pad 1, >= 256 channels on both sides, w + 2 <= 128.
+ * Replaces (reference): the weight gradient of conv2 of torchvision's Bottleneck (src/models/resnet_model.py:13-58) -- the reference
+ * itself has no fp8 path (src/experiments/main.py:158-159 is fp16 AMP): parity n/a, checked against the fp32 gradient of the dequantised operands. */
+int simhand_conv2d_wgrad_fp8_pays(const sh_conv_desc* d);
+size_t simhand_conv2d_wgrad_fp8_workspace_bytes(const sh_conv_desc* d);
+int simhand_conv2d_wgrad_fp8(const sh_conv_desc* d, const void* x_q, const void* dy_q, const float* x_state, const float* dy_state, float* dw_oihw,
+                             void* workspace, size_t workspace_bytes, sh_stream_t stream);
 int simhand_conv2d_dgrad_concat_ok(const sh_conv_desc* d, int c2);
 int simhand_conv2d_dgrad_dysrc_ok(const sh_conv_desc* d);
 int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, const sh_dgrad_opts* opts, sh_stream_t stream);

@@ -34,8 +34,8 @@ ROUTES = ("igemm128_fwd", "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "i
           "gemm1x1_dgrad", "c64_fwd", "c64_dgrad", "stem_fwd", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
           "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
           "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram", "wgrad_bnbwd", "ntxent_fused_dist",
-          "dgrad_dysrc", "fwd_chain", "r128_fwd", "r128_dgrad", "fwd_bnin", "n128_fwd", "n128_dgrad")
-ROUTE_COUNT = 39
+          "dgrad_dysrc", "fwd_chain", "r128_fwd", "r128_dgrad", "fwd_bnin", "n128_fwd", "n128_dgrad", "fp8_wgrad")
+ROUTE_COUNT = 40
 
 
 class SimhandHipError(RuntimeError):
@@ -212,6 +212,9 @@ SIGNATURES = {
     "simhand_conv2d_fwd_fp8_stat_blocks": (_I, [_P]),
     "simhand_conv2d_fwd_fp8_pays": (_I, [_P]),
     "simhand_conv2d_dgrad_fp8_pays": (_I, [_P]),
+    "simhand_conv2d_wgrad_fp8_pays": (_I, [_P]),
+    "simhand_conv2d_wgrad_fp8_workspace_bytes": (_S, [_P]),
+    "simhand_conv2d_wgrad_fp8": (_I, [_P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_bn_bwd_apply_fp8": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, C.c_int64, _I, _P]),
     "simhand_bn_apply_fp8": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, C.c_int64, _I, _P]),
     "simhand_conv2d_fwd_fp8": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),

@@ -52,14 +52,18 @@ __global__ __launch_bounds__(256) void fp8_amax_kernel(const T* __restrict__ x, 
 }
 
 // state = float[ST_LEN]: [0] scale, [1] 1/scale, [2] ring position, [3] calls, [4 .. 4+HIST) amax history.
-// mode 0 (current scaling): scale from amax_new alone; mode 1 (delayed): amax_new goes into the ring, the scale for
-// the NEXT call is 448 / max(ring) / 2^margin.  amax_new is consumed (reset to 0).
+// mode 0 (current scaling): scale from amax_new alone; mode 1 / 2 (delayed): amax_new goes into the ring, the scale for
+// the NEXT quantisation is 448 / max(ring) / 2^margin.  amax_new is consumed (reset to 0).
+// state[0] = the scale the NEXT quantisation uses; state[1] = 1 / (the scale of the codes that exist NOW): after mode 1 -- the update that
+// FOLLOWS a delayed site's quantisation -- that is the reciprocal of the scale the pass just used (until round 5 it was overwritten with the
+// next scale's, so every consumer launched behind the update -- the convolutions -- de-scaled by the wrong factor whenever the ring's
+// maximum had moved; BatchNorm and LARS hid it); modes 0 and 2 run BEFORE the quantisation they serve: 1 / new scale.
 __global__ void fp8_scale_update_kernel(float* __restrict__ state, unsigned* __restrict__ amax_new_bits, int hist, float margin_pow2, int mode) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float a = __uint_as_float(*amax_new_bits);
   *amax_new_bits = 0u;
   float m = a;
-  if (mode == 1) {
+  if (mode != 0) {
     const int pos = (int)state[2];
     state[4 + pos] = a;
     state[2] = (float)((pos + 1) % hist);
@@ -67,9 +71,10 @@ __global__ void fp8_scale_update_kernel(float* __restrict__ state, unsigned* __r
     for (int i = 0; i < hist; ++i) m = fmaxf(m, state[4 + i]);
   }
   state[3] += 1.f;
+  const float used = state[0];
   const float s = (m > 0.f && isfinite(m)) ? kFp8Max / (m * margin_pow2) : 1.f;
   state[0] = s;
-  state[1] = 1.f / s;
+  state[1] = mode == 1 ? 1.f / used : 1.f / s;
 }
 
 // q = e4m3(clamp(x * scale)); also folds max|x| of THIS tensor into amax_bits (input of the next scale update)
@@ -343,7 +348,7 @@ int simhand_fp8_amax(const void* x, int64_t count, int dtype, uint32_t* amax_bit
 
 int simhand_fp8_scale_update(float* state, uint32_t* amax_new_bits, int history, float margin_pow2, int delayed, sh_stream_t stream) {
   SH_REQUIRE(state && amax_new_bits && history >= 1 && margin_pow2 > 0.f, "fp8_scale_update: bad arguments");
-  fp8_scale_update_kernel<<<1, 64, 0, (hipStream_t)stream>>>(state, amax_new_bits, history, margin_pow2, delayed ? 1 : 0);
+  fp8_scale_update_kernel<<<1, 64, 0, (hipStream_t)stream>>>(state, amax_new_bits, history, margin_pow2, delayed < 0 || delayed > 2 ? 1 : delayed);
   return check_launch("fp8_scale_update");
 }
 

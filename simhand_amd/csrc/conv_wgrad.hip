@@ -773,6 +773,153 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args p) {
 
 
 // ======================================================================================================================
+// e4m3 form of wgrad3x3_kernel (3x3 / stride 1 / pad 1; BASELINE configs[4]): both operands are e4m3 CODES -- x_q [N][H][W][Cin] (what the
+// BatchNorm-apply in front of the fp8 forward already emits) and dy_q [N][H][W][Cout] (what the BatchNorm-backward apply emits for the fp8
+// data gradient) -- and the reduction over the padded pixel grid runs on v_mfma_scale_f32_16x16x128_f8f6f4: ONE matrix instruction per
+// (cout tile, tap) and 128 pixels where the bf16 kernel issues four.  Same decomposition: block = 64 cout x 64 cin x 9 taps, 4 waves side
+// by side along cin, x rows in an LDS ring with the taps as constant row shifts, dy chunk reused by all nine taps.
+//   k-step = 128 padded pixels; rows are 64 B (64 channels x 1 B); a DMA instruction fills 16 rows (lane l = row l >> 2, 16-B slot l & 3);
+//   the reduction index of an MFMA operand is the PIXEL, so both operands are read transposed: ds_read_b64_tr_b8 hands lane l of a
+//   16-lane group channel c0 + l of 8 consecutive pixels when lanes 2j, 2j + 1 address channels c0 .. c0 + 7 / c0 + 8 .. c0 + 15 of pixel
+//   p0 + j (layout probed in round 4: profiles/r04_tr8_layout.txt); four such reads = the 32 bytes (32 pixels of k block lane >> 4) of one
+//   operand, the same pixel order on both sides;
+//   the four 16-B channel slots of row R are rotated by (R >> 2) + 2 ((R >> 5) & 1) on the DMA source side: the 8 rows of one read and
+//   the rows of the neighbouring k block (+ 32) then fall on distinct bank quartets whatever the tap shift is;
+//   x ring = 4 chunks of 128 rows (window: chunks j - 1 .. j + 1 for |shift| <= W + 2 <= 128, chunk j + 2 in flight), 3 dy buffers;
+//   56 KB of LDS: two blocks per CU.  Partials = acc / (scale_x scale_dy) in wgrad_kernel's layout; the same reduce kernel.
+struct Wgrad3F8Args {
+  const unsigned char* x;   // e4m3 codes [N][H][W][Cin]
+  const unsigned char* dy;  // e4m3 codes [N][H][W][Cout]
+  float* part;              // [splitk][Cout][9*Cin]
+  const float* x_state;     // [1] = 1 / scale of the x codes
+  const float* dy_state;
+  int Cout, Cin, H, W;
+  int nt;
+  long long q_total;
+  int per_split;            // padded pixels per split (multiple of 128)
+  FastDiv div_pp, div_wp;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_f8_kernel(Wgrad3F8Args p) {
+  constexpr int KP = 128, NCH = 4, RING = NCH * KP, ROWB = 64;
+  constexpr int BACK = 1, AHEAD = 2, NDY = AHEAD + 1;   // chunk c + AHEAD is issued at step c: x one step before its first use, dy two
+  __shared__ __attribute__((aligned(16))) char smem[RING * ROWB + NDY * KP * ROWB];
+  char* ring = smem;
+  char* sdy = smem + RING * ROWB;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int wn = wave;
+  int logical = xcd_remap_w(blockIdx.x, gridDim.x);
+  const int nt_i = logical % p.nt; logical /= p.nt;
+  const int mt = p.Cout >> 6;
+  const int mt_i = logical % mt;
+  const int split = logical / mt;
+  const int k0 = mt_i * 64, c0 = nt_i * 64;
+  const long long q0 = (long long)split * p.per_split;
+  long long q1 = q0 + p.per_split;
+  if (q1 > p.q_total) q1 = p.q_total;
+  const int nk = q0 < q1 ? (int)((q1 - q0 + KP - 1) / KP) : 0;
+  const int WP = p.W + 1;
+
+  auto dma16 = [](const void* src, unsigned lds_addr) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src));
+  };
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int slot = lane & 3;
+  const char* zsrc = reinterpret_cast<const char*>(g_wg_zero_page) + slot * 16;
+  auto rot = [](int row) __attribute__((always_inline)) -> int { return ((row >> 2) + 2 * ((row >> 5) & 1)) & 3; };
+  // chunk c: 128 rows = 8 DMA instructions of 16 rows, instruction 2 w + i by wave w; lane l = row + (l >> 2), physical slot l & 3
+  auto dma_chunk = [&](int c, bool with_dy) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (2 * wave + i) * 16 + (lane >> 2);       // row inside the chunk
+      const long long q = q0 + (long long)c * KP + r;
+      const bool in = q >= 0 && q < p.q_total;
+      const unsigned qu = in ? (unsigned)q : 0u;              // q_total < 2^31 (checked on the host)
+      const unsigned img = fdiv(qu, p.div_pp);
+      const unsigned rem = qu - img * p.div_pp.d;
+      const unsigned hp = fdiv(rem, p.div_wp);
+      const unsigned wp = rem - hp * p.div_wp.d;
+      const bool ok = in && hp - 1u < (unsigned)p.H && wp - 1u < (unsigned)p.W;
+      const unsigned pix = (img * (unsigned)p.H + (hp - 1u)) * (unsigned)p.W + (wp - 1u);
+      const int ch = ((slot - rot(r)) & 3) * 16;              // logical channel slot this lane's physical slot holds (128 | chunk base: the key is r's)
+      const unsigned dst = ((((c + BACK) & (NCH - 1)) * KP) + (2 * wave + i) * 16) * ROWB;
+      dma16(ok ? reinterpret_cast<const char*>(p.x + (unsigned long long)pix * p.Cin + c0 + ch) : zsrc, smem_addr + dst);
+      if (with_dy)
+        dma16(ok && q < q1 ? reinterpret_cast<const char*>(p.dy + (unsigned long long)pix * p.Cout + k0 + ch) : zsrc,
+              smem_addr + RING * ROWB + ((c % NDY) * KP + (2 * wave + i) * 16) * ROWB);
+    }
+  };
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) acc[t][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // prologue in the order the loop's waits assume: x chunk -1 (look-back), then chunks 0 and 1 with their dy
+  dma_chunk(-1, false);
+  dma_chunk(0, true);
+  dma_chunk(1, true);
+
+  typedef __attribute__((ext_vector_type(2))) int v2i;
+  typedef __attribute__((ext_vector_type(8))) int i32x8;
+  typedef v2i __attribute__((address_space(3))) * lds2;
+  // one 32-byte operand: channel (16 sl + l16) of the 32 pixels of k block g starting at ring / buffer row `row0` (row0 includes 32 g)
+  auto frag = [&](const char* base, int row0, int mask, int sl) __attribute__((always_inline)) -> i32x8 {
+    i32x8 f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = (row0 + 8 * r + (l16 >> 1)) & mask;
+      const v2i v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2)(base + row * ROWB + (((sl + rot(row)) & 3) * 16) + (l16 & 1) * 8));
+      f[2 * r] = v[0];
+      f[2 * r + 1] = v[1];
+    }
+    return f;
+  };
+  int toff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) toff[t] = BACK * KP + 32 * g + (t / 3 - 1) * WP + (t % 3 - 1);   // >= 128 - (W + 2) >= 0
+
+  for (int j = 0; j < nk; ++j) {
+    // everything issued so far has landed (x chunk j + 1 and dy chunk j + 1 went out a whole step ago); after the barrier every wave's
+    // part is visible and every wave is done with step j - 1's operands
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    dma_chunk(j + AHEAD, true);  // ring slot (j + 3) & 3 = the one of chunk j - 2 (outside the window j - 1 .. j + 1); dy buffer (j + 2) % 3 = step j - 1's
+    const char* tA = sdy + (j % NDY) * (KP * ROWB);
+    i32x8 fa[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) fa[mi] = frag(tA, 32 * g, KP - 1, mi);
+    const int jb = (j * KP) & (RING - 1);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const i32x8 fb = frag(ring, jb + toff[t], RING - 1, wn);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        acc[t][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[mi], fb, acc[t][mi], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragment reads are done before the next barrier
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // C[m = cout][n = cin] per tap: lane holds cin = c0 + wn*16 + l16, couts k0 + mi*16 + 4g + r (the bf16 kernel's layout)
+  const float descale = p.x_state[1] * p.dy_state[1];
+  const long long row_len = 9ll * p.Cin;
+  float* dst = p.part + (long long)split * p.Cout * row_len;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = k0 + mi * 16 + 4 * g + r;
+        const int c = c0 + wn * 16 + l16;
+        dst[(long long)k * row_len + (long long)t * p.Cin + c] = acc[t][mi][r] * descale;
+      }
+}
+
+
+// ======================================================================================================================
 // 1x1 / stride-1 weight gradient for the layers with >= 256 channels on both sides (bf16): 256 x 256 tile, operands by LDS-DMA.
 // The pointer-walking kernel above stages a 256 x 128 tile through registers (192 B of operands per MFMA, one k-step of prefetch);
 // here both operand tiles of a 32-pixel k-step go global -> LDS by DMA three steps ahead (128 B per MFMA, nothing staged in VGPRs):
@@ -1279,6 +1426,62 @@ int simhand_conv2d_wgrad_bnbwd(const sh_conv_desc* d, const void* x, const void*
   SH_REQUIRE(c_real >= 0 && c_real <= d->cin, "conv2d_wgrad_bnbwd: c_real=%d outside [0, cin=%d]", c_real, d->cin);
   WgXform xf = {2, scale, shift, coef_a, coef_b, coef_c, y, dy_out, relu};
   return wgrad_impl(d, x, da, dw_oihw, c_real, workspace, workspace_bytes, stream, 0, 0, nullptr, &xf);
+}
+
+// ---- e4m3 weight gradient (3x3 / stride 1 with >= 256 channels on both sides: the layers whose forward and data gradient run on e4m3) ----
+static bool wgrad_f8_ok(const sh_conv_desc* d) {
+  return d != nullptr && d->dtype == SH_BF16 && d->r == 3 && d->s == 3 && d->pad == 1 && d->stride == 1 && d->cin % 64 == 0 && d->cout % 64 == 0 &&
+         d->cin >= 256 && d->cout >= 256 && d->w + 2 <= 128 && d->ho == d->h && d->wo == d->w &&
+         (long long)d->n * (d->h + 1) * (d->w + 1) < (1ll << 31) && (long long)d->n * d->h * d->w * (d->cin > d->cout ? d->cin : d->cout) < (1ll << 32);
+}
+static void plan3_f8(const sh_conv_desc* d, int* splitk, int* per) {
+  const long long q_total = (long long)d->n * (d->h + 1) * (d->w + 1);
+  const long long tiles = (long long)(d->cout / 64) * (d->cin / 64);
+  const long long ksteps = (q_total + 127) / 128;
+  long long sk = g_wg3_blocks / tiles;            // one full round of the two blocks a CU holds
+  const long long max_sk = (ksteps + 7) / 8;      // at least 8 k-steps (1024 padded pixels) per block
+  if (sk > max_sk) sk = max_sk;
+  if (sk < 1) sk = 1;
+  long long pr = (ksteps + sk - 1) / sk;
+  sk = (ksteps + pr - 1) / pr;
+  *splitk = (int)sk;
+  *per = (int)(pr * 128);
+}
+
+int simhand_conv2d_wgrad_fp8_pays(const sh_conv_desc* d) { return wgrad_f8_ok(d) ? 1 : 0; }
+
+size_t simhand_conv2d_wgrad_fp8_workspace_bytes(const sh_conv_desc* d) {
+  if (!wgrad_f8_ok(d)) return 0;
+  int sk, per;
+  plan3_f8(d, &sk, &per);
+  return (size_t)sk * d->cout * d->cin * 9 * sizeof(float);
+}
+
+int simhand_conv2d_wgrad_fp8(const sh_conv_desc* d, const void* x_q, const void* dy_q, const float* x_state, const float* dy_state, float* dw_oihw,
+                             void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+  SH_REQUIRE(wgrad_f8_ok(d), "conv2d_wgrad_fp8: only where simhand_conv2d_wgrad_fp8_pays(d) (3x3 / stride 1 / pad 1, >= 256 channels)");
+  SH_REQUIRE(x_q && dy_q && x_state && dy_state && dw_oihw && workspace, "conv2d_wgrad_fp8: NULL pointer");
+  SH_REQUIRE(workspace_bytes >= simhand_conv2d_wgrad_fp8_workspace_bytes(d), "conv2d_wgrad_fp8: workspace too small");
+  Wgrad3F8Args b;
+  int sk, per;
+  plan3_f8(d, &sk, &per);
+  b.x = (const unsigned char*)x_q; b.dy = (const unsigned char*)dy_q; b.part = (float*)workspace;
+  b.x_state = x_state; b.dy_state = dy_state;
+  b.Cout = d->cout; b.Cin = d->cin; b.H = d->h; b.W = d->w;
+  b.nt = d->cin / 64;
+  b.q_total = (long long)d->n * (d->h + 1) * (d->w + 1);
+  b.per_split = per;
+  b.div_pp = make_fastdiv((unsigned)((d->h + 1) * (d->w + 1)));
+  b.div_wp = make_fastdiv((unsigned)(d->w + 1));
+  hipStream_t s = (hipStream_t)stream;
+  const double mo = (double)d->n * d->h * d->w;
+  ProfScope ps(SH_PROF_CONV_WGRAD, s, 2.0 * mo * d->cout * d->cin * 9, mo * (d->cin + d->cout) + 4.0 * d->cout * d->cin * 9);
+  route_hit(SH_ROUTE_WGRAD3X3);
+  route_hit(SH_ROUTE_FP8_WGRAD);
+  wgrad3x3_f8_kernel<<<sk * (d->cout / 64) * (d->cin / 64), 256, 0, s>>>(b);
+  if (check_launch("conv2d_wgrad_fp8 (3x3)")) return 1;
+  launch_reduce(b.part, (long long)d->cout * d->cin * 9, sk, dw_oihw, d->cin, 9, d->cin, s);
+  return check_launch("conv2d_wgrad_fp8 (3x3) reduce");
 }
 
 int simhand_conv2d_wgrad_oihw(const sh_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int c_real, void* workspace,

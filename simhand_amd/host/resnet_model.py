@@ -125,7 +125,7 @@ class _Packed:
 
 class _Unit:
     """Saved tensors of one conv+BN unit for the backward pass."""
-    __slots__ = ("conv", "bn", "desc", "x", "y", "a", "st", "relu", "stem", "has_res", "mask", "x_in", "s2", "t2", "ws2")
+    __slots__ = ("conv", "bn", "desc", "x", "y", "a", "st", "relu", "stem", "has_res", "mask", "x_in", "s2", "t2", "ws2", "xq")
 
 
 class _Pending:
@@ -150,6 +150,7 @@ class ResNetEngine:
         # gradients stay bf16.  Scales: ops.FP8Scaler (per-tensor; weights current, activations delayed).
         self.fp8 = fp8
         self.fp8_all = False  # A/B: the round-2 fp8 set (every 3x3 and every 1x1 with >= 512 input channels)
+        self.fp8_wgrad = True  # fp8 configuration: e4m3 weight gradient of the 3x3 / stride-1 layers with >= 256 channels (A/B attribute)
         self._fp8_sites: Dict[int, tuple] = {}  # id(conv.weight) -> (activation scaler, weight scaler, packed weights, version)
         self._fp8_pre = None  # (activation tensor, its e4m3 codes) emitted by the BatchNorm-apply in front of an fp8 convolution
         self._packs: Dict[int, _Packed] = {}
@@ -383,6 +384,7 @@ class ResNetEngine:
             xq = pre[1]
         else:
             xq = site[0].quantize(x)
+        self._fp8_xq = (xq, site[0])  # kept with the unit: the e4m3 weight gradient reads the same codes
         return ops.conv2d_fwd_fp8(d, xq, site[2], site[0], site[1], want_stats=training)
 
     def _conv_bn(self, conv, bn, x, relu, residual, training, save: Optional[list], need_dgrad=True, gram_next=False, chain_conv=None,
@@ -397,6 +399,7 @@ class ResNetEngine:
         d = ops.conv_desc(n, h, w, cin, conv.out_channels, k, k, s, p, self.dtype)
         pk = self._pack(conv, need_t=save is not None and need_dgrad)
         chained, self._chain = self._chain, None
+        self._fp8_xq = None
         if pend is not None:
             # the unit in front left its BatchNorm + ReLU to this launch; its activation comes back as a by-product
             x, y, part = ops.conv2d_fwd_bnin(d, pend.y, pend.st, pk.krsc, want_stats=training)
@@ -435,6 +438,7 @@ class ResNetEngine:
             u.has_res = residual is not None
             u.mask = mask
             u.x_in = u.s2 = u.t2 = u.ws2 = None
+            u.xq = self._fp8_xq  # (codes of x, their scaler) when the forward ran on e4m3 operands
             save.append(u)
         if defer:
             return _Pending(y, st, save[-1] if save is not None else None)
@@ -665,6 +669,9 @@ class ResNetEngine:
             grads[w], dy = ops.conv2d_wgrad_bnbwd(d, u.x, da, u.y, u.st, coefs, u.relu, tuple(w.shape))
         elif u.stem:
             grads[w] = ops.stem_conv_wgrad(u.x, dy, d.h, d.w)
+        elif dyq is not None and self.fp8_wgrad and getattr(u, "xq", None) is not None and ops.conv2d_wgrad_fp8_pays(d):
+            # fp8 configuration: both operands already exist as e4m3 codes (x from the forward's BatchNorm-apply, dy from the pass above)
+            grads[w] = ops.conv2d_wgrad_fp8(d, u.xq[0], dyq, u.xq[1], f8[0])
         else:
             grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))  # split-K reduce writes weight.grad's layout
         if not need_dx:

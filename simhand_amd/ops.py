@@ -709,7 +709,7 @@ def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_d
         check(lib.simhand_bn_bwd_apply_fp8(_ptr(da), _ptr(aa), _ptr(y), _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), _ptr(dg), _ptr(db),
                                            _ptr(st.scale), _ptr(st.shift), mode, _ptr(dy), _ptr(q), _ptr(fp8_scaler.state), _ptr(fp8_scaler.amax_bits),
                                            m, c, _stream()), "bn_bwd_apply_fp8")
-        fp8_scaler._update(True)
+        fp8_scaler._update(1)
         fp8_scaler.calls += 1
         return dy, None, dg_l, db_l, q
     dy = torch.empty_like(y)
@@ -925,8 +925,10 @@ class FP8Scaler:
         self.amax_bits = torch.zeros(1, dtype=torch.int32, device=device)
         self.calls = 0
 
-    def _update(self, delayed: bool):
-        check(_lib_dev().simhand_fp8_scale_update(_ptr(self.state), _ptr(self.amax_bits), FP8_HISTORY, self.margin, int(delayed), _stream()),
+    def _update(self, mode: int):
+        """mode 0: current scaling (before the quantisation it serves); 1: a delayed site's update BEHIND its quantisation (state[1] keeps the
+        reciprocal of the scale the codes were made with); 2: a delayed site's first update, before its first quantisation."""
+        check(_lib_dev().simhand_fp8_scale_update(_ptr(self.state), _ptr(self.amax_bits), FP8_HISTORY, self.margin, int(mode), _stream()),
               "fp8_scale_update")
 
     def quantize(self, x: torch.Tensor) -> torch.Tensor:
@@ -935,12 +937,12 @@ class FP8Scaler:
         q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
         if not self.delayed or self.calls == 0:
             check(lib.simhand_fp8_amax(_ptr(x), x.numel(), dt(x.dtype), _ptr(self.amax_bits), _stream()), "fp8_amax")
-            self._update(self.delayed)  # current scaling (and, for a delayed site, the ring's first entry)
+            self._update(2 if self.delayed else 0)  # current scaling (and, for a delayed site, the ring's first entry)
             check(lib.simhand_fp8_quantize(_ptr(x), _ptr(q), x.numel(), dt(x.dtype), _ptr(self.state), None, _stream()), "fp8_quantize")
         else:
             check(lib.simhand_fp8_quantize(_ptr(x), _ptr(q), x.numel(), dt(x.dtype), _ptr(self.state), _ptr(self.amax_bits), _stream()),
                   "fp8_quantize")
-            self._update(True)  # this call's amax enters the ring: the scale of the NEXT call
+            self._update(1)  # this call's amax enters the ring: the scale of the NEXT call
         self.calls += 1
         return q
 
@@ -957,7 +959,7 @@ class FP8Scaler:
         q = torch.empty(y.shape, dtype=torch.uint8, device=y.device)
         check(lib.simhand_bn_apply_fp8(_ptr(y, torch.bfloat16), _ptr(st.scale), _ptr(st.shift), int(relu), _ptr(a), _ptr(q), _ptr(self.state),
                                        _ptr(self.amax_bits), m, c, _stream()), "bn_apply_fp8")
-        self._update(True)
+        self._update(1)
         self.calls += 1
         return a, q
 
@@ -967,7 +969,7 @@ class FP8Scaler:
         wq = torch.empty(k, r * s * c, dtype=torch.uint8, device=w_oihw.device)
         w = w_oihw.detach().contiguous()
         check(lib.simhand_fp8_amax(_ptr(w, _F32), w.numel(), _lib.SH_F32, _ptr(self.amax_bits), _stream()), "fp8_amax")
-        self._update(False)
+        self._update(0)
         check(lib.simhand_fp8_pack_krsc(_ptr(w), _ptr(wq), k, c, r, s, _ptr(self.state), _stream()), "fp8_pack_krsc")
         return wq
 
@@ -975,6 +977,22 @@ class FP8Scaler:
 def fp8_pack_crsk(scaler: FP8Scaler, w_oihw: torch.Tensor) -> torch.Tensor:
     """e4m3 CRSK weights [cin][r][s][cout] for the fp8 data gradient: the KRSC packer applied to the (cin, cout)-transposed filter."""
     return scaler.pack_weights(w_oihw.detach().permute(1, 0, 2, 3).contiguous())
+
+
+def conv2d_wgrad_fp8_pays(d: ConvDesc) -> bool:
+    """The layers whose weight gradient runs on e4m3 operands in the fp8 configuration (3x3 / stride 1, >= 256 channels on both sides)."""
+    return bool(_lib.load().simhand_conv2d_wgrad_fp8_pays(C.byref(d)))
+
+
+def conv2d_wgrad_fp8(d: ConvDesc, x_q, dy_q, x_scaler: FP8Scaler, dy_scaler: FP8Scaler) -> torch.Tensor:
+    """fp32 weight.grad [cout][cin][3][3] from the e4m3 codes of the activation and of dy (their scalers' state[1] = 1 / scale of the codes)."""
+    lib = _lib_dev()
+    nb = lib.simhand_conv2d_wgrad_fp8_workspace_bytes(C.byref(d))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x_q.device)
+    dw = torch.empty(d.cout, d.cin, 3, 3, dtype=torch.float32, device=x_q.device)
+    check(lib.simhand_conv2d_wgrad_fp8(C.byref(d), _ptr(x_q, torch.uint8), _ptr(dy_q, torch.uint8), _ptr(x_scaler.state), _ptr(dy_scaler.state),
+                                       _ptr(dw), _ptr(ws), nb, _stream()), "conv2d_wgrad_fp8")
+    return dw
 
 
 def conv2d_fwd_fp8_supported(d: ConvDesc) -> bool:

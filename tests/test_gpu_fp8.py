@@ -92,6 +92,85 @@ def test_fp8_conv_forward_fullsize_256ch_3x3_at_2048_images():
     assert ((s2 - yf.double().pow(2).mean(0)).abs() / yf.double().pow(2).mean(0)).max().item() <= 5e-3
 
 
+def test_delayed_scale_state_keeps_the_descale_of_the_codes_that_exist():
+    """state[0] = the scale the NEXT quantisation uses, state[1] = 1 / (the scale the LAST codes were made with): a consumer launched
+    behind the delayed update (every convolution is) must de-scale with the latter (round-5 fix: it used to read the next scale's)."""
+    from simhand_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(64, 32, generator=g).to(torch.bfloat16).to(DEV)
+    sd = ops.FP8Scaler(DEV, delayed=True, margin_bits=1)
+    sd.quantize(x)                       # calibration call: update runs BEFORE the pass, codes made with state[0]
+    s1 = float(sd.state[0])
+    assert abs(float(sd.state[1]) * s1 - 1.0) < 1e-6
+    big = (x.float() * 8).to(torch.bfloat16)
+    q2 = sd.quantize(big)                # made with s1; the update behind it moves state[0] (ring max is 8x now)
+    s2 = float(sd.state[0])
+    assert abs(s2 - s1 / 8) <= 1e-5 * s1
+    assert abs(float(sd.state[1]) * s1 - 1.0) < 1e-6, (float(sd.state[1]), 1 / s1, 1 / s2)   # NOT 1 / s2
+    want_codes = (big.float().cpu() * s1).clamp(-448, 448).to(torch.float8_e4m3fn)
+    assert torch.equal(q2.cpu(), want_codes.view(torch.uint8))                      # the codes were made with s1 ...
+    back = _deq(q2) * float(sd.state[1])                                            # ... and state[1] de-scales them
+    assert torch.allclose(back, want_codes.float() / s1, rtol=1e-6, atol=0)
+
+
+WGRAD_F8 = [(3, 14, 14, 256, 256), (5, 7, 7, 512, 512), (2, 28, 28, 256, 256), (7, 9, 13, 512, 256), (1, 31, 126, 256, 256), (70, 7, 7, 256, 512)]
+
+
+@pytest.mark.parametrize("shape", WGRAD_F8)
+def test_fp8_weight_gradient_against_fp32_of_the_dequantised_operands(shape):
+    """simhand_conv2d_wgrad_fp8: dW = dy^T x over e4m3 codes on the scaled K = 128 MFMA (reduction over pixels, ds_read_b64_tr_b8 operands,
+    x rows in an LDS ring, all nine taps per block).  Products of e4m3 values are exact in fp32: against the fp32 weight gradient of the
+    SAME dequantised operands only the summation order differs."""
+    from simhand_amd import ops
+
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, h, w, cin, generator=g).relu().to(torch.bfloat16).to(DEV)
+    dy = (torch.randn(n, h, w, cout, generator=g) * 0.03).to(torch.bfloat16).to(DEV)
+    d = ops.conv_desc(n, h, w, cin, cout, 3, 3, 1, 1, torch.bfloat16)
+    assert ops.conv2d_wgrad_fp8_pays(d)
+    sx, sdy = ops.FP8Scaler(DEV, delayed=True), ops.FP8Scaler(DEV, delayed=True)
+    xq, dyq = sx.quantize(x), sdy.quantize(dy)
+    ops.route_reset()
+    dw = ops.conv2d_wgrad_fp8(d, xq, dyq, sx, sdy)
+    torch.cuda.synchronize()
+    assert ops.route_counts()["fp8_wgrad"] == 1
+    xdq = (_deq(xq) * float(sx.state[1])).permute(0, 3, 1, 2).contiguous()
+    dydq = (_deq(dyq) * float(sdy.state[1])).permute(0, 3, 1, 2).contiguous()
+    want = torch.nn.grad.conv2d_weight(xdq, (cout, cin, 3, 3), dydq, padding=1)
+    err = (dw.cpu() - want).abs().max() / want.abs().max()
+    assert err <= 2e-4, err
+    # and it is the weight gradient of the bf16 operands up to e4m3's 3-bit significand (sanity of the scales): ~2^-4 relative per operand
+    ref = torch.nn.grad.conv2d_weight(x.float().cpu().permute(0, 3, 1, 2).contiguous(), (cout, cin, 3, 3), dy.float().cpu().permute(0, 3, 1, 2).contiguous(), padding=1)
+    cos = F.cosine_similarity(dw.cpu().flatten(), ref.flatten(), dim=0).item()
+    assert cos > 0.99, cos
+
+
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_fp8_weight_gradient_fullsize(n):
+    """At the benchmarked image counts (2048 = configs[1]'s, 4096 = BASELINE configs[4]'s per-GPU batch): 3x3 256 -> 256 @ 14^2; the e4m3
+    kernel against the bf16 all-taps kernel on the dequantised operands (both reduce 401 408 / 802 816 pixels in fp32)."""
+    from simhand_amd import ops
+
+    h, c = 14, 256
+    g = torch.Generator(device=DEV).manual_seed(n)
+    x = torch.randn(n, h, h, c, device=DEV, generator=g).relu().to(torch.bfloat16)
+    dy = (torch.randn(n, h, h, c, device=DEV, generator=g) * 0.03).to(torch.bfloat16)
+    d = ops.conv_desc(n, h, h, c, c, 3, 3, 1, 1, torch.bfloat16)
+    sx, sdy = ops.FP8Scaler(DEV, delayed=True), ops.FP8Scaler(DEV, delayed=True)
+    xq, dyq = sx.quantize(x), sdy.quantize(dy)
+    dw = ops.conv2d_wgrad_fp8(d, xq, dyq, sx, sdy)
+    # e4m3 VALUES are exactly representable in bf16: the bf16 all-taps kernel on the un-scaled code values computes the same products
+    xb = xq.view(torch.float8_e4m3fn).to(torch.bfloat16)
+    dyb = dyq.view(torch.float8_e4m3fn).to(torch.bfloat16)
+    assert torch.equal(xb.float(), xq.view(torch.float8_e4m3fn).float())
+    want = ops.conv2d_wgrad_oihw(d, xb, dyb, (c, c, 3, 3)) * (sx.state[1] * sdy.state[1])
+    torch.cuda.synchronize()
+    err = (dw - want).abs().max() / want.abs().max()
+    assert float(err) <= 2e-4, float(err)
+
+
 def _fp8_conv_case(shape, big):
     from simhand_amd import _lib, ops
 
