@@ -247,6 +247,48 @@ def test_fp8_data_gradient_on_the_256x256_kernel(shape, fused_sums):
         assert part is None
 
 
+@pytest.mark.parametrize("shape", [(256, 256, 14, 1), (512, 512, 7, 1), (256, 256, 28, 2)])
+def test_fp8_forward_and_data_gradient_at_configs4_batch(shape):
+    """The e4m3 instantiations of the 256 x 256 kernel at BASELINE configs[4]'s OWN per-GPU size (2048 pairs = 4096 images) through the default
+    dispatch -- the size-dependent tile plan (224-row tiles, rounds, tail) differs from the 2048-image one: forward and data gradient of the
+    3x3 layers of the fp8 set on 16 sampled images against fp32 convolutions of the dequantised operands (VERDICT r4 weak #1)."""
+    from simhand_amd import ops
+
+    cin, cout, h, stride = shape
+    n = 4096
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(n, h, h, cin, device=DEV, generator=g).relu().to(torch.bfloat16)
+    wt = torch.randn(cout, cin, 3, 3, device=DEV, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    d = ops.conv_desc(n, h, h, cin, cout, 3, 3, stride, 1, torch.bfloat16)
+    assert ops.conv2d_fwd_fp8_pays(d) and ops.conv2d_dgrad_fp8_pays(d)
+    sx, sw, sdy, swt = (ops.FP8Scaler(DEV, delayed=True), ops.FP8Scaler(DEV, delayed=False), ops.FP8Scaler(DEV, delayed=True),
+                        ops.FP8Scaler(DEV, delayed=False))
+    xq, wq = sx.quantize(x), sw.pack_weights(wt)
+    ops.hooks_reset()
+    ops.route_reset()
+    y, _ = ops.conv2d_fwd_fp8(d, xq, wq, sx, sw)
+    torch.cuda.synchronize()
+    assert ops.route_counts()["fp8_fwd"] == 1 and ops.route_counts()["igemm256_fwd"] == 1
+    idx = [0, 1, 2, 3, 1021, 2047, 2048, 2049] + list(range(n - 8, n))
+    xdq = _deq(xq[idx]).permute(0, 3, 1, 2) * float(sx.state[1])
+    wdq = _deq(wq).view(cout, 3, 3, cin).permute(0, 3, 1, 2) * float(sw.state[1])
+    want = F.conv2d(xdq, wdq, stride=stride, padding=1).permute(0, 2, 3, 1)
+    err = (y[idx].float().cpu() - want).abs().max() / want.abs().max()
+    assert err <= 1e-2, err
+    dy = (torch.randn(n, d.ho, d.wo, cout, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    dyq, wtq = sdy.quantize(dy), ops.fp8_pack_crsk(swt, wt)
+    ops.route_reset()
+    dx, _ = ops.conv2d_dgrad_ex(d, dy, ops.pack_crsk(wt, torch.bfloat16), fp8=(dyq, wtq, sdy, swt))
+    torch.cuda.synchronize()
+    assert ops.route_counts()["fp8_dgrad"] == 1 and ops.route_counts()["igemm256_dgrad"] == 1
+    dydq = (_deq(dyq[idx]) * float(sdy.state[1])).permute(0, 3, 1, 2).contiguous()
+    wtdq = _deq(wtq).view(cin, 3, 3, cout).permute(3, 0, 1, 2).contiguous() * float(swt.state[1])
+    want = torch.nn.grad.conv2d_input((len(idx), cin, h, h), wtdq, dydq, stride=stride, padding=1).permute(0, 2, 3, 1)
+    err = (dx[idx].float().cpu() - want).abs().max() / want.abs().max()
+    assert err <= 1e-2, err
+    assert bool(torch.isfinite(dx.float().sum()))
+
+
 def test_bn_backward_apply_with_fused_e4m3_emission_equals_the_two_pass_form():
     from simhand_amd import ops
 
