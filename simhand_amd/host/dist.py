@@ -254,9 +254,21 @@ class _StagedBucket:
 class _ThreadedBucket(_StagedBucket):
     """As _StagedBucket, but the issuing host thread never blocks: the D2H copy is enqueued on the side stream behind an event and a helper
     thread waits for `copied` and runs the (synchronous) gloo all-reduce of the HOST tensor.  Buckets of one process go through ONE helper
-    thread in submission order, so every rank issues its collectives in the same order."""
+    thread in submission order, so every rank issues its collectives in the same order -- on a process group OF THEIR OWN (same ranks,
+    created by every rank at its first bucket): the issuing thread keeps using `group` for the synchronised-BatchNorm sums meanwhile, and two
+    threads interleaving collectives on one gloo group pair them up differently on different ranks (the first closing run of round 5:
+    221 of 221 repetitions died with "Connection closed by peer" in the first BatchNorm sum of the backward)."""
 
     _pool = None
+    _groups = {}  # id(group) -> the helper thread's twin group
+
+    @staticmethod
+    def _twin(group):
+        key = id(group) if group is not None else None
+        if key not in _ThreadedBucket._groups:
+            ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
+            _ThreadedBucket._groups[key] = dist.new_group(ranks=ranks, backend="gloo")
+        return _ThreadedBucket._groups[key]
 
     def __init__(self, flat: torch.Tensor, group):  # noqa: super().__init__ intentionally not called (it blocks on `copied`)
         from concurrent.futures import ThreadPoolExecutor
@@ -276,11 +288,11 @@ class _ThreadedBucket(_StagedBucket):
             self.host.copy_(flat, non_blocking=True)
             copied = torch.cuda.Event()
             copied.record(cls._side)
-        host = self.host
+        host, twin = self.host, _ThreadedBucket._twin(group)
 
         def run():
             copied.synchronize()  # in the helper thread: the launch stream's host thread goes on issuing kernels
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=twin)
 
         self.work = _ThreadedBucket._pool.submit(run)
 

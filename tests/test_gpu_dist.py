@@ -58,6 +58,15 @@ def test_sync_batchnorm_path_reads_no_uninitialised_memory(world, size):
          env_extra={"SIMHAND_POISON_EVERY": "1", "SIMHAND_FORCE_SYNC_PATH": "1", "SIMHAND_DIST_DIAG": "1"})
 
 
+@pytest.mark.parametrize("staging", ["buckets", "thread", "off"])
+def test_sync_batchnorm_step_in_every_staging_mode(staging):
+    """The non-default arrangements of SIMHAND_GLOO_STAGING (instruments of the open issue in DESIGN 4a) must at least run the same step to the
+    same numbers once: "thread" reduces the gradient buckets from a helper thread ON A PROCESS GROUP OF ITS OWN while the issuing thread's
+    synchronised-BatchNorm sums use the main one (sharing one group, every repetition of the round-5 stress died in the first backward)."""
+    _run(2, "gloo", 29730 + ["buckets", "thread", "off"].index(staging), worker="_syncbn_worker.py", extra=("50",),
+         env_extra={"SIMHAND_GLOO_STAGING": staging, "SIMHAND_DIST_DIAG": "1"})
+
+
 def test_sharded_step_over_rccl():
     n = torch.cuda.device_count()
     if n < 2:
