@@ -704,6 +704,9 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
 #ifndef SH_PRIO256
 #define SH_PRIO256 0  // see the bf16 loop
 #endif
+#ifndef SH_SKEW256
+#define SH_SKEW256 0
+#endif
 template <bool DGRAD, int MI = 8, bool FP8 = false>
 __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   typedef bf16_t T;                                                             // stored results (and bf16 operands)
@@ -723,6 +726,18 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int wm = wave >> 2, wn = wave & 3;
+#if SH_ABL256 == 31  // diagnostic build: where a tile's cycles outside the loop go (stamps land in output rows 0 .. 7 of the tile)
+  const unsigned long long e_t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long e_t1 = 0, e_t2 = 0, e_t3 = 0, e_t4 = 0;
+#endif
+#if SH_SKEW256 > 0
+  // experiment: the blocks of the FIRST round start a few hundred cycles apart (CU i of each XCD sleeps i x 64 x SH_SKEW256 cycles), so that the
+  // 256 CUs do not reach their epilogues -- 32 MB of stores -- in the same microsecond round after round
+  if (blockIdx.x < 256) {
+    const int steps = (blockIdx.x >> 3) & 31;
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(SH_SKEW256);
+  }
+#endif
   int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int n_tile = logical % p.n_tiles;
   logical /= p.n_tiles;
@@ -818,7 +833,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     }
   };
   auto next_a = [&](int stage) __attribute__((always_inline)) {
-    if constexpr (DGRAD) if (p.a2 != nullptr && wa.cs == cs1) {
+    if constexpr (DGRAD && !FP8) if (p.a2 != nullptr && wa.cs == cs1) {  // (the e4m3 data gradient has no second segment: launch_igemm256_fp8_dgrad refuses one)
       // second K segment (1x1 / stride 1: pixel index == m): re-base the row pointers so that the same cs * KE offsets walk a2;
       // dead rows keep their h0 = -2^20
       const IT* a2 = reinterpret_cast<const IT*>(p.a2);
@@ -835,7 +850,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     advance(wa);
   };
   auto next_b = [&](int stage) __attribute__((always_inline)) {
-    if constexpr (DGRAD) if (p.a2 != nullptr && wb.cs == cs1) {  // second K segment: w2 [Ng][Ca2]
+    if constexpr (DGRAD && !FP8) if (p.a2 != nullptr && wb.cs == cs1) {  // second K segment: w2 [Ng][Ca2]
       pb0 = reinterpret_cast<const IT*>(p.w2) + (long long)(n0 + lrow) * p.Ca2 + chunk_b * VE - (long long)cs1 * KE;
       wrow64 = 64ll * p.Ca2;
     }
@@ -916,6 +931,9 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     for (int i = 0; i < 4; ++i) dma_a_part(i);
   }
   int sa = 0;  // kt % 3
+#if SH_ABL256 == 31
+  e_t1 = __builtin_amdgcn_s_memtime();
+#endif
 #if SH_ABL256 == 30  // diagnostic build: where a wave's cycles go at the top of a k-step (garbage output rows 0 .. 7 of the tile hold the stamps)
   unsigned long long st_dma = 0, st_bar = 0, st_all = __builtin_amdgcn_s_memtime();
 #endif
@@ -1046,6 +1064,9 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   st_all = __builtin_amdgcn_s_memtime() - st_all;
 #endif
   }
+#if SH_ABL256 == 31
+  e_t2 = __builtin_amdgcn_s_memtime();
+#endif
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS is reused by the epilogues
   if constexpr (FP8) {  // per-tensor scales: one multiply per accumulator, before the statistics and the stores
     const float descale = p.x_state[1] * p.w_state[1];
@@ -1056,7 +1077,11 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   }
 
   // ---- fused BatchNorm partial statistics (forward): lane holds pixel wm*128 + mi*16 + li, channels wn*64 + chan_of(ni, 4g + r)
+#if SH_ABL256 == 51 || SH_ABL256 == 52  // ablation: no BatchNorm partial sums
+  if (false) {
+#else
   if (!DGRAD && p.bn_partial != nullptr) {
+#endif
     float* red = reinterpret_cast<float*>(smem);  // [2 (wm)][2][BN]
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -1086,6 +1111,10 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     }
   }
 
+#if SH_ABL256 == 31
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  e_t3 = __builtin_amdgcn_s_memtime();
+#endif
   // ---- epilogue (as igemm_kernel): 16-B vectors from registers, channels ch0 + j*32 .. +8 of pixel row mi ----
   {
     constexpr int NCH = 2;
@@ -1156,10 +1185,12 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         v.z &= ((keep & 16u) ? 0x0000ffffu : 0u) | ((keep & 32u) ? 0xffff0000u : 0u);
         v.w &= ((keep & 64u) ? 0x0000ffffu : 0u) | ((keep & 128u) ? 0xffff0000u : 0u);
       }
-#if SH_ABL256 != 5
-      *reinterpret_cast<uint4*>(dst) = v;
-#else
+#if SH_ABL256 == 5 || SH_ABL256 == 52
       if (v.x == 0x12345678u) *reinterpret_cast<uint4*>(dst) = v;  // ablation: no output stores
+#elif SH_ABL256 == 50  // experiment: streaming (non-temporal) output stores
+      { typedef unsigned u32x4_t __attribute__((ext_vector_type(4))); __builtin_nontemporal_store((u32x4_t){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(dst)); }
+#else
+      *reinterpret_cast<uint4*>(dst) = v;
 #endif
       return v;
     };
@@ -1218,6 +1249,31 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         }
       }
     } else if (!DGRAD || p.fpartial == nullptr) {
+#if SH_ABL256 == 53  // experiment (plain forward store only): lanes li / li ^ 1 trade one 16-B chunk so that every store instruction writes whole 128-B lines
+      if (!DGRAD && !par && p.accumulate == 0) {
+        auto swap1 = [](unsigned v) __attribute__((always_inline)) -> unsigned {
+          return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
+        };
+        T* __restrict__ outp = reinterpret_cast<T*>(p.out);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const f32x4 c0 = acc[mi][0], c1 = acc[mi][1], c2 = acc[mi][2], c3 = acc[mi][3];
+          const unsigned a0 = pack_bf16x2(c0[0], c0[1]), a1 = pack_bf16x2(c0[2], c0[3]), a2 = pack_bf16x2(c1[0], c1[1]), a3 = pack_bf16x2(c1[2], c1[3]);
+          const unsigned b0 = pack_bf16x2(c2[0], c2[1]), b1 = pack_bf16x2(c2[2], c2[3]), b2 = pack_bf16x2(c3[0], c3[1]), b3 = pack_bf16x2(c3[2], c3[3]);
+          const bool odd = (li & 1) != 0;
+          // even lanes send their second channel group (b) and keep a; odd lanes send a and keep b
+          const unsigned r0 = swap1(odd ? a0 : b0), r1 = swap1(odd ? a1 : b1), r2 = swap1(odd ? a2 : b2), r3 = swap1(odd ? a3 : b3);
+          const long long row = (long long)m0 + wm * WR + mi * 16 + li;      // own row; the partner's is row ^ 1
+          const long long rowA = odd ? row - 1 : row, rowB = odd ? row : row + 1;
+          const int chx = ch0 + (odd ? 32 : 0);
+          const uint4 vA = odd ? make_uint4(r0, r1, r2, r3) : make_uint4(a0, a1, a2, a3);
+          const uint4 vB = odd ? make_uint4(b0, b1, b2, b3) : make_uint4(r0, r1, r2, r3);
+          if (rowA < p.Mg) *reinterpret_cast<uint4*>(outp + rowA * p.Ng + chx) = vA;
+          if (rowB < p.Mg) *reinterpret_cast<uint4*>(outp + rowB * p.Ng + chx) = vB;
+        }
+        return;
+      }
+#endif
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const long long pix = pixel_of(mi);
@@ -1300,6 +1356,19 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
       }
     }
   }
+#if SH_ABL256 == 31
+  e_t4 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  {
+    const unsigned long long e_t5 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    if (lane == 0 && n_tile == 0) {
+      float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + ((long long)m0 + wave) * p.Ng * 2);
+      o[0] = (float)(e_t1 - e_t0); o[1] = (float)(e_t2 - e_t1); o[2] = (float)(e_t3 - e_t2); o[3] = (float)(e_t4 - e_t3); o[4] = (float)(e_t5 - e_t4);
+      o[5] = (float)nk; o[6] = (float)(e_t0 & 0xffffffu); o[7] = (float)(e_t5 & 0xffffffu);
+    }
+  }
+#endif
 #if SH_ABL256 == 30
   __syncthreads();
   if (lane == 0 && n_tile == 0) {
@@ -1682,6 +1751,7 @@ static bool dgrad_fp8_ok(const sh_conv_desc* d) {  // the 3x3 layers the 256 x 2
          (long long)d->r * d->s * d->cout >= 1024;
 }
 static int launch_igemm256_fp8_dgrad(IgemmArgs a, hipStream_t s) {
+  SH_REQUIRE(a.a2 == nullptr, "conv2d_dgrad fp8: no second reduction segment in the e4m3 kernel");
   if (a.lda == 0) a.lda = a.Ca;
   int main_m, tail128, bm;
   split256(a.Mg, a.Ng, a.classes, &main_m, &tail128, &bm, false);
