@@ -113,7 +113,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
       const unsigned wp = rem - hp * p.div_wp.d;
       const bool ok = in && hp - 1u < (unsigned)p.H && wp - 1u < (unsigned)p.W;
       const unsigned pix = (img * (unsigned)p.H + (hp - 1u)) * (unsigned)p.W + (wp - 1u);
-      const int chunk = slot ^ ((row >> 1) & 7);                // ring row = 64 (c + 1) + row: same key
+      int chunk = slot ^ ((row >> 1) & 7);                      // ring row = 64 (c + 1) + row: same key
+      // opaque to the optimiser: left visible, `p.x + chunk * 8` is hoisted out of the step loop as two 64-bit VGPR pairs, which the data-gradient
+      // instantiation (256 registers: the filter alone is 144) spills -- and behind a scratch reload hipcc waits vmcnt(0), draining the counted DMA queue
+      asm volatile("" : "+v"(chunk));
       const char* src = ok ? reinterpret_cast<const char*>(p.x + (unsigned long long)pix * 64 + chunk * 8) : zsrc;
       dma16(src, ring_addr + ((((c + 1) * 64) & (RING - 1)) + wave * 16 + h * 8) * 128);
       if constexpr (BNIN) off[h] = ok ? pix * 64u + (unsigned)chunk * 8u : 0xffffffffu;  // 32-bit element offset: n*h*w*cin < 2^32 (simhand_conv2d_fwd_bnin_ok, re-checked in launch_c64_conv)
@@ -155,13 +158,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
   };
 
   // ---- fragment addressing: pixel row of lane = 64 (j + 1) + wm*32 + mi*16 + pl + off_t; key and tap offsets do not depend on j ----
-  int trow[9], tcol[9];
+  // ONE register per tap: ring byte offset of the lane's row (row * 128) plus its swizzled 16-B column (bits 4..6) -- kept as separate row / column
+  // arrays the eighteen values pushed the data-gradient instantiation over its 256 registers (scratch reloads inside the step loop)
+  int tadd[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     int off = (t / 3 - 1) * WP + (t % 3 - 1);
     if (p.dgrad) off = -off;  // dx[p] = sum_t dy[p - off_t] W[.][t][.]
-    trow[t] = 64 + wm * 32 + pl + off;      // >= 64 - 59 > 0
-    tcol[t] = (g ^ ((trow[t] >> 1) & 7)) * 16;  // chunk kk*4 + g of the k-step: kk = 1 flips bit 6
+    const int trow = 64 + wm * 32 + pl + off;      // >= 64 - 59 > 0
+    tadd[t] = trow * 128 + (g ^ ((trow >> 1) & 7)) * 16;  // chunk kk*4 + g of the k-step: kk = 1 flips bit 6
   }
 
   // output / statistics state
@@ -251,8 +256,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Args p) {
     const int jb = (j * 64 * 128) & (RING * 128 - 1);
     uint4 fr[2][4];
     auto load_tap = [&](int t, uint4 (&f)[4]) __attribute__((always_inline)) {
-      const int b = jb + trow[t] * 128;
-      const int a0 = (b & (RING * 128 - 1)) | tcol[t], a1 = ((b + 16 * 128) & (RING * 128 - 1)) | tcol[t];  // rows +16: same key
+      const int b = jb + tadd[t];  // (the column bits ride below the ring mask's lowest row bit)
+      const int a0 = b & (RING * 128 - 1), a1 = (b + 16 * 128) & (RING * 128 - 1);  // rows +16: same key
       f[0] = *reinterpret_cast<const uint4*>(ring + a0);
       f[1] = *reinterpret_cast<const uint4*>(ring + a1);
       f[2] = *reinterpret_cast<const uint4*>(ring + (a0 ^ 64));
