@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 5: data-gradient epilogues of the 256 x 256 kernel with their row operands requested ahead (chunk_load / chunk_out) vs the previous build
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+out=gpurun_out/r05_dgrad_epi.txt
+: > $out
+timeout 1200 python -m pytest tests/test_gpu_backbone_ops.py tests/test_gpu_fullsize.py tests/test_gpu_fp8.py -x -q -m gpu 2>&1 | tail -3 >> $out
+for v in prev new; do
+  echo "== $v" >> $out
+  if [ $v = new ]; then L=""; else L="scripts/abl/libprev.so"; fi
+  SIMHAND_LIB=$L timeout 300 python scripts/dgrad_epi_bench.py 2>&1 | grep -v amdgpu.ids >> $out
+done
+for i in 1 2 3; do
+for v in prev new; do
+  if [ $v = new ]; then L=""; else L="scripts/abl/libprev.so"; fi
+  SIMHAND_LIB=$L python bench.py --no-cpu-baseline --steps 8 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_step']; print('[$v]'.ljust(10), round(d['ms_per_step'],2), {a: round(b,2) for a,b in k.items() if a in ('conv_fwd','conv_dgrad','conv_wgrad','bn','misc')}, d['device_state']['sclk_mhz']['mean'])" >> $out
+done; done
+cat $out

@@ -1214,7 +1214,8 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
             const long long pix = pixel_of(mi);
-            rq[mi] = pix >= 0 ? *reinterpret_cast<const uint4*>(res + pix * p.Ng + ch) : make_uint4(0, 0, 0, 0);
+            // (rows past the range read row 0, never used: a conditional load is waited for at the join, one round trip per row)
+            rq[mi] = *reinterpret_cast<const uint4*>(res + (pix < 0 ? 0 : pix) * p.Ng + ch);
           }
         }
 #pragma unroll
