@@ -704,9 +704,6 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
 #ifndef SH_PRIO256
 #define SH_PRIO256 0  // see the bf16 loop
 #endif
-#ifndef SH_SKEW256
-#define SH_SKEW256 0
-#endif
 template <bool DGRAD, int MI = 8, bool FP8 = false>
 __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   typedef bf16_t T;                                                             // stored results (and bf16 operands)
@@ -729,14 +726,6 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
 #if SH_ABL256 == 31  // diagnostic build: where a tile's cycles outside the loop go (stamps land in output rows 0 .. 7 of the tile)
   const unsigned long long e_t0 = __builtin_amdgcn_s_memtime();
   unsigned long long e_t1 = 0, e_t2 = 0, e_t3 = 0, e_t4 = 0;
-#endif
-#if SH_SKEW256 > 0
-  // experiment: the blocks of the FIRST round start a few hundred cycles apart (CU i of each XCD sleeps i x 64 x SH_SKEW256 cycles), so that the
-  // 256 CUs do not reach their epilogues -- 32 MB of stores -- in the same microsecond round after round
-  if (blockIdx.x < 256) {
-    const int steps = (blockIdx.x >> 3) & 31;
-    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(SH_SKEW256);
-  }
 #endif
   int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int n_tile = logical % p.n_tiles;
@@ -862,7 +851,10 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
 #define SH_ABL256 0
 #endif
   // SH_ABL256 (ablation builds, garbage results; scripts/diag_r05*.sh): 1 = activations from the zero page, 9 = weights from the zero
-  // page, 8 = both (issue slots and LDS writes stay, L2 traffic goes), 2 / 3 / 4 = no activation / no weight / no DMAs at all
+  // page, 8 = both (issue slots and LDS writes stay, L2 traffic goes), 2 / 3 / 4 = no activation / no weight / no DMAs at all; 6 / 7 = half / none of the
+  // activation fragment reads; 5 / 51 / 52 = no output stores / no BatchNorm sums / neither; 30 / 31 = s_memtime stamps (k-step waits / tile phases:
+  // scripts/stamp256.py, stamp256_tile.py).
+  // Measured and removed again in round 5: non-temporal output stores (neutral), a start skew between the CUs of the first round (neutral).
   // part i (0..3) of a k-step's activation DMAs: tile rows lrow + 64 i (MI = 7: rows 224.. fetch the zero page -- every wave issues the
   // same number of DMAs, the counted waits below depend on it)
   auto dma_a_part = [&](int i) __attribute__((always_inline)) {
@@ -1187,8 +1179,6 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
       }
 #if SH_ABL256 == 5 || SH_ABL256 == 52
       if (v.x == 0x12345678u) *reinterpret_cast<uint4*>(dst) = v;  // ablation: no output stores
-#elif SH_ABL256 == 50  // experiment: streaming (non-temporal) output stores
-      { typedef unsigned u32x4_t __attribute__((ext_vector_type(4))); __builtin_nontemporal_store((u32x4_t){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(dst)); }
 #else
       *reinterpret_cast<uint4*>(dst) = v;
 #endif
@@ -1250,8 +1240,14 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         }
       }
     } else if (!DGRAD || p.fpartial == nullptr) {
-#if SH_ABL256 == 53  // experiment (plain forward store only): lanes li / li ^ 1 trade one 16-B chunk so that every store instruction writes whole 128-B lines
+      // plain forward store: lanes li / li ^ 1 trade one packed 16-B chunk (DPP quad_perm) so that every store instruction writes whole 128-B lines --
+      // 8 rows x 128 B instead of 16 rows x 64 B.  The CU's store path digests the whole-line form in 60 % of the cycles (scripts/probes/store_pattern.hip,
+      // profiles/r05_igemm256_tile_stamps.md): -1 us per tile, bit-identical.  (The epilogues with per-channel operands keep the 64-B form.)
+#if SH_ABL256 == 5 || SH_ABL256 == 52
+      if (false) {
+#else
       if (!DGRAD && !par && p.accumulate == 0) {
+#endif
         auto swap1 = [](unsigned v) __attribute__((always_inline)) -> unsigned {
           return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
         };
@@ -1272,18 +1268,17 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
           if (rowA < p.Mg) *reinterpret_cast<uint4*>(outp + rowA * p.Ng + chx) = vA;
           if (rowB < p.Mg) *reinterpret_cast<uint4*>(outp + rowB * p.Ng + chx) = vB;
         }
-        return;
-      }
-#endif
+      } else {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const long long pix = pixel_of(mi);
-        if (pix < 0) continue;
+        for (int mi = 0; mi < MI; ++mi) {
+          const long long pix = pixel_of(mi);
+          if (pix < 0) continue;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-          unsigned keep = 0xffu;
-          if (DGRAD && p.fmode == 4) keep = p.fmask[pix * (p.Ng / VE) + (ch0 + j * 32) / VE];  // masked store, no sums
-          chunk_out(mi, j, pix, keep);
+          for (int j = 0; j < NCH; ++j) {
+            unsigned keep = 0xffu;
+            if (DGRAD && p.fmode == 4) keep = p.fmask[pix * (p.Ng / VE) + (ch0 + j * 32) / VE];  // masked store, no sums
+            chunk_out(mi, j, pix, keep);
+          }
         }
       }
     } else {
