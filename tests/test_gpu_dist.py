@@ -74,6 +74,16 @@ def test_sharded_step_over_rccl():
     _run(min(n, 8) if min(n, 8) in (2, 4, 8) else 2, "nccl", 29641)
 
 
+def test_sync_batchnorm_and_overlapped_buckets_on_two_communicators_over_rccl():
+    """The arrangement ADVICE r4 wants gated on real hardware: synchronised-BatchNorm sums on the compute stream (first ncclComm) while the gradient
+    buckets overlap them on the high-priority side stream (second ncclComm), every collective audited, against the full-batch oracle and against the
+    torch.distributed gradients of the same step (tests/_syncbn_worker.py, nccl leg).  Needs one device per rank: skipped on a single-GPU box."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("RCCL needs one device per rank: this box has a single GPU (never executed so far: DESIGN 4a)")
+    _run(4 if n >= 4 else 2, "nccl", 29745, worker="_syncbn_worker.py", extra=("50",), env_extra={"SIMHAND_DIST_DIAG": "1"})
+
+
 def test_bench_self_launch_two_ranks():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment spawns its own ranks and prints ONE JSON line
     with n_gpus = 2 and the world size the backend reports.  On a 1-GPU box the ranks share the device over gloo
