@@ -25,6 +25,7 @@ ap.add_argument("--world", type=int, default=4)
 ap.add_argument("--size", default="50")
 ap.add_argument("--max-reps", type=int, default=10 ** 6)
 ap.add_argument("--diag", action="store_true")
+ap.add_argument("--rerun", action="store_true", help="with --diag: every rank runs the step twice and compares what it fed into each collective (LOCALDIFF lines)")
 args = ap.parse_args()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 log = open(os.path.join(ROOT, "gpurun_out", f"dist_stress_{args.tag}.log"), "w")
@@ -56,6 +57,8 @@ def group(gi):
             env["SIMHAND_DIST_DIAG"] = "1"
         if args.canary:
             env["SIMHAND_CANARY"] = "1"
+        if args.rerun:
+            env["SIMHAND_DIST_RERUN"] = "1"
         t0 = time.time()
         procs = [subprocess.Popen([sys.executable, worker, ROOT, "gloo", args.size], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(args.world)]
@@ -67,14 +70,14 @@ def group(gi):
                 p.kill()
                 outs.append(p.communicate()[0] + "\n[dist_stress] TIMEOUT")
         bad = [r for r, p in enumerate(procs) if p.returncode != 0]
-        audit = [ln for o in outs for ln in o.splitlines() if ln.startswith("AUDIT") and '"tag"' in ln]
+        audit = [ln for o in outs for ln in o.splitlines() if (ln.startswith("AUDIT") and '"tag"' in ln) or ln.startswith("LOCALDIFF")]
         with lock:
             stats["failed"] += 1 if bad else 0
             stats["audit_findings"] += len(audit)
         say(f"rep {rep} group {gi} {time.time() - t0:.1f}s {'FAILED ranks ' + str(bad) if bad else 'ok'} audit_findings {len(audit)}")
         if bad or audit:
             for r in (bad or range(args.world)):
-                say(f"--- rep {rep} rank {r} output tail ---\n{outs[r][-2500:]}")
+                say(f"--- rep {rep} rank {r} output tail ---\n{outs[r][-6000:]}")
 
 
 threads = [threading.Thread(target=group, args=(g,)) for g in range(args.groups)]

@@ -313,9 +313,11 @@ class CollectiveAudit:
 
     def __init__(self):
         self.records = []  # (tag, input clone, result tensor (live) or clone)
+        self.owners = []
 
-    def note(self, tag: str, pre: torch.Tensor, post: torch.Tensor) -> None:
+    def note(self, tag: str, pre: torch.Tensor, post: torch.Tensor, owners=None) -> None:
         self.records.append((tag, pre, post))
+        self.owners.append(owners)  # buckets: [(id(parameter), numel)] in flattening order (tests/_syncbn_worker.py names them)
 
     def verify(self, group=None) -> list:
         """-> list of findings (dicts), empty when every collective result equals the host re-computation."""
@@ -380,7 +382,7 @@ class OverlappedGradReducer:
             return
         flat = _bucket_flat([g for _, g in self._bucket], self.wire)
         if _AUDIT is not None:
-            _AUDIT.note(f"bucket{len(self._pending)}", flat.clone(), flat)
+            _AUDIT.note(f"bucket{len(self._pending)}", flat.clone(), flat, [(id(p), g.numel()) for p, g in self._bucket])
         if isinstance(self.group, RcclComm):
             from .. import ops
 
@@ -540,7 +542,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
             tensors = grads[i:lo]
             flat = _bucket_flat(tensors, wdt)
             if _AUDIT is not None:
-                _AUDIT.note(f"tail{len(pending)}", flat.clone(), flat)
+                _AUDIT.note(f"tail{len(pending)}", flat.clone(), flat, [(id(q), t.numel()) for q, t in zip(owners[i:lo], tensors)])
             if abi:  # stream-ordered on the current stream: nothing to wait for on the host
                 group.all_reduce_(flat, "sum")
                 work = None

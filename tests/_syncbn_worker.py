@@ -79,6 +79,61 @@ if audit is not None and world > 1:
     AUDIT_BAD = len(findings)
 else:
     AUDIT_BAD = 0
+if os.environ.get("SIMHAND_DIST_RERUN") and audit is not None and world > 1:
+    # scripts/dist_stress.py --rerun: the SAME step once more on every rank (the kernels are deterministic), and each rank compares what it
+    # fed into every collective -- its LOCAL BatchNorm sums and its local gradient buckets -- between the two runs.  A rank whose first run
+    # went wrong locally (the round-3..5 irregularity: all collectives exact, reduced gradients wrong) shows WHICH tensors differed first.
+    first, first_owners = audit.records, audit.owners
+    grads1 = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    bufs1 = {k: b.detach().clone() for k, b in model.named_buffers()}  # the second step must not move the running statistics the checks below read
+    audit2 = shdist.CollectiveAudit()
+    shdist.set_collective_audit(audit2)
+    model.zero_grad()
+    reducer2 = shdist.OverlappedGradReducer(bucket_bytes=int(os.environ.get("SIMHAND_TEST_BUCKET", 1 << 20)))
+    if not os.environ.get("SIMHAND_TEST_NO_REDUCER"):
+        model.encoder.engine.grad_reducer = reducer2
+    loss2 = model.training_step(shard, 0)["loss"]
+    loss2.backward()
+    shdist.allreduce_gradients(model.parameters(), bucket_bytes=1 << 20, skip=reducer2.reduced)
+    torch.cuda.synchronize()
+    shdist.set_collective_audit(None)
+    with torch.no_grad():
+        for k, b in model.named_buffers():
+            b.copy_(bufs1[k])
+        for k, p in model.named_parameters():  # and the checks read the FIRST run's reduced gradients
+            if k in grads1:
+                g2 = p.grad.detach().clone()
+                p.grad.copy_(grads1[k])
+                grads1[k] = g2
+    names = {id(p): k for k, p in model.named_parameters()}
+    ndiff = 0
+    if len(first) != len(audit2.records):
+        print(f"LOCALDIFF rank {rank}: {len(first)} collectives in run 1, {len(audit2.records)} in run 2", flush=True)
+    for i, ((tag, pre1, post1), (tag2, pre2, post2)) in enumerate(zip(first, audit2.records)):
+        for what, a, b in (("local input", pre1, pre2), ("result", post1, post2)):
+            a, b = a.detach().float().cpu().reshape(-1), b.detach().float().cpu().reshape(-1)
+            if a.shape == b.shape and torch.equal(a, b):
+                continue
+            ndiff += 1
+            if a.shape != b.shape:
+                print(f"LOCALDIFF rank {rank}: record {i} {tag} / {tag2} {what}: shapes {tuple(a.shape)} vs {tuple(b.shape)}", flush=True)
+                continue
+            d = (a - b).abs()
+            idx = d.nonzero().reshape(-1)
+            where = ""
+            if first_owners[i]:
+                off_, parts = 0, []
+                for pid, n_ in first_owners[i]:
+                    seg = d[off_:off_ + n_]
+                    if bool((seg != 0).any()):
+                        parts.append(f"{names.get(pid, '?')} {float(seg.max()) / (float(b[off_:off_ + n_].abs().max()) + 1e-30):.2e}")
+                    off_ += n_
+                where = " | " + "; ".join(parts[:12])
+            print(f"LOCALDIFF rank {rank}: record {i} {tag} {what}: {idx.numel()} of {a.numel()} elements differ between run 1 and run 2, first {int(idx[0])} last "
+                  f"{int(idx[-1])}, max abs {float(d.max()):.3e} (run-2 abs max {float(b.abs().max()):.3e}){where}", flush=True)
+    gd = [(k, float((p.grad - grads1[k]).abs().max()), float(grads1[k].abs().max())) for k, p in model.named_parameters() if k in grads1 and not torch.equal(p.grad, grads1[k])]  # run 1 (p.grad) vs run 2
+    print(f"RERUN rank {rank}: {ndiff} collective inputs / results differ between the two runs; loss {loss.item():.7f} vs {loss2.item():.7f}; {len(gd)} reduced "
+          f"gradients differ {[(k, f'{a:.2e}/{b:.2e}') for k, a, b in gd[:8]]}", flush=True)
 # every rank normalised with the same statistics: the running buffers agree bit for bit across ranks
 for k, buf in model.named_buffers():
     if buf.dtype.is_floating_point:
