@@ -70,7 +70,7 @@ def group(gi):
                 p.kill()
                 outs.append(p.communicate()[0] + "\n[dist_stress] TIMEOUT")
         bad = [r for r, p in enumerate(procs) if p.returncode != 0]
-        audit = [ln for o in outs for ln in o.splitlines() if (ln.startswith("AUDIT") and '"tag"' in ln) or ln.startswith("LOCALDIFF")]
+        audit = [ln for o in outs for ln in o.splitlines() if (ln.startswith("AUDIT") and '"tag"' in ln) or ln.startswith("LOCALFIRST")]
         with lock:
             stats["failed"] += 1 if bad else 0
             stats["audit_findings"] += len(audit)

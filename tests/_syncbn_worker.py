@@ -106,7 +106,7 @@ if os.environ.get("SIMHAND_DIST_RERUN") and audit is not None and world > 1:
                 p.grad.copy_(grads1[k])
                 grads1[k] = g2
     names = {id(p): k for k, p in model.named_parameters()}
-    ndiff = 0
+    ndiff, first_lines = 0, []
     if len(first) != len(audit2.records):
         print(f"LOCALDIFF rank {rank}: {len(first)} collectives in run 1, {len(audit2.records)} in run 2", flush=True)
     for i, ((tag, pre1, post1), (tag2, pre2, post2)) in enumerate(zip(first, audit2.records)):
@@ -129,8 +129,14 @@ if os.environ.get("SIMHAND_DIST_RERUN") and audit is not None and world > 1:
                         parts.append(f"{names.get(pid, '?')} {float(seg.max()) / (float(b[off_:off_ + n_].abs().max()) + 1e-30):.2e}")
                     off_ += n_
                 where = " | " + "; ".join(parts[:12])
-            print(f"LOCALDIFF rank {rank}: record {i} {tag} {what}: {idx.numel()} of {a.numel()} elements differ between run 1 and run 2, first {int(idx[0])} last "
-                  f"{int(idx[-1])}, max abs {float(d.max()):.3e} (run-2 abs max {float(b.abs().max()):.3e}){where}", flush=True)
+            line = (f"LOCALDIFF rank {rank}: record {i} of {len(first)} {tag} {what}: {idx.numel()} of {a.numel()} elements differ between run 1 and run 2, first {int(idx[0])} last "
+                    f"{int(idx[-1])}, max abs {float(d.max()):.3e} (run-2 abs max {float(b.abs().max()):.3e}){where}")
+            if len(first_lines) < 6:
+                first_lines.append(line)
+            if ndiff <= 12:
+                print(line, flush=True)
+    for line in first_lines:  # once more at the END of the output (scripts/dist_stress.py keeps the tail): where the two runs part
+        print(line.replace("LOCALDIFF", "LOCALFIRST"), flush=True)
     gd = [(k, float((p.grad - grads1[k]).abs().max()), float(grads1[k].abs().max())) for k, p in model.named_parameters() if k in grads1 and not torch.equal(p.grad, grads1[k])]  # run 1 (p.grad) vs run 2
     print(f"RERUN rank {rank}: {ndiff} collective inputs / results differ between the two runs; loss {loss.item():.7f} vs {loss2.item():.7f}; {len(gd)} reduced "
           f"gradients differ {[(k, f'{a:.2e}/{b:.2e}') for k, a, b in gd[:8]]}", flush=True)
