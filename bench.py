@@ -68,8 +68,13 @@ def parse():
                     help="bf16 = BASELINE's dtype (default); 16 = the reference's own policy: fp16 storage + dynamic loss scaling (fp16 build of the "
                          "library); fp8 = BASELINE configs[4]: bf16 storage, e4m3 operands where they pay (parity n/a); 32 = exact-fp32 parity mode")
     ap.add_argument("--experiment", default="handclr_w", choices=["handclr_w", "peclr_w", "simclr"])
-    ap.add_argument("--comm", default="torch", choices=["torch", "abi"],
-                    help="N > 1: collectives through torch.distributed (nccl = RCCL) or through the C ABI's own RCCL wrappers (simhand_comm_*)")
+    ap.add_argument("--comm", default="abi", choices=["abi", "torch"],
+                    help="N > 1: the step's collectives through the C ABI's own RCCL wrappers (simhand_comm_*: the communicator the product documents -- "
+                         "loss exchanges on the compute stream's ncclComm, gradient buckets overlapped on a second ncclComm's side stream; default) or "
+                         "through torch.distributed (nccl = RCCL; the fallback).  Rendezvous and the timing barrier use torch.distributed either way")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ARRANGEMENT ONLY (tests/_gloo_staging.py): the N ranks share the visible GPU(s) over gloo with host staging -- what a "
+                         "1-GPU box can run of the N > 1 code path; never a measurement")
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="N > 1: wire format of the gradient all-reduce buckets")
     ap.add_argument("--event-every", type=int, default=1,
                     help="HIP events bracket every launch of the roofline's kernel class in every Nth timed step (1 = every step, the default; "
@@ -86,7 +91,7 @@ def parse():
                          "the loss row block 2 b_loc x 2 b_loc R against a synthetic gathered Z_all / J_all, gradient buckets flattened and cast as on "
                          "the wire -- NO collective is executed (an upper bound on data-parallel efficiency where no multi-GPU node is available)")
     ap.add_argument("--no-loss-scaling", action="store_true", help="--precision 16 without the GradScaler (timing split only)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline AND the precision-16 companion line (profiling / A-B runs)")
     ap.add_argument("--cpu-pairs", type=int, default=32,
                     help="pairs in the CPU-baseline sample (default = the SURVEY 8d point B = 32; ~40 s on the box's host for ResNet-50)")
     ap.add_argument("--cpu-full", action="store_true",
@@ -360,14 +365,35 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))  # nothing above touched the GPU: the ranks are ordinary child processes
-    rank, local, world = shdist.init_from_env()
+    if args.share_gpu:  # the shared-GPU test arrangement (ranks on one device over gloo, device tensors staged through host memory)
+        from tests import _gloo_staging
+
+        rank, local, world = _gloo_staging.init_shared_gpu()
+    else:
+        rank, local, world = shdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     emu = max(1, args.emulate_world)
     if emu > 1 and world != 1:
         raise SystemExit("--emulate-world runs in ONE process (--gpus 1)")
     _lib.require_device()
+    if world > 1:
+        # the N > 1 line must be what it says: one rank per GPU over RCCL with every rank present -- anything else fails loudly here
+        got = dist.get_world_size()
+        if got != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the {dist.get_backend()} backend reports {got} ranks")
+        if not args.share_gpu:
+            if dist.get_backend() != "nccl":
+                raise SystemExit(f"bench.py: N > 1 runs over RCCL (backend nccl); torch.distributed came up with '{dist.get_backend()}'")
+            if torch.cuda.device_count() < args.gpus:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) are visible (one rank per GPU)")
     device = torch.device("cuda", torch.cuda.current_device())  # = LOCAL_RANK (init_from_env set it)
+    # measured parity of THIS build on THIS device (VERDICT r5 "Next" 7): the smoke-size step against the CPU oracle, before anything is timed
+    parity = None
+    if rank == 0 and args.precision != "fp8":
+        import __graft_entry__ as entry
+
+        parity = entry.parity_probe()
     model = make_model(args, world * emu).to(device).train()
     for kv in args.switch:   # A/B hooks (never set in the default run; recorded in the line's config)
         name, v = kv.split("=", 1)
@@ -507,7 +533,8 @@ def main():
                                    f"{args.per_gpu_batch} pairs/GPU of 2x{args.image_size}x{args.image_size}x3, linear MPJPE weighting, "
                                    f"crop+rotate un-warp, global negatives",
                        "global_batch": global_pairs, "per_gpu_batch": args.per_gpu_batch, "image_size": args.image_size,
-                       "parallelism": f"dp{world}", "loss": final_loss, "parity": "n/a (the reference has no fp8 path)" if args.precision == "fp8" else "oracle",
+                       "parallelism": f"dp{world}", "loss": final_loss,
+                       "parity": "n/a (the reference has no fp8 path)" if parity is None else parity,
                        "world_size_backend": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none",
                        "comm": ("abi (simhand_comm_*)" if group is not None else "torch.distributed") if world > 1 else "none",
@@ -547,6 +574,23 @@ def main():
             res["config"]["global_batch"] = args.per_gpu_batch  # what THIS process processed per step
         if not args.no_cpu_baseline and world == 1 and emu == 1:  # the CPU reference is timed at N = 1 only (the other ranks would idle behind it)
             res["cpu_baseline"] = cpu_baseline(args)
+        if args.precision == "bf16" and world == 1 and emu == 1 and not args.no_cpu_baseline and not (args.switch or args.engine):
+            # bf16 is the dtype BASELINE names and this line reports; the RECOMMENDED training mode is --precision 16 (the reference's own
+            # policy: fp16 storage + dynamic loss scaling) -- bf16 activations cost training quality (profiles/r05_stability_160steps.md:
+            # last-16 mean loss 4.47 vs 4.12 after 160 steps).  Its step time on this box, from a child process started after every timed
+            # region of this one has finished (an ordinary child: nothing is exec'ed over the initialised runtime).
+            res["recommended_precision"] = {"precision": "16", "why": "fp16 storage + GradScaler (src/experiments/main.py:158-159) tracks the fp32 loss curve; "
+                                            "bf16 storage does not (profiles/r05_stability_160steps.md)", "ms_per_step": None, "pairs_per_s": None}
+            try:
+                cmd = [sys.executable, os.path.abspath(__file__), "--precision", "16", "--steps", str(max(3, min(args.steps, 8))), "--warmup", "2",
+                       "--no-cpu-baseline", "--per-gpu-batch", str(args.per_gpu_batch), "--resnet", args.resnet, "--image-size", str(args.image_size),
+                       "--experiment", args.experiment]
+                out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+                d16 = json.loads(line)
+                res["recommended_precision"].update(ms_per_step=d16["ms_per_step"], pairs_per_s=d16["value"], dtype=d16["dtype"])
+            except Exception as e:  # noqa: BLE001 -- the companion figure must never cost the headline line
+                res["recommended_precision"]["error"] = repr(e)[:200]
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -12,16 +12,20 @@
  *     tensor); no ownership transfer, no allocation inside the library;
  *   - workspaces are caller-allocated after a *_workspace_bytes() query;
  *   - every launch takes an explicit hipStream_t (as void*) and is asynchronous.
- *     The PRODUCT surface (everything not named simhand_test_* / simhand_prof_* /
- *     simhand_route_*) holds no mutable global state: a call's result and kernel
+ *     The entry points of THIS header hold no mutable global state that a caller can observe: a call's result and kernel
  *     choice depend on its arguments only, concurrent callers on different streams
- *     do not interact.  Three diagnostic facilities are process-global by design
- *     and are NOT part of the drop-in surface: (a) the optional event profiler
- *     (simhand_prof_*), (b) the route counters (simhand_route_*), (c) the
- *     simhand_test_* namespace -- relaxed atomics that pick between kernels
- *     computing the same result, for A/B timing and for tests that must force a
- *     route at small sizes; their defaults are the measured-best routes, a product
- *     caller never calls them, and simhand_test_hooks_reset() restores them all;
+ *     do not interact.  The library's instruments -- the optional event profiler
+ *     (simhand_prof_*), the route counters (simhand_route_*) and the simhand_test_*
+ *     hooks (relaxed atomics that pick between kernels computing the same result) --
+ *     are process-global by design, are NOT part of the drop-in surface and are
+ *     declared in include/simhand_hip_test.h; a product caller never includes it.
+ *     Two device-side scratch areas are written but never read: the SINK pages
+ *     g_c64_sink (64 KB) and g_r128_sink (64 KB) of the 3x3 ring kernels
+ *     (conv3x3_c64.hip, conv3x3_ring.hip) receive the stores of pad positions, so
+ *     that every wave issues the same number of stores per step (the hand-counted
+ *     s_waitcnt of the LDS-DMA rings depends on it).  Every block writes them,
+ *     nobody loads from them: concurrent launches may interleave there freely;
+ *     the zero pages (g_zero_page, g_c64_zero_page) are read-only after load.
  *   - entry points marked EXPERIMENTAL were built, tested and measured slower than
  *     the default path; they stay for the experiment record,
  *     the engine does not call them by default and they may go away;
@@ -58,7 +62,9 @@ enum sh_weight_type { SH_W_NONE = 0, SH_W_LINEAR = 1, SH_W_NONLINEAR = 2,
  * 2 = round 3: `width` argument of simhand_proj_postprocess_fwd / _bwd / simhand_proj_stats, sh_dgrad_opts grew dy_src / dy_q / wt_q /
  * dy_state / w_state / sub_grad, tuning setters renamed simhand_test_*; 3 = round 4: this constant, the in-library environment switches
  * moved behind simhand_test_* hooks, the stem entry points of DESIGN 3; 4 = round 5: the two-pass / fused-backward stem entry points and
- * their route counters removed (sh_route renumbered from 36 on), SH_SW_COUNT unchanged).  A binding compares simhand_abi_version() with the
+ * their route counters removed (sh_route renumbered from 36 on), SH_SW_COUNT unchanged, and the last argument of simhand_fp8_scale_update
+ * became a mode 0 / 1 / 2 with state[1] = 1 / (scale of the existing codes) -- see the FP8 section; round 6 moved the instrument
+ * declarations (simhand_test_* / simhand_prof_* / simhand_route_*) to include/simhand_hip_test.h without changing a signature).  A binding compares simhand_abi_version() with the
  * SH_ABI_VERSION it was written against before its first call (simhand_amd/_lib.py load() does) -- a caller built against an older header
  * would otherwise pass shifted arguments or a short options struct unnoticed. */
 #define SH_ABI_VERSION 4
@@ -71,82 +77,6 @@ int simhand_half_format(void);
 const char* simhand_last_error(void);
 /* 0 when a gfx950 device is usable from this process */
 int simhand_device_check(void);
-
-/* ---- kernel-route counters: which hand-written kernel a call was dispatched to.  One atomic counter per route,
- * bumped at launch time.  Tests use them to PROVE that a parity run exercised a given kernel (e.g. that the bf16
- * ResNet-50 step really went through the 256x256 LDS-DMA tile kernel, the activation-stationary 1x1 kernel, the
- * register-resident 3x3 kernel, the all-taps weight gradient, the BatchNorm folds and the two-segment data gradient). */
-enum sh_route {
-  SH_ROUTE_IGEMM128_FWD = 0, SH_ROUTE_IGEMM128_DGRAD = 1,   /* 128 x {64,128} register-staged tile kernel */
-  SH_ROUTE_IGEMM256_FWD = 2, SH_ROUTE_IGEMM256_DGRAD = 3,   /* 256 x 256 LDS-DMA tile kernel */
-  SH_ROUTE_IGEMM256_TAIL = 4,                               /* ragged last round handed to the 128-row kernel */
-  SH_ROUTE_GEMM1X1_FWD = 5, SH_ROUTE_GEMM1X1_FWD_BNACT = 6, SH_ROUTE_GEMM1X1_DGRAD = 7,  /* activation-stationary 1x1 */
-  SH_ROUTE_C64_FWD = 8, SH_ROUTE_C64_DGRAD = 9,             /* 64->64 3x3, filter resident in registers */
-  SH_ROUTE_STEM_FWD = 10,
-  SH_ROUTE_FWD_BNACT = 11,                                  /* any forward with the BN + residual + ReLU epilogue */
-  SH_ROUTE_DGRAD_CONCAT = 12,                               /* data gradient with a second K segment */
-  SH_ROUTE_DGRAD_FUSED_SUMS = 13,                           /* data gradient emitting BN-backward sums / masked store */
-  SH_ROUTE_DGRAD_PARITY = 14,                               /* stride-2 data gradient as 4 parity classes */
-  SH_ROUTE_WGRAD3X3 = 15, SH_ROUTE_WGRAD_PLAIN = 16, SH_ROUTE_WGRAD_GENERIC = 17, SH_ROUTE_WGRAD_STEM = 18,
-  SH_ROUTE_WGRAD_COLSUM = 19,                               /* 1x1 weight gradient that also emits sum(dy) (Gram launches) */
-  SH_ROUTE_BN_FOLD_FWD = 20, SH_ROUTE_BN_FOLD_BWD = 21,     /* Gram-matrix BatchNorm fold (parameter-sized algebra) */
-  SH_ROUTE_BN_APPLY = 22, SH_ROUTE_BN_BWD_APPLY = 23,
-  SH_ROUTE_STEM_BN_POOL = 24,                               /* fused BN + ReLU + MaxPool (fwd or bwd) */
-  SH_ROUTE_NTXENT_FWD = 25, SH_ROUTE_NTXENT_BWD = 26,
-  SH_ROUTE_FP8_FWD = 27, SH_ROUTE_FP8_DGRAD = 28,           /* e4m3 MFMA (K = 128 per instruction) tile kernel */
-  SH_ROUTE_BN_APPLY_GRAM = 29,                              /* BN-apply + ReLU fused into the Gram (x^T x) launch */
-  SH_ROUTE_WGRAD_BNBWD = 30,                                /* BN-backward apply fused into the 1x1 weight gradient's dy loader */
-  SH_ROUTE_NTXENT_FUSED_DIST = 31,                          /* loss tile kernel computing the joint distances in-tile (no D block) */
-  SH_ROUTE_DGRAD_DYSRC = 32,                                /* BN-backward apply fused into the 1x1 data gradient's dy loader */
-  SH_ROUTE_FWD_CHAIN = 33,                                  /* conv3 + BN + residual + ReLU with the next block's conv1 chained on */
-  SH_ROUTE_R128_FWD = 34, SH_ROUTE_R128_DGRAD = 35,         /* 128->128 3x3: activation tile staged once in an LDS ring, weights streamed per tap */
-  SH_ROUTE_FWD_BNIN = 36,                                   /* 3x3 forward with the previous unit's BatchNorm + ReLU applied in its LDS ring */
-  SH_ROUTE_N128_FWD = 37, SH_ROUTE_N128_DGRAD = 38,         /* 1x1 with 128 destination channels behind a long reduction: 128 x 128 LDS-DMA tiles, two blocks per CU */
-  SH_ROUTE_FP8_WGRAD = 39,                                  /* e4m3 3x3 weight gradient (reduction over pixels on the scaled K = 128 MFMA) */
-  SH_ROUTE_COUNT = 40
-};
-int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
-int simhand_route_reset(void);
-/* every test / tuning hook back to its default */
-int simhand_test_hooks_reset(void);
-/* Kernel-selection switches that round 3 read from SIMHAND_* environment variables inside the library, now ordinary test hooks: the
- * library itself reads NO environment variable.  simhand_test_switch(which, value): value < 0 restores the built-in default;
- * simhand_test_hooks_reset() restores all of them.  Every switch selects between kernels that compute the same result. */
-enum sh_test_switch {
-  SH_SW_BN_GRID_APPLY = 0, /* block cap of bn_apply's grid (default 131072) */
-  SH_SW_BN_GRID_BWD = 1,   /* block cap of bn_bwd_apply's grid (default 131072) */
-  SH_SW_R128 = 2,          /* conv3x3_r128_kernel for the 128-channel 3x3 layers (default 1) */
-  SH_SW_G1_PF = 3,         /* branch-free fast variants of gemm1x1_kernel per K: bit 0 K = 64, bit 1 K = 128, bit 2 K = 256 (default 7) */
-  SH_SW_G1_CHAIN = 4,      /* chained next conv1 per K: bit 0 K = 64, bit 1 K = 128 (default 1); simhand_test_conv1x1_chain_mask overrides */
-  SH_SW_G1_LT = 5,         /* linear epilogue stores of gemm1x1_kernel: bit 0 forward, bit 1 data gradient (default 1) */
-  SH_SW_FUSE_S2 = 6,       /* BN-backward sums fused into stride-2 3x3 data gradients: 1 all, 2 only on the 256-wide kernel (default 0) */
-  SH_SW_WG_DMA = 7,        /* wgrad1x1_dma_kernel (default 1) */
-  SH_SW_WG3_S2 = 8,        /* stride-2 form of wgrad3x3_kernel (default 1) */
-  SH_SW_WG_BIG = 9,        /* 256 x 128 tiles of the plain 1x1 weight gradient (default 1) */
-  SH_SW_WG_WIDE = 10,      /* one tile across the wide side of the 64 <-> 256 weight gradients (default 1) */
-  SH_SW_STEM_WG256 = 11,   /* 64 x 256 tile of the stem weight gradient (default 1) */
-  SH_SW_STEM_RING = 12,    /* stem_ring_fwd_kernel at 224 x 224 (default 1) */
-  SH_SW_STEM_RING_LT = 13, /* its linear stores (default 1) */
-  SH_SW_STEM_WG_RING = 14, /* stem weight gradient with both operands in LDS rings (stem_wgrad_ring_kernel) at 224 x 224 (default 1) */
-  SH_SW_N128 = 15,         /* gemm_n128_kernel for the 1x1 layers with 128 destination channels and >= 256 of reduction (default 1) */
-  SH_SW_COUNT = 16
-};
-int simhand_test_switch(int which, int value);
-
-/* ---- optional per-kernel-class HIP-event profiler (used by bench.py) ----- */
-enum sh_prof_class { SH_PROF_CONV_FWD = 0, SH_PROF_CONV_DGRAD = 1, SH_PROF_CONV_WGRAD = 2,
-                     SH_PROF_BN = 3, SH_PROF_POOL = 4, SH_PROF_LOSS = 5, SH_PROF_MISC = 6,
-                     SH_PROF_OPT = 7 /* LARS + Adam update */, SH_PROF_NCLASS = 8 };
-int simhand_prof_enable(int on);
-/* bit c set = launches of class c record their event pair (default: all).  An event pair costs ~1-3 us of queue time per
- * launch, so a timed region records only the class it needs. */
-int simhand_prof_set_classes(uint32_t mask);
-/* blocks until recorded events completed; out_ms/out_flops/out_bytes/out_count are host arrays of SH_PROF_NCLASS */
-int simhand_prof_collect(double* out_ms, double* out_flops, double* out_bytes, int64_t* out_count);
-/* the individual records since the last collect / reset, in issue order (class, elapsed ms, algorithmic FLOPs and bytes of each launch);
- * does not clear them.  Diagnostic: scripts/launch_outliers.py lists the launches furthest above the time their own work allows. */
-int simhand_prof_records(int max_records, int* cls, double* ms, double* flops, double* bytes, int* n_out);
-int simhand_prof_reset(void);
 
 /* ===========================================================================
  * Loss: similarity-weighted NT-Xent over the gathered global batch
@@ -264,14 +194,6 @@ typedef struct sh_conv_desc {
  * partial (sum, sum of squares) of the fp32 accumulators per output channel:
  * bn_partial [nblk_m][2][cout] fp32 with nblk_m = simhand_conv2d_fwd_stat_blocks(). */
 int simhand_conv2d_fwd_stat_blocks(const sh_conv_desc* d);
-/* 64 -> 64 channel 3x3 / stride 1 / pad 1 bf16 layers (forward and store-only data gradient) run on the padded pixel
- * grid with the whole filter resident in registers (conv3x3_c64.hip); 0 routes them through the generic tile kernels
- * (tuning / test hook). */
-int simhand_test_conv3x3_c64_enable(int on);
-/* tuning hook: the 128 -> 128 channel 3x3 ring kernel (conv3x3_ring.hip): 1 on, 0 off (the 128 x 128 tile kernel), -1 back to the default */
-int simhand_test_conv3x3_r128_enable(int on);
-/* tuning / test hook of the short-K (cin or cout in {64,128,256}) bf16 stride-1 1x1 kernel: rows per block = 64*mf */
-int simhand_test_conv1x1_set_rows(int k, int mf);
 int simhand_conv2d_fwd(const sh_conv_desc* d, const void* x, const void* w, void* y, float* bn_partial, sh_stream_t stream);
 /* simhand_bn_apply (ReLU, no residual) + simhand_conv2d_fwd in ONE launch, for the 3x3 layers whose kernel keeps its activation rows in an
  * LDS ring (simhand_conv2d_fwd_bnin_ok(d): the 64 -> 64 ring kernel, e.g. 56 x 56, AND the 128 -> 128 ring kernel, e.g. 28 x 28, as long as
@@ -296,10 +218,6 @@ int simhand_stem_pack_weights(const float* w_oihw, void* wp, int dtype, sh_strea
 /* rows of the bn_partial buffer simhand_stem_conv_fwd fills: [blocks][2][64] */
 int simhand_stem_conv_fwd_stat_blocks(int n, int h, int w, int dtype);
 int simhand_stem_conv_fwd(const void* xp, const void* wp, void* y, float* bn_partial, int n, int h, int w, int dtype, sh_stream_t stream);
-/* bf16 route of simhand_stem_conv_fwd: 1 (default) = persistent direct-stem kernel (weights resident in LDS, next tile's rows in
- * flight under the current tile's MFMAs), 2 = activation-stationary kernel, one block per 256 rows, 0 = 128 x 64 tile kernel
- * (same k order, bit-identical outputs; tuning / test hook) */
-int simhand_test_stem_conv_route(int mode);
 size_t simhand_stem_conv_wgrad_workspace_bytes(int n, int h, int w, int dtype);
 int simhand_stem_conv_wgrad(const void* xp, const void* dy, float* dw_oihw, void* workspace, size_t workspace_bytes, int n, int h, int w, int dtype, sh_stream_t stream);
 /* dx = conv_transpose(dy, w).  wt = weights permuted to [Cin][R][S][Cout] (simhand_oihw_f32_to_crsk).
@@ -343,7 +261,6 @@ int simhand_conv2d_dgrad_stat_blocks(const sh_conv_desc* d, int accumulate, int 
 /* 1 if the fused form is the faster choice for this layer (callers keep the standalone pass otherwise);
  * simhand_test_conv2d_dgrad_fuse_1x1(1) forces it for the short-K 1x1 layers too (tuning hook) */
 int simhand_conv2d_dgrad_fuse_pays(const sh_conv_desc* d);
-int simhand_test_conv2d_dgrad_fuse_1x1(int on);
 int simhand_conv2d_dgrad_fused(const sh_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate, const void* res_grad,
                                const uint8_t* res_mask, const sh_bn_bwd_fuse* fuse, sh_stream_t stream);
 /* General form: accumulate modes as above, optional fusion, optional fp32 per-channel bias (length cin) added to the
@@ -422,8 +339,6 @@ int simhand_conv2d_dgrad_ex(const sh_conv_desc* d, const void* dy, const void* w
  * simhand_conv2d_fwd.  residual, relu_mask are required (ReLU is implied).  Only where simhand_conv2d_fwd_chain_ok(d) says so.
  * Replaces (reference): the bn3 / add / relu tail of one torchvision Bottleneck and conv1 of the next (src/models/resnet_model.py:13-58). */
 int simhand_conv2d_fwd_chain_ok(const sh_conv_desc* d);
-/* test / tuning hook: which input widths chain (bit 0: 64, bit 1: 128; -1 = default = 64 only: the 128-wide form measured no faster) */
-int simhand_test_conv1x1_chain_mask(int mask);
 int simhand_conv2d_fwd_chain_stat_blocks(const sh_conv_desc* d);
 int simhand_conv2d_fwd_bnact_chain(const sh_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                                    const void* residual, void* out, uint8_t* relu_mask, const void* chain_w, void* chain_y,
@@ -465,31 +380,8 @@ int simhand_bn_bwd_coefs(const float* mean, const float* invstd, const float* ga
  * columns, c_real = 147 = 3*7*7 -> exactly weight.grad.view(64, 147)). */
 int simhand_conv2d_wgrad_oihw(const sh_conv_desc* d, const void* x, const void* dy, float* dw_oihw, int c_real, void* workspace, size_t workspace_bytes, sh_stream_t stream);
 
-/* tuning hook: route the eligible bf16 layers (>= 256 destination channels, long reduction) to the 256x256 LDS-DMA
- * tile kernel (1 = default); the BN partial-sum block counts above follow the setting */
-int simhand_test_igemm256_enable(int on);
-/* 1 (default): a 256 x 256 launch whose last round of tiles would leave more than two thirds of the CUs idle hands those
- * m-tiles to a second launch of the 128-row kernel (same results bit for bit); 0 = single launch (tuning / test hook) */
-int simhand_test_igemm256_split_tail(int on);
 /* 224-row tiles of the 256 x 256 kernel (7 x 32 rows: 401 408 pixels = exactly 7 rounds of 256 CUs instead of 6.125): 0 off, 1 auto
  * (default: when they fill whole rounds and the 256-row plan does not), 2 forced whenever the pixel count is a multiple of 224 */
-int simhand_test_igemm256_tile224(int mode);
-
-/* tuning hook: non-temporal (streaming) loads / stores in the BatchNorm passes (1 = on [default]) */
-int simhand_test_bn_set_nt(int on);
-
-/* tuning hook: the all-taps 3x3 / stride-1 weight-gradient kernel (bf16; 1 = default, 0 = tap-by-tap kernel) */
-int simhand_test_wgrad3x3_enable(int on);
-/* test / tuning hook: the LDS-DMA 256 x 256 tile kernel for the bf16 1x1 weight gradients with >= 256 channels on both sides (1 = default) */
-int simhand_test_wgrad_dma_enable(int on);
-
-/* test hook: bf16 wgrad LDS transpose path (1 = ds_read_b64_tr_b16 [default], 0 = scalar LDS reads) */
-int simhand_test_wgrad_set_tr(int on);
-/* tuning hook: the bf16 1x1 / stride-1 weight gradient reduces 32 * kpm pixels per barrier (kpm 1 or 2, default 2) */
-int simhand_test_wgrad_plain_kpm(int kpm);
-/* tuning hook: blocks (tiles x split-K) a weight-gradient launch aims for: generic / 1x1 kernel, all-taps 3x3 kernel
- * (< 64 restores the default) */
-int simhand_test_wgrad_target_blocks(int n, int n3x3);
 
 /* layout / dtype transforms.  k_pad = padded length of one flattened KRSC weight row
  * (>= r*s*c; rows are zero padded) -- r*s*c for ordinary convs, 192 for the im2col'd stem. */
@@ -604,8 +496,17 @@ int simhand_colsum(const void* x, int64_t m, int c, int dtype, float* partial, f
  *   per-tensor scaling: q = e4m3(clamp(v * scale, +-448)).  A scale lives in a device `state` vector of
  *   simhand_fp8_state_floats(history) floats: [0] scale, [1] 1/scale, [2] ring position, [3] updates, [4..] amax ring.
  *   simhand_fp8_amax folds max|x| into *amax_bits (uint bits of a non-negative float, atomicMax: exact and deterministic);
- *   simhand_fp8_scale_update consumes *amax_bits: delayed = 0 -> scale = 448 / (amax * margin_pow2) (current scaling),
- *   delayed = 1 -> amax enters the ring and scale = 448 / (max(ring) * margin_pow2) (what the NEXT quantize call uses);
+ *   simhand_fp8_scale_update(state, amax_bits, history, margin, mode) consumes *amax_bits.  state[0] is always the scale the NEXT
+ *   quantisation uses; state[1] is 1 / (the scale the codes that exist NOW were made with) -- what a convolution launched behind the
+ *   update de-scales with:
+ *     mode 0 (current scaling; call it BEFORE the quantisation it serves): scale = 448 / (amax * margin_pow2), state[1] = 1 / scale;
+ *     mode 1 (delayed scaling; call it BEHIND the quantisation whose amax it consumes): amax enters the ring, state[0] = 448 /
+ *             (max(ring) * margin_pow2) for the next call, state[1] = 1 / (the scale that quantisation just used) -- NOT 1 / state[0];
+ *     mode 2 (a delayed site's FIRST update, before its first quantisation): the ring's first entry, state[1] = 1 / state[0].
+ *   (Until round 5 the argument was a 0 / 1 flag `delayed` and state[1] was always 1 / state[0]: a caller that ran the delayed update
+ *   behind its quantisation de-scaled the following convolutions with the NEXT scale.  Values outside 0..2 are treated as 1.)
+ *   A consumer that runs LATER than the next quantisation of the same site (a weight gradient in the backward) must keep its own copy
+ *   of state[0:2] taken right behind the quantisation (the engine does: host/resnet_model.py _conv_fwd_fp8).
  *   simhand_fp8_quantize converts with state[0] and (optionally) records the tensor's own amax for that next update.
  *   simhand_conv2d_fwd_fp8: y (bf16) = conv(q_x, q_w) / (scale_x scale_w) on v_mfma_scale_f32_16x16x128_f8f6f4 (all block
  *   scales 2^0), + the fused BatchNorm partial sums [ceil(n*ho*wo/128)][2][cout] of simhand_conv2d_fwd.  Needs cin, cout
@@ -613,7 +514,7 @@ int simhand_colsum(const void* x, int64_t m, int c, int dtype, float* partial, f
  * =========================================================================== */
 int simhand_fp8_state_floats(int history);
 int simhand_fp8_amax(const void* x, int64_t count, int dtype, uint32_t* amax_bits, sh_stream_t stream);
-int simhand_fp8_scale_update(float* state, uint32_t* amax_new_bits, int history, float margin_pow2, int delayed, sh_stream_t stream);
+int simhand_fp8_scale_update(float* state, uint32_t* amax_new_bits, int history, float margin_pow2, int mode, sh_stream_t stream);
 int simhand_fp8_quantize(const void* x, void* q, int64_t count, int dtype, const float* state, uint32_t* amax_bits, sh_stream_t stream);
 int simhand_fp8_pack_krsc(const float* w_oihw, void* q, int k, int c, int r, int s, const float* state, sh_stream_t stream);
 int simhand_conv2d_fwd_fp8_supported(const sh_conv_desc* d);

@@ -27,7 +27,7 @@ for cin, cout, h, stride, count in ((256, 256, 14, 1, 5), (512, 512, 7, 1, 2), (
     r["dgrad bf16"] = timed(lambda: ops.conv2d_dgrad_ex(d, dy, wc))
     r["dgrad fp8"] = timed(lambda: ops.conv2d_dgrad_ex(d, dy, wc, fp8=(dyq, wtq, sdy, swt)))
     r["wgrad bf16"] = timed(lambda: ops.conv2d_wgrad(d, x, dy))
-    r["wgrad fp8"] = timed(lambda: ops.conv2d_wgrad_fp8(d, xq, dyq, sx, sdy)) if ops.conv2d_wgrad_fp8_pays(d) else float("nan")
+    r["wgrad fp8"] = timed(lambda: ops.conv2d_wgrad_fp8(d, xq, dyq, sx.state, sdy.state)) if ops.conv2d_wgrad_fp8_pays(d) else float("nan")
     for k, v in r.items():
         if v == v: tot[k.split()[1]] += v * count
     print(f"({cin},{cout},3,{stride},{h}) x{count} n={n}: " + "  ".join(f"{k} {v:7.1f}" for k, v in r.items()) + " us")

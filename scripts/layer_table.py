@@ -25,6 +25,30 @@ SHAPES = [  # (cin, cout, k, stride, hin, count)
     (256, 256, 3, 1, 14, 5), (1024, 512, 1, 1, 14, 1), (512, 512, 3, 2, 14, 1), (512, 2048, 1, 1, 7, 3), (1024, 2048, 1, 2, 14, 1),
     (2048, 512, 1, 1, 7, 2), (512, 512, 3, 1, 7, 2),
 ]
+
+
+def shapes_for(resnet: str, image: int):
+    """The distinct convolution shapes (stem excluded) of a Bottleneck ResNet at `image`^2 with their counts -- SHAPES above is
+    shapes_for("50", 224).  Same enumeration order as the table of SURVEY Appendix C."""
+    counts = {"50": [3, 4, 6, 3], "101": [3, 4, 23, 3], "152": [3, 8, 36, 3]}[resnet]
+    out, cin, h = [], 64, image // 4
+    for i, nb in enumerate(counts):
+        p, s = 64 << i, (1 if i == 0 else 2)
+        ho = h // s
+        out.append((cin, p, 1, 1, h, 1))                       # entry conv1
+        out.append((p, p, 3, s, h, 1))                          # entry conv2 (v1.5: the stride sits here)
+        out.append((p, 4 * p, 1, 1, ho, nb))                    # conv3 of every block
+        out.append((cin, 4 * p, 1, s, h, 1))                    # shortcut
+        if nb > 1:
+            out.append((4 * p, p, 1, 1, ho, nb - 1))            # conv1 of the identity blocks
+            out.append((p, p, 3, 1, ho, nb - 1))                # conv2 of the identity blocks
+        cin, h = 4 * p, ho
+    merged = {}
+    for c_in, c_out, k, s, hh, n in out:
+        merged[(c_in, c_out, k, s, hh)] = merged.get((c_in, c_out, k, s, hh), 0) + n
+    return [key + (n,) for key, n in merged.items()]
+
+
 PEAK_TF, PEAK_GB = 2500.0, 6300.0  # dense bf16 MFMA; achievable HBM copy rate (MI355X_MICROARCH.md)
 
 
@@ -55,6 +79,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=2048)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--resnet", default="50", choices=["50", "101", "152"])
+    ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--alternates", action="store_true", help="also time every op under the other kernel routes (tuning hooks)")
     args = ap.parse_args()
     from simhand_amd import _lib
@@ -66,7 +92,8 @@ def main():
     rows = ["| layer (cin,cout,k,s,Hin) x count | op | kernel route | us | TFLOP/s | GB/s (algorithmic) | bound | fraction of bound |",
             "|---|---|---|---|---|---|---|---|"]
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
-    for cin, cout, k, s, h, cnt in SHAPES:
+    shapes = SHAPES if (args.resnet, args.image_size) == ("50", 224) else shapes_for(args.resnet, args.image_size)
+    for cin, cout, k, s, h, cnt in shapes:
         pad = 1 if k == 3 else 0
         d = ops.conv_desc(n, h, h, cin, cout, k, k, s, pad, dt)
         x = torch.randn(n, h, h, cin, device=dev).to(dt)
@@ -134,7 +161,7 @@ def main():
         del x, dy
         torch.cuda.empty_cache()
     rows.append("")
-    rows.append(f"sum over the 52 non-stem convolutions of ResNet-50 (count-weighted): fwd {tot['fwd']/1e3:.1f} ms, dgrad {tot['dgrad']/1e3:.1f} ms, "
+    rows.append(f"sum over the {sum(x[-1] for x in shapes)} non-stem convolutions of ResNet-{args.resnet} @ {args.image_size}^2 (count-weighted): fwd {tot['fwd']/1e3:.1f} ms, dgrad {tot['dgrad']/1e3:.1f} ms, "
                 f"wgrad {tot['wgrad']/1e3:.1f} ms at {n} images")
     text = "\n".join(rows)
     print(text)

@@ -1,9 +1,20 @@
-// Probe: sustained MFMA rate on RANDOM vs ZERO register operands, bf16 16x16x32 vs 32x32x16 vs the scaled e4m3 16x16x128 (the chip clocks to its power budget: which
-// shape buys more FLOP per joule?).  One wave per SIMD x 2 waves, operands in registers, no memory traffic.
-// build: hipcc --offload-arch=gfx950 -O3 -o scripts/probes/mfma_power scripts/probes/mfma_power.hip ; run on the GPU box.
+// Probe: sustained MFMA rate AND energy per FLOP on RANDOM vs ZERO register operands, bf16 16x16x32 vs 32x32x16 vs the scaled e4m3 16x16x128
+// (the chip clocks to its power budget: which shape buys more FLOP per joule?).  2 waves per SIMD, operands in registers, no memory traffic.
+// Round 6 (VERDICT r5 "Next" 3): the 32x32x16 loop of round 5 had 4 accumulators per wave, each used twice per iteration -- issue-bound on a
+// dependent chain even on zeros, so its column said nothing about the instruction.  Now 8 INDEPENDENT 32x32 accumulators per wave (128 acc registers,
+// 16 waves' worth of independent MFMAs per SIMD with 2 waves), one MFMA each per iteration; 16x16x32 keeps its 16 independent accumulators.  A host
+// thread samples the amdgpu hwmon power node while each shape runs ~1.5 s at the cap; pJ/FLOP = mean socket power / rate (idle power NOT subtracted).
+// build: hipcc --offload-arch=gfx950 -O3 -o scripts/probes/mfma_power scripts/probes/mfma_power.hip -lpthread ; run on the GPU box.
 #include <hip/hip_runtime.h>
+#include <dirent.h>
+#include <limits.h>
+#include <cctype>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
+#include <thread>
 #include <vector>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -43,19 +54,54 @@ __global__ __launch_bounds__(512, 1) void k(const uint4* in, float* out, int ite
         acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8[i & 1], b8[(i >> 1) & 1], acc[i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
     }
     for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-  } else {
-    f32x16 acc[4];
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  } else {  // 32x32x16 bf16: 8 independent accumulators, one MFMA each per iteration (32 768 FLOP each: the same FLOPs per iteration as 16 x 16x16x32)
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[(i + r) & 3]), __builtin_bit_cast(bf16x8, b[(i >> 1) + r]), acc[i], 0, 0, 0);
+      for (int i = 0; i < 8; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i & 3]), __builtin_bit_cast(bf16x8, b[(i >> 1) & 3]), acc[i], 0, 0, 0);
     }
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
   }
   out[blockIdx.x * 512 + tid] = s;
+}
+
+// ---- amdgpu hwmon sampling (socket power in uW, gfx clock in Hz) ----
+static std::string find_hwmon() {  // the hwmon directory of the card whose PCI address is HIP device 0's (a box can hold more cards than it shows)
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), 0) != hipSuccess) bus[0] = 0;
+  for (char* q = bus; *q; ++q) *q = (char)tolower(*q);
+  for (int c = 0; c < 128; ++c) {
+    const std::string dev = "/sys/class/drm/card" + std::to_string(c) + "/device";
+    char real[512];
+    if (!realpath(dev.c_str(), real)) continue;
+    std::string rp = real;
+    for (auto& ch : rp) ch = (char)tolower(ch);
+    if (bus[0] && rp.find(bus) == std::string::npos) continue;
+    std::string base = dev + "/hwmon";
+    DIR* d = opendir(base.c_str());
+    if (!d) continue;
+    while (dirent* e = readdir(d)) {
+      std::string n = e->d_name;
+      if (n.rfind("hwmon", 0) == 0) {
+        std::string p = base + "/" + n;
+        FILE* f = fopen((p + "/power1_average").c_str(), "r");
+        if (!f) f = fopen((p + "/power1_input").c_str(), "r");
+        if (f) { fclose(f); closedir(d); return p; }
+      }
+    }
+    closedir(d);
+  }
+  return "";
+}
+static double read_num(const std::string& p) {
+  FILE* f = fopen(p.c_str(), "r");
+  if (!f) return -1;
+  double v = -1;
+  if (fscanf(f, "%lf", &v) != 1) v = -1;
+  fclose(f);
+  return v;
 }
 
 int main() {
@@ -64,6 +110,9 @@ int main() {
   hipMalloc(&in, 4096 * 16); hipMalloc(&out, nblk * 512 * 4);
   std::vector<unsigned> h(4096 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const std::string hw = find_hwmon();
+  printf("hwmon: %s\n", hw.empty() ? "(none: power columns empty)" : hw.c_str());
+  printf("| operands | MFMA | ms / 20 launches | TFLOP/s | socket W | sclk MHz | pJ / FLOP |\n|---|---|---|---|---|---|---|\n");
   for (int mode = 0; mode < 2; ++mode) {
     for (auto& v : h) {  // bf16 pairs: random values ~ N(0,1)-ish magnitudes (random sign / exponent near 0 / mantissa), or zeros
       unsigned lo = 0x3f00u + (rand() & 0xff) + ((rand() & 1) << 15) , hi = 0x3f00u + (rand() & 0xff) + ((rand() & 1) << 15);
@@ -71,17 +120,38 @@ int main() {
     }
     hipMemcpy(in, h.data(), 4096 * 16, hipMemcpyHostToDevice);
     for (int shape : {16, 32, 128, 16, 32, 128}) {
-      for (int rep = 0; rep < 2; ++rep) {
-        hipEventRecord(e0);
+      auto launch20 = [&]() {
         for (int l = 0; l < 20; ++l) {
           if (shape == 16) k<16><<<nblk, 512>>>(in, out, iters); else if (shape == 32) k<32><<<nblk, 512>>>(in, out, iters); else k<128><<<nblk, 512>>>(in, out, iters);
         }
-        hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        // flops per block-iteration: 16x16x32: 16 MFMA x 16384 x 8 waves ; 32x32x16: 8 MFMA x 32768 x 8 waves -- equal
-        const double fl = 20.0 * nblk * (double)iters * 8 * 16 * (shape == 128 ? 65536.0 : 16384.0);
-        if (rep == 1) printf("%s operands, %s MFMA: %7.1f ms  %6.0f TFLOP/s\n", mode == 0 ? "random" : "zero  ", shape == 16 ? "16x16x32 bf16" : shape == 32 ? "32x32x16 bf16" : "16x16x128 e4m3 (scaled)", ms, fl / (ms * 1e-3) / 1e12);
-      }
+      };
+      launch20(); hipDeviceSynchronize();  // warm: the clock settles at the cap
+      std::atomic<bool> stop{false};
+      double pw_sum = 0, ck_sum = 0; long pw_n = 0;
+      std::thread smp([&]() {
+        if (hw.empty()) return;
+        std::string pp = hw + "/power1_average";
+        if (read_num(pp) < 0) pp = hw + "/power1_input";
+        while (!stop.load()) {
+          double p = read_num(pp), c = read_num(hw + "/freq1_input");
+          if (p > 0) { pw_sum += p * 1e-6; ck_sum += c > 0 ? c * 1e-6 : 0; ++pw_n; }
+          std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        }
+      });
+      const int reps = 8;  // ~1.3-2.5 s per row
+      hipEventRecord(e0);
+      for (int r = 0; r < reps; ++r) launch20();
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      stop = true; smp.join();
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      ms /= reps;
+      // flops per block-iteration: 16x16x32: 16 MFMA x 16384 x 8 waves ; 32x32x16: 8 MFMA x 32768 x 8 waves -- equal; e4m3: 16 x 65536 x 8
+      const double fl = 20.0 * nblk * (double)iters * 8 * 16 * (shape == 128 ? 65536.0 : 16384.0);
+      const double rate = fl / (ms * 1e-3);
+      const double pw = pw_n ? pw_sum / pw_n : 0, ck = pw_n ? ck_sum / pw_n : 0;
+      printf("| %s | %s | %.1f | %.0f | %.0f | %.0f | %.3f |\n", mode == 0 ? "random" : "zero", shape == 16 ? "16x16x32 bf16 (16 acc)" : shape == 32 ? "32x32x16 bf16 (8 acc)" : "16x16x128 e4m3 scaled (16 acc)",
+             ms, rate / 1e12, pw, ck, pw > 0 ? pw / rate * 1e12 : 0.0);
+      fflush(stdout);
     }
   }
   return 0;

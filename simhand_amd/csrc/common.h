@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "../../include/simhand_hip.h"
+#include "../../include/simhand_hip_test.h"  // route counters, event profiler, test hooks: implemented here, not part of the product surface
 
 namespace sh {
 

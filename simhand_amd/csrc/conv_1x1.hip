@@ -462,12 +462,8 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
       if constexpr (FAST) {  // this chunk's epilogue rows: younger than the tile fetch above, a whole chunk of MFMAs to land
         __builtin_amdgcn_sched_barrier(0);  // the machine scheduler would hoist them above the tile fetch
         if (ks == 0) {
-#ifndef SH_ABL_R
           if constexpr (EP == 2) load_res(nc);
           else if constexpr (PF != 0) load_pf(nc);
-#else   // ablation (garbage results): the epilogue rows are fetched once, by chunk 0 only
-          if (nc == 0) { if constexpr (EP == 2) load_res(0); else if constexpr (PF != 0) load_pf(0); }
-#endif
         }
         if constexpr (CH && K == 128) panel_load(nc + 1 < nch ? nc + 1 : 0);  // lands under this chunk's MFMAs (last: panel 0 again, unused)
         __builtin_amdgcn_sched_barrier(0);
@@ -548,11 +544,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
               }
             }
             const uint4 pv = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
-#if !defined(SH_ABL_S)
             if (!lt) *reinterpret_cast<uint4*>(dst) = pv;
-#else   // ablation: no output stores
-            if (pv.x == 0x12345678u) *reinterpret_cast<uint4*>(dst) = pv;
-#endif
             return pv;
           }
           uint4 v;

@@ -346,9 +346,9 @@ int simhand_fp8_amax(const void* x, int64_t count, int dtype, uint32_t* amax_bit
   return check_launch("fp8_amax");
 }
 
-int simhand_fp8_scale_update(float* state, uint32_t* amax_new_bits, int history, float margin_pow2, int delayed, sh_stream_t stream) {
+int simhand_fp8_scale_update(float* state, uint32_t* amax_new_bits, int history, float margin_pow2, int mode, sh_stream_t stream) {
   SH_REQUIRE(state && amax_new_bits && history >= 1 && margin_pow2 > 0.f, "fp8_scale_update: bad arguments");
-  fp8_scale_update_kernel<<<1, 64, 0, (hipStream_t)stream>>>(state, amax_new_bits, history, margin_pow2, delayed < 0 || delayed > 2 ? 1 : delayed);
+  fp8_scale_update_kernel<<<1, 64, 0, (hipStream_t)stream>>>(state, amax_new_bits, history, margin_pow2, mode < 0 || mode > 2 ? 1 : mode);
   return check_launch("fp8_scale_update");
 }
 

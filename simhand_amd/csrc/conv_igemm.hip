@@ -356,64 +356,28 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
   // chan_of(0, li) + a constant whose bits (2 and 5; fp32: 4 and 5) the swizzle key ignores: one offset per lane.
   const int rowb0 = wn * (BN / 2) + chan_of(0, li);
   const int fbo = rowb0 * 128 + ((g ^ key_b(rowb0)) * 16);
-#ifndef SH_ABL
-#define SH_ABL 0
-#endif
-  // SH_ABL (scripts/igemm_ablate.sh only; results are garbage): 1 = no LDS stores, 2 = no global loads, 3 = no MFMA,
-  // 4 = no fragment reads, 5 = no barriers
-#if SH_ABL == 4
-  uint4 fa_c[4], fb_c[NI];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) fa_c[mi] = *reinterpret_cast<const uint4*>(sA + fa_base + mi * 16 * 128 + fo0);
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) fb_c[ni] = *reinterpret_cast<const uint4*>(sB + fbo + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
-#endif
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = NBUF == 2 ? (ks & 1) : 0;
-#if SH_ABL != 2
     load_step(ks + 1 < nk);  // global loads in flight under the MFMAs (unconditional: see g_zero_page)
-#endif
     const char* cA = sA + buf * (128 * 128) + fa_base;
     const char* cB = sB + buf * (BN * 128);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       uint4 fa[4], fb[NI];
       const int fo = kk == 0 ? fo0 : (fo0 ^ 64);
-#if SH_ABL == 4
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) fa[mi] = fa_c[mi];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) fb[ni] = fb_c[ni];
-#else
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) fa[mi] = *reinterpret_cast<const uint4*>(cA + mi * 16 * 128 + fo);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
         fb[ni] = *reinterpret_cast<const uint4*>(cB + ((kk == 0 ? fbo : (fbo ^ 64)) + (chan_of(ni, 0) - chan_of(0, 0)) * 128));
-#endif
-#if SH_ABL == 3
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(fa[mi].x), "v"(fa[mi].y), "v"(fa[mi].z), "v"(fa[mi].w));
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(fb[ni].x), "v"(fb[ni].y), "v"(fb[ni].z), "v"(fb[ni].w));
-#else
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mma<T>::run(fb[ni], fa[mi], acc[mi][ni]);
-#endif
     }
-#if SH_ABL != 5
     if (NBUF == 1) __syncthreads();  // single buffer: every wave is done reading before the tile is overwritten
-#endif
-#if SH_ABL != 1
     store_step(NBUF == 2 ? (buf ^ 1) : 0);  // after the last step: zeros into a tile nobody reads again
-#else
-    asm volatile("" ::"v"(ra0.x), "v"(ra1.x), "v"(ra2.x), "v"(ra3.x), "v"(rb0.x), "v"(rb1.x), "v"(rb2.x), "v"(rb3.x));
-#endif
-#if SH_ABL != 5
     __syncthreads();
-#endif
   }
 
   // ---- fused BatchNorm partial statistics of the fp32 accumulators (registers -> LDS -> global) ----
@@ -701,9 +665,6 @@ __global__ __launch_bounds__(256, SH_IGEMM_NBUF == 1 ? SH_IGEMM_MINB : 2) void i
 // the swizzle do not change; a lane's two 16-B fragment chunks (g and g + 4) together are ONE operand of
 // v_mfma_scale_f32_16x16x128_f8f6f4 (twice the bf16 rate, K = 128 per instruction): 32 instead of 64 matrix instructions per k-step
 // for twice the reduction length -- and half the operand bytes per FLOP, which is what bounds this kernel's loop.
-#ifndef SH_PRIO256
-#define SH_PRIO256 0  // see the bf16 loop
-#endif
 template <bool DGRAD, int MI = 8, bool FP8 = false>
 __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   typedef bf16_t T;                                                             // stored results (and bf16 operands)
@@ -723,10 +684,6 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int wm = wave >> 2, wn = wave & 3;
-#if SH_ABL256 == 31  // diagnostic build: where a tile's cycles outside the loop go (stamps land in output rows 0 .. 7 of the tile)
-  const unsigned long long e_t0 = __builtin_amdgcn_s_memtime();
-  unsigned long long e_t1 = 0, e_t2 = 0, e_t3 = 0, e_t4 = 0;
-#endif
   int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int n_tile = logical % p.n_tiles;
   logical /= p.n_tiles;
@@ -847,13 +804,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     n_dB = smem_addr + B_BASE + stage * B_BYTES + dma_row0;
     advance(wb);
   };
-#ifndef SH_ABL256
-#define SH_ABL256 0
-#endif
-  // SH_ABL256 (ablation builds, garbage results; scripts/diag_r05*.sh): 1 = activations from the zero page, 9 = weights from the zero
-  // page, 8 = both (issue slots and LDS writes stay, L2 traffic goes), 2 / 3 / 4 = no activation / no weight / no DMAs at all; 6 / 7 = half / none of the
-  // activation fragment reads; 5 / 51 / 52 = no output stores / no BatchNorm sums / neither; 30 / 31 = s_memtime stamps (k-step waits / tile phases:
-  // scripts/stamp256.py, stamp256_tile.py).
+  // (The round-5 ablation and cycle-stamp builds of this kernel live on the branch r05-instrumented-kernels; what they measured: DESIGN 3b.)
   // Measured and removed again in round 5: non-temporal output stores (neutral), a start skew between the CUs of the first round (neutral).
   // part i (0..3) of a k-step's activation DMAs: tile rows lrow + 64 i (MI = 7: rows 224.. fetch the zero page -- every wave issues the
   // same number of DMAs, the counted waits below depend on it)
@@ -861,12 +812,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     auto dma_a = [&](const IT* pa, int h0, int w0) __attribute__((always_inline)) {
       const bool ok = a_live && (unsigned)(h0 + n_hoff) < (unsigned)p.Hs && (unsigned)(w0 + n_woff) < (unsigned)p.Ws;
       const char* src = ok ? reinterpret_cast<const char*>(pa + n_aoff) : zsrc;
-#if SH_ABL256 == 1 || SH_ABL256 == 8
-      src = zsrc;
-#endif
-#if SH_ABL256 != 2 && SH_ABL256 != 4
       dma16(src, n_dA + i * 64 * 128);
-#endif
     };
     if (i == 0) dma_a(pa0, h00, w00);
     else if (i == 1) dma_a(pa1, h01, w01);
@@ -875,12 +821,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   };
   auto dma_b_part = [&](int i) __attribute__((always_inline)) {
     const char* src = b_live ? reinterpret_cast<const char*>(pb0 + i * wrow64 + n_boff) : zsrc;
-#if SH_ABL256 == 9 || SH_ABL256 == 8
-    src = zsrc;
-#endif
-#if SH_ABL256 != 3 && SH_ABL256 != 4
     dma16(src, n_dB + i * 64 * 128);
-#endif
   };
   // the 8 DMA instructions a wave issues per k-step, in queue order: 0-3 = weights of step kt + 1, 4-7 = activations of step kt + 2
   auto dma_part = [&](int q) __attribute__((always_inline)) {
@@ -923,26 +864,9 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     for (int i = 0; i < 4; ++i) dma_a_part(i);
   }
   int sa = 0;  // kt % 3
-#if SH_ABL256 == 31
-  e_t1 = __builtin_amdgcn_s_memtime();
-#endif
-#if SH_ABL256 == 30  // diagnostic build: where a wave's cycles go at the top of a k-step (garbage output rows 0 .. 7 of the tile hold the stamps)
-  unsigned long long st_dma = 0, st_bar = 0, st_all = __builtin_amdgcn_s_memtime();
-#endif
   {
   for (int kt = 0; kt < nk; ++kt) {
-#if SH_ABL256 == 30
-    const unsigned long long ta = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    const unsigned long long tb = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const unsigned long long tc = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    st_dma += tb - ta;
-    st_bar += tc - tb;
-#else
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
     b_live = kt + 1 < nk;
     next_b((kt + 1) & 1);
     a_live = kt + 2 < nk;
@@ -991,9 +915,6 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         }
         dma_part(2 * q);
         dma_part(2 * q + 1);
-#if SH_PRIO256 == 3  // the younger wave of each SIMD is raised in every other group (see the bf16 loop)
-        if (wave >= 4) { if ((q & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#endif
       }
     } else {
     uint4 fb[2][NI], fa[2][2];
@@ -1004,17 +925,8 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
 #pragma unroll
     for (int grp = 0; grp < 8; ++grp) {
       const int kk = grp >> 2, q = grp & 3;
-      // SH_PRIO256 = 3: issue priority of the YOUNGER wave of each SIMD raised in every other MFMA group.  The block's waves w and w + 4 share
-      // a SIMD; at equal priority the arbiter favours the OLDER one in every slot, so waves 0-3 run ahead and sit ~880 cycles per k-step in the
-      // barrier while waves 4-7, alone on their SIMDs, cannot keep the matrix pipe busy (s_memtime stamps: profiles/
-      // r05_igemm256_barrier_stamps.txt).  Taking turns cuts the barrier wait 490 -> 143 cycles and the step 3105 -> 2895 cycles: +3-8 % per
-      // launch IN ISOLATION -- and NOTHING in the training step (three alternating same-box pairs 101.87 vs 102.05 ms, profiles/
-      // r05_power_wall.md): the step runs at the socket's power limit (1.31 kW sampled), the more efficient kernel draws more power and the
-      // clock gives the cycles back (sampled sclk 2203 -> 2162 MHz).  Off by default; kept as the measured example of that wall.  (Also
-      // measured: raised for the whole step -- the roles flip; first half only -- as good; s_setprio around every MFMA burst -- slower.)
-#if SH_PRIO256 == 3
-      if (wave >= 4) { if ((grp & 1) == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#endif
+      // (Measured in round 5 and not kept: the younger wave of each SIMD raised in issue priority in every other MFMA group -- +3-8 % per launch
+      // in isolation, nothing in the step, which runs at the socket's power limit: profiles/r05_power_wall.md, branch r05-instrumented-kernels.)
       if (grp < 7) {
         const int nkk = (grp + 1) >> 2, nq = (grp + 1) & 3;
         const int fo = nkk == 0 ? fo0 : (fo0 ^ 64);
@@ -1023,13 +935,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
           for (int ni = 0; ni < NI; ++ni)
             fb[1][ni] = *reinterpret_cast<const uint4*>(stb + (fbo ^ 64) + (chan_of(ni, 0) - chan_of(0, 0)) * 128);
         }
-#if SH_ABL256 == 6  // ablation (garbage results): half of the A fragment reads
-        if ((grp & 1) == 0) { fa[1][0] = fa[0][0]; fa[1][1] = fa[0][1]; } else {
-#elif SH_ABL256 == 7  // ablation: no A fragment reads after the first group of a k-step
-        if (true) { fa[(grp + 1) & 1][0] = fa[grp & 1][0]; fa[(grp + 1) & 1][1] = fa[grp & 1][1]; } else {
-#else
         {
-#endif
         fa[(grp + 1) & 1][0] = *reinterpret_cast<const uint4*>(st + fa_base + (2 * nq) * 16 * 128 + fo);
         if (2 * nq + 1 < MI) fa[(grp + 1) & 1][1] = *reinterpret_cast<const uint4*>(st + fa_base + (2 * nq + 1) * 16 * 128 + fo);
         }
@@ -1041,24 +947,10 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         for (int ni = 0; ni < NI; ++ni) acc[2 * q + 1][ni] = Mma<T>::run(fb[kk][ni], fa[grp & 1][1], acc[2 * q + 1][ni]);
       }
       dma_part(grp);  // one DMA instruction per MFMA group: the L1's request queue stays fed through the whole step
-#ifdef SH_ABL_VALU  // experiment: SH_ABL_VALU extra (dependent-free) VALU instructions per MFMA group
-      {
-        int t = lane;
-#pragma unroll
-        for (int e = 0; e < SH_ABL_VALU; ++e) asm volatile("v_add_u32 %0, %0, %1" : "+v"(t) : "v"(lane));
-        asm volatile("" ::"v"(t));
-      }
-#endif
     }
       }
   }
-#if SH_ABL256 == 30
-  st_all = __builtin_amdgcn_s_memtime() - st_all;
-#endif
   }
-#if SH_ABL256 == 31
-  e_t2 = __builtin_amdgcn_s_memtime();
-#endif
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS is reused by the epilogues
   if constexpr (FP8) {  // per-tensor scales: one multiply per accumulator, before the statistics and the stores
     const float descale = p.x_state[1] * p.w_state[1];
@@ -1069,11 +961,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
   }
 
   // ---- fused BatchNorm partial statistics (forward): lane holds pixel wm*128 + mi*16 + li, channels wn*64 + chan_of(ni, 4g + r)
-#if SH_ABL256 == 51 || SH_ABL256 == 52  // ablation: no BatchNorm partial sums
-  if (false) {
-#else
   if (!DGRAD && p.bn_partial != nullptr) {
-#endif
     float* red = reinterpret_cast<float*>(smem);  // [2 (wm)][2][BN]
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -1103,10 +991,6 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     }
   }
 
-#if SH_ABL256 == 31
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  e_t3 = __builtin_amdgcn_s_memtime();
-#endif
   // ---- epilogue (as igemm_kernel): 16-B vectors from registers, channels ch0 + j*32 .. +8 of pixel row mi ----
   {
     constexpr int NCH = 2;
@@ -1177,11 +1061,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         v.z &= ((keep & 16u) ? 0x0000ffffu : 0u) | ((keep & 32u) ? 0xffff0000u : 0u);
         v.w &= ((keep & 64u) ? 0x0000ffffu : 0u) | ((keep & 128u) ? 0xffff0000u : 0u);
       }
-#if SH_ABL256 == 5 || SH_ABL256 == 52
-      if (v.x == 0x12345678u) *reinterpret_cast<uint4*>(dst) = v;  // ablation: no output stores
-#else
       *reinterpret_cast<uint4*>(dst) = v;
-#endif
       return v;
     };
     if (!DGRAD && sizeof(T) == 2 && p.ep_scale != nullptr) {
@@ -1243,11 +1123,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
       // plain forward store: lanes li / li ^ 1 trade one packed 16-B chunk (DPP quad_perm) so that every store instruction writes whole 128-B lines --
       // 8 rows x 128 B instead of 16 rows x 64 B.  The CU's store path digests the whole-line form in 60 % of the cycles (scripts/probes/store_pattern.hip,
       // profiles/r05_igemm256_tile_stamps.md): -1 us per tile, bit-identical.  (The epilogues with per-channel operands keep the 64-B form.)
-#if SH_ABL256 == 5 || SH_ABL256 == 52
-      if (false) {
-#else
       if (!DGRAD && !par && p.accumulate == 0) {
-#endif
         auto swap1 = [](unsigned v) __attribute__((always_inline)) -> unsigned {
           return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
         };
@@ -1352,26 +1228,6 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
       }
     }
   }
-#if SH_ABL256 == 31
-  e_t4 = __builtin_amdgcn_s_memtime();
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  {
-    const unsigned long long e_t5 = __builtin_amdgcn_s_memtime();
-    __syncthreads();
-    if (lane == 0 && n_tile == 0) {
-      float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + ((long long)m0 + wave) * p.Ng * 2);
-      o[0] = (float)(e_t1 - e_t0); o[1] = (float)(e_t2 - e_t1); o[2] = (float)(e_t3 - e_t2); o[3] = (float)(e_t4 - e_t3); o[4] = (float)(e_t5 - e_t4);
-      o[5] = (float)nk; o[6] = (float)(e_t0 & 0xffffffu); o[7] = (float)(e_t5 & 0xffffffu);
-    }
-  }
-#endif
-#if SH_ABL256 == 30
-  __syncthreads();
-  if (lane == 0 && n_tile == 0) {
-    float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + ((long long)m0 + wave) * p.Ng * 2);
-    o[0] = (float)st_dma; o[1] = (float)st_bar; o[2] = (float)st_all; o[3] = (float)nk;
-  }
-#endif
 }
 
 // ======================================================================================================================

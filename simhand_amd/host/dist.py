@@ -2,7 +2,8 @@
 single-process nn.DataParallel, src/experiments/main.py:152-163).
 
 * ``init_from_env`` -- reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun) and
-  initialises ``torch.distributed`` (backend "nccl" == RCCL on ROCm; "gloo" on CPU tests).
+  initialises ``torch.distributed`` (backend "nccl" == RCCL on ROCm; "gloo" on CPU tests).  No other environment
+  variable is read by this module.
 * ``allreduce_gradients`` -- bucketed SUM all-reduce of parameter gradients.  The loss is
   already normalised by the GLOBAL row count N and every rank back-propagates only
   through its own rows, so the per-rank gradients ADD up to the single-process
@@ -22,18 +23,16 @@ import torch.distributed as dist
 HSA_IPC_ENV = "HSA_ENABLE_IPC_MODE_LEGACY"
 
 
-def init_from_env(backend: str = None) -> Tuple[int, int, int]:
-    """Returns (rank, local_rank, world_size); no-op for a single process."""
+def init_from_env(backend: str = None, device_index: int = None) -> Tuple[int, int, int]:
+    """Returns (rank, local_rank, world_size); no-op for a single process.  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT and nothing else.  device_index: the HIP device of this process when it is not LOCAL_RANK (the test arrangement
+    with several ranks on one GPU passes it, together with backend="gloo": tests/_gloo_staging.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault(HSA_IPC_ENV, "0")  # dmabuf IPC only on this pool
     if torch.cuda.is_available():
-        # SIMHAND_SHARE_GPU=1 (tests only): several ranks on one device, which RCCL refuses -> gloo
-        share = os.environ.get("SIMHAND_SHARE_GPU") == "1"
-        torch.cuda.set_device(local % torch.cuda.device_count() if share else local)
-        if share:
-            backend = backend or "gloo"
+        torch.cuda.set_device(local if device_index is None else device_index)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -168,24 +167,36 @@ def _bucket_views(flat: torch.Tensor, tensors: List[torch.Tensor]) -> List[torch
     return out
 
 
-# ---- torch.distributed collectives on DEVICE tensors -----------------------------------------------------------------------------
-# backend "nccl" (= RCCL, the product path) takes device tensors and orders every collective on its own stream.  backend "gloo"
-# carries HOST memory: torch's ProcessGroupGloo accepts a device tensor by staging it through pinned memory on pool streams of
-# its own, from its worker threads.  That arrangement only exists where ranks SHARE one GPU (tests on a 1-GPU box, RCCL refuses two
-# ranks per device), and it is where round 3 saw a corrupted collective result in ~2 % of 4-rank runs with an asynchronous bucket
-# and the synchronised-BatchNorm sums in flight together.  So the staging is done HERE, explicitly, and gloo only ever
-# sees host tensors: SIMHAND_GLOO_STAGING = "all" (default) | "buckets" (only the asynchronous gradient buckets; the experiment
-# that isolates them) | "thread" (as "all", but a bucket's staging never blocks the issuing host thread: the pinned copy is ordered by
-# events on a side stream and a SECOND host thread waits for it and runs the gloo all-reduce -- the launch stream keeps being fed as with
-# "off"; the stress variant ADVICE r4 asked for) | "off" (torch's own device path: the round-3 arrangement, kept for the stress script).
-# OPEN ISSUE: with "off" 2 of 76 four-rank shared-GPU runs produced a wrong LOCAL gradient (all audited collectives exact);
-# "all" made the symptom disappear (0 of 333) without identifying the cause -- it also adds host synchronisations that change timing.
-def _gloo_staging() -> str:
-    return os.environ.get("SIMHAND_GLOO_STAGING", "all")
+# ---- torch.distributed collectives ------------------------------------------------------------------------------------------------
+# The product transport hands tensors to torch.distributed as they are: backend "nccl" (= RCCL) takes device tensors and orders every
+# collective on its own stream; backend "gloo" takes the host tensors of the CPU tests.  What a test arrangement needs beyond that --
+# ranks SHARING one GPU over gloo, where device tensors have to be staged through host memory -- lives in tests/_gloo_staging.py and is
+# installed through set_transport(); the record-and-re-derive audit of scripts/dist_stress.py through set_collective_audit().  This
+# module reads no environment variable besides the rendezvous ones of init_from_env.
+class TorchTransport:
+    """all_reduce_ / all_gather_into / broadcast: synchronous w.r.t. the stream semantics of the backend; bucket(): an asynchronous SUM
+    all-reduce of a flat gradient bucket, returns an object with wait()."""
+
+    def all_reduce_(self, t: torch.Tensor, rop, group) -> None:
+        dist.all_reduce(t, op=rop, group=group)
+
+    def all_gather_into(self, out: torch.Tensor, x: torch.Tensor, group) -> None:
+        dist.all_gather_into_tensor(out, x, group=group)
+
+    def broadcast(self, t: torch.Tensor, src: int, group) -> None:
+        dist.broadcast(t, src=src, group=group)
+
+    def bucket(self, flat: torch.Tensor, group):
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
 
-def _is_gloo(group) -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "gloo"
+_TRANSPORT = TorchTransport()
+
+
+def set_transport(transport: "Optional[TorchTransport]" = None) -> None:
+    """Replace how this module hands tensors to torch.distributed (None = the product transport).  Tests only."""
+    global _TRANSPORT
+    _TRANSPORT = transport if transport is not None else TorchTransport()
 
 
 _REDUCE_OPS = {"sum": "SUM", "max": "MAX", "min": "MIN"}
@@ -193,160 +204,28 @@ _REDUCE_OPS = {"sum": "SUM", "max": "MAX", "min": "MIN"}
 
 def all_reduce_(t: torch.Tensor, op: str = "sum", group=None) -> torch.Tensor:
     """In-place all-reduce of a contiguous tensor over `group` (RcclComm, torch.distributed group or None = default group),
-    stream-ordered on the current stream.  gloo + device tensor: synchronous host staging (D2H on the current stream, gloo on the
-    host copy, H2D on the current stream) -- no foreign stream, no worker-thread device work."""
+    stream-ordered on the current stream."""
     if isinstance(group, RcclComm):
         return group.all_reduce_(t, op)
-    rop = getattr(dist.ReduceOp, _REDUCE_OPS[op])
-    if t.is_cuda and _is_gloo(group) and _gloo_staging() in ("all", "thread"):
-        host = t.cpu()
-        dist.all_reduce(host, op=rop, group=group)
-        t.copy_(host)
-        return t
-    dist.all_reduce(t, op=rop, group=group)
+    _TRANSPORT.all_reduce_(t, getattr(dist.ReduceOp, _REDUCE_OPS[op]), group)
     return t
 
 
 def all_gather_into(out: torch.Tensor, x: torch.Tensor, group=None) -> torch.Tensor:
-    """out [world * x.numel()] <- every rank's contiguous x in rank order; same staging rule as all_reduce_."""
+    """out [world * x.numel()] <- every rank's contiguous x in rank order."""
     if isinstance(group, RcclComm):
         group.all_gather_into(out, x)
         return out
-    if x.is_cuda and _is_gloo(group) and _gloo_staging() in ("all", "thread"):
-        hx = x.cpu()
-        ho = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(ho, hx, group=group)
-        out.copy_(ho)
-        return out
-    dist.all_gather_into_tensor(out, x, group=group)
+    _TRANSPORT.all_gather_into(out, x, group)
     return out
 
 
-class _StagedBucket:
-    """One asynchronous SUM all-reduce of a device bucket over gloo with the staging spelled out: side stream behind an event on
-    the launch stream -> pinned host tensor -> gloo all-reduce of the HOST tensor (asynchronous: gloo's worker thread touches host
-    memory only) -> wait() copies back on the current stream."""
-
-    _side = None
-
-    def __init__(self, flat: torch.Tensor, group):
-        cls = _StagedBucket
-        if cls._side is None or cls._side.device != flat.device:
-            cls._side = torch.cuda.Stream(device=flat.device)
-        self.flat = flat
-        self.host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
-        ready = torch.cuda.Event()
-        ready.record()                                  # the flatten, on the launch stream
-        flat.record_stream(cls._side)
-        with torch.cuda.stream(cls._side):
-            cls._side.wait_event(ready)
-            self.host.copy_(flat, non_blocking=True)
-            copied = torch.cuda.Event()
-            copied.record(cls._side)
-        copied.synchronize()                            # the host copy is complete before gloo reads it
-        self.work = dist.all_reduce(self.host, op=dist.ReduceOp.SUM, group=group, async_op=True)
-
-    def wait(self) -> None:
-        self.work.wait()
-        self.flat.copy_(self.host, non_blocking=True)   # current stream; the pinned block outlives the copy (host allocator events)
+# Observer hook: an object with note(tag, input clone, result tensor, owners) sees every collective this module issues (the audit of
+# tests/_gloo_staging.py keeps the inputs and re-derives each result on the host afterwards).  None = off (the product never sets it).
+_AUDIT = None
 
 
-class _ThreadedBucket(_StagedBucket):
-    """As _StagedBucket, but the issuing host thread never blocks: the D2H copy is enqueued on the side stream behind an event and a helper
-    thread waits for `copied` and runs the (synchronous) gloo all-reduce of the HOST tensor.  Buckets of one process go through ONE helper
-    thread in submission order, so every rank issues its collectives in the same order -- on a process group OF THEIR OWN (same ranks,
-    created by every rank at its first bucket): the issuing thread keeps using `group` for the synchronised-BatchNorm sums meanwhile, and two
-    threads interleaving collectives on one gloo group pair them up differently on different ranks (the first closing run of round 5:
-    221 of 221 repetitions died with "Connection closed by peer" in the first BatchNorm sum of the backward)."""
-
-    _pool = None
-    _groups = {}  # id(group) -> the helper thread's twin group
-
-    @staticmethod
-    def _twin(group):
-        key = id(group) if group is not None else None
-        if key not in _ThreadedBucket._groups:
-            ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
-            _ThreadedBucket._groups[key] = dist.new_group(ranks=ranks, backend="gloo")
-        return _ThreadedBucket._groups[key]
-
-    def __init__(self, flat: torch.Tensor, group):  # noqa: super().__init__ intentionally not called (it blocks on `copied`)
-        from concurrent.futures import ThreadPoolExecutor
-
-        cls = _StagedBucket
-        if cls._side is None or cls._side.device != flat.device:
-            cls._side = torch.cuda.Stream(device=flat.device)
-        if _ThreadedBucket._pool is None:
-            _ThreadedBucket._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="simhand-gloo")
-        self.flat = flat
-        self.host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
-        ready = torch.cuda.Event()
-        ready.record()
-        flat.record_stream(cls._side)
-        with torch.cuda.stream(cls._side):
-            cls._side.wait_event(ready)
-            self.host.copy_(flat, non_blocking=True)
-            copied = torch.cuda.Event()
-            copied.record(cls._side)
-        host, twin = self.host, _ThreadedBucket._twin(group)
-
-        def run():
-            copied.synchronize()  # in the helper thread: the launch stream's host thread goes on issuing kernels
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=twin)
-
-        self.work = _ThreadedBucket._pool.submit(run)
-
-    def wait(self) -> None:
-        self.work.result()
-        self.flat.copy_(self.host, non_blocking=True)
-
-
-def _staged_bucket(flat: torch.Tensor, group):
-    return _ThreadedBucket(flat, group) if _gloo_staging() == "thread" else _StagedBucket(flat, group)
-
-
-class CollectiveAudit:
-    """Diagnostic (SIMHAND_DIST_DIAG=1, tests / scripts/dist_stress.py only): keeps the INPUT of every collective issued through
-    this module next to its result and, at verify(), re-does each one on host copies with plain synchronous gloo -- so a wrong
-    gradient can be attributed to a collective that returned a wrong result from right inputs (transport) or to wrong inputs
-    (whatever produced them).  Records cost one clone per collective; verify() is called after the step."""
-
-    def __init__(self):
-        self.records = []  # (tag, input clone, result tensor (live) or clone)
-        self.owners = []
-
-    def note(self, tag: str, pre: torch.Tensor, post: torch.Tensor, owners=None) -> None:
-        self.records.append((tag, pre, post))
-        self.owners.append(owners)  # buckets: [(id(parameter), numel)] in flattening order (tests/_syncbn_worker.py names them)
-
-    def verify(self, group=None) -> list:
-        """-> list of findings (dicts), empty when every collective result equals the host re-computation."""
-        out = []
-        for i, (tag, pre, post) in enumerate(self.records):
-            chk = pre.detach().to("cpu", copy=True)  # (copy: a host tensor would be reduced in place)
-            dist.all_reduce(chk, op=dist.ReduceOp.SUM, group=group)
-            got = post.detach().cpu()
-            if got.dtype != chk.dtype:
-                got = got.to(chk.dtype)
-            bad = ~((got == chk) | (torch.isnan(got) & torch.isnan(chk)))
-            # a different summation ORDER is not a finding: ring all-reduce orders differ between the device path and the host re-do
-            tol = 1e-5 * float(chk.abs().max()) + 1e-12
-            bad &= (got - chk).abs() > tol
-            if bool(bad.any()):
-                idx = bad.reshape(-1).nonzero().reshape(-1)
-                own = pre.detach().cpu().to(chk.dtype)
-                out.append({"record": i, "tag": tag, "numel": chk.numel(), "n_bad": int(idx.numel()), "first_bad": int(idx[0]), "last_bad": int(idx[-1]),
-                            "max_abs_err": float((got - chk).abs().max()), "ref_abs_max": float(chk.abs().max()),
-                            "got_abs_max": float(got[torch.isfinite(got)].abs().max()) if bool(torch.isfinite(got).any()) else float("nan"),
-                            "equals_own_input": bool(torch.equal(got, own)),
-                            "bad_equal_own_input": bool(torch.equal(got.reshape(-1)[idx], own.reshape(-1)[idx]))})
-        return out
-
-
-_AUDIT: Optional[CollectiveAudit] = None
-
-
-def set_collective_audit(audit: Optional[CollectiveAudit]) -> None:
+def set_collective_audit(audit=None) -> None:
     global _AUDIT
     _AUDIT = audit
 
@@ -359,7 +238,7 @@ class OverlappedGradReducer:
     runs them on RCCL's own stream; with an ``RcclComm`` group they are issued on the side stream of the communicator's SECOND
     ncclComm behind an event on the launch stream (one ncclComm must not have collectives in flight from two streams: the compute
     stream's own collectives -- synchronised BatchNorm, the loss exchanges -- keep the first); over gloo (ranks sharing a GPU:
-    tests) through ``_StagedBucket``.  ``finish`` (end of the backbone's backward) waits and returns ``{parameter: reduced
+    tests) through the staging transport of tests/_gloo_staging.py.  ``finish`` (end of the backbone's backward) waits and returns ``{parameter: reduced
     gradient}`` whose tensors are VIEWS of the reduced buckets (nothing is copied back; the engine hands them to autograd as the
     gradients); ``reduced`` tells ``allreduce_gradients`` which parameters are done.  wire="bf16": buckets travel as bf16
     (half the ring time; the sum is then a bf16 sum).  xGMI is point to point (7 links x ~153 GB/s per GPU): a ResNet-50's
@@ -371,6 +250,7 @@ class OverlappedGradReducer:
         self._bucket: List[Tuple[object, torch.Tensor]] = []
         self._size = 0
         self._pending = []
+        self.side_buckets = 0  # buckets that went out on the side stream of an RcclComm's second communicator (overlapped)
 
     def active(self) -> bool:
         if isinstance(self.group, RcclComm):
@@ -401,12 +281,11 @@ class OverlappedGradReducer:
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
                     self.group.all_reduce_(flat, "sum", side=True)
+                self.side_buckets += 1
                 work = torch.cuda.Event()
                 work.record(side)
-        elif flat.is_cuda and _is_gloo(self.group) and _gloo_staging() in ("all", "buckets", "thread"):
-            work = _staged_bucket(flat, self.group)
         else:
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = _TRANSPORT.bucket(flat, self.group)
         self._pending.append((work, flat, self._bucket))
         self._bucket, self._size = [], 0
 
@@ -439,15 +318,9 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) ->
     """Parameters and buffers of rank `src` to every rank (replica consistency does not rest on identical seeding)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    stage = _is_gloo(group) and _gloo_staging() in ("all", "thread")
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            if stage and t.is_cuda:  # gloo carries host memory (see all_reduce_)
-                host = t.data.cpu()
-                dist.broadcast(host, src=src, group=group)
-                t.data.copy_(host)
-            else:
-                dist.broadcast(t.data, src=src, group=group)
+            _TRANSPORT.broadcast(t.data, src, group)
 
 
 def enable_sync_bn(group=None) -> bool:
@@ -546,10 +419,8 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
             if abi:  # stream-ordered on the current stream: nothing to wait for on the host
                 group.all_reduce_(flat, "sum")
                 work = None
-            elif flat.is_cuda and _is_gloo(group) and _gloo_staging() in ("all", "buckets", "thread"):
-                work = _staged_bucket(flat, group)
             else:
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+                work = _TRANSPORT.bucket(flat, group)
             pending.append((work, flat, i, lo))
             lo, size = i, 0
     for work, flat, i, hi in pending:

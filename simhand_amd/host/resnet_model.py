@@ -384,7 +384,10 @@ class ResNetEngine:
             xq = pre[1]
         else:
             xq = site[0].quantize(x)
-        self._fp8_xq = (xq, site[0])  # kept with the unit: the e4m3 weight gradient reads the same codes
+        # kept with the unit: the e4m3 weight gradient reads the same codes.  Their de-scale is SNAPSHOT here (state[0:2], one stream-ordered
+        # 8-byte copy): the live scaler's state[1] is overwritten by every later quantisation of this site -- a second forward, an eval
+        # forward or a recompute between this forward and its backward would otherwise de-scale dW by the wrong factor
+        self._fp8_xq = (xq, site[0].state[:2].clone())
         return ops.conv2d_fwd_fp8(d, xq, site[2], site[0], site[1], want_stats=training)
 
     def _conv_bn(self, conv, bn, x, relu, residual, training, save: Optional[list], need_dgrad=True, gram_next=False, chain_conv=None,
@@ -438,7 +441,7 @@ class ResNetEngine:
             u.has_res = residual is not None
             u.mask = mask
             u.x_in = u.s2 = u.t2 = u.ws2 = None
-            u.xq = self._fp8_xq  # (codes of x, their scaler) when the forward ran on e4m3 operands
+            u.xq = self._fp8_xq  # (codes of x, snapshot of their scale state) when the forward ran on e4m3 operands
             save.append(u)
         if defer:
             return _Pending(y, st, save[-1] if save is not None else None)
@@ -671,7 +674,7 @@ class ResNetEngine:
             grads[w] = ops.stem_conv_wgrad(u.x, dy, d.h, d.w)
         elif dyq is not None and self.fp8_wgrad and getattr(u, "xq", None) is not None and ops.conv2d_wgrad_fp8_pays(d):
             # fp8 configuration: both operands already exist as e4m3 codes (x from the forward's BatchNorm-apply, dy from the pass above)
-            grads[w] = ops.conv2d_wgrad_fp8(d, u.xq[0], dyq, u.xq[1], f8[0])
+            grads[w] = ops.conv2d_wgrad_fp8(d, u.xq[0], dyq, u.xq[1], f8[0].state)
         else:
             grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))  # split-K reduce writes weight.grad's layout
         if not need_dx:

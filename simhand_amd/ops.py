@@ -984,13 +984,15 @@ def conv2d_wgrad_fp8_pays(d: ConvDesc) -> bool:
     return bool(_lib.load().simhand_conv2d_wgrad_fp8_pays(C.byref(d)))
 
 
-def conv2d_wgrad_fp8(d: ConvDesc, x_q, dy_q, x_scaler: FP8Scaler, dy_scaler: FP8Scaler) -> torch.Tensor:
-    """fp32 weight.grad [cout][cin][3][3] from the e4m3 codes of the activation and of dy (their scalers' state[1] = 1 / scale of the codes)."""
+def conv2d_wgrad_fp8(d: ConvDesc, x_q, dy_q, x_state: torch.Tensor, dy_state: torch.Tensor) -> torch.Tensor:
+    """fp32 weight.grad [cout][cin][3][3] from the e4m3 codes of the activation and of dy.  x_state / dy_state: fp32 device vectors whose
+    element [1] is 1 / (the scale THESE codes were made with) -- an FP8Scaler's .state right behind the quantisation, or a snapshot of its
+    first two floats taken then (what the engine keeps for the forward's codes: the live state moves on with every later quantisation)."""
     lib = _lib_dev()
     nb = lib.simhand_conv2d_wgrad_fp8_workspace_bytes(C.byref(d))
     ws = torch.empty(nb, dtype=torch.uint8, device=x_q.device)
     dw = torch.empty(d.cout, d.cin, 3, 3, dtype=torch.float32, device=x_q.device)
-    check(lib.simhand_conv2d_wgrad_fp8(C.byref(d), _ptr(x_q, torch.uint8), _ptr(dy_q, torch.uint8), _ptr(x_scaler.state), _ptr(dy_scaler.state),
+    check(lib.simhand_conv2d_wgrad_fp8(C.byref(d), _ptr(x_q, torch.uint8), _ptr(dy_q, torch.uint8), _ptr(x_state, _F32), _ptr(dy_state, _F32),
                                        _ptr(dw), _ptr(ws), nb, _stream()), "conv2d_wgrad_fp8")
     return dw
 

@@ -14,13 +14,12 @@ import torch.distributed as dist
 
 ROOT, BACKEND = sys.argv[1], sys.argv[2]
 sys.path.insert(0, ROOT)
-if BACKEND == "gloo":
-    os.environ["SIMHAND_SHARE_GPU"] = "1"
 from oracle import step as orc  # noqa: E402
 from simhand_amd.host import dist as shdist  # noqa: E402
+from tests import _gloo_staging  # noqa: E402
 from tests.test_gpu_step import _product  # noqa: E402
 
-rank, local, world = shdist.init_from_env()
+rank, local, world = _gloo_staging.init_shared_gpu() if BACKEND == "gloo" else shdist.init_from_env()
 if os.environ.get("SIMHAND_POISON_WORKER"):  # torch.empty returns NaN patterns (tests/_poison.py)
     from tests._poison import poison
 
@@ -61,6 +60,8 @@ if BACKEND == "nccl" and world > 1:
     loss_abi.backward()
     shdist.allreduce_gradients(model.parameters(), group=comm, bucket_bytes=1 << 20, skip=model.encoder.engine.grad_reducer.reduced)
     torch.cuda.synchronize()
+    # per-rank BatchNorm statistics (the benchmarked arrangement): the buckets overlap the backward on the SECOND ncclComm's side stream
+    assert comm.side_stream() is not None and model.encoder.engine.grad_reducer.side_buckets > 0, model.encoder.engine.grad_reducer.side_buckets
     assert abs(loss_abi.item() - loss.item()) <= 1e-6 * abs(loss.item()), (loss_abi.item(), loss.item())
     # the ABI path's reduced gradients (side-stream buckets) against the torch.distributed path's, tensor by tensor
     for k, p in model.named_parameters():

@@ -11,14 +11,14 @@ import torch.distributed as dist
 
 ROOT, BACKEND, SIZE = sys.argv[1], sys.argv[2], sys.argv[3]
 sys.path.insert(0, ROOT)
-if BACKEND == "gloo":
-    os.environ["SIMHAND_SHARE_GPU"] = "1"
 from oracle import step as orc  # noqa: E402
 from simhand_amd import ops  # noqa: E402
 from simhand_amd.host import dist as shdist  # noqa: E402
+from tests import _gloo_staging  # noqa: E402
 from tests.test_gpu_step import _product  # noqa: E402
 
-rank, local, world = shdist.init_from_env()
+# "gloo": the ranks SHARE one GPU (device tensors staged through host memory by the test transport); "nccl": the product path
+rank, local, world = _gloo_staging.init_shared_gpu() if BACKEND == "gloo" else shdist.init_from_env()
 if os.environ.get("SIMHAND_POISON_WORKER"):  # torch.empty returns NaN patterns (tests/_poison.py)
     from tests._poison import poison
 
@@ -33,7 +33,7 @@ if os.environ.get("SIMHAND_CANARY"):  # every torch.empty of the step carries a 
     guard_every()
 audit = None
 if os.environ.get("SIMHAND_DIST_DIAG"):  # scripts/dist_stress.py: every collective's input kept and re-derived on the host afterwards
-    audit = shdist.CollectiveAudit()
+    audit = _gloo_staging.CollectiveAudit()
     shdist.set_collective_audit(audit)
 dev = torch.device("cuda", torch.cuda.current_device())
 AUG = ["color_jitter", "crop", "random_crop", "resize", "rotate"]
@@ -86,7 +86,7 @@ if os.environ.get("SIMHAND_DIST_RERUN") and audit is not None and world > 1:
     first, first_owners = audit.records, audit.owners
     grads1 = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
     bufs1 = {k: b.detach().clone() for k, b in model.named_buffers()}  # the second step must not move the running statistics the checks below read
-    audit2 = shdist.CollectiveAudit()
+    audit2 = _gloo_staging.CollectiveAudit()
     shdist.set_collective_audit(audit2)
     model.zero_grad()
     reducer2 = shdist.OverlappedGradReducer(bucket_bytes=int(os.environ.get("SIMHAND_TEST_BUCKET", 1 << 20)))
@@ -175,8 +175,9 @@ if rank == 0:
     print(f"rank 0 [sync BN, {BACKEND} x{world}, ResNet-{SIZE}]: loss {loss.item():.6f} == full-batch oracle {lo.item():.6f}; grad rel-L2 median "
           f"{errs[len(errs)//2]:.2e} max {errs[-1]:.2e}; running stats within {worst:.1e}")
 if BACKEND == "nccl" and world > 1:
-    # the same step with every exchange through the C ABI's RCCL wrappers: the synchronised-BatchNorm sums on the compute stream
-    # (first ncclComm) while the gradient buckets overlap them on the side stream (second ncclComm) -- reduced gradients tensor by tensor
+    # the same step with every exchange through the C ABI's RCCL wrappers.  Under synchronised BatchNorm the reducer keeps the gradient
+    # buckets IN ORDER on the launch stream (first ncclComm, next to the BatchNorm sums): the second communicator / side stream is the
+    # arrangement of the per-rank-statistics step (tests/_dist_worker.py asserts it is used there) -- reduced gradients tensor by tensor
     comm = shdist.RcclComm.from_torch_distributed()
     torch_grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
     model.zero_grad()
@@ -189,6 +190,7 @@ if BACKEND == "nccl" and world > 1:
     loss_abi.backward()
     shdist.allreduce_gradients(model.parameters(), group=comm, bucket_bytes=1 << 20, skip=red_abi.reduced)
     torch.cuda.synchronize()
+    assert red_abi.side_buckets == 0, red_abi.side_buckets
     assert abs(loss_abi.item() - loss.item()) <= 1e-6 * abs(loss.item()), (loss_abi.item(), loss.item())
     for k, p in model.named_parameters():
         if k in torch_grads:

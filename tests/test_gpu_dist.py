@@ -28,8 +28,8 @@ def _launch(world, backend, port, worker, extra, env_extra=None):
 
 def _run(world, backend, port, worker="_dist_worker.py", extra=(), env_extra=None):
     """R worker processes; a failed rank fails the test (no repetition).  With gloo the ranks SHARE this box's one GPU (RCCL refuses two
-    ranks per device) and every collective on a device tensor is staged through host memory by simhand_amd.host.dist itself
-    (SIMHAND_GLOO_STAGING): torch's ProcessGroupGloo only ever sees host tensors."""
+    ranks per device) and every collective on a device tensor is staged through host memory by the test transport
+    (tests/_gloo_staging.py, SIMHAND_GLOO_STAGING): torch's ProcessGroupGloo only ever sees host tensors."""
     res = _launch(world, backend, port, worker, extra, env_extra)
     for r, (rc, o) in enumerate(res):
         assert rc == 0, f"rank {r} failed:\n{o[-3000:]}"
@@ -74,26 +74,28 @@ def test_sharded_step_over_rccl():
     _run(min(n, 8) if min(n, 8) in (2, 4, 8) else 2, "nccl", 29641)
 
 
-def test_sync_batchnorm_and_overlapped_buckets_on_two_communicators_over_rccl():
-    """The arrangement ADVICE r4 wants gated on real hardware: synchronised-BatchNorm sums on the compute stream (first ncclComm) while the gradient
-    buckets overlap them on the high-priority side stream (second ncclComm), every collective audited, against the full-batch oracle and against the
-    torch.distributed gradients of the same step (tests/_syncbn_worker.py, nccl leg).  Needs one device per rank: skipped on a single-GPU box."""
+def test_sync_batchnorm_with_in_order_buckets_over_the_abi_communicator_rccl():
+    """Synchronised BatchNorm over RCCL: the sums and -- because two communicators with kernels in flight next to one-block-per-CU compute
+    kernels have no deadlock-freedom guarantee -- the gradient buckets IN ORDER on the launch stream of the ABI communicator
+    (`OverlappedGradReducer._flush`: side = None under bn_sync; the worker asserts side_buckets == 0), every collective audited, against the
+    full-batch oracle and against the torch.distributed gradients of the same step (tests/_syncbn_worker.py, nccl leg).  The OVERLAPPED
+    arrangement (buckets on the second ncclComm's high-priority side stream) is what test_sharded_step_over_rccl's ABI leg runs and asserts
+    (per-rank statistics: tests/_dist_worker.py, side_buckets > 0).  Needs one device per rank: skipped on a single-GPU box."""
     n = torch.cuda.device_count()
     if n < 2:
-        pytest.skip("RCCL needs one device per rank: this box has a single GPU (never executed so far: DESIGN 4a)")
+        pytest.skip("RCCL needs one device per rank: this box has a single GPU (never executed so far: DESIGN 4)")
     _run(4 if n >= 4 else 2, "nccl", 29745, worker="_syncbn_worker.py", extra=("50",), env_extra={"SIMHAND_DIST_DIAG": "1"})
 
 
 def test_bench_self_launch_two_ranks():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment spawns its own ranks and prints ONE JSON line
     with n_gpus = 2 and the world size the backend reports.  On a 1-GPU box the ranks share the device over gloo
-    (SIMHAND_SHARE_GPU=1: same code path, no RCCL); with >= 2 GPUs it runs over RCCL."""
+    (bench.py --share-gpu, the test arrangement of tests/_gloo_staging.py: same code path, no RCCL); with >= 2 GPUs it runs over RCCL."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    if torch.cuda.device_count() < 2:
-        env["SIMHAND_SHARE_GPU"] = "1"
+    share = ["--share-gpu"] if torch.cuda.device_count() < 2 else []
     env["MASTER_PORT"] = "29655"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--per-gpu-batch", "8",
-                          "--resnet", "18", "--image-size", "64", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                          "--resnet", "18", "--image-size", "64", "--no-cpu-baseline", *share], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout

@@ -133,7 +133,7 @@ def test_fp8_weight_gradient_against_fp32_of_the_dequantised_operands(shape):
     sx, sdy = ops.FP8Scaler(DEV, delayed=True), ops.FP8Scaler(DEV, delayed=True)
     xq, dyq = sx.quantize(x), sdy.quantize(dy)
     ops.route_reset()
-    dw = ops.conv2d_wgrad_fp8(d, xq, dyq, sx, sdy)
+    dw = ops.conv2d_wgrad_fp8(d, xq, dyq, sx.state, sdy.state)
     torch.cuda.synchronize()
     assert ops.route_counts()["fp8_wgrad"] == 1
     xdq = (_deq(xq) * float(sx.state[1])).permute(0, 3, 1, 2).contiguous()
@@ -160,7 +160,7 @@ def test_fp8_weight_gradient_fullsize(n):
     d = ops.conv_desc(n, h, h, c, c, 3, 3, 1, 1, torch.bfloat16)
     sx, sdy = ops.FP8Scaler(DEV, delayed=True), ops.FP8Scaler(DEV, delayed=True)
     xq, dyq = sx.quantize(x), sdy.quantize(dy)
-    dw = ops.conv2d_wgrad_fp8(d, xq, dyq, sx, sdy)
+    dw = ops.conv2d_wgrad_fp8(d, xq, dyq, sx.state, sdy.state)
     # e4m3 VALUES are exactly representable in bf16: the bf16 all-taps kernel on the un-scaled code values computes the same products
     xb = xq.view(torch.float8_e4m3fn).to(torch.bfloat16)
     dyb = dyq.view(torch.float8_e4m3fn).to(torch.bfloat16)
@@ -369,12 +369,23 @@ def test_simclr_rn50_step_fp8_tracks_bf16_and_the_oracle_over_several_steps():
                 grads_ok = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
                 assert grads_ok
                 g0 = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
+            if i == 2:  # a step on the DELAYED path (every site has history): the 3x3 weight gradients of stages 3 and 4, norms kept
+                n2 = {k: float(p.grad.detach().double().norm()) for k, p in model.named_parameters()
+                      if p.grad is not None and ".conv2.weight" in k and (".6." in k or ".7." in k)}
             opt.step()
             losses.append(float(out["loss"]))
-        runs[mode] = (losses, z0, ops.route_counts()["fp8_fwd"], ops.route_counts()["fp8_dgrad"], g0)
-    lb, zb, nb, _, gb = runs["bf16"]
-    lf, zf, nf, ndg, gf = runs["fp8"]
+        rc = ops.route_counts()
+        runs[mode] = (losses, z0, rc["fp8_fwd"], rc["fp8_dgrad"], g0, rc["fp8_wgrad"], n2)
+    lb, zb, nb, _, gb, nwb, n2b = runs["bf16"]
+    lf, zf, nf, ndg, gf, nwf, n2f = runs["fp8"]
     assert ndg >= 5 * 9, ndg  # and their data gradients
+    # the e4m3 weight gradient is on by default: the seven stride-1 3x3 layers with >= 256 channels, every step (the cosine
+    # below is scale-invariant and would not see a wrong x_state / dy_state wiring or the route silently not taken)
+    assert nwb == 0 and nwf == 5 * 7, (nwb, nwf)
+    assert len(n2f) == 9 and set(n2f) == set(n2b)
+    ratios = {k: n2f[k] / n2b[k] for k in n2f}
+    print("fp8 / bf16 norm of the stage-3/4 conv2 weight gradients at step 2 (delayed scaling):", {k: round(v, 3) for k, v in ratios.items()})
+    assert all(0.9 <= r <= 1.1 for r in ratios.values()), ratios
     # first step's parameter gradients (same weights in both runs) of the fp8 run against the bf16 run's: e4m3 operands in nine 3x3
     # forwards and data gradients, ReLU kinks on top -- a sanity band (a wrong scale or layout gives cosines near 0), not parity
     cosg = sorted(float(F.cosine_similarity(gf[k].flatten().double(), gb[k].flatten().double(), dim=0)) for k in gf if gb[k].abs().max() > 1e-7)
@@ -393,3 +404,40 @@ def test_simclr_rn50_step_fp8_tracks_bf16_and_the_oracle_over_several_steps():
     for a, c in zip(lf, lb):
         assert abs(a - c) <= 3e-2 * abs(c), (lf, lb)
     assert abs(lf[-1] - lf[0]) > 1e-4  # the optimizer moved the fp8 run too
+
+
+def test_fp8_weight_gradient_descale_is_the_one_of_the_forwards_codes():
+    """the e4m3 weight gradient reads the activation codes of ITS forward; their de-scale must be the one they were made with,
+    not whatever the site's live scaler holds at backward time.  Forward (grad) -> a second forward of a 3x larger batch under no_grad
+    (moves every activation site's ring and scale) -> backward of the first: every parameter gradient must equal, bit for bit, the run
+    without the intermediate forward (the kernels are deterministic; the dy sites see the same history in both runs)."""
+    from simhand_amd import _lib, ops
+    from tests.test_gpu_configs import _oracle, _product
+
+    b, img = 4, 224
+    om = _oracle("simclr", "50", {}, 37, 0.1)
+    batch = {k: v.to(DEV) for k, v in orc.synthetic_batch(b, size=img, seed=37).items()}
+    loud = {k: (v * 3.0 if k.startswith("transformed_image") else v) for k, v in batch.items()}
+    _lib.load().simhand_test_igemm256_enable(2)
+    try:
+        got = {}
+        for disturb in (False, True):
+            model = _product("SimCLR", "50", {}, om, torch.bfloat16, b)
+            model.set_compute_dtype(torch.bfloat16, fp8=True)
+            # two warm steps: every delayed site has history, so the measured step takes the fused (delayed) quantisation paths
+            for i in range(2):
+                model.zero_grad(set_to_none=True)
+                model.training_step(batch, i)["loss"].backward()
+            model.zero_grad(set_to_none=True)
+            ops.route_reset()
+            out = model.training_step(batch, 2)
+            if disturb:
+                with torch.no_grad():
+                    model.training_step(loud, 3)
+            out["loss"].backward()
+            assert ops.route_counts()["fp8_wgrad"] >= 7
+            got[disturb] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        bad = [k for k in got[False] if not torch.equal(got[False][k], got[True][k])]
+        assert not bad, bad[:5]
+    finally:
+        ops.hooks_reset()

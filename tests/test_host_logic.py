@@ -329,7 +329,8 @@ assert torch.allclose(mean, full.mean(0), atol=1e-12) and torch.allclose(var, fu
 # an asynchronous bucket stays in flight while BatchNorm sums are exchanged (no serialisation, no retry: DESIGN 4), and the collective
 # audit (what scripts/dist_stress.py runs with) re-derives every recorded collective on the host: clean run -> no finding; a result
 # tampered with after the fact -> exactly that record is reported
-audit = shdist.CollectiveAudit(); shdist.set_collective_audit(audit)
+from tests._gloo_staging import CollectiveAudit
+audit = CollectiveAudit(); shdist.set_collective_audit(audit)
 shdist.enable_sync_bn()                                                          # re-install: the audited callable
 red3 = shdist.OverlappedGradReducer(bucket_bytes=16)
 q3 = [torch.nn.Parameter(torch.zeros(n)) for n in (6, 5)]
