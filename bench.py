@@ -90,6 +90,8 @@ def parse():
                     help="ONE process runs the rank-local work of an R-rank step (BASELINE configs[2] at R = 8): its own pairs through the backbone, "
                          "the loss row block 2 b_loc x 2 b_loc R against a synthetic gathered Z_all / J_all, gradient buckets flattened and cast as on "
                          "the wire -- NO collective is executed (an upper bound on data-parallel efficiency where no multi-GPU node is available)")
+    ap.add_argument("--lib", default=None, metavar="PATH", help="A/B timing only: another build of libsimhand_hip.so (scripts/build_variant.sh)")
+    ap.add_argument("--lib-f16", default=None, metavar="PATH", help="A/B timing only: another build of libsimhand_hip_f16.so")
     ap.add_argument("--no-loss-scaling", action="store_true", help="--precision 16 without the GradScaler (timing split only)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline AND the precision-16 companion line (profiling / A-B runs)")
     ap.add_argument("--cpu-pairs", type=int, default=32,
@@ -363,8 +365,21 @@ def main():
     from simhand_amd import _lib, ops
     from simhand_amd.host import dist as shdist
 
+    if args.lib or args.lib_f16:
+        _lib.set_library_paths(args.lib, args.lib_f16)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))  # nothing above touched the GPU: the ranks are ordinary child processes
+    # measured parity of THIS build on THIS device (VERDICT r5 "Next" 7): the smoke-size step against the CPU oracle, before anything is timed --
+    # and before torch.distributed exists in this process (with a process group up the loss would exchange its rows with ranks that are
+    # not running the probe)
+    parity = None
+    env_rank, env_local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if env_rank == 0 and args.precision != "fp8":
+        import __graft_entry__ as entry
+
+        _lib.require_device()
+        torch.cuda.set_device(env_local % max(1, torch.cuda.device_count()) if args.share_gpu else env_local)
+        parity = entry.parity_probe()
     if args.share_gpu:  # the shared-GPU test arrangement (ranks on one device over gloo, device tensors staged through host memory)
         from tests import _gloo_staging
 
@@ -388,12 +403,6 @@ def main():
             if torch.cuda.device_count() < args.gpus:
                 raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) are visible (one rank per GPU)")
     device = torch.device("cuda", torch.cuda.current_device())  # = LOCAL_RANK (init_from_env set it)
-    # measured parity of THIS build on THIS device (VERDICT r5 "Next" 7): the smoke-size step against the CPU oracle, before anything is timed
-    parity = None
-    if rank == 0 and args.precision != "fp8":
-        import __graft_entry__ as entry
-
-        parity = entry.parity_probe()
     model = make_model(args, world * emu).to(device).train()
     for kv in args.switch:   # A/B hooks (never set in the default run; recorded in the line's config)
         name, v = kv.split("=", 1)
@@ -540,7 +549,8 @@ def main():
                        "comm": ("abi (simhand_comm_*)" if group is not None else "torch.distributed") if world > 1 else "none",
                        "grad_wire": args.grad_wire if world > 1 else "n/a",
                        "batchnorm": "synchronised" if (world > 1 and args.sync_bn) else "per-rank statistics",
-                       "ab_hooks": (args.switch + args.engine) or "none (production dispatch)"},
+                       "ab_hooks": (args.switch + args.engine + ([f"lib={args.lib}"] if args.lib else []) + ([f"lib_f16={args.lib_f16}"] if args.lib_f16 else []))
+                                   or "none (production dispatch)"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "hbm": hbm, "launches": d["count"], "avg_launch_ms": d["ms"] / max(1, d["count"]),
                          "event_steps": f"{len(range(0, args.steps, every))} of the {args.steps} timed steps (every {every})",

@@ -64,10 +64,12 @@ enum sh_weight_type { SH_W_NONE = 0, SH_W_LINEAR = 1, SH_W_NONLINEAR = 2,
  * moved behind simhand_test_* hooks, the stem entry points of DESIGN 3; 4 = round 5: the two-pass / fused-backward stem entry points and
  * their route counters removed (sh_route renumbered from 36 on), SH_SW_COUNT unchanged, and the last argument of simhand_fp8_scale_update
  * became a mode 0 / 1 / 2 with state[1] = 1 / (scale of the existing codes) -- see the FP8 section; round 6 moved the instrument
- * declarations (simhand_test_* / simhand_prof_* / simhand_route_*) to include/simhand_hip_test.h without changing a signature).  A binding compares simhand_abi_version() with the
+ * declarations (simhand_test_* / simhand_prof_* / simhand_route_*) to include/simhand_hip_test.h without changing a signature;
+ * 5 = round 6: simhand_conv2d_wgrad_colsum_sums, simhand_bn_apply_gram_sums, simhand_bn_bwd_finalize_raw_coefs, simhand_bn_finalize_ticket added (merged
+ * parameter-sized launches), SH_SW_FOLD_LEGACY added to sh_test_switch).  A binding compares simhand_abi_version() with the
  * SH_ABI_VERSION it was written against before its first call (simhand_amd/_lib.py load() does) -- a caller built against an older header
  * would otherwise pass shifted arguments or a short options struct unnoticed. */
-#define SH_ABI_VERSION 4
+#define SH_ABI_VERSION 5
 int simhand_abi_version(void);
 /* The library ships in two builds of the same sources: libsimhand_hip.so, whose 16-bit storage type (SH_BF16 below) is bfloat16 -- and
  * libsimhand_hip_f16.so, where the same enum value means IEEE fp16 (11-bit significand: the storage type of the reference's
@@ -353,6 +355,11 @@ int simhand_conv2d_wgrad(const sh_conv_desc* d, const void* x, const void* dy, f
 int simhand_conv2d_wgrad_splits(const sh_conv_desc* d);
 int simhand_conv2d_wgrad_colsum(const sh_conv_desc* d, const void* x, const void* dy, float* dw, float* dy_colsum, void* workspace,
                                 size_t workspace_bytes, sh_stream_t stream);
+/* Round 6: the same with the channel sums FOLDED -- dy_sum[cout] = sum over splits of dy_colsum[split][0][.], added in the order
+ * simhand_bn_bwd_finalize_raw uses (bit-identical) -- by the launch that reduces the split-K partials: two launches instead of three
+ * (dy_colsum stays the scratch buffer it was; needs simhand_conv2d_wgrad_splits(d) < 4096). */
+int simhand_conv2d_wgrad_colsum_sums(const sh_conv_desc* d, const void* x, const void* dy, float* dw, float* dy_colsum, float* dy_sum,
+                                     void* workspace, size_t workspace_bytes, sh_stream_t stream);
 /* BatchNorm passes fused into the operand loaders of the bf16 1x1 / stride-1 weight-gradient kernel (its tiles are staged
  * global -> registers -> LDS, so a per-channel transform between load and store costs VALU only):
  *  simhand_bn_apply_gram: y = raw conv output [m][c] of a conv + BN (+ReLU) unit whose activation feeds a FOLDED 1x1
@@ -368,6 +375,9 @@ int simhand_conv2d_wgrad_colsum(const sh_conv_desc* d, const void* x, const void
  * (src/models/resnet_model.py:13-58). */
 int simhand_bn_apply_gram(const sh_conv_desc* d, const void* y, const float* scale, const float* shift, int relu, void* a, float* s2,
                           float* colsum_partial, void* workspace, size_t workspace_bytes, sh_stream_t stream);
+/* Round 6: + colsum[c] = sum a, folded inside the split-K reduction launch (as simhand_conv2d_wgrad_colsum_sums) */
+int simhand_bn_apply_gram_sums(const sh_conv_desc* d, const void* y, const float* scale, const float* shift, int relu, void* a, float* s2,
+                               float* colsum_partial, float* colsum, void* workspace, size_t workspace_bytes, sh_stream_t stream);
 /* EXPERIMENTAL (off in the engine: measured -4.3 ms BatchNorm / +8.5 ms weight gradient per step) */
 int simhand_conv2d_wgrad_bnbwd(const sh_conv_desc* d, const void* x, const void* da, const void* y, const float* scale, const float* shift,
                                const float* coef_a, const float* coef_b, const float* coef_c, int relu, void* dy_out, float* dw_oihw,
@@ -409,6 +419,13 @@ int simhand_bn_finalize(const float* partial, int nblk, int64_t m, int c, const 
                         const float* pre_bias, float eps, float momentum, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
                         void* workspace, size_t workspace_bytes, sh_stream_t stream);
+/* Round 6: both levels of the fold in ONE launch -- the block that draws the last ticket finalizes (bit-identical statistics).  ticket: a
+ * caller-owned uint32 on the device, ZERO before the first call, not shared by launches that may run concurrently (one per stream); every
+ * call leaves it zero (stream-ordered). */
+int simhand_bn_finalize_ticket(const float* partial, int nblk, int64_t m, int c, const float* gamma, const float* beta,
+                               const float* pre_bias, float eps, float momentum, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                               void* workspace, size_t workspace_bytes, uint32_t* ticket, sh_stream_t stream);
 /* eval mode (model.eval(), validation_step): scale/shift from the running statistics */
 int simhand_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                             int c, float* scale, float* shift, sh_stream_t stream);
@@ -467,6 +484,10 @@ int simhand_maxpool_bn_bwd_apply(const void* dz, const uint8_t* idx, const void*
 size_t simhand_bn_bwd_finalize_raw_workspace_bytes(int nblk, int c);
 int simhand_bn_bwd_finalize_raw(const float* partial, int nblk, int c, const float* mean, const float* invstd, float* dgamma,
                                 float* dbeta, void* workspace, size_t workspace_bytes, sh_stream_t stream);
+/* Round 6: the same + the coefficients of dy = A g - B y + C (simhand_bn_bwd_coefs: coefs [3][c] = A, B, C) out of the same launch */
+int simhand_bn_bwd_finalize_raw_coefs(const float* partial, int nblk, int c, const float* mean, const float* invstd, const float* gamma,
+                                      int64_t m, float* dgamma, float* dbeta, float* coefs, void* workspace, size_t workspace_bytes,
+                                      sh_stream_t stream);
 int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const float* mean, const float* invstd,
                          const float* gamma, const float* dgamma, const float* dbeta, const float* scale, const float* shift,
                          int relu, void* dy, void* dres, int64_t m, int c, int dtype, sh_stream_t stream);

@@ -48,7 +48,8 @@ enum sh_route {
   SH_ROUTE_FWD_BNIN = 36,                                   /* 3x3 forward with the previous unit's BatchNorm + ReLU applied in its LDS ring */
   SH_ROUTE_N128_FWD = 37, SH_ROUTE_N128_DGRAD = 38,         /* 1x1 with 128 destination channels behind a long reduction: 128 x 128 LDS-DMA tiles, two blocks per CU */
   SH_ROUTE_FP8_WGRAD = 39,                                  /* e4m3 3x3 weight gradient (reduction over pixels on the scaled K = 128 MFMA) */
-  SH_ROUTE_COUNT = 40
+  SH_ROUTE_STEM_RING_FWD = 40, SH_ROUTE_STEM_RING_WGRAD = 41,  /* the stem's LDS-ring kernels (forward: 128^2 / 224^2 / 256^2 inputs; weight gradient: 224^2) */
+  SH_ROUTE_COUNT = 42
 };
 int simhand_route_counts(int64_t* out /*[SH_ROUTE_COUNT]*/);
 int simhand_route_reset(void);
@@ -74,7 +75,10 @@ enum sh_test_switch {
   SH_SW_STEM_RING_LT = 13, /* its linear stores (default 1) */
   SH_SW_STEM_WG_RING = 14, /* stem weight gradient with both operands in LDS rings (stem_wgrad_ring_kernel) at 224 x 224 (default 1) */
   SH_SW_N128 = 15,         /* gemm_n128_kernel for the 1x1 layers with 128 destination channels and >= 256 of reduction (default 1) */
-  SH_SW_COUNT = 16
+  SH_SW_FOLD_LEGACY = 16,  /* 1 = the round-5 launch chains of the folded BatchNorm algebra and of the Gram / colsum reductions (separate centre,
+                            * slice-sum, bias, channel-sum and coefficient launches) instead of the merged ones of round 6 -- same numbers bit for bit
+                            * (default 0) */
+  SH_SW_COUNT = 17
 };
 int simhand_test_switch(int which, int value);
 

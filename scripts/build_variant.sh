@@ -1,5 +1,5 @@
 #!/bin/bash
-# Variant build of ONE source file into scripts/abl/lib<name>.so (A/B timing on one GPU box via SIMHAND_LIB); run HERE.
+# Variant build of ONE source file into scripts/abl/lib<name>.so (A/B timing on one GPU box: bench.py --lib PATH / simhand_amd._lib.set_library_paths); run HERE.
 # usage: scripts/build_variant.sh <name> <file.hip> <extra hipcc flags...>
 set -e
 name=$1; src=$2; shift 2

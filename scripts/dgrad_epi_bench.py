@@ -1,8 +1,13 @@
 """Data-gradient forms of the 256 x 256 kernel whose epilogues load per-chunk operands (bias, residual gradient + masks, fused BatchNorm-backward sums),
-at 2048 images: time per launch next to the plain store of the same shape (isolation; A/B two builds with SIMHAND_LIB)."""
+at 2048 images: time per launch next to the plain store of the same shape (isolation; A/B two builds with --lib PATH)."""
 import sys, time, math, torch
 sys.path.insert(0, ".")
 from simhand_amd import ops
+
+if "--lib" in sys.argv:  # another build of the library (scripts/build_variant.sh), before its first use
+    from simhand_amd import _lib as _sh_lib
+
+    _sh_lib.set_library_paths(sys.argv[sys.argv.index("--lib") + 1])
 DEV, dt = "cuda", torch.bfloat16
 def timed(fn, iters=20):
     fn(); fn(); torch.cuda.synchronize()

@@ -1,8 +1,13 @@
 """Forward 1x1 convolutions with the BatchNorm + residual + ReLU epilogue on the 256 x 256 kernel (the conv3 / shortcut layers of stages 3-4), 2048 images:
-plain forward next to the epilogue form (isolation; A/B two builds with SIMHAND_LIB)."""
+plain forward next to the epilogue form (isolation; A/B two builds with --lib PATH)."""
 import sys, time, math, torch
 sys.path.insert(0, ".")
 from simhand_amd import ops
+
+if "--lib" in sys.argv:  # another build of the library (scripts/build_variant.sh), before its first use
+    from simhand_amd import _lib as _sh_lib
+
+    _sh_lib.set_library_paths(sys.argv[sys.argv.index("--lib") + 1])
 DEV, dt = "cuda", torch.bfloat16
 def timed(fn, iters=20):
     fn(); fn(); torch.cuda.synchronize()

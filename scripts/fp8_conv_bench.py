@@ -1,8 +1,13 @@
 """The 3x3 layers of the fp8 set at BASELINE configs[4]'s per-GPU batch (4096 images): forward / data gradient / weight gradient, bf16 vs e4m3,
-each looped 20 times after a warm-up (isolation numbers; A/B two builds with SIMHAND_LIB)."""
+each looped 20 times after a warm-up (isolation numbers; A/B two builds with --lib PATH)."""
 import sys, time, torch
 sys.path.insert(0, ".")
 from simhand_amd import ops
+
+if "--lib" in sys.argv:  # another build of the library (scripts/build_variant.sh), before its first use
+    from simhand_amd import _lib as _sh_lib
+
+    _sh_lib.set_library_paths(sys.argv[sys.argv.index("--lib") + 1])
 DEV = "cuda"
 def timed(fn, iters=20):
     fn(); fn(); torch.cuda.synchronize()

@@ -1,8 +1,13 @@
 """The layer-1 conv3 folded data gradient (64 <- 256 + 64 second segment + bias + fused BatchNorm-backward sums; the generic 128 x 64 tile kernel), 2048 images,
-and the stage-2 / short-K siblings that share igemm_kernel: time per launch (isolation; A/B two builds with SIMHAND_LIB)."""
+and the stage-2 / short-K siblings that share igemm_kernel: time per launch (isolation; A/B two builds with --lib PATH)."""
 import sys, time, math, torch
 sys.path.insert(0, ".")
 from simhand_amd import ops
+
+if "--lib" in sys.argv:  # another build of the library (scripts/build_variant.sh), before its first use
+    from simhand_amd import _lib as _sh_lib
+
+    _sh_lib.set_library_paths(sys.argv[sys.argv.index("--lib") + 1])
 DEV, dt = "cuda", torch.bfloat16
 def timed(fn, iters=20):
     fn(); fn(); torch.cuda.synchronize()

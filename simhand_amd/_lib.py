@@ -17,10 +17,25 @@ import threading
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SIMHAND_LIB: another build of the same library (A/B timing of a kernel change on one GPU box)
-LIB_PATH = os.environ.get("SIMHAND_LIB") or os.path.join(_HERE, "libsimhand_hip.so")
+# (another build of the same library for an A/B timing run: set_library_paths below)
+LIB_PATH = os.path.join(_HERE, "libsimhand_hip.so")
 # the fp16-storage build of the same sources (csrc/Makefile, -DSH_H16_FP16): the reference's precision=16
-LIB_PATH_F16 = os.environ.get("SIMHAND_LIB_F16") or os.path.join(_HERE, "libsimhand_hip_f16.so")
+LIB_PATH_F16 = os.path.join(_HERE, "libsimhand_hip_f16.so")
+
+
+def set_library_paths(bf16: str = None, f16: str = None) -> None:
+    """Another build of the library (scripts/build_variant.sh) for a same-box A/B run: call BEFORE the first load() of that format
+    (bench.py --lib / --lib-f16).  The package reads no environment variable for this (round 6; SIMHAND_LIB until round 5)."""
+    global LIB_PATH, LIB_PATH_F16
+    if bf16 is not None:
+        if "bf16" in _libs:
+            raise SimhandHipError("set_library_paths: the bf16 library is already loaded")
+        LIB_PATH = bf16
+    if f16 is not None:
+        if "f16" in _libs:
+            raise SimhandHipError("set_library_paths: the fp16 library is already loaded")
+        LIB_PATH_F16 = f16
+
 
 # enums of include/simhand_hip.h
 SH_F32, SH_BF16, SH_FP8_E4M3 = 0, 1, 2
@@ -34,8 +49,8 @@ ROUTES = ("igemm128_fwd", "igemm128_dgrad", "igemm256_fwd", "igemm256_dgrad", "i
           "gemm1x1_dgrad", "c64_fwd", "c64_dgrad", "stem_fwd", "fwd_bnact", "dgrad_concat", "dgrad_fused_sums", "dgrad_parity",
           "wgrad3x3", "wgrad_plain", "wgrad_generic", "wgrad_stem", "wgrad_colsum", "bn_fold_fwd", "bn_fold_bwd", "bn_apply",
           "bn_bwd_apply", "stem_bn_pool", "ntxent_fwd", "ntxent_bwd", "fp8_fwd", "fp8_dgrad", "bn_apply_gram", "wgrad_bnbwd", "ntxent_fused_dist",
-          "dgrad_dysrc", "fwd_chain", "r128_fwd", "r128_dgrad", "fwd_bnin", "n128_fwd", "n128_dgrad", "fp8_wgrad")
-ROUTE_COUNT = 40
+          "dgrad_dysrc", "fwd_chain", "r128_fwd", "r128_dgrad", "fwd_bnin", "n128_fwd", "n128_dgrad", "fp8_wgrad", "stem_ring_fwd", "stem_ring_wgrad")
+ROUTE_COUNT = 42
 
 
 class SimhandHipError(RuntimeError):
@@ -90,7 +105,7 @@ _L = C.c_int64
 _F = C.c_float
 _S = C.c_size_t
 
-ABI_VERSION = 4  # include/simhand_hip.h SH_ABI_VERSION this table was written against (checked in load())
+ABI_VERSION = 5  # include/simhand_hip.h SH_ABI_VERSION this table was written against (checked in load())
 
 # name -> (restype, argtypes); every symbol include/simhand_hip.h declares
 SIGNATURES = {
@@ -137,8 +152,10 @@ SIGNATURES = {
     "simhand_stem_conv_wgrad": (_I, [_P, _P, _P, _P, _S, _I, _I, _I, _I, _P]),
     "simhand_conv2d_wgrad_splits": (_I, [C.POINTER(ConvDesc)]),
     "simhand_conv2d_wgrad_colsum": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _S, _P]),
+    "simhand_conv2d_wgrad_colsum_sums": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_conv2d_wgrad_oihw": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _S, _P]),
     "simhand_bn_apply_gram": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _P, _P, _P, _S, _P]),
+    "simhand_bn_apply_gram_sums": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _P, _P, _P, _P, _S, _P]),
     "simhand_conv2d_wgrad_bnbwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _S, _P]),
     "simhand_bn_bwd_coefs": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
     "simhand_test_wgrad_set_tr": (_I, [_I]),
@@ -158,6 +175,7 @@ SIGNATURES = {
     "simhand_bn_partial_stats": (_I, [_P, _L, _I, _I, _P, _P]),
     "simhand_bn_finalize_workspace_bytes": (_S, [_I, _I]),
     "simhand_bn_finalize": (_I, [_P, _I, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "simhand_bn_finalize_ticket": (_I, [_P, _I, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P, _P]),
     "simhand_bn_eval_params": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "simhand_bn_apply": (_I, [_P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P]),
     "simhand_bn_bwd_partial": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P, _P]),
@@ -171,6 +189,7 @@ SIGNATURES = {
     "simhand_maxpool_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "simhand_bn_bwd_finalize_raw_workspace_bytes": (_S, [_I, _I]),
     "simhand_bn_bwd_finalize_raw": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
+    "simhand_bn_bwd_finalize_raw_coefs": (_I, [_P, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _S, _P]),
     "simhand_conv2d_dgrad_stat_blocks": (_I, [C.POINTER(ConvDesc), _I, _I, _I]),
     "simhand_test_conv3x3_c64_enable": (_I, [_I]),
     "simhand_test_conv3x3_r128_enable": (_I, [_I]),

@@ -85,9 +85,7 @@ __global__ __launch_bounds__(256) void bn_partial_stats_kernel(const T* __restri
 }
 
 // level-1 partial [nblk][2][c] float -> level-2 [nchunk][2][c] double
-__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partial, int nblk, int c,
-                                                            double* __restrict__ lvl2) {
-  __shared__ double red[4][2][64];
+__device__ __forceinline__ void fold_partials_body(double (*red)[2][64], const float* __restrict__ partial, int nblk, int c, double* lvl2) {
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int ch = blockIdx.y * 64 + cl;
   const int b0 = blockIdx.x * kChunk;
@@ -124,16 +122,19 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ lvl2, int nchunk, int64_t m, int c,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          const float* __restrict__ pre_bias, float eps, float momentum,
-                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                          int64_t* __restrict__ nbt, float* __restrict__ mean_o,
-                                                          float* __restrict__ invstd_o, float* __restrict__ scale_o,
-                                                          float* __restrict__ shift_o) {
-  const int ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch == 0 && nbt) nbt[0] += 1;
-  if (ch >= c) return;
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partial, int nblk, int c,
+                                                            double* __restrict__ lvl2) {
+  __shared__ double red[4][2][64];
+  fold_partials_body(red, partial, nblk, c, lvl2);
+}
+
+// one channel's statistics from its level-2 sums
+__device__ __forceinline__ void bn_finalize_channel(const int ch, const double* lvl2, int nchunk, int64_t m, int c,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ pre_bias, float eps, float momentum,
+                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                    float* __restrict__ mean_o, float* __restrict__ invstd_o, float* __restrict__ scale_o,
+                                                    float* __restrict__ shift_o) {
   double s1 = 0.0, s2 = 0.0;
   {
     double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
@@ -168,6 +169,52 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     running_mean[ch] = (1.0f - momentum) * running_mean[ch] + momentum * (float)mfull;
     running_var[ch] = (1.0f - momentum) * running_var[ch] + momentum * (float)unbiased;
   }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ lvl2, int nchunk, int64_t m, int c,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ pre_bias, float eps, float momentum,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          int64_t* __restrict__ nbt, float* __restrict__ mean_o,
+                                                          float* __restrict__ invstd_o, float* __restrict__ scale_o,
+                                                          float* __restrict__ shift_o) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch == 0 && nbt) nbt[0] += 1;
+  if (ch >= c) return;
+  bn_finalize_channel(ch, lvl2, nchunk, m, c, gamma, beta, pre_bias, eps, momentum, running_mean, running_var, mean_o, invstd_o, scale_o, shift_o);
+}
+
+// Round 6: both levels in ONE launch.  Every block folds its chunk exactly as fold_partials_kernel does, publishes its level-2 row
+// (agent-scope release: __threadfence + a relaxed atomic ticket) and leaves; the block that draws the LAST ticket acquires, resets the
+// ticket for the next launch on this stream and runs bn_finalize_kernel's per-channel code for all channels -- the same additions in the
+// same order, bit-identical statistics, one kernel boundary less on the critical path of every conv + BatchNorm unit.  `ticket` is a
+// caller-owned uint32 that is ZERO before the first call and that no concurrent launch shares (one per stream); every launch leaves it zero.
+__global__ __launch_bounds__(256) void bn_finalize_ticket_kernel(const float* __restrict__ partial, int nblk, int nchunk, int64_t m, int c,
+                                                                 double* lvl2, unsigned* ticket, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ pre_bias,
+                                                                 float eps, float momentum, float* __restrict__ running_mean,
+                                                                 float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                                 float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                                 float* __restrict__ scale_o, float* __restrict__ shift_o) {
+  __shared__ double red[4][2][64];
+  __shared__ int s_last;
+  fold_partials_body(red, partial, nblk, c, lvl2);
+  __threadfence();  // this block's level-2 row is visible device-wide (across the XCDs' L2s) before its ticket is
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned total = gridDim.x * gridDim.y;
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == total - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();  // acquire: the other blocks' rows
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nbt) nbt[0] += 1;
+  }
+  for (int ch = threadIdx.x; ch < c; ch += 256)
+    bn_finalize_channel(ch, lvl2, nchunk, m, c, gamma, beta, pre_bias, eps, momentum, running_mean, running_var, mean_o, invstd_o, scale_o, shift_o);
 }
 
 __global__ __launch_bounds__(256) void bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -397,7 +444,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const TIn* __rest
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                const float* __restrict__ mean = nullptr,
                                                                const float* __restrict__ invstd = nullptr,
-                                                               double* __restrict__ lvl2 = nullptr) {
+                                                               double* __restrict__ lvl2 = nullptr,
+                                                               const float* __restrict__ gamma = nullptr, float inv_m = 0.f,
+                                                               float* __restrict__ coefs = nullptr) {
   __shared__ double red[64][2][16];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cl;
@@ -434,9 +483,18 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const TIn* __rest
     lvl2[((int64_t)blockIdx.y * 2 + 1) * c + ch] = t2;
     return;
   }
-  dbeta[ch] = (float)t1;
+  const float db = (float)t1;
   // raw sums (sum g, sum g*y) from the fused dgrad epilogue: sum g*xhat = invstd * (sum g*y - mean * sum g)
-  dgamma[ch] = mean != nullptr ? (float)((double)invstd[ch] * (t2 - (double)mean[ch] * t1)) : (float)t2;
+  const float dg = mean != nullptr ? (float)((double)invstd[ch] * (t2 - (double)mean[ch] * t1)) : (float)t2;
+  dbeta[ch] = db;
+  dgamma[ch] = dg;
+  if (coefs != nullptr) {  // round 6: bn_bwd_coefs_kernel's arithmetic on the sums just rounded (coefs = [3][c]: A, B, C of dy = A g - B y + C)
+    const float a = __fmul_rn(gamma[ch], invstd[ch]);
+    const float b = __fmul_rn(__fmul_rn(__fmul_rn(a, invstd[ch]), dg), inv_m);
+    coefs[ch] = a;
+    coefs[c + ch] = b;
+    coefs[2 * c + ch] = __fadd_rn(__fmul_rn(__fmul_rn(-a, db), inv_m), __fmul_rn(mean[ch], b));
+  }
 }
 
 template <typename T, bool NT>
@@ -962,7 +1020,10 @@ __device__ __forceinline__ double block_sum256(double v, double* red) {  // 256 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void fold_sgemm_kernel(const float* __restrict__ a, int sam, int sak, int round_a,
                                                          const float* __restrict__ b, int sbk, int sbn, int m, int n, int k,
-                                                         float* __restrict__ cf, T* __restrict__ ct, int ldc, int kper) {
+                                                         float* __restrict__ cf, T* __restrict__ ct, int ldc, int kper,
+                                                         const float* __restrict__ ct2 = nullptr, double inv_m = 0.0) {
+  // ct2 != nullptr (round 6): B is the raw Gram matrix S2 [k][n] and is CENTRED on load, B(k, n) - ct2[k] ct2[n] inv_m in fp64 rounded to fp32 --
+  // fold_center_kernel's expression element by element (bit-identical operand), without the launch and the cw x cw round trip
   __shared__ float sa[16][68], sb[16][68];
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // outputs rows ty*4.., cols tx*4..
@@ -991,7 +1052,12 @@ __global__ __launch_bounds__(256) void fold_sgemm_kernel(const float* __restrict
       }
       sa[ak][am] = av;
       const int bn_ = b_n_fast ? id & 63 : id >> 4, bk = b_n_fast ? id >> 6 : id & 15;
-      sb[bk][bn_] = (n0 + bn_ < n && k0 + bk < k) ? b[(int64_t)(k0 + bk) * sbk + (int64_t)(n0 + bn_) * sbn] : 0.f;
+      float bv = 0.f;
+      if (n0 + bn_ < n && k0 + bk < k) {
+        bv = b[(int64_t)(k0 + bk) * sbk + (int64_t)(n0 + bn_) * sbn];
+        if (ct2 != nullptr) bv = (float)__dsub_rn((double)bv, __dmul_rn(__dmul_rn((double)ct2[k0 + bk], (double)ct2[n0 + bn_]), inv_m));
+      }
+      sb[bk][bn_] = bv;
     }
     __syncthreads();
 #pragma unroll
@@ -1050,7 +1116,7 @@ __global__ __launch_bounds__(256) void fold_center_kernel(const float* __restric
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)cw * cw) return;
   const int j = (int)(i / cw), k = (int)(i - (int64_t)j * cw);
-  out[i] = (float)((double)s2[i] - (double)t2[j] * (double)t2[k] * inv_m);
+  out[i] = (float)__dsub_rn((double)s2[i], __dmul_rn(__dmul_rn((double)t2[j], (double)t2[k]), inv_m));  // (pinned roundings: the product's loader repeats it)
 }
 
 __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restrict__ w, int round_bf16, const float* __restrict__ s2,
@@ -1060,22 +1126,32 @@ __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float* __restric
                                                           float* __restrict__ running_var, int64_t* __restrict__ nbt,
                                                           float* __restrict__ mean_o, float* __restrict__ invstd_o,
                                                           float* __restrict__ scale_o, float* __restrict__ shift_o,
-                                                          float* __restrict__ ws2) {
+                                                          float* __restrict__ ws2, const float* __restrict__ part = nullptr, int ks = 1) {
   __shared__ double red[256];
   __shared__ double s_mean;
   const int c = blockIdx.x;
   double sy = 0.0, sy2 = 0.0;
-  for (int j = threadIdx.x; j < cw; j += 256) {  // ws2 holds W S2c (CENTRED Gram) from fold_sgemm_kernel
+  // part != nullptr (round 6): the product arrives as `ks` split-K slices [ks][cc][cw]; they are added here in fold_sum_kernel's order
+  // (z = 0 .. ks - 1 into a float), once per loop below -- the same float both times, and the fold_sum launch is gone
+  const int64_t count = (int64_t)gridDim.x * cw;
+  auto ws2c = [&](int j) -> float {
+    const int64_t o = (int64_t)c * cw + j;
+    if (part == nullptr) return ws2[o];
+    float t = 0.f;
+    for (int z = 0; z < ks; ++z) t += part[(int64_t)z * count + o];
+    return t;
+  };
+  for (int j = threadIdx.x; j < cw; j += 256) {  // W S2c (CENTRED Gram) from fold_sgemm_kernel
     const float wv = fold_w(w, c * cw + j, round_bf16);
     sy += (double)wv * (double)t2[j];
-    sy2 += (double)ws2[(int64_t)c * cw + j] * (double)wv;
+    sy2 += (double)ws2c(j) * (double)wv;
   }
   sy = block_sum256(sy, red);
   sy2 = block_sum256(sy2, red);
   if (threadIdx.x == 0) s_mean = sy / (double)m;
   __syncthreads();
   // the backward's algebra wants the UN-centred product: W S2 = W S2c + (W t2) t2^T / M = ws2c + mean_c t2
-  for (int j = threadIdx.x; j < cw; j += 256) ws2[(int64_t)c * cw + j] = (float)((double)ws2[(int64_t)c * cw + j] + s_mean * (double)t2[j]);
+  for (int j = threadIdx.x; j < cw; j += 256) ws2[(int64_t)c * cw + j] = (float)((double)ws2c(j) + s_mean * (double)t2[j]);
   if (threadIdx.x == 0) {
     if (c == 0 && nbt) nbt[0] += 1;
     const double mean = s_mean;
@@ -1150,6 +1226,35 @@ __global__ __launch_bounds__(1024) void bn_fold_bias_kernel(const float* __restr
   }
 }
 
+// Round 6: the split-K sum of W^T diag(B) W (fold_sum_kernel<T, 1>'s arithmetic, 1024 elements per block) and bias = C W (bn_fold_bias_kernel,
+// unchanged) in ONE launch: blocks [0, nsum) add the slices, blocks [nsum, nsum + ceil(cw / 32)) reduce the bias columns.
+template <typename T>
+__global__ __launch_bounds__(1024) void fold_sum_bias_kernel(const float* __restrict__ part, int ks, int64_t count, T* __restrict__ ct, int nsum,
+                                                             const float* __restrict__ w, int round_bf16, const float* __restrict__ ccoef,
+                                                             int cc, int cw, float* __restrict__ bias) {
+  __shared__ float red[32][33];
+  if ((int)blockIdx.x < nsum) {
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i >= count) return;
+    float t = 0.f;
+    for (int z = 0; z < ks; ++z) t += part[(int64_t)z * count + i];
+    Elem<T>::store(ct + i, -t);
+    return;
+  }
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int j = ((int)blockIdx.x - nsum) * 32 + tx;
+  float acc = 0.f;
+  if (j < cw)
+    for (int c = ty; c < cc; c += 32) acc += ccoef[c] * fold_w(w, c * cw + j, round_bf16);
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && j < cw) {
+    float t = 0.f;
+    for (int r = 0; r < 32; ++r) t += red[r][tx];
+    bias[j] = t;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t m, int c, int rows_per_blk,
                                                      float* __restrict__ partial) {
@@ -1192,11 +1297,11 @@ __global__ void bn_bwd_coefs_kernel(const float* __restrict__ mean, const float*
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= c) return;
   // dy = gamma invstd (g - mean(g) - xhat mean(g xhat)),  xhat = (y - mean) invstd   ->   A g - B y + C
-  const float a = gamma[i] * invstd[i];
-  const float b = a * invstd[i] * dgamma[i] * inv_m;
+  const float a = __fmul_rn(gamma[i], invstd[i]);                       // (pinned roundings: bn_bwd_finalize_kernel repeats them)
+  const float b = __fmul_rn(__fmul_rn(__fmul_rn(a, invstd[i]), dgamma[i]), inv_m);
   ca[i] = a;
   cb[i] = b;
-  cc[i] = -a * dbeta[i] * inv_m + mean[i] * b;
+  cc[i] = __fadd_rn(__fmul_rn(__fmul_rn(-a, dbeta[i]), inv_m), __fmul_rn(mean[i], b));
 }
 
 }  // namespace sh
@@ -1258,6 +1363,27 @@ int simhand_bn_finalize(const float* partial, int nblk, int64_t m, int c, const 
   bn_finalize_kernel<<<ceil_div(c, 256), 256, 0, s>>>((const double*)workspace, nchunk, m, c, gamma, beta, pre_bias, eps, momentum,
                                                        running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift);
   return check_launch("bn_finalize");
+}
+
+int simhand_bn_finalize_ticket(const float* partial, int nblk, int64_t m, int c, const float* gamma, const float* beta,
+                               const float* pre_bias, float eps, float momentum, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                               void* workspace, size_t workspace_bytes, uint32_t* ticket, sh_stream_t stream) {
+  SH_REQUIRE(ticket != nullptr, "bn_finalize_ticket: NULL ticket");
+  if (sw(SH_SW_FOLD_LEGACY))
+    return simhand_bn_finalize(partial, nblk, m, c, gamma, beta, pre_bias, eps, momentum, running_mean, running_var, num_batches_tracked, mean,
+                               invstd, scale, shift, workspace, workspace_bytes, stream);
+  SH_REQUIRE(partial && mean && invstd && scale && shift && workspace, "bn_finalize_ticket: NULL pointer");
+  SH_REQUIRE(nblk >= 1 && m >= 1 && c >= 1, "bn_finalize_ticket: bad shape");
+  SH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_ticket: running stats must be given together");
+  SH_REQUIRE(workspace_bytes >= simhand_bn_finalize_workspace_bytes(nblk, c), "bn_finalize_ticket: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunk = ceil_div(nblk, kChunk);
+  ProfScope ps(SH_PROF_BN, s, 0, (double)nblk * 2 * c * 4);
+  bn_finalize_ticket_kernel<<<dim3(nchunk, ceil_div(c, 64)), 256, 0, s>>>(partial, nblk, nchunk, m, c, (double*)workspace, ticket, gamma, beta,
+                                                                          pre_bias, eps, momentum, running_mean, running_var,
+                                                                          num_batches_tracked, mean, invstd, scale, shift);
+  return check_launch("bn_finalize_ticket");
 }
 
 int simhand_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
@@ -1347,6 +1473,30 @@ int simhand_bn_bwd_finalize_raw(const float* partial, int nblk, int c, const flo
     bn_bwd_finalize_kernel<float><<<ceil_div(c, 16), 1024, 0, s>>>(partial, nblk, c, dgamma, dbeta, mean, invstd);
   }
   return check_launch("bn_bwd_finalize_raw");
+}
+
+// the same + the coefficients (A, B, C) of dy = A g - B y + C (simhand_bn_bwd_coefs) out of the SAME launch: coefs [3][c]
+int simhand_bn_bwd_finalize_raw_coefs(const float* partial, int nblk, int c, const float* mean, const float* invstd, const float* gamma, int64_t m,
+                                      float* dgamma, float* dbeta, float* coefs, void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+  SH_REQUIRE(partial && mean && invstd && gamma && dgamma && dbeta && coefs && m >= 1, "bn_bwd_finalize_raw_coefs: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (sw(SH_SW_FOLD_LEGACY)) {  // the round-5 pair of launches
+    if (simhand_bn_bwd_finalize_raw(partial, nblk, c, mean, invstd, dgamma, dbeta, workspace, workspace_bytes, stream)) return 1;
+    return simhand_bn_bwd_coefs(mean, invstd, gamma, dgamma, dbeta, m, c, coefs, coefs + c, coefs + 2 * c, stream);
+  }
+  ProfScope ps(SH_PROF_BN, s, 0, (double)nblk * 2 * c * 4);
+  const float inv_m = (float)(1.0 / (double)m);
+  const int sl = raw_slices(nblk);
+  if (sl > 1) {
+    SH_REQUIRE(workspace && workspace_bytes >= simhand_bn_bwd_finalize_raw_workspace_bytes(nblk, c), "bn_bwd_finalize_raw_coefs: workspace too small");
+    double* lvl2 = (double*)workspace;
+    bn_bwd_finalize_kernel<float><<<dim3(ceil_div(c, 16), sl), 1024, 0, s>>>(partial, nblk, c, nullptr, nullptr, nullptr, nullptr, lvl2);
+    if (check_launch("bn_bwd_finalize_raw_coefs fold")) return 1;
+    bn_bwd_finalize_kernel<double><<<ceil_div(c, 16), 1024, 0, s>>>(lvl2, sl, c, dgamma, dbeta, mean, invstd, nullptr, gamma, inv_m, coefs);
+  } else {
+    bn_bwd_finalize_kernel<float><<<ceil_div(c, 16), 1024, 0, s>>>(partial, nblk, c, dgamma, dbeta, mean, invstd, nullptr, gamma, inv_m, coefs);
+  }
+  return check_launch("bn_bwd_finalize_raw_coefs");
 }
 
 int simhand_bn_bwd_apply(const void* da, const void* a, const void* y, const float* mean, const float* invstd, const float* gamma,
@@ -1514,27 +1664,42 @@ int simhand_bn_fold_fwd(const float* w, int round_bf16, const float* s2, const f
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(SH_PROF_BN, s, 2.0 * cc * (double)cw * cw, 4.0 * ((double)cc * cw * 2 + (double)cw * cw));
   route_hit(SH_ROUTE_BN_FOLD_FWD);
-  // ws2[c][j] = sum_i W[c][i] S2[i][j]
-  {
-    int ks, kper;
-    const int tiles = ceil_div(cw, 64) * ceil_div(cc, 64);
-    fold_split(tiles, cw, &ks, &kper);
-    SH_REQUIRE(workspace && workspace_bytes >= simhand_bn_fold_workspace_bytes(cc, cw), "bn_fold_fwd: workspace too small");
-    float* s2c = (float*)workspace + (workspace_bytes / sizeof(float) - (size_t)cw * cw);  // the tail of the workspace
-    fold_center_kernel<<<ceil_div((int64_t)cw * cw, 256), 256, 0, s>>>(s2, t2, cw, 1.0 / (double)m, s2c);
-    if (check_launch("bn_fold_fwd centre")) return 1;
-    float* dst = ks > 1 ? (float*)workspace : ws2;
-    fold_sgemm_kernel<float, 0><<<dim3(ceil_div(cw, 64), ceil_div(cc, 64), ks), 256, 0, s>>>(w, cw, 1, round_bf16, s2c, cw, 1, cc, cw, cw, dst,
-                                                                                             nullptr, cw, kper);
-    if (check_launch("bn_fold_fwd gemm")) return 1;
-    if (ks > 1) {
-      const int64_t count = (int64_t)cc * cw;
-      fold_sum_kernel<float, 0><<<ceil_div(count, 256), 256, 0, s>>>(dst, ks, count, ws2, nullptr);
-      if (check_launch("bn_fold_fwd sum")) return 1;
+  if (sw(SH_SW_FOLD_LEGACY)) {  // the round-5 chain (centre, product, slice sum, per-channel): four launches, same numbers bit for bit (tests)
+    // ws2[c][j] = sum_i W[c][i] S2[i][j]
+    {
+      int ks, kper;
+      const int tiles = ceil_div(cw, 64) * ceil_div(cc, 64);
+      fold_split(tiles, cw, &ks, &kper);
+      SH_REQUIRE(workspace && workspace_bytes >= simhand_bn_fold_workspace_bytes(cc, cw), "bn_fold_fwd: workspace too small");
+      float* s2c = (float*)workspace + (workspace_bytes / sizeof(float) - (size_t)cw * cw);  // the tail of the workspace
+      fold_center_kernel<<<ceil_div((int64_t)cw * cw, 256), 256, 0, s>>>(s2, t2, cw, 1.0 / (double)m, s2c);
+      if (check_launch("bn_fold_fwd centre")) return 1;
+      float* dst = ks > 1 ? (float*)workspace : ws2;
+      fold_sgemm_kernel<float, 0><<<dim3(ceil_div(cw, 64), ceil_div(cc, 64), ks), 256, 0, s>>>(w, cw, 1, round_bf16, s2c, cw, 1, cc, cw, cw, dst,
+                                                                                               nullptr, cw, kper);
+      if (check_launch("bn_fold_fwd gemm")) return 1;
+      if (ks > 1) {
+        const int64_t count = (int64_t)cc * cw;
+        fold_sum_kernel<float, 0><<<ceil_div(count, 256), 256, 0, s>>>(dst, ks, count, ws2, nullptr);
+        if (check_launch("bn_fold_fwd sum")) return 1;
+      }
     }
+    bn_fold_fwd_kernel<<<cc, 256, 0, s>>>(w, round_bf16, s2, t2, cc, cw, m, gamma, beta, eps, momentum, running_mean, running_var,
+                                          num_batches_tracked, mean, invstd, scale, shift, ws2);
+    return check_launch("bn_fold_fwd");
   }
+  // ws2[c][j] = sum_i W[c][i] S2c[i][j]: the Gram matrix is centred in the product's operand loader, the split-K slices are added by the
+  // per-channel kernel behind it -- two launches (round 6; four until round 5: centre, product, slice sum, per-channel)
+  int ks, kper;
+  const int tiles = ceil_div(cw, 64) * ceil_div(cc, 64);
+  fold_split(tiles, cw, &ks, &kper);
+  SH_REQUIRE(workspace && workspace_bytes >= simhand_bn_fold_workspace_bytes(cc, cw), "bn_fold_fwd: workspace too small");
+  float* dst = ks > 1 ? (float*)workspace : ws2;
+  fold_sgemm_kernel<float, 0><<<dim3(ceil_div(cw, 64), ceil_div(cc, 64), ks), 256, 0, s>>>(w, cw, 1, round_bf16, s2, cw, 1, cc, cw, cw, dst,
+                                                                                           nullptr, cw, kper, t2, 1.0 / (double)m);
+  if (check_launch("bn_fold_fwd gemm")) return 1;
   bn_fold_fwd_kernel<<<cc, 256, 0, s>>>(w, round_bf16, s2, t2, cc, cw, m, gamma, beta, eps, momentum, running_mean, running_var,
-                                        num_batches_tracked, mean, invstd, scale, shift, ws2);
+                                        num_batches_tracked, mean, invstd, scale, shift, ws2, ks > 1 ? dst : nullptr, ks);
   return check_launch("bn_fold_fwd");
 }
 
@@ -1564,13 +1729,23 @@ int simhand_bn_fold_bwd(const float* w, int round_bf16, const float* gmat, const
   else
     fold_sgemm_kernel<bf16_t, 1><<<grid, 256, 0, s>>>(w, 1, cw, round_bf16, bw, cw, 1, cw, cw, cc, part, (bf16_t*)wm, cw, kper);
   if (check_launch("bn_fold_bwd gemm")) return 1;
-  if (ks > 1) {
-    const int64_t count = (int64_t)cw * cw;
-    if (dtype == SH_F32) fold_sum_kernel<float, 1><<<ceil_div(count, 256), 256, 0, s>>>(part, ks, count, nullptr, (float*)wm);
-    else fold_sum_kernel<bf16_t, 1><<<ceil_div(count, 256), 256, 0, s>>>(part, ks, count, nullptr, (bf16_t*)wm);
-    if (check_launch("bn_fold_bwd sum")) return 1;
+  if (sw(SH_SW_FOLD_LEGACY)) {  // the round-5 tail: slice sum and bias as two launches
+    if (ks > 1) {
+      const int64_t count = (int64_t)cw * cw;
+      if (dtype == SH_F32) fold_sum_kernel<float, 1><<<ceil_div(count, 256), 256, 0, s>>>(part, ks, count, nullptr, (float*)wm);
+      else fold_sum_kernel<bf16_t, 1><<<ceil_div(count, 256), 256, 0, s>>>(part, ks, count, nullptr, (bf16_t*)wm);
+      if (check_launch("bn_fold_bwd sum")) return 1;
+    }
+    bn_fold_bias_kernel<<<ceil_div(cw, 32), 1024, 0, s>>>(w, round_bf16, ccoef, cc, cw, bias);
+    return check_launch("bn_fold_bias");
   }
-  bn_fold_bias_kernel<<<ceil_div(cw, 32), 1024, 0, s>>>(w, round_bf16, ccoef, cc, cw, bias);
+  // slice sum (when the product was split) + bias = C W in one launch
+  const int64_t count = (int64_t)cw * cw;
+  const int nsum = ks > 1 ? (int)ceil_div(count, 1024) : 0;
+  if (dtype == SH_F32)
+    fold_sum_bias_kernel<float><<<nsum + ceil_div(cw, 32), 1024, 0, s>>>(part, ks, count, (float*)wm, nsum, w, round_bf16, ccoef, cc, cw, bias);
+  else
+    fold_sum_bias_kernel<bf16_t><<<nsum + ceil_div(cw, 32), 1024, 0, s>>>(part, ks, count, (bf16_t*)wm, nsum, w, round_bf16, ccoef, cc, cw, bias);
   return check_launch("bn_fold_bias");
 }
 

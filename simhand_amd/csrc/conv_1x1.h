@@ -77,6 +77,6 @@ int launch_stem_ring(const void* xp, const void* w, void* y, float* partial, int
 void stem_ring_enable(int on);
 // stem_bwd.hip: the stem's weight gradient with both operands in LDS rings (224 x 224, 16-bit storage); workspace = blocks x 64 x 224 floats
 int stem_wgrad_ring_blocks(int n);
-int launch_stem_wgrad_ring(const void* xp, const void* dy, float* dw_oihw, float* workspace, int n, int hp, int wp, hipStream_t s);
+int launch_stem_wgrad_ring(const void* xp, const void* dy, float* dw_oihw, float* workspace, int n, int hp, int wp, int wo, hipStream_t s);
 
 }  // namespace sh

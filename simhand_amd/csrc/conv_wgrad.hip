@@ -512,12 +512,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
 // outputs with many splits (64x64 1x1: 1536 splits of 16 KB) still fill the chip.  `c_real > 0` writes the result in
 // OIHW order [Cout][c_real][R][S] (the layout of the reference's nn.Conv2d.weight.grad), dropping padded channels.
 template <int SL>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, long long count, int splitk,
-                                                           float* __restrict__ dw, int cin, int rs, int c_real) {
+__device__ __forceinline__ void wgrad_reduce_body(const int vblock, float4* red, const float* __restrict__ part, long long count, int splitk,
+                                                  float* __restrict__ dw, int cin, int rs, int c_real) {
   constexpr int COLS = 256 / SL;
-  __shared__ float4 red[SL > 1 ? 256 : 1];
   const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
-  const long long i = ((long long)blockIdx.x * COLS + col) * 4;
+  const long long i = ((long long)vblock * COLS + col) * 4;
   float4 s = make_float4(0, 0, 0, 0);
   if (i < count)
     for (int k = sl; k < splitk; k += SL) {
@@ -564,6 +563,47 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (c + j < c_real) dw[(k * c_real + c + j) * rs + tap] = v[j];
 }
 
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, long long count, int splitk,
+                                                           float* __restrict__ dw, int cin, int rs, int c_real) {
+  __shared__ float4 red[SL > 1 ? 256 : 1];
+  wgrad_reduce_body<SL>(blockIdx.x, red, part, count, splitk, dw, cin, rs, c_real);
+}
+
+// Round 6: the split-K reduction AND the fold of the per-split channel sums (dy_colsum rows of a Gram / colsum launch) in ONE launch --
+// blocks [0, nred) are wgrad_reduce_kernel<SL>'s, blocks [nred, nred + ceil(c / 4)) fold column 0 of cs_part [splits][2][c] to cs_out[c]
+// exactly as bn_bwd_finalize_kernel<float> does with mean = 0, invstd = 1 (64 row lanes x 4 independent double chains, the 64 lane sums added
+// in lane order), four channels per 256-thread block instead of sixteen per 1024: the same additions in the same order per channel, so
+// both outputs are bit-identical to the two launches this replaces (40 launches per ResNet-50 step).
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ part, long long count, int splitk, float* __restrict__ dw,
+                                                           int cin, int rs, int c_real, int nred, const float* __restrict__ cs_part, int splits,
+                                                           int c, float* __restrict__ cs_out) {
+  __shared__ float4 red[SL > 1 ? 256 : 1];
+  __shared__ double redc[64][4];
+  if ((int)blockIdx.x < nred) {
+    wgrad_reduce_body<SL>(blockIdx.x, red, part, count, splitk, dw, cin, rs, c_real);
+    return;
+  }
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int ch = ((int)blockIdx.x - nred) * 4 + cl;
+  double a1[4] = {0.0, 0.0, 0.0, 0.0};
+  if (ch < c) {
+    int b = rl;
+    for (; b + 3 * 64 < splits; b += 4 * 64) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a1[j] += (double)cs_part[((long long)(b + j * 64) * 2 + 0) * c + ch];
+    }
+    for (; b < splits; b += 64) a1[0] += (double)cs_part[((long long)b * 2 + 0) * c + ch];
+  }
+  redc[rl][cl] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+  __syncthreads();
+  if (rl != 0 || ch >= c) return;
+  double t1 = 0.0;
+  for (int j = 0; j < 64; ++j) t1 += redc[j][cl];  // fixed order: deterministic
+  cs_out[ch] = (float)t1;
+}
+
 static void launch_reduce(const float* part, long long count, int splitk, float* dw, int cin, int rs, int c_real, hipStream_t s) {
   const long long groups = count / 4;
   if (splitk <= 4)
@@ -574,6 +614,23 @@ static void launch_reduce(const float* part, long long count, int splitk, float*
     wgrad_reduce_kernel<16><<<ceil_div(groups, 16), 256, 0, s>>>(part, count, splitk, dw, cin, rs, c_real);
 }
 
+
+// split-K reduction + fold of the channel sums in one launch (wgrad_finish_kernel); the SL choice is launch_reduce's
+static void launch_finish(const float* part, long long count, int splitk, float* dw, int cin, int rs, int c_real, const float* cs_part, int splits,
+                          int c, float* cs_out, hipStream_t s) {
+  const long long groups = count / 4;
+  const int nfin = ceil_div(c, 4);
+  if (splitk <= 4) {
+    const int nred = (int)ceil_div(groups, 256);
+    wgrad_finish_kernel<1><<<nred + nfin, 256, 0, s>>>(part, count, splitk, dw, cin, rs, c_real, nred, cs_part, splits, c, cs_out);
+  } else if (splitk <= 32 || groups >= 16384) {
+    const int nred = (int)ceil_div(groups, 64);
+    wgrad_finish_kernel<4><<<nred + nfin, 256, 0, s>>>(part, count, splitk, dw, cin, rs, c_real, nred, cs_part, splits, c, cs_out);
+  } else {
+    const int nred = (int)ceil_div(groups, 16);
+    wgrad_finish_kernel<16><<<nred + nfin, 256, 0, s>>>(part, count, splitk, dw, cin, rs, c_real, nred, cs_part, splits, c, cs_out);
+  }
+}
 
 // ======================================================================================================================
 // 3x3 / stride 1 / pad 1 weight gradient, all nine taps in one block (bf16).
@@ -1239,7 +1296,7 @@ struct WgXform {  // operand transform of the 1x1 pointer-walking kernel (see Wg
 
 static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, float* dw, int c_real, void* workspace,
                       size_t workspace_bytes, sh_stream_t stream, int stem_hp = 0, int stem_wp = 0, float* dy_colsum = nullptr,
-                      const WgXform* xf = nullptr) {
+                      const WgXform* xf = nullptr, float* colsum_sum = nullptr) {
   SH_REQUIRE(d != nullptr, "conv2d_wgrad: desc is NULL");
   SH_REQUIRE(x && dy && dw && workspace, "conv2d_wgrad: NULL pointer");
   SH_REQUIRE(d->dtype == SH_F32 || d->dtype == SH_BF16, "conv2d_wgrad: bad dtype %d", d->dtype);
@@ -1290,7 +1347,8 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
     route_hit(SH_ROUTE_WGRAD_PLAIN);
     wgrad1x1_dma_kernel<<<sk * b.mt * b.nt, 512, 0, s1>>>(b);
     if (check_launch("conv2d_wgrad (1x1, DMA tiles)")) return 1;
-    launch_reduce(b.part, (long long)d->cout * d->cin, sk, dw, d->cin, 1, c_real, s1);
+    if (colsum_sum != nullptr) launch_finish(b.part, (long long)d->cout * d->cin, sk, dw, d->cin, 1, c_real, dy_colsum, sk, d->cout, colsum_sum, s1);
+    else launch_reduce(b.part, (long long)d->cout * d->cin, sk, dw, d->cin, 1, c_real, s1);
     return check_launch("conv2d_wgrad (1x1, DMA tiles) reduce");
   }
   WgradArgs a;
@@ -1386,7 +1444,8 @@ static int wgrad_impl(const sh_conv_desc* d, const void* x, const void* dy, floa
 #undef SH_WG
   if (check_launch("conv2d_wgrad")) return 1;
   const long long count = (long long)d->cout * d->cin * d->r * d->s;
-  launch_reduce(a.part, count, a.splitk, dw, d->cin, d->r * d->s, c_real, s);
+  if (colsum_sum != nullptr) launch_finish(a.part, count, a.splitk, dw, d->cin, d->r * d->s, c_real, dy_colsum, a.splitk, d->cout, colsum_sum, s);
+  else launch_reduce(a.part, count, a.splitk, dw, d->cin, d->r * d->s, c_real, s);
   return check_launch("conv2d_wgrad reduce");
 }
 
@@ -1408,6 +1467,23 @@ int simhand_conv2d_wgrad_colsum(const sh_conv_desc* d, const void* x, const void
                                 size_t workspace_bytes, sh_stream_t stream) {
   SH_REQUIRE(dy_colsum != nullptr, "conv2d_wgrad_colsum: NULL dy_colsum");
   return wgrad_impl(d, x, dy, dw, 0, workspace, workspace_bytes, stream, 0, 0, dy_colsum);
+}
+
+// the same, with the channel sums folded to dy_sum[cout] inside the reduction launch (dy_colsum stays the scratch it was)
+int simhand_conv2d_wgrad_colsum_sums(const sh_conv_desc* d, const void* x, const void* dy, float* dw, float* dy_colsum, float* dy_sum,
+                                     void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+  SH_REQUIRE(dy_colsum != nullptr && dy_sum != nullptr, "conv2d_wgrad_colsum_sums: NULL dy_colsum / dy_sum");
+  SH_REQUIRE(d != nullptr && simhand_conv2d_wgrad_splits(d) < 4096, "conv2d_wgrad_colsum_sums: >= 4096 splits (use simhand_conv2d_wgrad_colsum + simhand_bn_bwd_finalize_raw)");
+  return wgrad_impl(d, x, dy, dw, 0, workspace, workspace_bytes, stream, 0, 0, dy_colsum, nullptr, dy_sum);
+}
+
+int simhand_bn_apply_gram_sums(const sh_conv_desc* d, const void* y, const float* scale, const float* shift, int relu, void* a, float* s2,
+                               float* colsum_partial, float* colsum, void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+  SH_REQUIRE(d != nullptr && d->cin == d->cout, "bn_apply_gram_sums: the descriptor must be the c -> c 1x1 Gram descriptor");
+  SH_REQUIRE(y && scale && shift && a && s2 && colsum_partial && colsum, "bn_apply_gram_sums: NULL pointer");
+  SH_REQUIRE(simhand_conv2d_wgrad_splits(d) < 4096, "bn_apply_gram_sums: >= 4096 splits");
+  WgXform xf = {1, scale, shift, nullptr, nullptr, nullptr, nullptr, a, relu};
+  return wgrad_impl(d, y, y, s2, 0, workspace, workspace_bytes, stream, 0, 0, colsum_partial, &xf, colsum);
 }
 
 int simhand_bn_apply_gram(const sh_conv_desc* d, const void* y, const float* scale, const float* shift, int relu, void* a, float* s2,
@@ -1504,7 +1580,7 @@ static void stem_wgrad_desc(sh_conv_desc* d, int n, int h, int w, int dtype) {
 static bool stem_wgrad_ring_ok(int n, int h, int w, int dtype) {
   int hp, wp, ho, wo;
   if (n < 1 || dtype != SH_BF16 || !sw(SH_SW_STEM_WG_RING) || simhand_stem_geometry(h, w, &hp, &wp, &ho, &wo)) return false;
-  return stem_ring_geometry_ok(hp, wp, ho, wo);
+  return stem_ring_geometry_ok(hp, wp, ho, wo);  // 224^2 and, since round 6, 128^2 inputs
 }
 
 size_t simhand_stem_conv_wgrad_workspace_bytes(int n, int h, int w, int dtype) {
@@ -1527,7 +1603,7 @@ int simhand_stem_conv_wgrad(const void* xp, const void* dy, float* dw_oihw, void
     const double mo = (double)n * 112 * 112;
     ProfScope ps(SH_PROF_CONV_WGRAD, (hipStream_t)stream, 2.0 * mo * 64 * 147, 2.0 * (mo * 64 + (double)n * hp * wp * 4));
     route_hit(SH_ROUTE_WGRAD_STEM);
-    launch_stem_wgrad_ring(xp, dy, dw_oihw, (float*)workspace, n, hp, wp, (hipStream_t)stream);
+    launch_stem_wgrad_ring(xp, dy, dw_oihw, (float*)workspace, n, hp, wp, d.wo, (hipStream_t)stream);
     return check_launch("stem_conv_wgrad (LDS rings)");
   }
   return wgrad_impl(&d, xp, dy, dw_oihw, -1, workspace, workspace_bytes, stream, hp, wp);

@@ -39,15 +39,23 @@ __device__ __forceinline__ uint4 sb_frag_tr(const char* base, int stride, int co
 // (wgrad3x3_kernel's layout).  256 threads, 78 KB of LDS: two blocks per CU, persistent over images; deterministic per-block partials.
 struct StemWgradArgs {
   const bf16_t* xp;   // [n][hp][wp][4]
-  const bf16_t* dy;   // [n][112][112][64]
+  const bf16_t* dy;   // [n][WO][WO][64]
   float* part;        // [grid][64][224]
   int n, hp, wp;
 };
 
+// Round 6: the output width is a template parameter -- 112 (224 x 224 inputs) and 64 (128 x 128: the reference's `--resize` recipe,
+// training_config.json:38-41): KS = ceil(WO / 32) k-steps per conv row, WO / 8 dy pieces of 1 KB per row dealt to the four waves (PPW each,
+// the surplus into the sink), 1 + PPW DMAs per wave and step -- the counted wait follows.
+template <int WO>
 __global__ __launch_bounds__(256, 2) void stem_wgrad_ring_kernel(StemWgradArgs p) {
   constexpr int SLOT = 2048, NSLOT = 14, D = 2;   // rows 2 ho .. 2 ho + 10 live (11 consecutive rows); 14 slots keep two blocks per CU
-  constexpr int HO = 112, WO = 112;
-  constexpr int DYSLOT = 128 * 128;                    // 112 real pixel rows of 128 B + 16 rows that stay zero
+  constexpr int HO = WO;
+  constexpr int KS = (WO + 31) / 32;                   // 32-pixel k-steps per conv row
+  constexpr int PIECES = WO / 8, PPW = (PIECES + 3) / 4;
+  constexpr int ZR = KS * 32 - WO;                     // pixel rows of a dy slot that stay zero (16 at WO = 112)
+  constexpr int DYSLOT = KS * 32 * 128;                // WO real pixel rows of 128 B + ZR rows that stay zero
+  static_assert(WO % 8 == 0 && WO * 16 + 8 * 16 <= SLOT, "a padded input row must fit a ring slot");
   __shared__ __attribute__((aligned(16))) char ring[NSLOT * SLOT + 128];
   __shared__ __attribute__((aligned(16))) char dyr[3 * DYSLOT];
   __shared__ __attribute__((aligned(16))) char sink[1024];
@@ -70,9 +78,10 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_ring_kernel(StemWgradArgs p
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) dw[f][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // zero for the block's life: the ring's overrun pad, pixel rows 112..127 of the three dy slots
+  // zero for the block's life: the ring's overrun pad, pixel rows WO .. 32 KS - 1 of the three dy slots
   if (tid < 8) *reinterpret_cast<uint4*>(ring + NSLOT * SLOT + tid * 16) = make_uint4(0, 0, 0, 0);
-  for (int i = tid; i < 3 * 16 * 8; i += 256) *reinterpret_cast<uint4*>(dyr + (i / 128) * DYSLOT + 112 * 128 + (i % 128) * 16) = make_uint4(0, 0, 0, 0);
+  if (ZR > 0)
+    for (int i = tid; i < 3 * ZR * 8; i += 256) *reinterpret_cast<uint4*>(dyr + (i / (ZR * 8)) * DYSLOT + WO * 128 + (i % (ZR * 8)) * 16) = make_uint4(0, 0, 0, 0);
 
   // the lane's fixed part of the dy source address inside a 1-KB piece: pixel (lane >> 3) of the piece, LDS chunk lane & 7 = rotated group
   // (lane & 7) >> 1, half lane & 1; piece k holds pixels 8 k .. 8 k + 7, whose rotation (px >> 1) & 3 = (4 k + (lane >> 4)) & 3
@@ -86,20 +95,20 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_ring_kernel(StemWgradArgs p
       const bool ok = y < p.hp && c < nchunk;
       dma16(ok ? xbase + (long long)y * row_bytes + c * 16 : zsrc, ring_addr + (unsigned)(y % NSLOT) * SLOT + hf * 1024);
     };
-    // piece k (0..13) of dy row `row` -> slot row % 3
+    // piece k (0 .. PIECES - 1) of dy row `row` -> slot row % 3
     auto dma_dy = [&](int row, int k) __attribute__((always_inline)) {
       const int px = 8 * k + dpix;
       const int grp = ((dch >> 1) - ((px >> 1) & 3)) & 3;                 // LDS group = (source group + rotation) & 3
       const char* src = dybase + ((long long)row * WO + px) * 128 + (grp * 2 + (dch & 1)) * 16;
       dma16(row < HO ? src : zsrc, dyr_addr + (unsigned)(row % 3) * DYSLOT + k * 1024);
     };
-    // every wave issues FIVE DMAs per step: one input half row, four dy pieces (14 real ones over the four waves + two into the sink)
+    // every wave issues 1 + PPW DMAs per step: one input half row, PPW dy pieces (WO = 112: FIVE -- 14 real pieces over the four waves + two into the sink)
     auto dma_step = [&](int ho) __attribute__((always_inline)) {
       dma_in(2 * (ho + D) + 5 + (wave >> 1), wave & 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = wave * 4 + i;
-        if (k < 14) dma_dy(ho + D, k);
+      for (int i = 0; i < PPW; ++i) {
+        const int k = wave * PPW + i;
+        if (k < PIECES) dma_dy(ho + D, k);
         else dma16(zsrc, sink_addr);
       }
     };
@@ -109,21 +118,21 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_ring_kernel(StemWgradArgs p
 #pragma unroll
     for (int r0 = 0; r0 < D; ++r0)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = wave * 4 + i;
-        if (k < 14) dma_dy(r0, k);
+      for (int i = 0; i < PPW; ++i) {
+        const int k = wave * PPW + i;
+        if (k < PIECES) dma_dy(r0, k);
         else dma16(zsrc, sink_addr);
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int ho = 0; ho < HO; ++ho) {
-      // only LDS-DMAs in the vector-memory queue, five per wave and step, in order: everything but the previous step's five has landed
-      asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // only LDS-DMAs in the vector-memory queue, 1 + PPW per wave and step, in order: everything but the previous step's has landed
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(1 + PPW) : "memory");
       dma_step(ho);
       const char* dyb = dyr + (ho % 3) * DYSLOT;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         // A = dy^T: channel tile mt = 32-B group mt of the pixel row, rotated by (px >> 1) & 3; lane (p, g) supplies pixel 32 ks + 4 g + (p >> 2)
         uint4 af[4];
         {
@@ -187,11 +196,13 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const float* __res
 
 int stem_wgrad_ring_blocks(int n) { return n < 512 ? n : 512; }   // two blocks per CU
 
-int launch_stem_wgrad_ring(const void* xp, const void* dy, float* dw_oihw, float* workspace, int n, int hp, int wp, hipStream_t s) {
+int launch_stem_wgrad_ring(const void* xp, const void* dy, float* dw_oihw, float* workspace, int n, int hp, int wp, int wo, hipStream_t s) {
   StemWgradArgs a;
   a.xp = (const bf16_t*)xp; a.dy = (const bf16_t*)dy; a.part = workspace; a.n = n; a.hp = hp; a.wp = wp;
   const int grid = stem_wgrad_ring_blocks(n);
-  stem_wgrad_ring_kernel<<<grid, 256, 0, s>>>(a);
+  route_hit(SH_ROUTE_STEM_RING_WGRAD);
+  if (wo == 64) stem_wgrad_ring_kernel<64><<<grid, 256, 0, s>>>(a);
+  else stem_wgrad_ring_kernel<112><<<grid, 256, 0, s>>>(a);
   stem_bwd_reduce_kernel<<<(64 * 147 + 255) / 256, 256, 0, s>>>(workspace, grid, dw_oihw);
   return 0;
 }

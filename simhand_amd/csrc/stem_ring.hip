@@ -12,10 +12,12 @@
 // the kernel is not held by store latency but by the write rate itself, 3.3 GB in 1.12 ms next to 0.9 GB of reads.)
 // In the padded layout filter row r of output pixel (ho, wo) is the run of 8 taps x 4 channels at padded pixel (2 ho + r, 2 wo): the 8 k-elements of MFMA lane (li, g) -- taps 2g, 2g + 1 -- are the 16 bytes at byte 16 (wo + g) of
 // ring row 2 ho + r: ONE aligned ds_read_b128, consecutive lanes on consecutive chunks (conflict-free), no transposition, no gather.
-//   7 waves, one 16-pixel m-tile each (7 x 16 = 112 = the output row), all 64 output channels: 28 MFMAs per wave and output row against
-//   7 fragment reads; the 64 x 224 filter lives in registers (28 fragments = 112 VGPRs per lane) for the block's life;
+//   NW waves, one 16-pixel m-tile each (NW x 16 = the output row: 7 x 16 = 112 at 224^2), all 64 output channels: 28 MFMAs per wave and output
+//   row against 7 fragment reads; the 64 x 224 filter lives in registers (28 fragments = 112 VGPRs per lane) for the block's life;
 //   BatchNorm partial sums of the fp32 results ride in registers across the image: one [2][64] row per block (= per image).
-// Only for the 224 x 224 geometry (wo = 112); other sizes keep the activation-stationary kernel.
+// Round 6: NW is a template parameter -- 7 (224 x 224: BASELINE's geometry) and 4 (128 x 128: the reference's own `--resize` recipe,
+// src/experiments/config/training_config.json:38-41, two blocks per CU); other sizes keep the activation-stationary kernel (a padded row
+// of a 256 x 256 input no longer fits a 2-KB ring slot).
 //
 // (Round 4 also carried a two-pass / recompute form of the stem -- statistics-only and BN + ReLU + MaxPool-epilogue variants of this
 // kernel plus a fused backward: built, bit-exact, +1.0 ms in the step; removed in round 5, see docs/lab-notes.md and git history.)
@@ -46,11 +48,12 @@ struct StemRingArgs {
 // LT: the wave's 16 pixels x 128 B of an output row are 2 KB CONTIGUOUS in memory; with LT the packed chunks go through a wave-private
 // 2-KB LDS block (16-B chunks XOR-swizzled by the pixel, conflict-free both ways) and leave as two fully linear 1-KB store instructions
 // (lane l: bytes 16 l), the shape of the BatchNorm streaming passes, instead of 16 segments of 64 B per instruction.
-template <bool LT>
-__global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
+template <bool LT, int NW = 7>
+__global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void stem_ring_fwd_kernel(StemRingArgs p) {
+  static_assert(NW >= 4 && NW <= 8, "waves 0-3 are the loader waves; a block has at most 512 threads");
   constexpr int SLOT = 2048, NSLOT = 32, D = 2;  // D: steps between a row's request and its use (2 D + 7 <= NSLOT rows)
   __shared__ __attribute__((aligned(16))) char ring[NSLOT * SLOT];
-  __shared__ __attribute__((aligned(16))) char tbuf[LT ? 7 * 2048 : 16];
+  __shared__ __attribute__((aligned(16))) char tbuf[LT ? NW * 2048 : 16];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int img = blockIdx.x;
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
     }
 
   // ---- prologue: rows 0 .. 2 D + 4 (steps 0 .. D - 1), two half-row instructions each, over the 7 waves; waited for in full --------------
-  for (int k = wave; k < 2 * (2 * D + 5); k += 7) dma_half(k >> 1, k & 1);
+  for (int k = wave; k < 2 * (2 * D + 5); k += NW) dma_half(k >> 1, k & 1);
   // everything the prologue requested (filter fragments, rows) is waited for HERE, with the builtin: a load the compiler still counts as
   // pending on the loop's entry path would make its waitcnt pass drain the whole queue in every iteration (see conv_1x1.hip on vmcnt)
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (p.partial != nullptr) {
-    float* red = reinterpret_cast<float*>(ring);  // [7 waves][2][64]
+    float* red = reinterpret_cast<float*>(ring);  // [NW waves][2][64]
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
       const int which = tid >> 6, c = tid & 63;
       float t = 0.f;
 #pragma unroll
-      for (int wv = 0; wv < 7; ++wv) t += red[(wv * 2 + which) * 64 + c];
+      for (int wv = 0; wv < NW; ++wv) t += red[(wv * 2 + which) * 64 + c];
       p.partial[((long long)img * 2 + which) * 64 + c] = t;
     }
   }
@@ -172,13 +175,14 @@ __global__ __launch_bounds__(448, 1) void stem_ring_fwd_kernel(StemRingArgs p) {
 static hook_t g_stem_ring{-1};  // -1 = simhand_test_switch(SH_SW_STEM_RING) (default on), 0 / 1 forced
 void stem_ring_enable(int on) { g_stem_ring = on < 0 ? -1 : (on ? 1 : 0); }
 
-// the 224 x 224 geometry: one 16-pixel m-tile per wave of the 448-thread block, a padded row inside a 2-KB ring slot
-bool stem_ring_geometry_ok(int hp, int wp, int ho, int wo) { return wo == 112 && ho == 112 && wp * 8 <= 2048 && hp >= 2 * ho + 5; }
+// one 16-pixel m-tile per wave (wo = 16 NW with NW in {4, 7}: 128^2 and 224^2 inputs), a padded row inside a 2-KB ring slot
+static bool stem_ring_wo_ok(int wo) { return wo == 64 || wo == 112; }
+bool stem_ring_geometry_ok(int hp, int wp, int ho, int wo) { return stem_ring_wo_ok(wo) && ho == wo && wp * 8 <= 2048 && hp >= 2 * ho + 5; }
 
 bool stem_ring_ok(int n, int hp, int wp, int ho, int wo) {
   const int env = sw(SH_SW_STEM_RING);
   const int h = g_stem_ring;
-  return (h >= 0 ? h : env) && wo == 112 && wp * 8 <= 2048 && hp >= 2 * ho + 5 && n >= 1;
+  return (h >= 0 ? h : env) && stem_ring_wo_ok(wo) && wp * 8 <= 2048 && hp >= 2 * ho + 5 && n >= 1;
 }
 
 int launch_stem_ring(const void* xp, const void* w, void* y, float* partial, int n, int hp, int wp, int ho, int wo, hipStream_t s) {
@@ -186,8 +190,15 @@ int launch_stem_ring(const void* xp, const void* w, void* y, float* partial, int
   a.xp = (const bf16_t*)xp; a.w = (const bf16_t*)w; a.y = (bf16_t*)y; a.partial = partial;
   a.hp = hp; a.wp = wp; a.ho = ho; a.wo = wo;
   const int lt = sw(SH_SW_STEM_RING_LT);
-  if (lt) stem_ring_fwd_kernel<true><<<n, 448, 0, s>>>(a);
-  else stem_ring_fwd_kernel<false><<<n, 448, 0, s>>>(a);
+  route_hit(SH_ROUTE_STEM_RING_FWD);
+#define SH_SR(NW)                                                         \
+  do {                                                                    \
+    if (lt) stem_ring_fwd_kernel<true, NW><<<n, NW * 64, 0, s>>>(a);      \
+    else stem_ring_fwd_kernel<false, NW><<<n, NW * 64, 0, s>>>(a);        \
+  } while (0)
+  if (wo == 64) SH_SR(4);
+  else SH_SR(7);
+#undef SH_SR
   return 0;
 }
 

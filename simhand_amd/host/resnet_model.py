@@ -652,14 +652,15 @@ class ResNetEngine:
             f8 = self._fp8_site_bwd(u.conv, da.device)
         bw = ops.bn_backward(da, u.a, u.y, u.st, u.bn.weight.detach(), m, c, u.relu, False,
                              mask_from_y=u.relu and not u.has_res, relu_mask=relu_mask, raw_partial=raw_partial,
-                             apply=not (fuse_apply or fuse_dg), fp8_scaler=f8[0] if f8 is not None else None)
+                             apply=not (fuse_apply or fuse_dg), fp8_scaler=f8[0] if f8 is not None else None,
+                             want_coefs=fuse_apply or fuse_dg)
         dy, _, dg, db = bw[:4]
-        dyq = bw[4] if len(bw) > 4 else None
+        dyq = bw[4] if (len(bw) > 4 and not (fuse_apply or fuse_dg)) else None
+        coefs = bw[4] if (fuse_apply or fuse_dg) else None  # (A, B, C) of dy = A g - B y + C, from the launch that folded the sums
         grads[u.bn.weight] = dg
         grads[u.bn.bias] = db
         if fuse_dg:
             # data gradient FIRST: it derives dy from (da, y) while loading its operand rows and writes it out for the weight gradient
-            coefs = ops.bn_bwd_coefs(u.st, u.bn.weight.detach(), dg, db, m)
             pk = self._pack(u.conv, need_t=True)
             dy = torch.empty_like(u.y)
             dxm, _ = ops.conv2d_dgrad_ex(d, None, pk.crsk, dx=dx_into, accumulate=dx_into is not None, res_grad=res_grad, res_mask=res_mask,
@@ -668,7 +669,6 @@ class ResNetEngine:
             grads[w] = ops.conv2d_wgrad_oihw(d, u.x, dy, tuple(w.shape))
             return dxm, None
         if fuse_apply:
-            coefs = ops.bn_bwd_coefs(u.st, u.bn.weight.detach(), dg, db, m)
             grads[w], dy = ops.conv2d_wgrad_bnbwd(d, u.x, da, u.y, u.st, coefs, u.relu, tuple(w.shape))
         elif u.stem:
             grads[w] = ops.stem_conv_wgrad(u.x, dy, d.h, d.w)

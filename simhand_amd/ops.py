@@ -380,9 +380,15 @@ def conv2d_wgrad_colsum(d: ConvDesc, x, dy):
     nb = lib.simhand_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
     dw = torch.empty(d.cout, d.r * d.s * d.cin, dtype=torch.float32, device=x.device)
-    part = torch.empty(lib.simhand_conv2d_wgrad_splits(C.byref(d)), 2, d.cout, dtype=torch.float32, device=x.device)
-    check(lib.simhand_conv2d_wgrad_colsum(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(part), _ptr(ws), nb, _stream()), "conv2d_wgrad_colsum")
-    return dw, bn_channel_sums(part, d.cout)
+    splits = lib.simhand_conv2d_wgrad_splits(C.byref(d))
+    part = torch.empty(splits, 2, d.cout, dtype=torch.float32, device=x.device)
+    if _FOLD_LEGACY or splits >= 4096:  # round-5 form: the channel sums folded by a launch of their own
+        check(lib.simhand_conv2d_wgrad_colsum(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(part), _ptr(ws), nb, _stream()), "conv2d_wgrad_colsum")
+        return dw, bn_channel_sums(part, d.cout)
+    sums = torch.empty(d.cout, dtype=torch.float32, device=x.device)
+    check(lib.simhand_conv2d_wgrad_colsum_sums(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(part), _ptr(sums), _ptr(ws), nb, _stream()),
+          "conv2d_wgrad_colsum_sums")
+    return dw, sums
 
 
 def bn_apply_gram(y: torch.Tensor, st: "BNState", relu: bool = True):
@@ -395,10 +401,16 @@ def bn_apply_gram(y: torch.Tensor, st: "BNState", relu: bool = True):
     ws = torch.empty(nb, dtype=torch.uint8, device=y.device)
     a = torch.empty_like(y)
     s2 = torch.empty(c, c, dtype=torch.float32, device=y.device)
-    part = torch.empty(lib.simhand_conv2d_wgrad_splits(C.byref(d)), 2, c, dtype=torch.float32, device=y.device)
-    check(lib.simhand_bn_apply_gram(C.byref(d), _ptr(y, H16()), _ptr(st.scale), _ptr(st.shift), int(relu), _ptr(a), _ptr(s2), _ptr(part),
-                                    _ptr(ws), nb, _stream()), "bn_apply_gram")
-    return a, s2, bn_channel_sums(part, c)
+    splits = lib.simhand_conv2d_wgrad_splits(C.byref(d))
+    part = torch.empty(splits, 2, c, dtype=torch.float32, device=y.device)
+    if _FOLD_LEGACY or splits >= 4096:
+        check(lib.simhand_bn_apply_gram(C.byref(d), _ptr(y, H16()), _ptr(st.scale), _ptr(st.shift), int(relu), _ptr(a), _ptr(s2), _ptr(part),
+                                        _ptr(ws), nb, _stream()), "bn_apply_gram")
+        return a, s2, bn_channel_sums(part, c)
+    t2 = torch.empty(c, dtype=torch.float32, device=y.device)
+    check(lib.simhand_bn_apply_gram_sums(C.byref(d), _ptr(y, H16()), _ptr(st.scale), _ptr(st.shift), int(relu), _ptr(a), _ptr(s2), _ptr(part),
+                                         _ptr(t2), _ptr(ws), nb, _stream()), "bn_apply_gram_sums")
+    return a, s2, t2
 
 
 def bn_bwd_coefs(st: "BNState", gamma, dgamma, dbeta, m: int):
@@ -613,6 +625,19 @@ def bn_sync_active() -> bool:
     return _BN_SYNC is not None
 
 
+_TICKETS: dict = {}
+
+
+def _ticket(device) -> torch.Tensor:
+    """The zero-initialised ticket word of the CURRENT stream on `device` (simhand_bn_finalize_ticket: launches that may run concurrently
+    must not share one; every launch leaves it zero)."""
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(16, dtype=torch.int32, device=device)
+    return t
+
+
 def bn_partial_stats(y: torch.Tensor, m: int, c: int) -> torch.Tensor:
     lib = _lib_dev()
     nblk = lib.simhand_bn_stat_blocks(m, c)
@@ -637,9 +662,10 @@ def bn_finalize(part: torch.Tensor, m: int, c: int, gamma, beta, running_mean, r
     nblk = part.shape[0]
     nb = lib.simhand_bn_finalize_workspace_bytes(nblk, c)
     ws = torch.empty(nb, dtype=torch.uint8, device=part.device)
-    check(lib.simhand_bn_finalize(_ptr(part), nblk, m, c, _ptr(gamma), _ptr(beta), _ptr(pre_bias), eps, momentum,
-                                  _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(st.mean), _ptr(st.invstd),
-                                  _ptr(st.scale), _ptr(st.shift), _ptr(ws), nb, _stream()), "bn_finalize")
+    # one launch: the block that draws the last ticket finalizes (the ticket word is this stream's, zero between launches)
+    check(lib.simhand_bn_finalize_ticket(_ptr(part), nblk, m, c, _ptr(gamma), _ptr(beta), _ptr(pre_bias), eps, momentum,
+                                         _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(st.mean), _ptr(st.invstd),
+                                         _ptr(st.scale), _ptr(st.shift), _ptr(ws), nb, _ptr(_ticket(part.device)), _stream()), "bn_finalize_ticket")
     return st
 
 
@@ -666,7 +692,7 @@ def bn_apply(y, st: BNState, m: int, c: int, relu: bool, residual=None, out=None
 
 
 def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_dres: bool, mask_from_y: bool = False,
-                relu_mask=None, raw_partial=None, apply: bool = True, fp8_scaler: "Optional[FP8Scaler]" = None):
+                relu_mask=None, raw_partial=None, apply: bool = True, fp8_scaler: "Optional[FP8Scaler]" = None, want_coefs: bool = False):
     """Returns (dy, dres or None, dgamma, dbeta).  raw_partial: (sum g, sum g*y) tiles from conv2d_dgrad_fused -- the
     standalone partial-sum pass is skipped.  mask_from_y: the unit had no residual add, so the ReLU mask is
     recomputed from y (the stored activation is not read).  relu_mask: bit mask from bn_apply(want_mask=True) --
@@ -678,12 +704,19 @@ def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_d
     aa = relu_mask if mode == 3 else (a if mode == 1 else None)
     dg = torch.empty(c, dtype=torch.float32, device=dev)
     db = torch.empty(c, dtype=torch.float32, device=dev)
+    coefs = None
     if raw_partial is not None:
         # sums of g and g*y came out of the epilogue of the dgrad that produced `da` (conv2d_dgrad_fused)
         nb = lib.simhand_bn_bwd_finalize_raw_workspace_bytes(raw_partial.shape[0], c)
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-        check(lib.simhand_bn_bwd_finalize_raw(_ptr(raw_partial), raw_partial.shape[0], c, _ptr(st.mean), _ptr(st.invstd), _ptr(dg),
-                                              _ptr(db), _ptr(ws), nb, _stream()), "bn_bwd_finalize_raw")
+        if want_coefs and not apply and _BN_SYNC is None and not _FOLD_LEGACY:
+            # the consumer applies dy = A g - B y + C itself: (A, B, C) leave the launch that folds the sums (round 6)
+            coefs = torch.empty(3, c, dtype=torch.float32, device=dev)
+            check(lib.simhand_bn_bwd_finalize_raw_coefs(_ptr(raw_partial), raw_partial.shape[0], c, _ptr(st.mean), _ptr(st.invstd), _ptr(gamma), m,
+                                                        _ptr(dg), _ptr(db), _ptr(coefs), _ptr(ws), nb, _stream()), "bn_bwd_finalize_raw_coefs")
+        else:
+            check(lib.simhand_bn_bwd_finalize_raw(_ptr(raw_partial), raw_partial.shape[0], c, _ptr(st.mean), _ptr(st.invstd), _ptr(dg),
+                                                  _ptr(db), _ptr(ws), nb, _stream()), "bn_bwd_finalize_raw")
     else:
         nblk = lib.simhand_bn_stat_blocks(m, c)
         part = torch.empty(nblk, 2, c, dtype=torch.float32, device=dev)
@@ -693,6 +726,10 @@ def bn_backward(da, a, y, st: BNState, gamma, m: int, c: int, relu: bool, want_d
     if not apply:  # sums only: the caller fuses the apply into a consumer (conv2d_wgrad_bnbwd)
         if _BN_SYNC is not None:
             raise RuntimeError("bn_backward(apply=False): the fused-apply consumers take local sums; not available under bn_sync")
+        if want_coefs:
+            if coefs is None:  # (no raw partial sums, or the legacy chain: the coefficient launch of its own)
+                return None, None, dg, db, bn_bwd_coefs(st, gamma, dg, db, m)
+            return None, None, dg, db, (coefs[0], coefs[1], coefs[2])
         return None, None, dg, db
     dg_l, db_l = dg, db
     if _BN_SYNC is not None:  # dy needs the sums over every rank's positions; the returned parameter gradients stay local
@@ -1132,17 +1169,25 @@ def route_counts() -> dict:
 
 # include/simhand_hip.h enum sh_test_switch (the kernel-selection switches that were SIMHAND_* environment variables in round 3)
 TEST_SWITCHES = {"BN_GRID_APPLY": 0, "BN_GRID_BWD": 1, "R128": 2, "G1_PF": 3, "G1_CHAIN": 4, "G1_LT": 5, "FUSE_S2": 6, "WG_DMA": 7,
-                 "WG3_S2": 8, "WG_BIG": 9, "WG_WIDE": 10, "STEM_WG256": 11, "STEM_RING": 12, "STEM_RING_LT": 13, "STEM_WG_RING": 14, "N128": 15}
+                 "WG3_S2": 8, "WG_BIG": 9, "WG_WIDE": 10, "STEM_WG256": 11, "STEM_RING": 12, "STEM_RING_LT": 13, "STEM_WG_RING": 14, "N128": 15, "FOLD_LEGACY": 16}
+
+
+_FOLD_LEGACY = False  # mirror of SH_SW_FOLD_LEGACY for the wrappers below whose merged form is another ENTRY POINT, not another kernel
 
 
 def test_switch(name: str, value: int) -> None:
     """simhand_test_switch: value < 0 = the built-in default.  Tests / A-B timing only (bench.py --switch NAME=V)."""
+    global _FOLD_LEGACY
     check(_lib.load().simhand_test_switch(TEST_SWITCHES[name.upper()], int(value)), "test_switch")
+    if name.upper() == "FOLD_LEGACY":
+        _FOLD_LEGACY = int(value) > 0
 
 
 def hooks_reset() -> None:
     """Every test / tuning hook of the library back to its default."""
+    global _FOLD_LEGACY
     _lib.load().simhand_test_hooks_reset()
+    _FOLD_LEGACY = False
 
 
 # --------------------------------------------------------------------- profiler

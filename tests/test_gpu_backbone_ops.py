@@ -145,13 +145,16 @@ def test_stem_im2col_conv(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("n,h,w", [(3, 36, 36), (2, 64, 48), (5, 31, 45), (1, 224, 224), (3, 224, 224)])
+@pytest.mark.parametrize("n,h,w", [(3, 36, 36), (2, 64, 48), (5, 31, 45), (1, 224, 224), (3, 224, 224), (2, 128, 128), (5, 128, 128), (2, 256, 256)])
 def test_stem_direct_conv(dtype, n, h, w):
     """7x7/2 stem read straight from the zero-padded NHWC4 input (no im2col matrix): forward, fused BN partial sums and
-    weight gradient against ATen; odd sizes exercise the ragged last tile and the bottom/right halo; the 224 x 224 cases run the
-    one-block-per-image LDS-ring kernel (stem_ring.hip) and compare it bit for bit with the tile kernel."""
+    weight gradient against ATen; odd sizes exercise the ragged last tile and the bottom/right halo; the 224 x 224 cases -- and since round 6 the
+    128 x 128 ones (the reference's `--resize` recipe, training_config.json:38-41) -- run the one-block-per-image LDS-ring kernels
+    (stem_ring.hip, stem_bwd.hip; route counters asserted) and compare the forward bit for bit with the tile kernel; 256 x 256 (a padded row no
+    longer fits a ring slot) stays on the activation-stationary kernel."""
     from simhand_amd import ops
 
+    ops.route_reset()
     g = torch.Generator().manual_seed(12)
     x = torch.randn(n, 3, h, w, generator=g)
     wt = torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147)
@@ -168,6 +171,8 @@ def test_stem_direct_conv(dtype, n, h, w):
     assert torch.equal(xp.float().cpu(), ref)
     wpk = ops.stem_pack_weights(wt.to(DEV), dtype)
     yd, part = ops.stem_conv_fwd(xp, wpk, h, w)
+    ring = dtype == torch.bfloat16 and h == w and h in (128, 224)
+    assert ops.route_counts()["stem_ring_fwd"] == (1 if ring else 0)
     _check(yd.float().cpu().permute(0, 3, 1, 2), y.detach(), _tol(dtype), "stem fwd")
     m = n * ho * wo
     yf = y.detach().permute(0, 2, 3, 1).reshape(m, 64)
@@ -185,6 +190,7 @@ def test_stem_direct_conv(dtype, n, h, w):
             _check(part.sum(0).cpu(), part_tile.sum(0).cpu(), 1e-5, f"partials vs route {route}")
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
     dw = ops.stem_conv_wgrad(xp, dyd, h, w).cpu()
+    assert ops.route_counts()["stem_ring_wgrad"] == (1 if ring else 0)
     _check(dw, wr.grad, 2e-5 if dtype == torch.float32 else 2e-3, "stem wgrad")
 
 

@@ -198,6 +198,19 @@ BF16_ROUTES_RN50 = ("stem_fwd", "stem_bn_pool", "c64_fwd", "c64_dgrad", "gemm1x1
                     "bn_bwd_apply", "ntxent_fwd", "ntxent_bwd", "fwd_chain", "dgrad_dysrc", "fwd_bnin", "n128_fwd", "n128_dgrad")
 
 
+def test_rn50_handclr_w_bf16_at_the_reference_128px_geometry():
+    """The reference's own training geometry (README recipes pass --resize; src/experiments/config/training_config.json:38-41 resizes to 128 x 128):
+    the ResNet-50 handclr_w bf16 step at 128^2 against the oracle and its bf16-storage twin, with the routes the production dispatch takes at
+    that geometry asserted -- since round 6 the stem's LDS-ring kernels (forward and weight gradient) take 128 x 128 inputs too
+    (VERDICT r5 "Next" 4); stage grids 32^2 / 16^2 / 8^2 / 4^2."""
+    res = _run_case("HandCLR_W", "simhand_w", "50", dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg"), 16, 128, 13, True)
+    for r in BF16_ROUTES_RN50 + ("stem_ring_fwd", "stem_ring_wgrad", "r128_fwd", "r128_dgrad"):
+        assert res["routes"][r] > 0, f"the 128 x 128 step never ran the {r} route"
+    assert res["routes"]["stem_ring_fwd"] == 1 and res["routes"]["stem_ring_wgrad"] == 1
+    _check_bf16(res, loss_band=1e-2, zcos_floor=0.999, gmed_floor=0.995, gp10_floor=0.99, flip_frac=0.02)
+    assert res["z_min_cos_hip"] >= 0.995, res["z_min_cos_hip"]
+
+
 def test_config1_rn50_handclr_w_bf16_every_route_against_oracle():
     """BASELINE configs[1] arithmetic (ResNet-50 handclr_w, bf16, 224^2, linear MPJPE weights, crop + rotate un-warp) at 8
     pairs, with the 256 x 256 kernel taking every layer it legally can (as it does at the benchmarked 2048 images)."""

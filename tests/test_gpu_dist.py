@@ -95,7 +95,7 @@ def test_bench_self_launch_two_ranks():
     share = ["--share-gpu"] if torch.cuda.device_count() < 2 else []
     env["MASTER_PORT"] = "29655"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--per-gpu-batch", "8",
-                          "--resnet", "18", "--image-size", "64", "--no-cpu-baseline", *share], env=env, capture_output=True, text=True, timeout=900)
+                          "--resnet", "18", "--image-size", "64", "--no-cpu-baseline", *share], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
