@@ -204,7 +204,7 @@ def test_rn50_handclr_w_bf16_at_the_reference_128px_geometry():
     that geometry asserted -- since round 6 the stem's LDS-ring kernels (forward and weight gradient) take 128 x 128 inputs too
     (VERDICT r5 "Next" 4); stage grids 32^2 / 16^2 / 8^2 / 4^2."""
     res = _run_case("HandCLR_W", "simhand_w", "50", dict(weight_type="linear", diff_type="mpjpe", pos_neg="pos_neg"), 16, 128, 13, True)
-    for r in BF16_ROUTES_RN50 + ("stem_ring_fwd", "stem_ring_wgrad", "r128_fwd", "r128_dgrad"):
+    for r in BF16_ROUTES_RN50 + ("stem_ring_fwd", "stem_ring_wgrad"):
         assert res["routes"][r] > 0, f"the 128 x 128 step never ran the {r} route"
     assert res["routes"]["stem_ring_fwd"] == 1 and res["routes"]["stem_ring_wgrad"] == 1
     _check_bf16(res, loss_band=1e-2, zcos_floor=0.999, gmed_floor=0.995, gp10_floor=0.99, flip_frac=0.02)
