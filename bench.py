@@ -429,9 +429,36 @@ def main():
         reducer = shdist.OverlappedGradReducer(group, wire=args.grad_wire)
         model.encoder.engine.grad_reducer = reducer
     if world > 1:  # backbone gradients go out block by block during the backward pass; the head's follow in allreduce_gradients
+        comm_note = None
         if args.comm == "abi" and dist.get_backend() == "nccl":  # bootstrap over torch.distributed, data path on the ABI communicator
-            group = shdist.RcclComm.from_torch_distributed()
-            model.process_group = group
+            # the two ncclComms (compute stream + side stream) and a first all-reduce through each; EVERY rank must succeed, otherwise all ranks
+            # fall back to torch.distributed together (a line that says so is worth more than no line: this path has never met > 1 GPU)
+            ok, err = 1, ""
+            try:
+                group = shdist.RcclComm.from_torch_distributed()
+                probe = torch.ones(8, dtype=torch.float32, device=device)
+                group.all_reduce_(probe, "sum")
+                side = group.side_stream()
+                if side is not None:
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        group.all_reduce_(probe, "sum", side=True)
+                    torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                if abs(float(probe[0]) - float(world) ** (2 if side is not None else 1)) > 1e-3:
+                    raise RuntimeError(f"probe all-reduce returned {float(probe[0])} on {world} ranks")
+            except Exception as e:  # noqa: BLE001
+                ok, err, group = 0, repr(e)[:300], None
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag) == 0:
+                if group is not None:
+                    group.close()
+                group = None
+                comm_note = f"torch.distributed (FALLBACK: the ABI communicator failed on at least one rank{': ' + err if err else ''})"
+                print(f"bench.py[rank {rank}]: --comm abi unavailable, falling back to torch.distributed: {err or 'another rank failed'}", file=sys.stderr, flush=True)
+            else:
+                model.process_group = group
         reducer = shdist.OverlappedGradReducer(group, wire=args.grad_wire)
         model.encoder.engine.grad_reducer = reducer
         if args.sync_bn:
@@ -546,7 +573,7 @@ def main():
                        "parity": "n/a (the reference has no fp8 path)" if parity is None else parity,
                        "world_size_backend": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none",
-                       "comm": ("abi (simhand_comm_*)" if group is not None else "torch.distributed") if world > 1 else "none",
+                       "comm": (comm_note or ("abi (simhand_comm_*: two ncclComms, gradient buckets on the side stream)" if group is not None else "torch.distributed")) if world > 1 else "none",
                        "grad_wire": args.grad_wire if world > 1 else "n/a",
                        "batchnorm": "synchronised" if (world > 1 and args.sync_bn) else "per-rank statistics",
                        "ab_hooks": (args.switch + args.engine + ([f"lib={args.lib}"] if args.lib else []) + ([f"lib_f16={args.lib_f16}"] if args.lib_f16 else []))
