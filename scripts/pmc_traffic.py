@@ -27,7 +27,7 @@ cls = {"conv_fwd": (r"igemm_kernel<unsigned short, false", r"igemm256_kernel<fal
                     r"conv3x3_r128_kernel<[01]", r"gemm_n128_kernel<false", r"stem_ring_fwd_kernel", r"igemm_kernel<float, false"),
        "conv_dgrad": (r"igemm_kernel<unsigned short, true", r"igemm256_kernel<true", r"gemm1x1_kernel<\d+, \d+, true", r"conv3x3_c64_kernel<2",
                       r"conv3x3_r128_kernel<2", r"conv3x3_r128_s2dgrad_kernel", r"gemm_n128_kernel<true", r"igemm_kernel<float, true"),
-       "conv_wgrad": (r"wgrad_kernel<", r"wgrad3x3_kernel", r"wgrad1x1_dma_kernel", r"stem_wgrad_ring_kernel", r"wgrad_reduce_kernel", r"stem_bwd_reduce_kernel")}
+       "conv_wgrad": (r"wgrad_kernel<", r"wgrad3x3_kernel", r"wgrad1x1_dma_kernel", r"stem_wgrad_ring_kernel", r"wgrad_reduce_kernel", r"wgrad_finish_kernel", r"stem_bwd_reduce_kernel")}
 fam = {"batchnorm passes": (r"bn_apply_kernel", r"bn_bwd_apply", r"bn_bwd_partial", r"bn_partial", r"bn_relu_maxpool", r"pool_bn_bwd", r"bn_finalize", r"bn_bwd_finalize"),
        "folded-BatchNorm algebra": (r"fold_", r"bn_fold"),
        "pooling / layout / packing": (r"pool", r"subsample", r"scatter", r"pack_", r"stem_pad", r"nchw", r"cast"),

@@ -29,10 +29,11 @@ cat "$out/${tag}_bench_b1024.json"
 [ "$fast" = 1 ] && { ls -la "$out"; exit 0; }
 # the other configurations of the same step on this box (one line each): simclr bf16 vs fp8 (BASELINE configs[4] arithmetic; also at its
 # per-GPU batch of 2048 pairs = 4096 images), precision 16
-# (fp16 storage + GradScaler: the reference's policy), ResNet-18 / ResNet-152
+# (fp16 storage + GradScaler: the reference's policy), ResNet-18 / ResNet-152, and the reference's own 128 x 128 geometry (training_config.json:38-41)
+# at a matched pixel count (3136 pairs) and at the headline's pair count
 {
-  for cfg in "--experiment simclr" "--experiment simclr --precision fp8" "--experiment simclr --per-gpu-batch 2048" "--experiment simclr --precision fp8 --per-gpu-batch 2048" "--precision 16" "--resnet 18" "--resnet 152 --experiment peclr_w --per-gpu-batch 512"; do
-    python bench.py --steps 8 --warmup 3 --no-cpu-baseline $cfg 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.readlines()[-1]); print('| bench.py $cfg |', round(d['ms_per_step'], 2), 'ms/step |', round(d['value']), 'pairs/s |', d['dtype'], '|')"
+  for cfg in "--experiment simclr" "--experiment simclr --precision fp8" "--experiment simclr --per-gpu-batch 2048" "--experiment simclr --precision fp8 --per-gpu-batch 2048" "--precision 16" "--resnet 18" "--resnet 152 --experiment peclr_w --per-gpu-batch 512" "--image-size 128 --per-gpu-batch 3136" "--image-size 128"; do
+    python bench.py --steps 8 --warmup 3 --no-cpu-baseline $cfg 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.readlines()[-1]); print('| bench.py $cfg |', round(d['ms_per_step'], 2), 'ms/step |', round(d['value']), 'pairs/s |', d['dtype'], '|', round(d['roofline']['step_tflops_per_gpu']), 'TFLOP/s whole step =', round(d['roofline']['step_tflops_per_gpu'] / d['roofline']['peak'], 3), 'of', round(d['roofline']['peak']), '| dominant class', d['roofline']['kernel'], round(d['roofline']['frac'], 3), '|')"
   done
 } > "$out/${tag}_other_configs.md"
 cat "$out/${tag}_other_configs.md"
