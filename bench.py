@@ -94,6 +94,8 @@ def parse():
     ap.add_argument("--lib-f16", default=None, metavar="PATH", help="A/B timing only: another build of libsimhand_hip_f16.so")
     ap.add_argument("--no-loss-scaling", action="store_true", help="--precision 16 without the GradScaler (timing split only)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline AND the precision-16 companion line (profiling / A-B runs)")
+    ap.add_argument("--no-parity-probe", action="store_true",
+                    help="skip the smoke-size oracle comparison in front of the run (rocprofv3 passes: its ResNet-18 launches would be counted into the tables)")
     ap.add_argument("--cpu-pairs", type=int, default=32,
                     help="pairs in the CPU-baseline sample (default = the SURVEY 8d point B = 32; ~40 s on the box's host for ResNet-50)")
     ap.add_argument("--cpu-full", action="store_true",
@@ -374,7 +376,7 @@ def main():
     # not running the probe)
     parity = None
     env_rank, env_local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-    if env_rank == 0 and args.precision != "fp8":
+    if env_rank == 0 and args.precision != "fp8" and not args.no_parity_probe:
         import __graft_entry__ as entry
 
         _lib.require_device()
@@ -570,7 +572,7 @@ def main():
                                    f"crop+rotate un-warp, global negatives",
                        "global_batch": global_pairs, "per_gpu_batch": args.per_gpu_batch, "image_size": args.image_size,
                        "parallelism": f"dp{world}", "loss": final_loss,
-                       "parity": "n/a (the reference has no fp8 path)" if parity is None else parity,
+                       "parity": parity if parity is not None else ("n/a (the reference has no fp8 path)" if args.precision == "fp8" else "not probed (--no-parity-probe)"),
                        "world_size_backend": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none",
                        "comm": (comm_note or ("abi (simhand_comm_*: two ncclComms, gradient buckets on the side stream)" if group is not None else "torch.distributed")) if world > 1 else "none",

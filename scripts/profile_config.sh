@@ -12,10 +12,10 @@ out=$root/gpurun_out/cfg
 mkdir -p "$out"
 export TMPDIR=/tmp
 rm -rf /tmp/pc_kt /tmp/pc_f /tmp/pc_w
-rocprofv3 --kernel-trace --stats -d /tmp/pc_kt -o kt -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /tmp/pc_kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/pc_kt -o kt -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-probe "$@" > /tmp/pc_kt.log 2>&1
 python scripts/rocpd_stats.py /tmp/pc_kt/kt_results.db "$out/${tag}_kernel_stats.md" > /dev/null || tail -5 /tmp/pc_kt.log
-rocprofv3 --pmc FETCH_SIZE -d /tmp/pc_f -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > /tmp/pc_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d /tmp/pc_w -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > /tmp/pc_w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d /tmp/pc_f -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-probe "$@" > /tmp/pc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d /tmp/pc_w -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-probe "$@" > /tmp/pc_w.log 2>&1
 python scripts/pmc_traffic.py /tmp/pc_f/f_results.db /tmp/pc_w/w_results.db "$out/${tag}_hbm_traffic.md" "$out/${tag}_hbm_traffic.json" > /dev/null || tail -5 /tmp/pc_f.log
 python scripts/layer_table.py --images "$images" $lt_args --out "$out/${tag}_layer_table.md" > /dev/null 2> /tmp/pc_lt.log || tail -5 /tmp/pc_lt.log
 python bench.py --steps 8 --warmup 3 --no-cpu-baseline "$@" 2> /tmp/pc_b.log | tail -1 > "$out/${tag}.json" || tail -5 /tmp/pc_b.log

@@ -11,6 +11,6 @@ bash scripts/profile_config.sh r06_rn50_128px 6272 "--image-size 128" -- --image
 bash scripts/profile_config.sh r06_fp8_b2048 4096 "" -- --experiment simclr --precision fp8 --per-gpu-batch 2048
 bash scripts/profile_config.sh r06_rn152_b512 1024 "--resnet 152" -- --resnet 152 --experiment peclr_w --per-gpu-batch 512
 rm -rf /tmp/tl
-rocprofv3 --kernel-trace -d /tmp/tl -o tl -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline > /tmp/tl.log 2>&1
+rocprofv3 --kernel-trace -d /tmp/tl -o tl -- python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-parity-probe > /tmp/tl.log 2>&1
 python scripts/timeline.py /tmp/tl/tl_results.db gpurun_out/cfg/r06_step_timeline.txt
 head -1 gpurun_out/cfg/r06_step_timeline.txt

@@ -10,17 +10,17 @@ root=$(pwd)
 out=$root/gpurun_out/refresh
 rm -rf "$out" && mkdir -p "$out"
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-probe > /tmp/kt.log 2>&1
 python scripts/rocpd_stats.py /tmp/prof_kt/kt_results.db "$out/${tag}_bench_b1024_kernel_stats.md" > /dev/null
-rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_f -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_w -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_f -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-probe > /tmp/f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_w -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-probe > /tmp/w.log 2>&1
 python scripts/pmc_traffic.py /tmp/prof_f/f_results.db /tmp/prof_w/w_results.db "$out/${tag}_bench_b1024_hbm_traffic.md" "$out/hbm_traffic.json" > /dev/null
 fast=${REFRESH_FAST:-0}
 # matrix-core utilisation (own pass: counters only, program directly after --)
-[ "$fast" = 1 ] || rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d /tmp/prof_m -o m -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/m.log 2>&1
+[ "$fast" = 1 ] || rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d /tmp/prof_m -o m -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-probe > /tmp/m.log 2>&1
 [ "$fast" = 1 ] || python scripts/pmc_mfma.py /tmp/prof_m/m_results.db "$out/${tag}_bench_b1024_mfma_util.md" /tmp/prof_kt/kt_results.db > /dev/null || tail -5 /tmp/m.log
 [ "$fast" = 1 ] || python scripts/layer_table.py --out "$out/${tag}_layer_table.md" > /dev/null 2>&1
-tail -3 /tmp/f.log /tmp/w.log | cut -c1-200
+tail -n 3 /tmp/f.log | cut -c1-200; tail -n 3 /tmp/w.log | cut -c1-200
 # the bench line last: its roofline.traffic reads the PMC-derived bytes per launch written just above
 cp "$out/hbm_traffic.json" "$root/profiles/hbm_traffic.json"
 python bench.py --cpu-full > "$out/${tag}_bench_b1024.log" 2>&1

@@ -368,6 +368,76 @@ def test_sharded_loss_and_grad_allreduce_gloo(tmp_path, world):
         assert f"rank {r} ok" in o
 
 
+TRANSPORT_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from simhand_amd.host import dist as shdist
+from tests import _gloo_staging
+rank, local, world = shdist.init_from_env("gloo")
+tot = world * (world + 1) // 2
+for mode in (None, "all", "buckets", "thread", "off"):
+    shdist.set_transport(None if mode is None else _gloo_staging.GlooStagingTransport(mode))   # "thread": the twin group is created HERE, on every rank
+    t = torch.full((5,), float(rank + 1)); shdist.all_reduce_(t)
+    assert torch.equal(t, torch.full((5,), float(tot))), (mode, t)
+    out = torch.empty(world * 3); shdist.all_gather_into(out, torch.full((3,), float(rank)))
+    assert torch.equal(out, torch.arange(world, dtype=torch.float32).repeat_interleave(3)), (mode, out)
+    m = torch.nn.Linear(3, 2); shdist.broadcast_module_state(m)
+    ref = [p.detach().clone() for p in m.parameters()]
+    for q in ref: dist.broadcast(q, src=0)
+    assert all(torch.equal(a, b) for a, b in zip(m.parameters(), ref)), mode
+    red = shdist.OverlappedGradReducer(bucket_bytes=16)
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (6, 5, 3)]
+    red.submit([(p, torch.full((p.numel(),), float(rank + 1) * (i + 1))) for i, p in enumerate(ps)])
+    got = red.finish()
+    assert all(torch.equal(got[p], torch.full((p.numel(),), float(tot) * (i + 1))) for i, p in enumerate(ps)), mode
+    assert red.side_buckets == 0
+shdist.set_transport(None)
+try:
+    _gloo_staging.GlooStagingTransport("sometimes")
+    raise SystemExit("expected a ValueError")
+except ValueError:
+    pass
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_transports_of_the_data_parallel_module_gloo_world2(tmp_path):
+    """host/dist.py hands tensors to torch.distributed through a replaceable transport (round 6): the product transport and every mode of the
+    shared-GPU test transport (tests/_gloo_staging.py; host tensors pass through untouched, "thread" creates its twin group eagerly on all
+    ranks) carry all_reduce_ / all_gather_into / broadcast_module_state / the overlapped bucket reducer to the same results."""
+    script = tmp_path / "tworker.py"
+    script.write_text(TRANSPORT_WORKER)
+    world = 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29627", WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+        assert f"rank {r} ok" in o
+
+
+def test_product_modules_read_only_the_documented_environment_variables():
+    """the package reads the rendezvous variables and SAVED_MODELS_BASE_PATH (the reference's own), nothing else."""
+    import re
+
+    allowed = {"WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY", "SAVED_MODELS_BASE_PATH", "PL_GLOBAL_SEED"}
+    found = set()
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "simhand_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                found |= set(re.findall(r"os\.environ(?:\.get|\.setdefault)?\s*[\[(]\s*[\"']([A-Za-z0-9_]+)[\"']", src))
+                found |= set(re.findall(r"getenv\(\s*[\"']([A-Za-z0-9_]+)[\"']", src))
+                if "HSA_IPC_ENV" in src:
+                    found.add("HSA_ENABLE_IPC_MODE_LEGACY")
+    assert found <= allowed, sorted(found - allowed)
+    for f in os.listdir(os.path.join(ROOT, "simhand_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(ROOT, "simhand_amd", "csrc", f)).read(), f
+
+
 def _torchvision_resnet_keys(layers, bottleneck):
     """The state-dict key list of torchvision.models.resnet{18,34,50,101,152} (v0.13), written out from its published
     module structure: conv1, bn1, layer1..4 (blocks with conv/bn pairs and an optional downsample = Sequential(conv, bn)), fc."""
