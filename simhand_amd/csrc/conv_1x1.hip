@@ -331,8 +331,12 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
     for (int mi = 0; mi < (EP ? MF : 1); ++mi) {
       const long long row = mbase + mi * 16 + li;
       const long long ra = mbase + mi * 16 + (lane >> 3), rb = ra + 8;  // line-shaped: rows l >> 3 and + 8, chunk l & 7
-      rq[mi][0] = *reinterpret_cast<const uint4*>(p.ep_res + (FAST || ra < p.M ? ra : 0) * p.N + nc2 * 64 + (lane & 7) * 8);
-      rq[mi][1] = *reinterpret_cast<const uint4*>(p.ep_res + (FAST || rb < p.M ? rb : 0) * p.N + nc2 * 64 + (lane & 7) * 8);
+      // non-temporal (round 6): the residual is the block INPUT on its last forward use and 3.3 GB wide at stage 1 -- streaming it past the
+      // caches (and the output below) leaves L2 to the weight tiles every block re-reads: -0.6 ms per step, three same-box pairs
+      // (profiles/r06_cache_policy_ab.txt; the same hint on the data gradient's residual-gradient rows and stores costs +0.9 ms: those tensors are
+      // re-read by the very next launches)
+      rq[mi][0] = ld16<true>(p.ep_res + (FAST || ra < p.M ? ra : 0) * p.N + nc2 * 64 + (lane & 7) * 8);
+      rq[mi][1] = ld16<true>(p.ep_res + (FAST || rb < p.M ? rb : 0) * p.N + nc2 * 64 + (lane & 7) * 8);
     }
   };
   if constexpr (EP) {
@@ -689,8 +693,11 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
                 const uint4 r0 = *reinterpret_cast<const uint4*>(tw + tr0), r1 = *reinterpret_cast<const uint4*>(tw + tr0 + 1024);
                 const long long rowa = mbase + mi * 16 + (lane >> 3);
                 bf16_t* da = p.out + rowa * p.N + n0 + (lane & 7) * 8;
-                if (FAST || rowa < p.M) *reinterpret_cast<uint4*>(da) = r0;
-                if (FAST || rowa + 8 < p.M) *reinterpret_cast<uint4*>(da + 8ll * p.N) = r1;
+                // linear stores: forward launches only (SH_SW_G1_LT bit 0).  Non-temporal when the epilogue is the BatchNorm + residual form (EP != 0:
+                // the block output, next read two launches later and far larger than the caches); the plain forward's raw conv output is read by
+                // the very next launch and stays cached
+                if (FAST || rowa < p.M) st16<(EP != 0 && !DGRAD)>(da, r0);
+                if (FAST || rowa + 8 < p.M) st16<(EP != 0 && !DGRAD)>(da + 8ll * p.N, r1);
                 if constexpr (EP != 0) {
                   if (EP == 2 || (EP == 1 && p.ep_relu && p.ep_mask != nullptr)) {
                     // the pixel's eight mask bytes (chunks g and 4 + g of the four lanes li + 16 g) meet in one lane: one 8-B store per

@@ -1085,7 +1085,9 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
           for (int mi = 0; mi < MI; ++mi) {
             const long long pix = pixel_of(mi);
             // (rows past the range read row 0, never used: a conditional load is waited for at the join, one round trip per row)
-            rq[mi] = *reinterpret_cast<const uint4*>(res + (pix < 0 ? 0 : pix) * p.Ng + ch);
+            // non-temporal (round 6, as in conv_1x1.hip): the residual on its last forward use and the block output below stream past the
+            // caches -- forward class -0.35 ms per step in three same-box pairs (profiles/r06_cache_policy_ab.txt)
+            rq[mi] = ld16<true>(res + (pix < 0 ? 0 : pix) * p.Ng + ch);
           }
         }
 #pragma unroll
@@ -1116,7 +1118,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
             }
             if (p.ep_mask != nullptr) p.ep_mask[pix * (p.Ng / 8) + ch / 8] = (unsigned char)bits;
           }
-          Vec16<bf16_t>::store(outb + pix * p.Ng + ch, o);
+          Vec16<bf16_t>::store<true>(outb + pix * p.Ng + ch, o);
         }
       }
     } else if (!DGRAD || p.fpartial == nullptr) {
