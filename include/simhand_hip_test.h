@@ -64,7 +64,7 @@ enum sh_test_switch {
   SH_SW_R128 = 2,          /* conv3x3_r128_kernel for the 128-channel 3x3 layers (default 1) */
   SH_SW_G1_PF = 3,         /* branch-free fast variants of gemm1x1_kernel per K: bit 0 K = 64, bit 1 K = 128, bit 2 K = 256 (default 7) */
   SH_SW_G1_CHAIN = 4,      /* chained next conv1 per K: bit 0 K = 64, bit 1 K = 128 (default 1); simhand_test_conv1x1_chain_mask overrides */
-  SH_SW_G1_LT = 5,         /* linear epilogue stores of gemm1x1_kernel: bit 0 forward, bit 1 data gradient (default 1) */
+  SH_SW_G1_LT = 5,         /* linear epilogue stores of gemm1x1_kernel: bit 0 forward, bit 1 data gradient (default 3; round 6: the data gradient too, -0.2 ms in its class) */
   SH_SW_FUSE_S2 = 6,       /* BN-backward sums fused into stride-2 3x3 data gradients: 1 all, 2 only on the 256-wide kernel (default 0) */
   SH_SW_WG_DMA = 7,        /* wgrad1x1_dma_kernel (default 1) */
   SH_SW_WG3_S2 = 8,        /* stride-2 form of wgrad3x3_kernel (default 1) */

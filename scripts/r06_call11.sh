@@ -3,8 +3,8 @@ set -u
 mkdir -p gpurun_out/cfg
 {
 for i in 1 2 3; do
-for v in "" "--lib scripts/abl/libstemnt.so"; do
+for v in "" "--lib scripts/abl/libbnst256.so" "--lib scripts/abl/libbnst1024.so"; do
 python bench.py --no-cpu-baseline --no-parity-probe --steps 8 --warmup 3 $v 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_step']; print('[$v]'.ljust(40), round(d['ms_per_step'],2), {a: round(b,2) for a,b in k.items() if a in ('conv_fwd','conv_dgrad','conv_wgrad','bn','misc')})"
 done; done
-} > gpurun_out/cfg/r06_stem_nt_ab.txt 2>&1
-cat gpurun_out/cfg/r06_stem_nt_ab.txt
+} > gpurun_out/cfg/r06_bn_cached_st_ab.txt 2>&1
+cat gpurun_out/cfg/r06_bn_cached_st_ab.txt

@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
                 const uint4 r0 = *reinterpret_cast<const uint4*>(tw + tr0), r1 = *reinterpret_cast<const uint4*>(tw + tr0 + 1024);
                 const long long rowa = mbase + mi * 16 + (lane >> 3);
                 bf16_t* da = p.out + rowa * p.N + n0 + (lane & 7) * 8;
-                // linear stores: forward launches only (SH_SW_G1_LT bit 0).  Non-temporal when the epilogue is the BatchNorm + residual form (EP != 0:
+                // linear stores (SH_SW_G1_LT: bit 0 forward, bit 1 data gradient).  Non-temporal when the epilogue is the BatchNorm + residual form (EP != 0:
                 // the block output, next read two launches later and far larger than the caches); the plain forward's raw conv output is read by
                 // the very next launch and stays cached
                 if (FAST || rowa < p.M) st16<(EP != 0 && !DGRAD)>(da, r0);
@@ -847,7 +847,8 @@ bool gemm1x1_sub_ok(const Gemm1x1Args& a, int k) {
 }
 
 int launch_gemm1x1(const Gemm1x1Args& a_in, int k, bool dgrad, hipStream_t s) {
-  // bit 0: forward launches, bit 1: data gradients (measured neutral there: their stores are not what they wait for)
+  // bit 0: forward launches, bit 1: data gradients (round 4: measured neutral there; round 6, re-measured on the final tree: data-gradient class
+  // 34.54 -> 34.32 ms in three same-box pairs, profiles/r06_cache_policy_ab.txt -- on by default now)
   const int lt_env = sw(SH_SW_G1_LT);
   Gemm1x1Args a = a_in;
   a.lt = (lt_env >> (dgrad ? 1 : 0)) & 1;

@@ -74,7 +74,7 @@ ProfScope::~ProfScope() {
 }
 
 static hook_t g_sw[SH_SW_COUNT];
-static const int g_sw_default[SH_SW_COUNT] = {131072, 131072, 1, 7, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0};
+static const int g_sw_default[SH_SW_COUNT] = {131072, 131072, 1, 7, 1, 3, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0};
 static struct SwInit { SwInit() { for (auto& h : g_sw) h.store(-1, std::memory_order_relaxed); } } g_sw_init;
 int sw(int which) {
   const int v = g_sw[which].load(std::memory_order_relaxed);
