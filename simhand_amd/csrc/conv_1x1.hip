@@ -696,8 +696,11 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
                 // linear stores (SH_SW_G1_LT: bit 0 forward, bit 1 data gradient).  Non-temporal when the epilogue is the BatchNorm + residual form (EP != 0:
                 // the block output, next read two launches later and far larger than the caches); the plain forward's raw conv output is read by
                 // the very next launch and stays cached
-                if (FAST || rowa < p.M) st16<(EP != 0 && !DGRAD)>(da, r0);
-                if (FAST || rowa + 8 < p.M) st16<(EP != 0 && !DGRAD)>(da + 8ll * p.N, r1);
+                // ... and for the DATA gradient of the stage-1 / stage-2 layers (K <= 128: dx is 3.3 / 1.6 GB, far beyond the caches, although the next
+                // launch reads it): -0.6 ms per step in three same-box pairs; at K = 256 (0.8 GB) the hint is neutral (profiles/r06_cache_policy_ab.txt)
+                constexpr bool NT_OUT = (EP != 0 && !DGRAD) || (DGRAD && !FUSE && K <= 128);
+                if (FAST || rowa < p.M) st16<NT_OUT>(da, r0);
+                if (FAST || rowa + 8 < p.M) st16<NT_OUT>(da + 8ll * p.N, r1);
                 if constexpr (EP != 0) {
                   if (EP == 2 || (EP == 1 && p.ep_relu && p.ep_mask != nullptr)) {
                     // the pixel's eight mask bytes (chunks g and 4 + g of the four lanes li + 16 g) meet in one lane: one 8-B store per
