@@ -348,6 +348,23 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
   }
 
   // ---- PF: residual gradient + masks of chunk 0
+  // Round 6: the block's rows of the 1-bit masks are staged in LDS ONCE.  A mask row is N / 8 bytes (128 at N = 1024) of which every 64-channel
+  // chunk uses 8: read from global memory chunk by chunk, a row's line had to survive in L2 for the whole life of the block -- under this
+  // kernel's own streams it did not, and rocprofv3 counted 1.75 GB of HBM reads per launch where the operands are 1.13 GB (1024 <- 256 @ 14^2,
+  // 2048 images: profiles/r06_g1_dgrad_traffic.txt).  16-B slots XOR-swizzled by the row: the 16 rows a read touches spread over the banks.
+  constexpr int MROWS = 64 * MF, MRB = K == 64 ? 32 : 128;   // staged rows, bytes per staged row (N <= 256 at K = 64, <= 1024 otherwise: launch_gemm1x1)
+  __shared__ __attribute__((aligned(16))) char sMk[PF ? (PF == 1 ? 2 : 1) * MROWS * MRB : 16];
+  const int mnb = p.N >> 3, mnv = mnb >> 4;                  // bytes / 16-B vectors per mask row
+  if constexpr (PF != 0) {
+    const long long brow = (long long)blockIdx.x * MROWS;
+    for (int v = tid; v < MROWS * mnv; v += 256) {
+      const int row = v / mnv, c = v - row * mnv;
+      const int dst = row * MRB + ((c ^ (row & (mnv - 1))) << 4);
+      *reinterpret_cast<uint4*>(sMk + dst) = *reinterpret_cast<const uint4*>(p.fmask + (brow + row) * mnb + c * 16);
+      if constexpr (PF == 1)
+        *reinterpret_cast<uint4*>(sMk + MROWS * MRB + dst) = *reinterpret_cast<const uint4*>(p.res_mask + (brow + row) * mnb + c * 16);
+    }
+  }
   uint4 pg[PF ? MF : 1][2];
   uint2 pm[PF ? MF : 1], pk[PF ? MF : 1];
   // PF == 3: the shortcut gradient `sub` lives on the EVEN pixels.  A 16-pixel group starts on an even column (M, W even), so its eight even
@@ -380,9 +397,12 @@ __global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 
         const long long ra = mbase + mi * 16 + (lane >> 3);  // line-shaped: rows l >> 3 and + 8, chunk l & 7 (whole blocks: every row exists)
         pg[mi][0] = *reinterpret_cast<const uint4*>(p.res_grad + ra * p.N + nc2 * 64 + (lane & 7) * 8);
         pg[mi][1] = *reinterpret_cast<const uint4*>(p.res_grad + (ra + 8) * p.N + nc2 * 64 + (lane & 7) * 8);
-        pm[mi] = *reinterpret_cast<const uint2*>(p.res_mask + r * (p.N >> 3) + nc2 * 8);
       }
-      pk[mi] = *reinterpret_cast<const uint2*>(p.fmask + r * (p.N >> 3) + nc2 * 8);
+      // the chunk's 8 mask bytes of this lane's pixel row, from the staged copy (row of the block = wave * 16 MF + mi * 16 + li)
+      const int lrow = wave * (16 * MF) + mi * 16 + li;
+      const int moff = lrow * MRB + ((((nc2 >> 1) ^ (lrow & (mnv - 1))) << 4) | ((nc2 & 1) << 3));
+      if constexpr (PF == 1) pm[mi] = *reinterpret_cast<const uint2*>(sMk + MROWS * MRB + moff);
+      pk[mi] = *reinterpret_cast<const uint2*>(sMk + moff);
     }
   };
 
@@ -825,6 +845,10 @@ static int pf_of(int k) {
 
 int gemm1x1_rows_per_block(int k) { return 64 * mf_of(k); }
 
+// the fast data-gradient variants (PF) stage their block's mask rows in LDS: N / 8 bytes per row in whole, XOR-swizzled 16-B slots inside a
+// fixed row pitch (32 B at K = 64, 128 B otherwise)
+static bool pf_masks_ok(int k, int n) { return n >= 128 && (n & (n - 1)) == 0 && n <= (k == 64 ? 256 : 1024); }
+
 // chained next conv1: K = 64 (128-row blocks, all panels resident: N <= 256) and K = 128 (64-row blocks, streamed panels: N <= 512)
 // bit 0: K = 64, bit 1: K = 128; -1 = simhand_test_switch(SH_SW_G1_CHAIN), default 1 (test / tuning hooks).  K = 128 is OFF by default:
 // measured at 2048 x 28^2 the chained launch takes 1353 us against 908 + 434 for the two separate ones (its 64-row blocks and the
@@ -846,7 +870,7 @@ int gemm1x1_chain_rows(int k) { return k == 64 ? 128 : 64; }
 bool gemm1x1_sub_ok(const Gemm1x1Args& a, int k) {
   const int mf = mf_of(k);
   return a.fpartial == nullptr && a.accumulate == 0 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && a.M % (64 * mf) == 0 &&
-         pf_of(k) && a.sub_h % 2 == 0 && a.sub_w % 2 == 0 && a.M < (1ll << 31);
+         pf_of(k) && pf_masks_ok(k, a.N) && a.sub_h % 2 == 0 && a.sub_w % 2 == 0 && a.M < (1ll << 31);
 }
 
 int launch_gemm1x1(const Gemm1x1Args& a_in, int k, bool dgrad, hipStream_t s) {
@@ -876,11 +900,11 @@ int launch_gemm1x1(const Gemm1x1Args& a_in, int k, bool dgrad, hipStream_t s) {
 #define SH_G1(KV, MFV)                                                                          \
   do {                                                                                          \
     if (dgrad && a.fpartial != nullptr) gemm1x1_kernel<KV, MFV, true, true><<<nblk, 256, 0, s>>>(a);  \
-    else if (dgrad && a.accumulate == 2 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && full && pf_of(KV))  \
+    else if (dgrad && a.accumulate == 2 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && full && pf_of(KV) && pf_masks_ok(KV, a.N))  \
       gemm1x1_kernel<KV, MFV, true, false, 0, 1><<<nblk, 256, 0, s>>>(a);                       \
-    else if (dgrad && a.accumulate == 0 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && full && pf_of(KV) && a.sub != nullptr)  \
+    else if (dgrad && a.accumulate == 0 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && full && pf_of(KV) && pf_masks_ok(KV, a.N) && a.sub != nullptr)  \
       gemm1x1_kernel<KV, MFV, true, false, 0, 3><<<nblk, 256, 0, s>>>(a);                       \
-    else if (dgrad && a.accumulate == 0 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && full && pf_of(KV))  \
+    else if (dgrad && a.accumulate == 0 && a.fmode == 4 && a.fmask != nullptr && a.bias == nullptr && full && pf_of(KV) && pf_masks_ok(KV, a.N))  \
       gemm1x1_kernel<KV, MFV, true, false, 0, 2><<<nblk, 256, 0, s>>>(a);                       \
     else if (dgrad) gemm1x1_kernel<KV, MFV, true><<<nblk, 256, 0, s>>>(a);                      \
     else if (a.ep_scale != nullptr && a.ep_res != nullptr && a.ep_relu && a.ep_mask != nullptr && full && pf_of(KV))  \
