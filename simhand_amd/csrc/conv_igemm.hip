@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
       }
       return ok ? pix : -1;
     };
-    auto chunk_out = [&](int mi, int j, long long pix, unsigned keep = 0xffu) __attribute__((always_inline)) -> uint4 {
+    auto chunk_out = [&](int mi, int j, long long pix, unsigned keep = 0xffu, bool do_store = true) __attribute__((always_inline)) -> uint4 {
       uint4 v;
       f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
       if (DGRAD && p.bias != nullptr) {
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         v.z &= ((keep & 16u) ? 0x0000ffffu : 0u) | ((keep & 32u) ? 0xffff0000u : 0u);
         v.w &= ((keep & 64u) ? 0x0000ffffu : 0u) | ((keep & 128u) ? 0xffff0000u : 0u);
       }
-      *reinterpret_cast<uint4*>(dst) = v;
+      if (do_store) *reinterpret_cast<uint4*>(dst) = v;
       return v;
     };
     if (!DGRAD && sizeof(T) == 2 && p.ep_scale != nullptr) {
@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
     } else if (!DGRAD || p.fpartial == nullptr) {
       // plain forward store: lanes li / li ^ 1 trade one packed 16-B chunk (DPP quad_perm) so that every store instruction writes whole 128-B lines --
       // 8 rows x 128 B instead of 16 rows x 64 B.  The CU's store path digests the whole-line form in 60 % of the cycles (scripts/probes/store_pattern.hip,
-      // profiles/r05_igemm256_tile_stamps.md): -1 us per tile, bit-identical.  (The epilogues with per-channel operands keep the 64-B form.)
+      // profiles/r05_igemm256_tile_stamps.md): -1 us per tile, bit-identical.  (The fused-sums data-gradient epilogue below does the same since round 6; the BatchNorm + residual one and the plain data-gradient stores keep the 64-B form.)
       if (!DGRAD && !par && p.accumulate == 0) {
         auto swap1 = [](unsigned v) __attribute__((always_inline)) -> unsigned {
           return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
@@ -1160,61 +1160,92 @@ __global__ __launch_bounds__(512, 1) void igemm256_kernel(IgemmArgs p) {
         }
       }
     } else {
-      // fused BatchNorm-backward partial sums of the previous unit (see igemm_kernel)
-      float* red = reinterpret_cast<float*>(smem);  // [2 (wm)][2][BN]
+      // fused BatchNorm-backward partial sums of the previous unit (arithmetic and summation order of igemm_kernel's; bit-identical to the round 1-5 form).
+      // Round 6: (a) the y rows come through LDS -- each wave's 2 MI LDS-DMA instructions go out back to back into lane-private 16-B slots (no swizzle,
+      // no barrier: a lane reads what its own DMA lane wrote).  The register form asked for a row's first 64-B half, worked through MI row groups and then
+      // asked for the second half: by then the 128-B line had left L2 and HBM delivered it twice (666 MB read per 256-channel 3x3 launch for 472 MB of
+      // operands, profiles/r06_i256_dgrad_traffic.txt; 3.1 GB per step).  (b) Row-outer order, both channel halves of a row in hand: lanes li / li ^ 1 trade
+      // one packed chunk and every store instruction writes whole 128-B lines, as the plain forward epilogue above.  The 32 registers of the y rows pay for
+      // the second half's coefficients and sums.  Data-gradient class -0.13 ms per step in 5 of 5 same-box pairs (profiles/r06_cache_policy_ab.txt).
+      float* red = reinterpret_cast<float*>(smem + 8 * MI * NCH * 1024);  // [2 (wm)][2][BN], behind the y slots
       const T* __restrict__ fy = reinterpret_cast<const T*>(p.fy);
+      const char* yslot = smem + (wave * MI * NCH) * 1024 + lane * 16;
+      if (p.fmode != 4) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const long long pix = pixel_of(mi);
+          const T* src = fy + (pix < 0 ? 0 : pix) * p.Ng + ch0;
+#pragma unroll
+          for (int j = 0; j < NCH; ++j) dma16(src + j * 32, smem_addr + ((wave * MI + mi) * NCH + j) * 1024);
+        }
+      }
+      float sc0[VE], sh0[VE], sc1[VE], sh1[VE], s10[VE], s20[VE], s11[VE], s21[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) sc0[e] = sh0[e] = sc1[e] = sh1[e] = s10[e] = s20[e] = s11[e] = s21[e] = 0.f;
+      if (p.fmode == 2) {
+#pragma unroll
+        for (int e = 0; e < VE; e += 4) {
+          const float4 a4 = *reinterpret_cast<const float4*>(p.fscale + ch0 + e), b4 = *reinterpret_cast<const float4*>(p.fshift + ch0 + e);
+          const float4 c4 = *reinterpret_cast<const float4*>(p.fscale + ch0 + 32 + e), d4 = *reinterpret_cast<const float4*>(p.fshift + ch0 + 32 + e);
+          sc0[e] = a4.x; sc0[e + 1] = a4.y; sc0[e + 2] = a4.z; sc0[e + 3] = a4.w;
+          sh0[e] = b4.x; sh0[e + 1] = b4.y; sh0[e + 2] = b4.z; sh0[e + 3] = b4.w;
+          sc1[e] = c4.x; sc1[e + 1] = c4.y; sc1[e + 2] = c4.z; sc1[e + 3] = c4.w;
+          sh1[e] = d4.x; sh1[e + 1] = d4.y; sh1[e + 2] = d4.z; sh1[e + 3] = d4.w;
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      auto swap1 = [](unsigned v) __attribute__((always_inline)) -> unsigned {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
+      };
+      auto sums = [&](const uint4& v, const uint4& y, unsigned bits, float (&sc)[VE], float (&sh)[VE], float (&s1)[VE], float (&s2)[VE]) __attribute__((always_inline)) {
+        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+        const unsigned y4[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int e = 2 * i + h;
+            const float gq = h == 0 ? h16_lo(w4[i]) : h16_hi(w4[i]);
+            const float yy = h == 0 ? h16_lo(y4[i]) : h16_hi(y4[i]);
+            bool on = true;
+            if (p.fmode == 2) on = yy * sc[e] + sh[e] > 0.f;
+            else if (p.fmode == 3) on = (bits >> e) & 1u;
+            const float gv = on ? gq : 0.f;
+            s1[e] += gv;
+            s2[e] += gv * yy;
+          }
+        }
+      };
+      const bool odd = (li & 1) != 0;
+      const int chx = ch0 + (odd ? 32 : 0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const long long pix = pixel_of(mi);
+        const long long ppix = (long long)(((unsigned long long)swap1((unsigned)((unsigned long long)pix >> 32)) << 32) | swap1((unsigned)pix));
+        uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+        if (pix >= 0) {
+          const unsigned b0 = p.fmode >= 3 ? (unsigned)p.fmask[pix * (p.Ng / VE) + ch0 / VE] : 0xffu;
+          const unsigned b1 = p.fmode >= 3 ? (unsigned)p.fmask[pix * (p.Ng / VE) + (ch0 + 32) / VE] : 0xffu;
+          const uint4 y0 = p.fmode != 4 ? *reinterpret_cast<const uint4*>(yslot + (mi * NCH + 0) * 1024) : make_uint4(0, 0, 0, 0);
+          const uint4 y1 = p.fmode != 4 ? *reinterpret_cast<const uint4*>(yslot + (mi * NCH + 1) * 1024) : make_uint4(0, 0, 0, 0);
+          va = chunk_out(mi, 0, pix, b0, false);
+          vb = chunk_out(mi, 1, pix, b1, false);
+          sums(va, y0, b0, sc0, sh0, s10, s20);
+          sums(vb, y1, b1, sc1, sh1, s11, s21);
+        }
+        // even lanes send their second channel group (vb) and keep va; odd lanes send va and keep vb
+        const unsigned r0 = swap1(odd ? va.x : vb.x), r1 = swap1(odd ? va.y : vb.y), r2 = swap1(odd ? va.z : vb.z), r3 = swap1(odd ? va.w : vb.w);
+        const long long pixA = odd ? ppix : pix, pixB = odd ? pix : ppix;
+        const uint4 vA = odd ? make_uint4(r0, r1, r2, r3) : va;
+        const uint4 vB = odd ? vb : make_uint4(r0, r1, r2, r3);
+        if (pixA >= 0) *reinterpret_cast<uint4*>(out + pixA * p.Ng + chx) = vA;
+        if (pixB >= 0) *reinterpret_cast<uint4*>(out + pixB * p.Ng + chx) = vB;
+      }
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {
-        const int ch = ch0 + j * 32;
-        float sc[VE], sh[VE], s1[VE], s2[VE];
-#pragma unroll
-        for (int e = 0; e < VE; ++e) sc[e] = sh[e] = s1[e] = s2[e] = 0.f;
-        if (p.fmode == 2) {  // 16-B loads (the per-element conditional form compiles to one dword load per coefficient)
-#pragma unroll
-          for (int e = 0; e < VE; e += 4) {
-            const float4 a4 = *reinterpret_cast<const float4*>(p.fscale + ch + e), b4 = *reinterpret_cast<const float4*>(p.fshift + ch + e);
-            sc[e] = a4.x; sc[e + 1] = a4.y; sc[e + 2] = a4.z; sc[e + 3] = a4.w;
-            sh[e] = b4.x; sh[e + 1] = b4.y; sh[e + 2] = b4.z; sh[e + 3] = b4.w;
-          }
-        }
-        // all y rows / mask bytes of this 32-channel group are requested before the first one is used (rows past the range read row
-        // 0, branch-free): one exposed round trip per group instead of one per 16-pixel row -- the block is alone on its CU
-        uint4 yq[MI];
-        unsigned bq[MI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const long long pix = pixel_of(mi);
-          const long long pc = pix < 0 ? 0 : pix;
-          yq[mi] = p.fmode != 4 ? *reinterpret_cast<const uint4*>(fy + pc * p.Ng + ch) : make_uint4(0, 0, 0, 0);
-          bq[mi] = p.fmode >= 3 ? (unsigned)p.fmask[pc * (p.Ng / VE) + ch / VE] : 0xffu;
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const long long pix = pixel_of(mi);
-          if (pix < 0) continue;
-          const unsigned y4[4] = {yq[mi].x, yq[mi].y, yq[mi].z, yq[mi].w};
-          const unsigned bits = bq[mi];
-          const uint4 v = chunk_out(mi, j, pix, bits);
-          const unsigned w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const int e = 2 * i + h;
-              const float gq = h == 0 ? h16_lo(w4[i]) : h16_hi(w4[i]);
-              const float yy = h == 0 ? h16_lo(y4[i]) : h16_hi(y4[i]);
-              bool on = true;
-              if (p.fmode == 2) on = yy * sc[e] + sh[e] > 0.f;
-              else if (p.fmode == 3) on = (bits >> e) & 1u;  // mode 4: the value is already masked
-              const float gv = on ? gq : 0.f;
-              s1[e] += gv;
-              s2[e] += gv * yy;
-            }
-          }
-        }
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
-          const float t1 = row16_sum(s1[e]), t2 = row16_sum(s2[e]);
+          const float t1 = row16_sum(j == 0 ? s10[e] : s11[e]), t2 = row16_sum(j == 0 ? s20[e] : s21[e]);
           if (li == 0) {
             const int c = wn * 64 + g * VE + j * 32 + e;
             red[(wm * 2 + 0) * BN + c] = t1;
@@ -1352,87 +1383,115 @@ __global__ __launch_bounds__(256, 2) void gemm_n128_kernel(IgemmArgs p) {
   const int ch0 = wn * 64 + g * VE;
   float* red = reinterpret_cast<float*>(smem);  // [2 (wm)][2][BN]
   const bool sums = DGRAD ? p.fpartial != nullptr : p.bn_partial != nullptr;
+  {
+    // row-outer (round 6, as igemm256_kernel's fused-sums epilogue): both 64-B halves of every y line are requested together, and lanes li / li ^ 1 trade
+    // one packed chunk so that every store instruction writes whole 128-B lines.  Arithmetic and summation order are unchanged (bit-identical).  The
+    // channel-half-outer form wrote a row's two halves one y round trip apart: 561 MB reached HBM for the 411 MB of the stage-2 folded data gradient
+    // (now 414), 670 -> 630 us per launch in isolation (scripts/i256_dgrad_traffic.py n128_fold, profiles/r06_i256_dgrad_traffic.txt).
+    float s1[2][VE], s2[2][VE], sc[2][VE], sh[2][VE], bb[2][VE];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int ch = ch0 + j * 32;
-    float s1[VE], s2[VE], sc[VE], sh[VE], bb[VE];
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int e = 0; e < VE; ++e) s1[e] = s2[e] = sc[e] = bb[e] = 0.f, sh[e] = 1.f;  // (no ReLU: the gate y * 0 + 1 > 0 is open)
-    uint4 yq[MI];
+      for (int e = 0; e < VE; ++e) s1[j][e] = s2[j][e] = sc[j][e] = bb[j][e] = 0.f, sh[j][e] = 1.f;  // (no ReLU: the gate y * 0 + 1 > 0 is open)
+    uint4 yq[MI][2];
     if constexpr (DGRAD) {
-      if (p.bias != nullptr) {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ch), b1 = *reinterpret_cast<const float4*>(p.bias + ch + 4);
-        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-      }
-      if (sums) {
-        if (p.fmode == 2) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ch = ch0 + j * 32;
+        if (p.bias != nullptr) {
+          const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ch), b1 = *reinterpret_cast<const float4*>(p.bias + ch + 4);
+          bb[j][0] = b0.x; bb[j][1] = b0.y; bb[j][2] = b0.z; bb[j][3] = b0.w; bb[j][4] = b1.x; bb[j][5] = b1.y; bb[j][6] = b1.z; bb[j][7] = b1.w;
+        }
+        if (sums && p.fmode == 2) {
 #pragma unroll
           for (int e = 0; e < VE; e += 4) {
             const float4 a4 = *reinterpret_cast<const float4*>(p.fscale + ch + e), b4 = *reinterpret_cast<const float4*>(p.fshift + ch + e);
-            sc[e] = a4.x; sc[e + 1] = a4.y; sc[e + 2] = a4.z; sc[e + 3] = a4.w;
-            sh[e] = b4.x; sh[e + 1] = b4.y; sh[e + 2] = b4.z; sh[e + 3] = b4.w;
+            sc[j][e] = a4.x; sc[j][e + 1] = a4.y; sc[j][e + 2] = a4.z; sc[j][e + 3] = a4.w;
+            sh[j][e] = b4.x; sh[j][e + 1] = b4.y; sh[j][e + 2] = b4.z; sh[j][e + 3] = b4.w;
           }
         }
-        // all y rows of this 32-channel group are requested before the first is used (rows past the range read row 0, branch-free)
+      }
+      if (sums) {  // all y rows are requested before the first is used (rows past the range read row 0, branch-free)
         const T* __restrict__ fy = reinterpret_cast<const T*>(p.fy);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           const long long pix = m0 + wm * 64 + mi * 16 + li;
-          yq[mi] = *reinterpret_cast<const uint4*>(fy + (pix < p.Mg ? pix : 0) * BN + ch);
+          const T* src = fy + (pix < p.Mg ? pix : 0) * BN + ch0;
+          yq[mi][0] = *reinterpret_cast<const uint4*>(src);
+          yq[mi][1] = *reinterpret_cast<const uint4*>(src + 32);
         }
       }
     }
+    auto swap1 = [](unsigned v) __attribute__((always_inline)) -> unsigned {
+      return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
+    };
+    const bool odd = (li & 1) != 0;
+    const int chx = ch0 + (odd ? 32 : 0);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const long long pix = m0 + wm * 64 + mi * 16 + li;
       const bool ok = pix < p.Mg;
-      const f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
-      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      if constexpr (DGRAD) {
+      uint4 oj[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bb[e];
-      }
-      uint4 o;
-      o.x = pack_bf16x2(v[0], v[1]);
-      o.y = pack_bf16x2(v[2], v[3]);
-      o.z = pack_bf16x2(v[4], v[5]);
-      o.w = pack_bf16x2(v[6], v[7]);
-      if (ok) *reinterpret_cast<uint4*>(out + pix * BN + ch) = o;
-      if (sums) {
-        if constexpr (DGRAD) {  // sums of the STORED gradient (as igemm_kernel): g = bf16(result) gated by the recomputed ReLU mask
-          const unsigned w4[4] = {o.x, o.y, o.z, o.w};
-          const unsigned y4[4] = {yq[mi].x, yq[mi].y, yq[mi].z, yq[mi].w};
+      for (int j = 0; j < 2; ++j) {
+        const f32x4 lo = acc[mi][2 * j], hi = acc[mi][2 * j + 1];
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if constexpr (DGRAD) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int e = 0; e < 8; ++e) v[e] += bb[j][e];
+        }
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]);
+        o.w = pack_bf16x2(v[6], v[7]);
+        oj[j] = o;
+        if (sums) {
+          if constexpr (DGRAD) {  // sums of the STORED gradient (as igemm_kernel): g = bf16(result) gated by the recomputed ReLU mask
+            const unsigned w4[4] = {o.x, o.y, o.z, o.w};
+            const unsigned y4[4] = {yq[mi][j].x, yq[mi][j].y, yq[mi][j].z, yq[mi][j].w};
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const int e = 2 * i + h;
-              const float gq = h == 0 ? h16_lo(w4[i]) : h16_hi(w4[i]);
-              const float yy = h == 0 ? h16_lo(y4[i]) : h16_hi(y4[i]);
-              const bool on = ok && yy * sc[e] + sh[e] > 0.f;
-              const float gv = on ? gq : 0.f;
-              s1[e] += gv;
-              s2[e] += gv * yy;
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const int e = 2 * i + h;
+                const float gq = h == 0 ? h16_lo(w4[i]) : h16_hi(w4[i]);
+                const float yy = h == 0 ? h16_lo(y4[i]) : h16_hi(y4[i]);
+                const bool on = ok && yy * sc[j][e] + sh[j][e] > 0.f;
+                const float gv = on ? gq : 0.f;
+                s1[j][e] += gv;
+                s2[j][e] += gv * yy;
+              }
+          } else {  // forward: BatchNorm partial statistics of the fp32 results
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float ve = ok ? v[e] : 0.f;
+              s1[j][e] += ve;
+              s2[j][e] += ve * ve;
             }
-        } else {  // forward: BatchNorm partial statistics of the fp32 results
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float ve = ok ? v[e] : 0.f;
-            s1[e] += ve;
-            s2[e] += ve * ve;
           }
         }
       }
+      // even lanes send their second channel group and keep the first; odd lanes the other way round (rows pix and pix ^ 1 are the pair's: m0 is even)
+      const uint4 va = oj[0], vb = oj[1];
+      const unsigned r0 = swap1(odd ? va.x : vb.x), r1 = swap1(odd ? va.y : vb.y), r2 = swap1(odd ? va.z : vb.z), r3 = swap1(odd ? va.w : vb.w);
+      const long long pixA = odd ? pix - 1 : pix, pixB = odd ? pix : pix + 1;
+      const uint4 vA = odd ? make_uint4(r0, r1, r2, r3) : va;
+      const uint4 vB = odd ? vb : make_uint4(r0, r1, r2, r3);
+      if (pixA < p.Mg) *reinterpret_cast<uint4*>(out + pixA * BN + chx) = vA;
+      if (pixB < p.Mg) *reinterpret_cast<uint4*>(out + pixB * BN + chx) = vB;
     }
     if (sums) {
 #pragma unroll
-      for (int e = 0; e < VE; ++e) {
-        const float t1 = row16_sum(s1[e]), t2 = row16_sum(s2[e]);
-        if (li == 0) {
-          red[(wm * 2 + 0) * BN + ch + e] = t1;
-          red[(wm * 2 + 1) * BN + ch + e] = t2;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const float t1 = row16_sum(s1[j][e]), t2 = row16_sum(s2[j][e]);
+          if (li == 0) {
+            red[(wm * 2 + 0) * BN + ch0 + j * 32 + e] = t1;
+            red[(wm * 2 + 1) * BN + ch0 + j * 32 + e] = t2;
+          }
         }
-      }
     }
   }
   if (sums) {
