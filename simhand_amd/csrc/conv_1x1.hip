@@ -85,7 +85,9 @@ template <int K, int MF, bool DGRAD, bool FUSE = false, int EP = 0, int PF = 0, 
 #ifndef SH_G1_CH_MINB
 #define SH_G1_CH_MINB 2
 #endif
-__global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 && !ST) ? (CH ? SH_G1_CH_MINB : SH_G1_FWD_MINB) : 2)) void gemm1x1_kernel(Gemm1x1Args p) {
+// (the 256-row K = 128 form of the masked + merged data gradient exists for the block-size tuning hook only -- simhand_test_conv1x1_set_rows; with its block's
+// mask rows in LDS it fits once per CU, and says so instead of leaving the compiler to miss a target of two)
+__global__ __launch_bounds__(256, FUSE ? SH_G1_FUSE_MINB : ((!DGRAD && K <= 128 && !ST) ? (CH ? SH_G1_CH_MINB : SH_G1_FWD_MINB) : ((DGRAD && K == 128 && MF == 4 && PF == 1) ? 1 : 2))) void gemm1x1_kernel(Gemm1x1Args p) {
   constexpr int KC = K < 128 ? K : 128;   // k elements per weight tile
   constexpr int KSTEPS = K / KC;          // weight tiles per 64-channel chunk
   constexpr int KK = KC / 32;             // MFMA k-steps per weight tile
